@@ -1,0 +1,171 @@
+"""Seeded synthetic path records in the reference's ``path_info`` format.
+
+Scene assets of the reference are not in its repository (README.md:26), so the
+benchmark and the parity tests run on synthetic records whose *shape* follows
+the record logged by ``EPSMIntegrator.sample_path`` (epsm.py:547, 648-654) and
+whose *values* follow the generator specified in SURVEY.md section 8(d).
+
+``path_info[0] = {"cam": (N,3)}``; ``path_info[k]`` for k = 1..K holds
+``active (N) bool, bsdf (N) int32 flags, ismesh (N) f32, light (N,3),
+active_em (N) bool, points [p0,p1,p2,p] 4x(N,3), uv [b0,b1] 2x(N),
+normal (N,3), normals [n0,n1,n2] 3x(N,3), eta (N), hf (N,3)``.
+"""
+from __future__ import annotations
+
+import torch
+
+# include/mitsuba/render/bsdf.h:40-101
+BSDF_NULL = 0x1
+BSDF_DIFFUSE_REFLECTION = 0x2
+BSDF_GLOSSY_REFLECTION = 0x8
+BSDF_DELTA_REFLECTION = 0x20
+BSDF_DELTA_TRANSMISSION = 0x40
+BSDF_FRONT_SIDE = 0x8000
+BSDF_BACK_SIDE = 0x10000
+BSDF_NON_SYMMETRIC = 0x4000
+BSDF_DIFFUSE = 0x2 | 0x4
+
+FLAGS_DIFFUSE = BSDF_DIFFUSE_REFLECTION | BSDF_FRONT_SIDE
+FLAGS_ROUGHCONDUCTOR = BSDF_GLOSSY_REFLECTION | BSDF_FRONT_SIDE
+FLAGS_DIELECTRIC = (BSDF_DELTA_REFLECTION | BSDF_DELTA_TRANSMISSION | BSDF_FRONT_SIDE
+                    | BSDF_BACK_SIDE | BSDF_NON_SYMMETRIC)
+FLAGS_NULL = BSDF_NULL | BSDF_FRONT_SIDE | BSDF_BACK_SIDE
+
+PROFILES = ("bathroom", "caustic", "pool", "specular", "mixed")
+
+
+def _u(gen, shape, lo, hi, device, dtype):
+    return torch.rand(shape, generator=gen, device=device, dtype=dtype) * (hi - lo) + lo
+
+
+def synth_path_info(n_paths: int, n_vertices: int, seed: int = 0, device="cpu",
+                    profile: str = "bathroom", dtype=torch.float32,
+                    p_terminate: float = 0.1, p_no_light: float = 0.1,
+                    p_not_mesh: float = 0.02, tangent_scale: float = 1e-3):
+    """Returns ``(path_info, dlduv, dldp)``.
+
+    ``dlduv`` has the reference shape ``(N, 1, 2L)`` with L = K+1 and only the
+    first two columns non-zero (epsm.py:256, 268-269); ``dldp`` is ``(N, 3)``.
+
+    Profiles (diffuse-vertex placement):
+      bathroom  vertex 1 specular w.p. 0.7; P(diffuse at k)=0.6 for k>=2;
+                reflection (eta=1) with 20 % dielectric refraction vertices.
+      caustic   vertex 1 diffuse, then 1..3 specular vertices, then diffuse.
+      pool      as caustic but every specular vertex refracts (eta 1.33 / 1/1.33),
+                chain length uniform in 1..K-1 ("deep specular chains").
+      specular  no diffuse vertex at all (full-length chains, worst case work).
+      mixed     each of the above on a quarter of the paths, plus Null vertices.
+    """
+    if profile not in PROFILES:
+        raise ValueError(f"unknown profile {profile!r}")
+    N, K = int(n_paths), int(n_vertices)
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234567 + 7919 * int(seed))
+    f = dict(device=dev, dtype=dtype)
+
+    cam = torch.tensor([0.0, 0.0, 5.0], **f).expand(N, 3).contiguous()
+    info = [{"cam": cam}]
+
+    # --- which vertices are diffuse -------------------------------------
+    r = torch.rand((N, K), generator=gen, device=dev)
+    if profile == "mixed":
+        sel = torch.randint(0, 4, (N,), generator=gen, device=dev)
+    else:
+        sel = torch.full((N,), {"bathroom": 0, "caustic": 1, "pool": 2, "specular": 3}[profile],
+                         device=dev, dtype=torch.int64)
+    kk = torch.arange(1, K + 1, device=dev)[None, :]
+    diff_bath = torch.where(kk == 1, r < 0.3, r < 0.6)
+    chain = torch.randint(1, max(2, min(4, K)), (N, 1), generator=gen, device=dev)
+    diff_caus = (kk == 1) | (kk >= chain + 2)
+    chain_p = torch.randint(1, max(2, K), (N, 1), generator=gen, device=dev)
+    diff_pool = (kk == 1) | (kk >= chain_p + 2)
+    diff_spec = torch.zeros((N, K), dtype=torch.bool, device=dev)
+    s = sel[:, None]
+    is_diffuse = torch.where(s == 0, diff_bath, torch.where(s == 1, diff_caus,
+                             torch.where(s == 2, diff_pool, diff_spec)))
+
+    alive = torch.ones((N,), dtype=torch.bool, device=dev)
+    for k in range(1, K + 1):
+        # triangle centres zig-zag so that consecutive vertices are >= 1.5 apart
+        centre = torch.tensor([1.6 * ((k % 2) * 2 - 1) * 0.5, 0.35 * k, 2.5 - 2.0 * (k % 2)], **f)
+        p = [centre + _u(gen, (N, 3), -0.5, 0.5, dev, dtype) for _ in range(3)]
+        b0 = _u(gen, (N,), 0.0, 0.5, dev, dtype)
+        b1 = _u(gen, (N,), 0.0, 0.5, dev, dtype)
+        base_n = torch.tensor([0.1, 0.2, 1.0], **f)
+        nrm = []
+        for _ in range(3):
+            v = base_n + 0.2 * _u(gen, (N, 3), -0.5, 0.5, dev, dtype)
+            nrm.append(v / torch.linalg.norm(v, dim=-1, keepdim=True))
+        pos = p[0] * b0[:, None] + p[1] * b1[:, None] + p[2] * (1 - b0 - b1)[:, None]
+        nint = nrm[0] * b0[:, None] + nrm[1] * b1[:, None] + nrm[2] * (1 - b0 - b1)[:, None]
+        nint = nint / torch.linalg.norm(nint, dim=-1, keepdim=True)
+
+        refr = torch.rand((N,), generator=gen, device=dev)
+        enter = torch.rand((N,), generator=gen, device=dev) < 0.5
+        eta_glass = torch.where(enter, torch.tensor(1.5, **f), torch.tensor(1.0 / 1.5, **f))
+        eta_water = torch.where(enter, torch.tensor(1.33, **f), torch.tensor(1.0 / 1.33, **f))
+        is_refr = torch.where(sel == 2, torch.ones_like(enter), refr < 0.2)
+        eta = torch.where(is_refr, torch.where(sel == 2, eta_water, eta_glass), torch.tensor(1.0, **f))
+        dflag = is_diffuse[:, k - 1]
+        eta = torch.where(dflag, torch.tensor(1.0, **f), eta)
+        flags = torch.where(dflag, torch.tensor(FLAGS_DIFFUSE, device=dev),
+                            torch.where(is_refr, torch.tensor(FLAGS_DIELECTRIC, device=dev),
+                                        torch.tensor(FLAGS_ROUGHCONDUCTOR, device=dev)))
+        if profile == "mixed":
+            null_v = torch.rand((N,), generator=gen, device=dev) < 0.03
+            flags = torch.where(null_v & ~dflag, torch.tensor(FLAGS_NULL, device=dev), flags)
+        hf = torch.cat([0.05 * _u(gen, (N, 2), -0.5, 0.5, dev, dtype),
+                        torch.ones((N, 1), **f)], dim=-1)
+        # only roughconductor exports hf (roughconductor.cpp:255); zero elsewhere
+        hf = torch.where((flags == FLAGS_ROUGHCONDUCTOR)[:, None], hf, torch.zeros_like(hf))
+        light = torch.tensor([0.0, 4.0, 4.0], **f) + _u(gen, (N, 3), 0.0, 1.0, dev, dtype)
+
+        if k > 1:
+            alive = alive & (torch.rand((N,), generator=gen, device=dev) >= p_terminate)
+        active_em = alive & (torch.rand((N,), generator=gen, device=dev) >= p_no_light)
+        ismesh = (torch.rand((N,), generator=gen, device=dev) >= p_not_mesh).to(dtype)
+
+        info.append({
+            "it": k - 1,
+            "active": alive.clone(),
+            "bsdf": flags.to(torch.int32),
+            "ismesh": ismesh,
+            "light": light,
+            "active_em": active_em,
+            "points": [p[0], p[1], p[2], pos],
+            "uv": [b0, b1],
+            "normal": nint,
+            "normals": nrm,
+            "eta": eta,
+            "hf": hf,
+        })
+
+    L = K + 1
+    dlduv = torch.zeros((N, 1, 2 * L), **f)
+    dlduv[:, 0, :2] = torch.randn((N, 2), generator=gen, device=dev, dtype=dtype) * tangent_scale
+    dldp = torch.randn((N, 3), generator=gen, device=dev, dtype=dtype) * tangent_scale
+    return info, dlduv, dldp
+
+
+def path_info_to(path_info, device=None, dtype=None):
+    """Deep copy of a ``path_info`` list onto another device / float dtype."""
+    out = []
+    for rec in path_info:
+        r = {}
+        for k, v in rec.items():
+            def conv(t):
+                t = t.detach().clone()
+                if dtype is not None and t.is_floating_point():
+                    t = t.to(dtype)
+                if device is not None:
+                    t = t.to(device)
+                return t
+            if isinstance(v, (list, tuple)):
+                r[k] = [conv(x) for x in v]
+            elif isinstance(v, torch.Tensor):
+                r[k] = conv(v)
+            else:
+                r[k] = v
+        out.append(r)
+    return out
