@@ -1,0 +1,86 @@
+"""Shared helpers of the test-suite: golden loading and the parity metric."""
+from __future__ import annotations
+
+import glob
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_files(prefix="calc_grad_"):
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+
+
+def golden_id(path):
+    return os.path.basename(path)[len("calc_grad_"):-len(".npz")]
+
+
+def load_golden(path, dtype=torch.float32, device="cpu"):
+    """-> (variant, path_info, dlduv, dldp, ref) in the reference's path_info format."""
+    z = np.load(path)
+    K = int(z["K"])
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(device)
+    info = [{"cam": f(z["cam"])}]
+    for k in range(1, K + 1):
+        pre = f"v{k}_"
+        info.append({
+            "it": k - 1,
+            "active": torch.from_numpy(z[pre + "active"].astype(bool)).to(device),
+            "bsdf": torch.from_numpy(z[pre + "bsdf"].astype(np.int64)).to(torch.int32).to(device),
+            "ismesh": f(z[pre + "ismesh"]),
+            "light": f(z[pre + "light"]),
+            "active_em": torch.from_numpy(z[pre + "active_em"].astype(bool)).to(device),
+            "points": [f(z[pre + "p0"]), f(z[pre + "p1"]), f(z[pre + "p2"]), f(z[pre + "p"])],
+            "uv": [f(z[pre + "b0"]), f(z[pre + "b1"])],
+            "normal": f(z[pre + "normal"]),
+            "normals": [f(z[pre + "n0"]), f(z[pre + "n1"]), f(z[pre + "n2"])],
+            "eta": f(z[pre + "eta"]),
+            "hf": f(z[pre + "hf"]),
+        })
+    ref = {k: torch.from_numpy(z[k]) for k in z.files if k.startswith("ref")}
+    return str(z["variant"]), info, f(z["dlduv"]), f(z["dldp"]), ref
+
+
+def stack3(fp, lg, dg):
+    """(P+2K, N, 3) float64 stack of the three output lists."""
+    return torch.cat([torch.stack([x.detach().cpu().double() for x in lst]) for lst in (fp, lg, dg)], dim=0)
+
+
+def parity_report(mine: torch.Tensor, truth: torch.Tensor, yard: torch.Tensor | None = None,
+                  clip: float = 0.1, rel: float = 2e-4, yard_factor: float = 16.0):
+    """Per-path parity of fp32 results against a float64 truth.
+
+    ``mine``, ``truth``, ``yard``: (A, N, 3) stacks (all outputs of every path).
+    A path passes when the max-norm error over its outputs is at most
+    ``rel * scale + yard_factor * (error of the yardstick fp32 implementation)``
+    with ``scale`` = max |truth| over the path's outputs (>= 1e-6).  Components
+    whose truth lies within 2 % of the +-clip outlier threshold (epsm.py:932-944)
+    are excluded: the clamp is discontinuous and any rounding flips them.
+    Returns dict(frac_bad, worst, n_straddle, median_rel).
+    """
+    mine = mine.double(); truth = truth.double()
+    strad = torch.zeros_like(truth, dtype=torch.bool)
+    if clip and clip > 0 and np.isfinite(clip):
+        strad = (truth.abs() > 0.98 * clip) | ((truth == 0) & (mine.abs() > 0.98 * clip))
+        if yard is not None:
+            strad |= (yard.double().abs() > 0.98 * clip) & (truth == 0)
+    err = torch.where(strad, torch.zeros_like(truth), (mine - truth).abs())
+    # a clamp straddler poisons its whole path only through that component, so mask per component
+    scale = torch.where(strad, torch.zeros_like(truth), truth.abs()).amax(dim=(0, 2)).clamp_min(1e-6)
+    e_path = err.amax(dim=(0, 2))
+    tol = rel * scale
+    if yard is not None:
+        yerr = torch.where(strad, torch.zeros_like(truth), (yard.double() - truth).abs()).amax(dim=(0, 2))
+        tol = tol + yard_factor * yerr
+    bad = e_path > tol
+    return {
+        "frac_bad": float(bad.double().mean()),
+        "n_bad": int(bad.sum()),
+        "worst": float((e_path / scale).max()),
+        "median_rel": float((e_path / scale).median()),
+        "n_straddle": int(strad.sum()),
+        "bad_idx": torch.nonzero(bad).flatten()[:8].tolist(),
+    }

@@ -1,0 +1,152 @@
+"""Generate golden vectors by running the REFERENCE's own ``calc_grad``.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/gen_golden.py
+
+Each ``tests/golden/calc_grad_*.npz`` holds
+  * the inputs (fp32): the path records of epsm.py:648-654, ``dlduv``, ``dldp``;
+  * ``ref32_*``: outputs of the reference run as shipped (fp32);
+  * ``ref64_*``: outputs of the same reference code run under torch.float64 on
+    the exact fp32 inputs cast to double -- the rounding-free anchor that pins
+    every mask / overwrite rule of epsm.py:745-1200.
+Only data is written; no reference source is copied.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+import ref_stub  # noqa: E402
+from epsm_mitsuba3_amd.synth import synth_path_info, path_info_to, FLAGS_NULL  # noqa: E402
+
+warnings.filterwarnings("ignore", message="Using torch.cross")
+
+VEC3 = ("p0", "p1", "p2", "n0", "n1", "n2", "hf", "light")
+
+
+def flatten(path_info, dlduv, dldp):
+    d = {"cam": path_info[0]["cam"].numpy(), "dlduv": dlduv.numpy(), "dldp": dldp.numpy()}
+    for k in range(1, len(path_info)):
+        r = path_info[k]
+        pre = f"v{k}_"
+        for j in range(3):
+            d[pre + f"p{j}"] = r["points"][j].numpy()
+            d[pre + f"n{j}"] = r["normals"][j].numpy()
+        d[pre + "p"] = r["points"][3].numpy()
+        d[pre + "normal"] = r["normal"].numpy()
+        d[pre + "b0"] = r["uv"][0].numpy()
+        d[pre + "b1"] = r["uv"][1].numpy()
+        d[pre + "eta"] = r["eta"].numpy()
+        d[pre + "hf"] = r["hf"].numpy()
+        d[pre + "light"] = r["light"].numpy()
+        d[pre + "bsdf"] = r["bsdf"].numpy().astype(np.uint32)
+        d[pre + "active"] = r["active"].numpy().astype(np.uint8)
+        d[pre + "active_em"] = r["active_em"].numpy().astype(np.uint8)
+        d[pre + "ismesh"] = r["ismesh"].numpy().astype(np.float32)
+    return d
+
+
+def run_reference(variant, path_info, dlduv, dldp):
+    out = {}
+    for tag, dt in (("ref32", torch.float32), ("ref64", torch.float64)):
+        pi = path_info_to(path_info, dtype=dt)
+        fp, lg, dg = ref_stub.reference_calc_grad(variant, pi, dlduv.to(dt), dldp.to(dt))
+        out[tag + "_param"] = torch.stack(fp).numpy()
+        out[tag + "_light"] = torch.stack(lg).numpy()
+        out[tag + "_diffuse"] = torch.stack(dg).numpy()
+    return out
+
+
+def edge_case_records(K=4, seed=11, nan_normals=True):
+    """Hand-made hard cases layered over a 'mixed' batch (N=96).
+
+    ``nan_normals=False`` for the caustic variant: with an axis-aligned shading
+    normal the reference itself aborts there (torch.linalg.inv raises "singular"
+    at epsm.py:1076), so that input has no reference behaviour to pin."""
+    N = 96
+    pi, dlduv, dldp = synth_path_info(N, K, seed=seed, profile="mixed", tangent_scale=2e-5)
+    g = torch.Generator().manual_seed(99)
+    # (iv) shading normal exactly along +-x at some vertex: tangent = 0/0 -> NaN -> 0 (epsm.py:746-748, 856)
+    for k, rows in (((1, slice(0, 6)), (2, slice(6, 12)), (3, slice(12, 16))) if nan_normals else ()):
+        for j in range(3):
+            pi[k]["normals"][j][rows] = torch.tensor([1.0, 0.0, 0.0])
+        pi[k]["normals"][1][rows.start] = torch.tensor([-1.0, 0.0, 0.0]) if k == 3 else torch.tensor([1.0, 0.0, 0.0])
+    # inactive tails filled with zeros, as a masked Dr.Jit lane would leave them
+    for k in (3, 4):
+        rows = slice(16, 28) if k == 3 else slice(16, 40)
+        pi[k]["active"][rows] = False
+        pi[k]["active_em"][rows] = False
+        for key in ("light", "hf", "normal"):
+            pi[k][key][rows] = 0
+        for j in range(3):
+            pi[k]["points"][j][rows] = 0
+            pi[k]["normals"][j][rows] = 0
+        pi[k]["points"][3][rows] = 0
+        pi[k]["uv"][0][rows] = 0
+        pi[k]["uv"][1][rows] = 0
+        pi[k]["eta"][rows] = 0
+        pi[k]["bsdf"][rows] = 0
+        pi[k]["ismesh"][rows] = 0
+    # non-mesh hits in the middle of a chain, Null vertices, no emitter sample anywhere
+    pi[2]["ismesh"][40:46] = 0
+    pi[1]["ismesh"][46:50] = 0
+    pi[2]["bsdf"][50:56] = FLAGS_NULL
+    pi[3]["bsdf"][56:60] = FLAGS_NULL
+    for k in range(1, K + 1):
+        pi[k]["active_em"][60:66] = False
+    # general dlduv: tangents on the barycentrics of every vertex, not only the first
+    # (render_backward never produces this, epsm.py:256; calc_grad accepts it)
+    dlduv[66:96, 0, :] = torch.randn((30, dlduv.shape[-1]), generator=g) * 2e-5
+    # large tangents: every output beyond the +-0.1 clamp (epsm.py:932-944)
+    dlduv[80:88] *= 1e4
+    dldp[80:88] *= 1e4
+    return pi, dlduv, dldp
+
+
+def main():
+    if not ref_stub.available():
+        raise SystemExit("reference not present; golden vectors can only be generated in the build container")
+    cases = []
+    for variant in ("manifold", "manifold_caustic"):
+        for K in (1, 2, 3, 4, 5):
+            cases.append((f"{variant}_K{K}_mixed", variant, lambda K=K: synth_path_info(
+                128, K, seed=100 + K, profile="mixed", tangent_scale=2e-5)))
+    cases.append(("manifold_K5_specular", "manifold", lambda: synth_path_info(
+        96, 5, seed=7, profile="specular", tangent_scale=1e-5)))
+    cases.append(("manifold_K5_bathroom", "manifold", lambda: synth_path_info(
+        96, 5, seed=8, profile="bathroom", tangent_scale=2e-5)))
+    cases.append(("manifold_caustic_K5_pool", "manifold_caustic", lambda: synth_path_info(
+        96, 5, seed=9, profile="pool", tangent_scale=1e-5)))
+    cases.append(("manifold_caustic_K4_caustic", "manifold_caustic", lambda: synth_path_info(
+        96, 4, seed=10, profile="caustic", tangent_scale=2e-5)))
+    cases.append(("manifold_K4_edge", "manifold", edge_case_records))
+    cases.append(("manifold_caustic_K4_edge", "manifold_caustic", lambda: edge_case_records(nan_normals=False)))
+
+    total = 0
+    for name, variant, make in cases:
+        pi, dlduv, dldp = make()
+        d = flatten(pi, dlduv, dldp)
+        d.update(run_reference(variant, pi, dlduv, dldp))
+        d["variant"] = np.array(variant)
+        d["K"] = np.array(len(pi) - 1)
+        path = os.path.join(HERE, f"calc_grad_{name}.npz")
+        np.savez_compressed(path, **d)
+        sz = os.path.getsize(path)
+        total += sz
+        nz = float((d["ref32_param"] != 0).mean())
+        print(f"{name:36s} N={d['cam'].shape[0]:4d} {sz/1024:7.1f} KiB  nonzero(param)={nz:.3f} "
+              f"max|g|={np.abs(d['ref32_param']).max():.4f}")
+    print(f"total {total/1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
