@@ -1,0 +1,66 @@
+"""Loader of the product library ``libepsm_hip.so`` (C ABI: include/epsm.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an
+exception is raised.  ``import torch`` happens first on purpose -- torch-ROCm
+ships its own ``libamdhip64.so.7`` and the dynamic loader then binds our
+library to that same HIP runtime, so torch streams / device pointers are valid
+inside our kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch  # noqa: F401  (must be loaded before libepsm_hip.so, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libepsm_hip.so")
+_lib = None
+
+
+class EpsmError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compiles the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.run(["make", "-C", src_dir, "-s", "clean"], check=True)
+    subprocess.run(["make", "-C", src_dir, "-s"], check=True)
+    return LIB_PATH
+
+
+def _declare(lib):
+    lib.epsm_abi_version.restype = C.c_int
+    lib.epsm_abi_version.argtypes = []
+    lib.epsm_last_error.restype = C.c_char_p
+    lib.epsm_last_error.argtypes = []
+    lib.epsm_num_param_grads.restype = C.c_int
+    lib.epsm_num_param_grads.argtypes = [C.c_int, C.c_int]
+    lib.epsm_manifold_grad.restype = C.c_int
+    lib.epsm_manifold_grad.argtypes = [
+        C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_float,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise EpsmError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or make -C epsm_mitsuba3_amd/csrc). There is no CPU fallback.")
+        _lib = _declare(C.CDLL(LIB_PATH))
+        if _lib.epsm_abi_version() != 1:
+            raise EpsmError("libepsm_hip.so ABI version mismatch")
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().epsm_last_error().decode("utf-8", "replace")
+        raise EpsmError(f"{what} failed with code {rc}: {msg}")

@@ -1,0 +1,128 @@
+// epsm_hip.hip -- gfx950 kernels + C ABI (include/epsm.h) of the EPSM hot path.
+//
+// One lane = one light path (wave64, 256-thread workgroups).  Inputs are read
+// straight from the reference's own tensor layout ((N,3) fp32 rows: consecutive
+// lanes read consecutive 12-byte rows, i.e. fully coalesced dwordx3 streams);
+// nothing is staged through HBM between the constraint Jacobian, the block
+// solve and the gradient: the per-path state lives in VGPRs (epsm_path_core.h).
+// MFMA is deliberately unused: the per-path systems are 2x2 blocks on a band of
+// at most 5, not a dense contraction.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/epsm.h"
+#include "epsm_path_core.h"
+
+using namespace epsm;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+constexpr int kBlock = 256;
+
+template <int K, int VARIANT, bool FULL_D>
+__global__ __launch_bounds__(kBlock) void epsm_grad_kernel(GradArgs<float> A, int dcols) {
+    const int64_t i = (int64_t) blockIdx.x * kBlock + threadIdx.x;
+    if (i >= A.N) return;
+    if (VARIANT == EPSM_VARIANT_MANIFOLD)
+        manifold_path<float, K, FULL_D>(A, i, dcols);
+    else
+        caustic_path<float, K, FULL_D>(A, i, dcols);
+}
+
+template <int K, int VARIANT, bool FULL_D>
+hipError_t launch(const GradArgs<float> &A, int dcols, hipStream_t s) {
+    const int64_t blocks = (A.N + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL((epsm_grad_kernel<K, VARIANT, FULL_D>), dim3((unsigned) blocks), dim3(kBlock), 0, s, A, dcols);
+    return hipGetLastError();
+}
+
+template <int VARIANT, bool FULL_D>
+hipError_t launch_k(int K, const GradArgs<float> &A, int dcols, hipStream_t s) {
+    switch (K) {
+        case 1: return launch<1, VARIANT, FULL_D>(A, dcols, s);
+        case 2: return launch<2, VARIANT, FULL_D>(A, dcols, s);
+        case 3: return launch<3, VARIANT, FULL_D>(A, dcols, s);
+        case 4: return launch<4, VARIANT, FULL_D>(A, dcols, s);
+        default: return launch<5, VARIANT, FULL_D>(A, dcols, s);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int epsm_abi_version(void) { return EPSM_ABI_VERSION; }
+
+const char *epsm_last_error(void) { return g_err; }
+
+int epsm_num_param_grads(int variant, int K) {
+    return variant == EPSM_VARIANT_MANIFOLD_CAUSTIC ? 5 * K - 2 : 5 * K;
+}
+
+int epsm_manifold_grad(int variant, int64_t N, int K,
+                       const float *cam, const EpsmVertexRecord *verts,
+                       const float *dlduv, int64_t dlduv_stride, int dlduv_cols,
+                       const float *dldp, float clip,
+                       float *out_param, float *out_light, float *out_diffuse,
+                       void *stream) {
+    g_err[0] = 0;
+    if (variant != EPSM_VARIANT_MANIFOLD && variant != EPSM_VARIANT_MANIFOLD_CAUSTIC)
+        return fail(EPSM_EINVAL, "epsm_manifold_grad: unknown variant%s");
+    if (K < 1 || K > EPSM_MAX_VERTICES) return fail(EPSM_EINVAL, "epsm_manifold_grad: K must be in 1..5%s");
+    if (N < 0 || (N + kBlock - 1) / kBlock > 0x7fffffffLL) return fail(EPSM_EINVAL, "epsm_manifold_grad: bad N%s");
+    if (!cam || !verts || !dlduv || !dldp || !out_param || !out_light || !out_diffuse)
+        return fail(EPSM_EINVAL, "epsm_manifold_grad: NULL argument%s");
+    if (dlduv_cols < 0 || dlduv_stride < (dlduv_cols < 2 * K ? dlduv_cols : 2 * K))
+        return fail(EPSM_EINVAL, "epsm_manifold_grad: dlduv_stride smaller than the columns to read%s");
+    GradArgs<float> A;
+    memset(&A, 0, sizeof(A));
+    A.N = N;
+    A.cam = cam;
+    for (int k = 0; k < K; ++k) {
+        const EpsmVertexRecord &v = verts[k];
+        if (!v.p0 || !v.p1 || !v.p2 || !v.n0 || !v.n1 || !v.n2 || !v.b0 || !v.b1 || !v.eta || !v.light ||
+            !v.bsdf || !v.active || !v.active_em || !v.ismesh)
+            return fail(EPSM_EINVAL, "epsm_manifold_grad: NULL pointer in a vertex record%s");
+        VertexPtrs<float> &o = A.v[k];
+        o.p0 = (const float *) v.p0; o.p1 = (const float *) v.p1; o.p2 = (const float *) v.p2;
+        o.n0 = (const float *) v.n0; o.n1 = (const float *) v.n1; o.n2 = (const float *) v.n2;
+        o.b0 = (const float *) v.b0; o.b1 = (const float *) v.b1; o.eta = (const float *) v.eta;
+        o.light = (const float *) v.light;
+        o.bsdf = v.bsdf; o.active = v.active; o.active_em = v.active_em; o.ismesh = v.ismesh;
+    }
+    A.dlduv = dlduv;
+    A.dlduv_stride = dlduv_stride;
+    A.dldp = dldp;
+    A.clip = (clip > 0.0f && clip <= 3.402823466e+38f) ? clip : 0.0f;
+    A.out_param = out_param;
+    A.out_light = out_light;
+    A.out_diffuse = out_diffuse;
+    if (N == 0) return EPSM_OK;
+    int dcols = dlduv_cols > 2 * K ? 2 * K : dlduv_cols;
+    const bool full_d = dcols > 2;
+    hipStream_t s = (hipStream_t) stream;
+    hipError_t e;
+    if (variant == EPSM_VARIANT_MANIFOLD)
+        e = full_d ? launch_k<EPSM_VARIANT_MANIFOLD, true>(K, A, dcols, s)
+                   : launch_k<EPSM_VARIANT_MANIFOLD, false>(K, A, dcols, s);
+    else
+        e = full_d ? launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, true>(K, A, dcols, s)
+                   : launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, false>(K, A, dcols, s);
+    if (e != hipSuccess) {
+        if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorNoBinaryForGpu ||
+            e == hipErrorInsufficientDriver)
+            return fail(EPSM_ENODEV, "epsm_manifold_grad: %s", hipGetErrorString(e));
+        return fail(EPSM_ELAUNCH, "epsm_manifold_grad: %s", hipGetErrorString(e));
+    }
+    return EPSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,568 @@
+// epsm_path_core.h -- per-path arithmetic of the EPSM manifold-gradient hot path.
+//
+// One call = one light path: builds the 2x2 blocks of the projected half-vector
+// constraint Jacobian in barycentric coordinates, solves the block system in
+// ADJOINT form and emits the per-vertex parameter gradients.  It restates what
+//     ManifoldIntegrator.calc_grad          (epsm.py:745-946)
+//     ManifoldCausticIntegrator.calc_grad   (epsm.py:952-1200)
+// compute, without ever forming the dense (2L x 2L) `constraint` matrix, the
+// (N,2L,3) per-parameter Jacobians or a dense inverse (epsm.py:768-771,848):
+//
+//   * the reference contracts `dlduv . (-inv(cur) . J_p)` (epsm.py:850-851); with
+//     y := cur^-T dlduv  this is  g_p = - sum_k y_k^T dC_k/dp, i.e. ONE reverse
+//     sweep of constraint k seeded with the 2-vector y_k yields the gradient
+//     w.r.t. every input of that constraint at once;
+//   * "manifold": cur is block tridiagonal (2x2 blocks) -> block LU forward
+//     recursion for the pivots, backward recursion for y; the sum over depths
+//     id = 1..K and over the two sub-paths (light sample / continuing) is
+//     folded into the seeds, so every constraint is swept once per version;
+//   * "manifold_caustic": the row of the diffuse receiver is replaced by the
+//     pseudo-constraint wo2 (epsm.py:1028,1051-1066,1116,1141-1157), which makes
+//     cur a block upper-triangular band after a cyclic row shift -> one forward
+//     recursion, no backward pass.
+//
+// The file is plain C++ templated on the scalar type; hipcc compiles it into
+// the gfx950 kernels (epsm_kernels.hip) and tests/host_harness compiles the
+// SAME code for the CPU in fp32/fp64 so the algebra can be checked against the
+// oracle without a GPU.  It is not a CPU fallback: the product library only
+// exports the HIP path.
+#pragma once
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define EPSM_HD __host__ __device__ __forceinline__
+#else
+#define EPSM_HD inline __attribute__((always_inline))
+#endif
+
+namespace epsm {
+
+constexpr int kMaxVertices = 5;          // EPSM_MAX_VERTICES
+constexpr uint32_t kBsdfNull = 0x1u;     // bsdf.h:40
+constexpr uint32_t kBsdfDiffuse = 0x6u;  // bsdf.h:101
+
+// ----------------------------------------------------------------------------
+// tiny linear algebra
+// ----------------------------------------------------------------------------
+template <typename R> struct V3 { R x, y, z; };
+template <typename R> struct V2 { R x, y; };
+template <typename R> struct M2 { R a, b, c, d; };   // [[a,b],[c,d]]
+
+template <typename R> EPSM_HD V3<R> mk3(R x, R y, R z) { V3<R> v; v.x = x; v.y = y; v.z = z; return v; }
+template <typename R> EPSM_HD V3<R> zero3() { return mk3<R>(R(0), R(0), R(0)); }
+template <typename R> EPSM_HD V3<R> operator+(V3<R> a, V3<R> b) { return mk3<R>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename R> EPSM_HD V3<R> operator-(V3<R> a, V3<R> b) { return mk3<R>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename R> EPSM_HD V3<R> operator-(V3<R> a) { return mk3<R>(-a.x, -a.y, -a.z); }
+template <typename R> EPSM_HD V3<R> operator*(V3<R> a, R s) { return mk3<R>(a.x * s, a.y * s, a.z * s); }
+template <typename R> EPSM_HD R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename R> EPSM_HD V3<R> cross(V3<R> a, V3<R> b) {
+    return mk3<R>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// a + b*s
+template <typename R> EPSM_HD V3<R> madd(V3<R> a, V3<R> b, R s) { return mk3<R>(a.x + b.x * s, a.y + b.y * s, a.z + b.z * s); }
+
+template <typename R> EPSM_HD V2<R> mk2(R x, R y) { V2<R> v; v.x = x; v.y = y; return v; }
+template <typename R> EPSM_HD V2<R> operator+(V2<R> a, V2<R> b) { return mk2<R>(a.x + b.x, a.y + b.y); }
+template <typename R> EPSM_HD V2<R> operator-(V2<R> a, V2<R> b) { return mk2<R>(a.x - b.x, a.y - b.y); }
+template <typename R> EPSM_HD V2<R> operator*(V2<R> a, R s) { return mk2<R>(a.x * s, a.y * s); }
+// row vector times matrix
+template <typename R> EPSM_HD V2<R> vmul(V2<R> v, M2<R> m) { return mk2<R>(v.x * m.a + v.y * m.c, v.x * m.b + v.y * m.d); }
+template <typename R> EPSM_HD M2<R> mmul(M2<R> p, M2<R> q) {
+    M2<R> r;
+    r.a = p.a * q.a + p.b * q.c; r.b = p.a * q.b + p.b * q.d;
+    r.c = p.c * q.a + p.d * q.c; r.d = p.c * q.b + p.d * q.d;
+    return r;
+}
+template <typename R> EPSM_HD M2<R> msub(M2<R> p, M2<R> q) { M2<R> r; r.a = p.a - q.a; r.b = p.b - q.b; r.c = p.c - q.c; r.d = p.d - q.d; return r; }
+template <typename R> EPSM_HD M2<R> minv(M2<R> m) {
+    R det = m.a * m.d - m.b * m.c;
+    R id = R(1) / det;
+    M2<R> r; r.a = m.d * id; r.b = -m.b * id; r.c = -m.c * id; r.d = m.a * id;
+    return r;
+}
+
+EPSM_HD bool finite_(float x) { return fabsf(x) <= 3.402823466e+38f; }
+EPSM_HD bool finite_(double x) { return fabs(x) <= 1.7976931348623157e+308; }
+template <typename R> EPSM_HD bool finite2(V2<R> v) { return finite_(v.x) && finite_(v.y); }
+EPSM_HD float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+EPSM_HD double rsqrt_(double x) { return 1.0 / sqrt(x); }
+EPSM_HD float realmax_(float) { return 3.402823466e+38f; }
+EPSM_HD double realmax_(double) { return 1.7976931348623157e+308; }
+
+// ----------------------------------------------------------------------------
+// kernel arguments (typed twin of EpsmVertexRecord, include/epsm.h)
+// ----------------------------------------------------------------------------
+template <typename R> struct VertexPtrs {
+    const R *p0, *p1, *p2, *n0, *n1, *n2, *b0, *b1, *eta, *light;
+    const uint32_t *bsdf;
+    const uint8_t *active, *active_em, *ismesh;
+};
+
+template <typename R> struct GradArgs {
+    int64_t N;
+    const R *cam;
+    VertexPtrs<R> v[kMaxVertices];
+    const R *dlduv;          // row n at dlduv + n*dlduv_stride
+    int64_t dlduv_stride;
+    const R *dldp;           // (N,3)
+    R clip;                  // <= 0: clamp disabled
+    R *out_param;            // (P,N,3)
+    R *out_light;            // (K,N,3)
+    R *out_diffuse;          // (K,N,3)
+};
+
+template <typename R> EPSM_HD V3<R> load3(const R *base, int64_t i) {
+    const R *p = base + 3 * i;
+    return mk3<R>(p[0], p[1], p[2]);
+}
+
+// torch.nan_to_num followed by the +-clip outlier removal (epsm.py:856, 932-944)
+template <typename R> EPSM_HD R finalize(R g, R clip) {
+    if (g != g) g = R(0);
+    R mx = realmax_(g);
+    g = g > mx ? mx : (g < -mx ? -mx : g);
+    if (clip > R(0) && (g > clip || g < -clip)) g = R(0);
+    return g;
+}
+template <typename R> EPSM_HD void store3(R *base, int64_t slot, int64_t N, int64_t i, V3<R> g, R clip) {
+    R *p = base + (slot * N + i) * 3;
+    p[0] = finalize(g.x, clip);
+    p[1] = finalize(g.y, clip);
+    p[2] = finalize(g.z, clip);
+}
+
+// ----------------------------------------------------------------------------
+// geometry of one logged vertex
+// ----------------------------------------------------------------------------
+template <typename R> struct Geo {      // from "points" + "uv": x = p0 b0 + p1 b1 + p2 (1-b0-b1)  (epsm.py:758-759)
+    V3<R> x, e1, e2;                    // e_j = dx/db_j = p_j - p2
+    R b0, b1;
+};
+template <typename R> EPSM_HD Geo<R> load_geo(const VertexPtrs<R> &v, int64_t i) {
+    Geo<R> g;
+    V3<R> p0 = load3(v.p0, i), p1 = load3(v.p1, i), p2 = load3(v.p2, i);
+    g.b0 = v.b0[i];
+    g.b1 = v.b1[i];
+    R b2 = R(1) - g.b0 - g.b1;
+    g.x = p0 * g.b0 + p1 * g.b1 + p2 * b2;
+    g.e1 = p0 - p2;
+    g.e2 = p1 - p2;
+    return g;
+}
+template <typename R> struct Nrm { V3<R> n, dn1, dn2; };   // epsm.py:761-762 (un-normalised interpolation)
+template <typename R> EPSM_HD Nrm<R> load_nrm(const VertexPtrs<R> &v, int64_t i, R b0, R b1) {
+    Nrm<R> o;
+    V3<R> n0 = load3(v.n0, i), n1 = load3(v.n1, i), n2 = load3(v.n2, i);
+    R b2 = R(1) - b0 - b1;
+    o.n = n0 * b0 + n1 * b1 + n2 * b2;
+    o.dn1 = n0 - n2;
+    o.dn2 = n1 - n2;
+    return o;
+}
+
+// local frame of epsm.py:746-756: rows t, n^ x t, n^;  t = normalize(0,-n^_z,n^_y)
+template <typename R> struct Frame { V3<R> nn, t, bt; R inv_n, inv_v; };
+template <typename R> EPSM_HD Frame<R> make_frame(V3<R> n) {
+    Frame<R> f;
+    f.inv_n = rsqrt_(dot(n, n));
+    f.nn = n * f.inv_n;
+    V3<R> v = mk3<R>(R(0), -f.nn.z, f.nn.y);
+    f.inv_v = rsqrt_(dot(v, v));
+    f.t = v * f.inv_v;
+    f.bt = cross(f.nn, f.t);
+    return f;
+}
+// adjoint of the frame rows -> adjoint of the un-normalised normal
+template <typename R> EPSM_HD V3<R> frame_rev(const Frame<R> &f, V3<R> tb, V3<R> btb, V3<R> nb) {
+    nb = nb + cross(f.t, btb);
+    tb = tb + cross(btb, f.nn);
+    V3<R> vb = (tb - f.t * dot(f.t, tb)) * f.inv_v;
+    nb.z -= vb.y;
+    nb.y += vb.z;
+    return (nb - f.nn * dot(f.nn, nb)) * f.inv_n;
+}
+
+// C = [ normalize(R wi + eta R wo) ]_xy, wi = normalize(xp-xc), wo = normalize(xn-xc)  (epsm.py:809-821)
+template <typename R> struct HalfVec {
+    V3<R> wi, wo, u;          // u = wi + eta wo (world space); |R u| = |u|
+    R inv_a, inv_b, inv_u, eta;
+    R rx, ry, rz;             // normalised half vector in the local frame
+};
+template <typename R> EPSM_HD HalfVec<R> halfvec_fwd(V3<R> xp, V3<R> xc, V3<R> xn, const Frame<R> &f, R eta) {
+    HalfVec<R> h;
+    V3<R> a = xp - xc, b = xn - xc;
+    h.inv_a = rsqrt_(dot(a, a));
+    h.inv_b = rsqrt_(dot(b, b));
+    h.wi = a * h.inv_a;
+    h.wo = b * h.inv_b;
+    h.eta = eta;
+    h.u = madd(h.wi, h.wo, eta);
+    h.inv_u = rsqrt_(dot(h.u, h.u));
+    h.rx = dot(f.t, h.u) * h.inv_u;
+    h.ry = dot(f.bt, h.u) * h.inv_u;
+    h.rz = dot(f.nn, h.u) * h.inv_u;
+    return h;
+}
+template <typename R> struct Sweep { V3<R> gxp, gxc, gxn, gn; };
+
+// reverse sweep of s0*C_x + s1*C_y
+template <typename R> EPSM_HD Sweep<R> halfvec_rev(const Frame<R> &f, const HalfVec<R> &h, R s0, R s1) {
+    Sweep<R> o;
+    R re = s0 * h.rx + s1 * h.ry;
+    R r0 = (s0 - h.rx * re) * h.inv_u, r1 = (s1 - h.ry * re) * h.inv_u, r2 = (-h.rz * re) * h.inv_u;
+    V3<R> wib = f.t * r0 + f.bt * r1 + f.nn * r2;
+    V3<R> ab = (wib - h.wi * dot(h.wi, wib)) * h.inv_a;
+    V3<R> wob = wib * h.eta;
+    V3<R> bb = (wob - h.wo * dot(h.wo, wob)) * h.inv_b;
+    o.gxp = ab;
+    o.gxn = bb;
+    o.gxc = -(ab + bb);
+    o.gn = frame_rev(f, h.u * r0, h.u * r1, h.u * r2);
+    return o;
+}
+// reverse sweep of s0*wo2_x + s1*wo2_y, wo2 = R normalize(xn-xc)   (epsm.py:1028,1116)
+template <typename R> EPSM_HD Sweep<R> wo2_rev(const Frame<R> &f, const HalfVec<R> &h, R s0, R s1) {
+    Sweep<R> o;
+    V3<R> wob = f.t * s0 + f.bt * s1;
+    V3<R> bb = (wob - h.wo * dot(h.wo, wob)) * h.inv_b;
+    o.gxp = zero3<R>();
+    o.gxn = bb;
+    o.gxc = -bb;
+    o.gn = frame_rev(f, h.wo * s0, h.wo * s1, zero3<R>());
+    return o;
+}
+template <typename R> EPSM_HD Sweep<R> zero_sweep() {
+    Sweep<R> o; o.gxp = o.gxc = o.gxn = o.gn = zero3<R>(); return o;
+}
+template <typename R> EPSM_HD Sweep<R> comb(const Sweep<R> &a, R s0, const Sweep<R> &b, R s1) {
+    Sweep<R> o;
+    o.gxp = a.gxp * s0 + b.gxp * s1; o.gxc = a.gxc * s0 + b.gxc * s1;
+    o.gxn = a.gxn * s0 + b.gxn * s1; o.gn = a.gn * s0 + b.gn * s1;
+    return o;
+}
+
+// row i of a 2x2 block = (g . e1, g . e2)
+template <typename R> EPSM_HD M2<R> block2(V3<R> g0, V3<R> g1, V3<R> e1, V3<R> e2) {
+    M2<R> m; m.a = dot(g0, e1); m.b = dot(g0, e2); m.c = dot(g1, e1); m.d = dot(g1, e2); return m;
+}
+template <typename R> EPSM_HD M2<R> madd2(M2<R> p, M2<R> q) { M2<R> r; r.a = p.a + q.a; r.b = p.b + q.b; r.c = p.c + q.c; r.d = p.d + q.d; return r; }
+
+template <typename R, bool FULL_D> EPSM_HD V2<R> load_d(const GradArgs<R> &A, int64_t i, int k /*1-based*/, int dcols) {
+    if (!FULL_D && k > 1) return mk2<R>(R(0), R(0));
+    const R *row = A.dlduv + i * A.dlduv_stride;
+    int c = 2 * (k - 1);
+    R x = c < dcols ? row[c] : R(0);
+    R y = c + 1 < dcols ? row[c + 1] : R(0);
+    return mk2<R>(x, y);
+}
+
+// ----------------------------------------------------------------------------
+// per-depth masks from the flag words (no geometry needed)
+// ----------------------------------------------------------------------------
+template <int K> struct Flags {
+    bool diffuse[K + 2], null_[K + 2], active[K + 2], active_em[K + 2], mesh[K + 2];
+};
+template <typename R, int K> EPSM_HD Flags<K> load_flags(const GradArgs<R> &A, int64_t i) {
+    Flags<K> f;
+#pragma unroll
+    for (int k = 1; k <= K; ++k) {
+        uint32_t b = A.v[k - 1].bsdf[i];
+        f.diffuse[k] = (b & kBsdfDiffuse) != 0;
+        f.null_[k] = (b & kBsdfNull) != 0;
+        f.active[k] = A.v[k - 1].active[i] != 0;
+        f.active_em[k] = A.v[k - 1].active_em[i] != 0;
+        f.mesh[k] = A.v[k - 1].ismesh[i] != 0;
+    }
+    f.diffuse[0] = f.null_[0] = f.active[0] = f.active_em[0] = f.mesh[0] = false;
+    f.diffuse[K + 1] = f.null_[K + 1] = f.active[K + 1] = f.active_em[K + 1] = f.mesh[K + 1] = false;
+    return f;
+}
+
+// ============================================================================
+// "manifold"  (epsm.py:745-946)
+// ============================================================================
+template <typename R, int K, bool FULL_D>
+EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols) {
+    const Flags<K> fl = load_flags<R, K>(A, i);
+
+    // term masks (epsm.py:793-802, 852-855, 916-920).  wN[id]: light-sampling
+    // sub-path at depth id; wC[id]: continuing sub-path x_{id-1},x_id,x_{id+1}.
+    bool wN[K + 1], wC[K + 1];
+    int nv = 0;                       // last vertex whose geometry is needed
+    {
+        bool valid = true;
+        int hasdiffuse = 0;
+#pragma unroll
+        for (int id = 1; id <= K; ++id) {
+            valid = valid && fl.mesh[id];
+            hasdiffuse += fl.diffuse[id] ? 1 : 0;
+            valid = valid && (hasdiffuse < 2);
+            const bool spec = valid && (hasdiffuse == 0);
+            wN[id] = spec && fl.active[id] && fl.active_em[id];
+            wC[id] = (id < K) && spec && fl.active[id + 1] && fl.diffuse[id + 1];
+            if (wN[id]) nv = id;
+            if (wC[id]) nv = id + 1;
+        }
+    }
+
+    // ---- pass 1: forward recursion (pivots of the continuing rows, z vectors)
+    struct Keep { V3<R> x, e1, e2, n, light; R eta, b0, b1; };
+    Keep kp[K + 2];
+    M2<R> Sinv[K + 1];
+    V2<R> z[K + 1], zN[K + 1];
+    z[0] = mk2<R>(R(0), R(0));
+
+    const V3<R> cam = load3(A.cam, i);
+    Geo<R> gnext;
+    if (nv >= 1) gnext = load_geo(A.v[0], i);
+    M2<R> Aup;                        // A^C_{k-1,k}: continuing row k-1, column block k
+    Aup.a = Aup.b = Aup.c = Aup.d = R(0);
+
+#pragma unroll
+    for (int k = 1; k <= K; ++k) {
+        if (k <= nv) {
+            const Geo<R> g = gnext;
+            kp[k].x = g.x; kp[k].e1 = g.e1; kp[k].e2 = g.e2; kp[k].b0 = g.b0; kp[k].b1 = g.b1;
+            const bool has_next = (k < K) && (k + 1 <= nv);
+            if (has_next) gnext = load_geo(A.v[k < K ? k : K - 1], i);
+            const Nrm<R> nr = load_nrm(A.v[k - 1], i, g.b0, g.b1);
+            kp[k].n = nr.n;
+            kp[k].eta = A.v[k - 1].eta[i];
+            kp[k].light = load3(A.v[k - 1].light, i);
+            const Frame<R> fr = make_frame(nr.n);
+            const V3<R> xp = (k == 1) ? cam : kp[k - 1].x;
+            const V2<R> dk = load_d<R, FULL_D>(A, i, k, dcols);
+
+            V2<R> rhs = dk;
+            M2<R> T;                  // Sinv_{k-1} A^C_{k-1,k}
+            T.a = T.b = T.c = T.d = R(0);
+            if (k > 1) {
+                rhs = dk - vmul(z[k - 1], Aup);
+                T = mmul(Sinv[k - 1], Aup);
+            }
+            // light-sampling version (next point = emitter sample)
+            {
+                const HalfVec<R> h = halfvec_fwd(xp, g.x, kp[k].light, fr, kp[k].eta);
+                const Sweep<R> s0 = halfvec_rev(fr, h, R(1), R(0));
+                const Sweep<R> s1 = halfvec_rev(fr, h, R(0), R(1));
+                M2<R> Akk = madd2(block2(s0.gxc, s1.gxc, g.e1, g.e2), block2(s0.gn, s1.gn, nr.dn1, nr.dn2));
+                M2<R> S = Akk;
+                if (k > 1) S = msub(Akk, mmul(block2(s0.gxp, s1.gxp, kp[k - 1].e1, kp[k - 1].e2), T));
+                zN[k] = vmul(rhs, minv(S));
+            }
+            // continuing version (next point = x_{k+1})
+            if (has_next) {
+                const HalfVec<R> h = halfvec_fwd(xp, g.x, gnext.x, fr, kp[k].eta);
+                const Sweep<R> s0 = halfvec_rev(fr, h, R(1), R(0));
+                const Sweep<R> s1 = halfvec_rev(fr, h, R(0), R(1));
+                M2<R> Akk = madd2(block2(s0.gxc, s1.gxc, g.e1, g.e2), block2(s0.gn, s1.gn, nr.dn1, nr.dn2));
+                M2<R> S = Akk;
+                if (k > 1) S = msub(Akk, mmul(block2(s0.gxp, s1.gxp, kp[k - 1].e1, kp[k - 1].e2), T));
+                Sinv[k] = minv(S);
+                z[k] = vmul(rhs, Sinv[k]);
+                Aup = block2(s0.gxn, s1.gxn, gnext.e1, gnext.e2);
+            }
+        }
+    }
+
+    // ---- pass 2: backward recursion of the adjoint seeds + seeded sweeps
+    const R clip = A.clip;
+    V2<R> carry = mk2<R>(R(0), R(0));  // sum over deeper terms of their y_k
+    int W = 0;                         // number of live terms with depth > k
+    V3<R> GP = zero3<R>();             // d/dx_k through constraint k+1 (x_k as previous vertex)
+#pragma unroll
+    for (int k = K; k >= 1; --k) {
+        V3<R> gp0 = zero3<R>(), gp1 = gp0, gp2 = gp0, gnrm = gp0, gm = gp0, glight = gp0, gdiff = gp0;
+        if (k <= nv) {
+            const bool fN = wN[k] && finite2(zN[k]);
+            const bool fC = wC[k] && finite2(z[k]);
+            V2<R> sN = fN ? zN[k] : mk2<R>(R(0), R(0));
+            V2<R> sC = carry;
+            if (fC) sC = sC + z[k];
+            const bool has_next = (k < K) && (k + 1 <= nv);
+            const Frame<R> fr = make_frame(kp[k].n);
+            const V3<R> xp = (k == 1) ? cam : kp[k - 1].x;
+            Sweep<R> a = zero_sweep<R>(), c = zero_sweep<R>();
+            if (sN.x != R(0) || sN.y != R(0)) {
+                const HalfVec<R> h = halfvec_fwd(xp, kp[k].x, kp[k].light, fr, kp[k].eta);
+                a = halfvec_rev(fr, h, sN.x, sN.y);
+            }
+            if (has_next && (sC.x != R(0) || sC.y != R(0))) {
+                const HalfVec<R> h = halfvec_fwd(xp, kp[k].x, kp[k + 1].x, fr, kp[k].eta);
+                c = halfvec_rev(fr, h, sC.x, sC.y);
+            }
+            const V3<R> Gx = -(a.gxc + c.gxc + GP);
+            gp0 = Gx * kp[k].b0;
+            gp1 = Gx * kp[k].b1;
+            gp2 = Gx * (R(1) - kp[k].b0 - kp[k].b1);
+            gnrm = -(a.gn + c.gn);
+            if (has_next) gm = mk3<R>(sC.x, sC.y, R(0));   // dC/dm = -I on continuing rows (epsm.py:883)
+            glight = -a.gxn;
+            if (fC) gdiff = -c.gxn;                        // carry == 0 whenever fC (a diffuse x_{k+1} ends the chain)
+            GP = a.gxp + c.gxp;
+            W += (fN ? 1 : 0) + (fC ? 1 : 0);
+            if (k > 1) {
+                if (W > 0) {
+                    V2<R> q = mk2<R>(dot(GP, kp[k - 1].e1), dot(GP, kp[k - 1].e2));
+                    carry = z[k - 1] * R(W) - vmul(q, Sinv[k - 1]);
+                } else {
+                    carry = mk2<R>(R(0), R(0));
+                }
+            }
+        }
+        store3(A.out_param, 5 * (k - 1) + 0, A.N, i, gp0, clip);
+        store3(A.out_param, 5 * (k - 1) + 1, A.N, i, gp1, clip);
+        store3(A.out_param, 5 * (k - 1) + 2, A.N, i, gp2, clip);
+        store3(A.out_param, 5 * (k - 1) + 3, A.N, i, gnrm, clip);
+        store3(A.out_param, 5 * (k - 1) + 4, A.N, i, gm, clip);
+        store3(A.out_light, k - 1, A.N, i, glight, clip);
+        if (k < K) store3(A.out_diffuse, k, A.N, i, gdiff, clip);
+    }
+    // diffuse_grad[0] = dldp where the first hit is diffuse (epsm.py:791-792)
+    V3<R> d0 = fl.diffuse[1] ? load3(A.dldp, i) : zero3<R>();
+    store3(A.out_diffuse, 0, A.N, i, d0, clip);
+}
+
+// ============================================================================
+// "manifold_caustic"  (epsm.py:952-1200)
+// ============================================================================
+// Outputs can only be non-zero when the first hit is diffuse (dlduv is zeroed
+// otherwise, epsm.py:999) and then only through continuing sub-paths: every
+// light-sampling term is masked by `hasdiffuse>0` (epsm.py:1083,1090), so
+// light_grad == 0.  With the receiver x_1 diffuse, row block 1 of `cur` holds
+// the pseudo-constraint wo2 of the CURRENT depth (column block id only) and
+// rows 2..id the half-vector constraints: unknowns y_2.. follow a forward
+// recursion that does not depend on the depth, y_1 closes it per depth.
+template <typename R, int K, bool FULL_D>
+EPSM_HD void caustic_path(const GradArgs<R> &A, int64_t i, int dcols) {
+    const Flags<K> fl = load_flags<R, K>(A, i);
+    const R clip = A.clip;
+    constexpr int P = 5 * K - 2;
+
+    bool wP[K + 1], wD[K + 1];
+    int nv = 0, idstar = 0;
+    {
+        bool valid = true;
+        int hasdiffuse = 0;
+#pragma unroll
+        for (int id = 1; id <= K; ++id) {
+            valid = valid && fl.mesh[id];
+            hasdiffuse += fl.diffuse[id] ? 1 : 0;
+            valid = valid && (hasdiffuse < 2);
+            const bool base = (id < K) && fl.diffuse[1] && valid && fl.active[id + 1];
+            wP[id] = base && fl.diffuse[id + 1];                        // epsm.py:1172-1174
+            wD[id] = base && (fl.diffuse[id + 1] || fl.null_[id + 1]);  // epsm.py:1180-1182
+            if (wD[id]) nv = id + 1;
+            if (wP[id]) idstar = id;    // at most one: the next diffuse vertex invalidates deeper terms
+        }
+    }
+
+    const V3<R> cam = load3(A.cam, i);
+    Geo<R> gcur, gnext;
+    if (nv >= 1) gnext = load_geo(A.v[0], i);
+    V2<R> vprev = mk2<R>(R(0), R(0)), vcur = vprev;   // v_{k-1}, v_k   (v_1 = 0)
+    V2<R> rprev = vprev;                               // r_{k-1}
+    M2<R> Aup; Aup.a = Aup.b = Aup.c = Aup.d = R(0);   // A_{k-1,k}
+    V3<R> xprev = cam, e1prev = zero3<R>(), e2prev = zero3<R>();
+    R b0prev = R(0), b1prev = R(0);
+    V3<R> Gx_prev = zero3<R>();        // -(d/dx_{k-1}) gathered so far for vertex k-1
+    bool poisoned = false;             // a live term turned out non-finite: zero every param gradient (nan_to_num)
+
+#pragma unroll
+    for (int k = 1; k <= K; ++k) {
+        V3<R> gnrm = zero3<R>(), gm = gnrm, gdiff = gnrm;
+        V3<R> Gx = zero3<R>();
+        R b0 = R(0), b1 = R(0);
+        const bool live = (k < K) && (k + 1 <= nv);    // depth k has a continuing sub-path we need
+        if (live) {
+            gcur = gnext;
+            gnext = load_geo(A.v[k < K ? k : K - 1], i);
+            b0 = gcur.b0; b1 = gcur.b1;
+            const Nrm<R> nr = load_nrm(A.v[k - 1], i, gcur.b0, gcur.b1);
+            const R eta = A.v[k - 1].eta[i];
+            const Frame<R> fr = make_frame(nr.n);
+            const HalfVec<R> h = halfvec_fwd(xprev, gcur.x, gnext.x, fr, eta);
+            const V2<R> dk = load_d<R, FULL_D>(A, i, k, dcols);
+            // pseudo-constraint rows (always needed: they close the system at depth k)
+            const Sweep<R> w0 = wo2_rev(fr, h, R(1), R(0));
+            const Sweep<R> w1 = wo2_rev(fr, h, R(0), R(1));
+            const M2<R> Wk = madd2(block2(w0.gxc, w1.gxc, gcur.e1, gcur.e2), block2(w0.gn, w1.gn, nr.dn1, nr.dn2));
+            V2<R> rk = dk;
+            Sweep<R> c0 = zero_sweep<R>(), c1 = c0;
+            if (k >= 2) {
+                c0 = halfvec_rev(fr, h, R(1), R(0));
+                c1 = halfvec_rev(fr, h, R(0), R(1));
+                const M2<R> Akm = block2(c0.gxp, c1.gxp, e1prev, e2prev);
+                const M2<R> Akk = madd2(block2(c0.gxc, c1.gxc, gcur.e1, gcur.e2), block2(c0.gn, c1.gn, nr.dn1, nr.dn2));
+                vcur = vmul(rprev, minv(Akm));                       // y_k for every depth >= k
+                rk = dk - vmul(vcur, Akk) - vmul(vprev, Aup);
+                Aup = block2(c0.gxn, c1.gxn, gnext.e1, gnext.e2);
+            }
+            const V2<R> uk = vmul(rk, minv(Wk));                      // y_1 at depth k
+            const bool fin = finite2(uk) && finite2(vcur);
+            const bool inP = (k <= idstar);                           // rows of this vertex carry weight 1
+            if (inP && !fin && k == idstar) poisoned = true;
+            // continuing constraint of vertex k, seed v_k (k>=2), weight [k <= id*]
+            const Sweep<R> cs = comb(c0, vcur.x, c1, vcur.y);
+            // pseudo-constraint of depth k, seed u_k, weight [k == id*]
+            const Sweep<R> ws = comb(w0, uk.x, w1, uk.y);
+            if (inP) {
+                Gx = -cs.gxc;
+                gnrm = -cs.gn;
+                if (k >= 2) gm = mk3<R>(vcur.x, vcur.y, R(0));
+                // x_{k-1} as previous vertex of constraint k
+                Gx_prev = Gx_prev - cs.gxp;
+                if (k == idstar) {
+                    Gx = Gx - ws.gxc;
+                    gnrm = gnrm - ws.gn;
+                }
+            }
+            if (wD[k] && fin) {
+                // epsm.py:1139-1157: row block id (gxn, plus the stale wo2[0] gradient on its
+                // second row) and the pseudo rows (d wo2 / d x_{k+1})
+                if (k >= 2) {
+                    const Sweep<R> wx = comb(w0, uk.x + vcur.y, w1, uk.y);
+                    gdiff = -(wx.gxn + cs.gxn);
+                } else {
+                    gdiff = -ws.gxn;
+                }
+            }
+            rprev = rk;
+            vprev = vcur;
+        }
+        // vertex k-1 is complete once constraint k has been swept
+        if (k >= 2) {
+            const R b2p = R(1) - b0prev - b1prev;
+            store3(A.out_param, 5 * (k - 2) + 0, A.N, i, Gx_prev * b0prev, clip);
+            store3(A.out_param, 5 * (k - 2) + 1, A.N, i, Gx_prev * b1prev, clip);
+            store3(A.out_param, 5 * (k - 2) + 2, A.N, i, Gx_prev * b2p, clip);
+        }
+        if (k < K) {
+            store3(A.out_param, 5 * (k - 1) + 3, A.N, i, gnrm, clip);
+            store3(A.out_param, 5 * (k - 1) + 4, A.N, i, gm, clip);
+            store3(A.out_diffuse, k, A.N, i, gdiff, clip);
+        }
+        store3(A.out_light, k - 1, A.N, i, zero3<R>(), clip);
+        Gx_prev = Gx;
+        if (live) {
+            xprev = gcur.x; e1prev = gcur.e1; e2prev = gcur.e2;
+        }
+        b0prev = b0; b1prev = b1;
+    }
+    // last vertex: only p0,p1,p2 are registered and no continuing row exists for it
+    {
+        const R b2p = R(1) - b0prev - b1prev;
+        store3(A.out_param, 5 * (K - 1) + 0, A.N, i, Gx_prev * b0prev, clip);
+        store3(A.out_param, 5 * (K - 1) + 1, A.N, i, Gx_prev * b1prev, clip);
+        store3(A.out_param, 5 * (K - 1) + 2, A.N, i, Gx_prev * b2p, clip);
+    }
+    if (poisoned) {
+        for (int q = 0; q < P; ++q) store3(A.out_param, q, A.N, i, zero3<R>(), clip);
+    }
+    V3<R> d0 = fl.diffuse[1] ? load3(A.dldp, i) : zero3<R>();
+    store3(A.out_diffuse, 0, A.N, i, d0, clip);
+}
+
+}  // namespace epsm

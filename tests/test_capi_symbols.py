@@ -1,0 +1,65 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol
+include/epsm.h declares; argument validation works without touching a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "epsm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(epsm_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from epsm_mitsuba3_amd import _lib
+    if not os.path.isfile(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_header_declares_something():
+    syms = declared_symbols()
+    assert "epsm_manifold_grad" in syms and len(syms) >= 4
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"{s} declared in include/epsm.h but not exported"
+
+
+def test_abi_version_and_counts(lib):
+    assert lib.epsm_abi_version() == 1
+    assert lib.epsm_num_param_grads(0, 5) == 25
+    assert lib.epsm_num_param_grads(1, 5) == 23
+
+
+def test_argument_validation_without_device(lib):
+    from epsm_mitsuba3_amd.records import EpsmVertexRecord
+    recs = (EpsmVertexRecord * 1)()
+    rc = lib.epsm_manifold_grad(0, 16, 9, None, C.addressof(recs), None, 4, 2, None, 0.1, None, None, None, None)
+    assert rc == -22
+    assert b"K must be" in lib.epsm_last_error()
+    rc = lib.epsm_manifold_grad(7, 16, 2, None, C.addressof(recs), None, 4, 2, None, 0.1, None, None, None, None)
+    assert rc == -22
+
+
+def test_vertex_record_layout_matches_header():
+    from epsm_mitsuba3_amd.records import EpsmVertexRecord
+    text = open(os.path.join(ROOT, "include", "epsm.h")).read()
+    body = re.search(r"typedef struct EpsmVertexRecord \{(.*?)\} EpsmVertexRecord;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^const\s+\w+\s*", "", decl)
+        names += [n.strip(" *") for n in decl.split(",")]
+    assert names == [f[0] for f in EpsmVertexRecord._fields_]
+    assert C.sizeof(EpsmVertexRecord) == 8 * len(names)
