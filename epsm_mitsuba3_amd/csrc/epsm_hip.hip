@@ -78,6 +78,7 @@ int epsm_manifold_grad(int variant, int64_t N, int K,
         return fail(EPSM_EINVAL, "epsm_manifold_grad: unknown variant%s");
     if (K < 1 || K > EPSM_MAX_VERTICES) return fail(EPSM_EINVAL, "epsm_manifold_grad: K must be in 1..5%s");
     if (N < 0 || (N + kBlock - 1) / kBlock > 0x7fffffffLL) return fail(EPSM_EINVAL, "epsm_manifold_grad: bad N%s");
+    if (N == 0) return EPSM_OK;   /* empty wavefront: nothing to read or write */
     if (!cam || !verts || !dlduv || !dldp || !out_param || !out_light || !out_diffuse)
         return fail(EPSM_EINVAL, "epsm_manifold_grad: NULL argument%s");
     if (dlduv_cols < 0 || dlduv_stride < (dlduv_cols < 2 * K ? dlduv_cols : 2 * K))
@@ -101,11 +102,10 @@ int epsm_manifold_grad(int variant, int64_t N, int K,
     A.dlduv = dlduv;
     A.dlduv_stride = dlduv_stride;
     A.dldp = dldp;
-    A.clip = (clip > 0.0f && clip <= 3.402823466e+38f) ? clip : 0.0f;
+    A.clip = (clip > 0.0f && clip <= 3.402823466e+38f) ? clip : 3.402823466e+38f;
     A.out_param = out_param;
     A.out_light = out_light;
     A.out_diffuse = out_diffuse;
-    if (N == 0) return EPSM_OK;
     int dcols = dlduv_cols > 2 * K ? 2 * K : dlduv_cols;
     const bool full_d = dcols > 2;
     hipStream_t s = (hipStream_t) stream;

@@ -76,9 +76,11 @@ template <typename R> EPSM_HD M2<R> mmul(M2<R> p, M2<R> q) {
     return r;
 }
 template <typename R> EPSM_HD M2<R> msub(M2<R> p, M2<R> q) { M2<R> r; r.a = p.a - q.a; r.b = p.b - q.b; r.c = p.c - q.c; r.d = p.d - q.d; return r; }
+EPSM_HD float rcp_(float x);
+EPSM_HD double rcp_(double x);
 template <typename R> EPSM_HD M2<R> minv(M2<R> m) {
     R det = m.a * m.d - m.b * m.c;
-    R id = R(1) / det;
+    R id = rcp_(det);
     M2<R> r; r.a = m.d * id; r.b = -m.b * id; r.c = -m.c * id; r.d = m.a * id;
     return r;
 }
@@ -86,8 +88,27 @@ template <typename R> EPSM_HD M2<R> minv(M2<R> m) {
 EPSM_HD bool finite_(float x) { return fabsf(x) <= 3.402823466e+38f; }
 EPSM_HD bool finite_(double x) { return fabs(x) <= 1.7976931348623157e+308; }
 template <typename R> EPSM_HD bool finite2(V2<R> v) { return finite_(v.x) && finite_(v.y); }
+// 1/sqrt(x) and 1/x.  On gfx950 the IEEE expansions of sqrtf and '/' cost ~10
+// VALU instructions each; v_rsq_f32 / v_rcp_f32 (1 ulp) plus one Newton step is
+// within an ulp of them in 4 / 3 instructions.  x = 0 still yields a non-finite
+// value (inf -> NaN through the Newton step), which is what the NaN -> 0 rule of
+// the reference (epsm.py:746-748, 856) relies on.
+#if defined(__HIP_DEVICE_COMPILE__)
+EPSM_HD float rsqrt_(float x) {
+    float y = __builtin_amdgcn_rsqf(x);
+    float e = fmaf(-x * y, y, 1.0f);
+    return fmaf(0.5f * y, e, y);
+}
+EPSM_HD float rcp_(float x) {
+    float y = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, y, 1.0f), y, y);
+}
+#else
 EPSM_HD float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+EPSM_HD float rcp_(float x) { return 1.0f / x; }
+#endif
 EPSM_HD double rsqrt_(double x) { return 1.0 / sqrt(x); }
+EPSM_HD double rcp_(double x) { return 1.0 / x; }
 EPSM_HD float realmax_(float) { return 3.402823466e+38f; }
 EPSM_HD double realmax_(double) { return 1.7976931348623157e+308; }
 
@@ -118,13 +139,14 @@ template <typename R> EPSM_HD V3<R> load3(const R *base, int64_t i) {
     return mk3<R>(p[0], p[1], p[2]);
 }
 
-// torch.nan_to_num followed by the +-clip outlier removal (epsm.py:856, 932-944)
+// torch.nan_to_num followed by the +-clip outlier removal (epsm.py:856, 932-944):
+// NaN -> 0; +-inf -> +-max, which the clamp then zeroes; |g| > clip -> 0.  One
+// ordered compare does all three (it is false for NaN).  `clip` is the largest
+// finite value when the caller disabled the clamp, so non-finite values still
+// come out as 0 there (nan_to_num would give +-max for an infinity).
 template <typename R> EPSM_HD R finalize(R g, R clip) {
-    if (g != g) g = R(0);
-    R mx = realmax_(g);
-    g = g > mx ? mx : (g < -mx ? -mx : g);
-    if (clip > R(0) && (g > clip || g < -clip)) g = R(0);
-    return g;
+    R a = g < R(0) ? -g : g;
+    return a <= clip ? g : R(0);
 }
 template <typename R> EPSM_HD void store3(R *base, int64_t slot, int64_t N, int64_t i, V3<R> g, R clip) {
     R *p = base + (slot * N + i) * 3;
@@ -342,8 +364,10 @@ EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols) {
                 rhs = dk - vmul(z[k - 1], Aup);
                 T = mmul(Sinv[k - 1], Aup);
             }
-            // light-sampling version (next point = emitter sample)
-            {
+            // light-sampling version (next point = emitter sample); its rows never serve
+            // deeper terms (those see the continuing rows), so it is needed only when live
+            zN[k] = mk2<R>(R(0), R(0));
+            if (wN[k]) {
                 const HalfVec<R> h = halfvec_fwd(xp, g.x, kp[k].light, fr, kp[k].eta);
                 const Sweep<R> s0 = halfvec_rev(fr, h, R(1), R(0));
                 const Sweep<R> s1 = halfvec_rev(fr, h, R(0), R(1));

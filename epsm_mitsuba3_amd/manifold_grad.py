@@ -38,7 +38,7 @@ def manifold_grad_packed(variant: str, rec: PackedRecords, dlduv: torch.Tensor, 
     d = dlduv.detach()
     if d.dtype != torch.float32 or d.device != dev:
         d = d.to(device=dev, dtype=torch.float32)
-    d = d.reshape(N, -1)
+    d = d.reshape(N, d.numel() // N if N > 0 else d.shape[-1])
     if not d.is_contiguous():
         d = d.contiguous()
     p = dldp.detach()

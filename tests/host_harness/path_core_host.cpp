@@ -27,7 +27,7 @@ static GradArgs<R> make_args(int64_t N, int K, const void *cam, const EpsmVertex
     A.dlduv = (const R *) dlduv;
     A.dlduv_stride = stride;
     A.dldp = (const R *) dldp;
-    A.clip = (clip > 0 && clip < 1e300) ? (R) clip : (R) 0;
+    A.clip = (clip > 0 && clip < 1e300) ? (R) clip : realmax_(R(0));
     A.out_param = (R *) op; A.out_light = (R *) ol; A.out_diffuse = (R *) od;
     return A;
 }
