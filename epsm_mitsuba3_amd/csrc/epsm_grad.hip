@@ -1,4 +1,4 @@
-// epsm_hip.hip -- gfx950 kernels + C ABI (include/epsm.h) of the EPSM hot path.
+// epsm_grad.hip -- gfx950 kernel + C ABI entry of calc_grad (include/epsm.h: epsm_manifold_grad).
 //
 // One lane = one light path (wave64, 256-thread workgroups).  Inputs are read
 // straight from the reference's own tensor layout ((N,3) fp32 rows: consecutive
@@ -7,23 +7,34 @@
 // solve and the gradient: the per-path state lives in VGPRs (epsm_path_core.h).
 // MFMA is deliberately unused: the per-path systems are 2x2 blocks on a band of
 // at most 5, not a dense contraction.
-#include <hip/hip_runtime.h>
-#include <stdio.h>
 #include <string.h>
 
-#include "../../include/epsm.h"
+#include "epsm_common.h"
 #include "epsm_path_core.h"
 
 using namespace epsm;
 
-namespace {
+namespace epsm_host {
 
-thread_local char g_err[512] = "";
-
-int fail(int code, const char *fmt, const char *detail = "") {
-    snprintf(g_err, sizeof(g_err), fmt, detail);
+char *err_buf() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+int fail(int code, const char *what, const char *detail) {
+    snprintf(err_buf(), 512, "%s%s%s", what, detail[0] ? ": " : "", detail);
     return code;
 }
+int hip_fail(const char *what, hipError_t e) {
+    const bool nodev = e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorNoBinaryForGpu ||
+                       e == hipErrorInsufficientDriver;
+    return fail(nodev ? EPSM_ENODEV : EPSM_ELAUNCH, what, hipGetErrorString(e));
+}
+
+}  // namespace epsm_host
+
+using epsm_host::fail;
+
+namespace {
 
 constexpr int kBlock = 256;
 
@@ -61,7 +72,7 @@ extern "C" {
 
 int epsm_abi_version(void) { return EPSM_ABI_VERSION; }
 
-const char *epsm_last_error(void) { return g_err; }
+const char *epsm_last_error(void) { return epsm_host::err_buf(); }
 
 int epsm_num_param_grads(int variant, int K) {
     return variant == EPSM_VARIANT_MANIFOLD_CAUSTIC ? 5 * K - 2 : 5 * K;
@@ -73,16 +84,16 @@ int epsm_manifold_grad(int variant, int64_t N, int K,
                        const float *dldp, float clip,
                        float *out_param, float *out_light, float *out_diffuse,
                        void *stream) {
-    g_err[0] = 0;
+    epsm_host::err_buf()[0] = 0;
     if (variant != EPSM_VARIANT_MANIFOLD && variant != EPSM_VARIANT_MANIFOLD_CAUSTIC)
-        return fail(EPSM_EINVAL, "epsm_manifold_grad: unknown variant%s");
-    if (K < 1 || K > EPSM_MAX_VERTICES) return fail(EPSM_EINVAL, "epsm_manifold_grad: K must be in 1..5%s");
-    if (N < 0 || (N + kBlock - 1) / kBlock > 0x7fffffffLL) return fail(EPSM_EINVAL, "epsm_manifold_grad: bad N%s");
+        return fail(EPSM_EINVAL, "epsm_manifold_grad: unknown variant");
+    if (K < 1 || K > EPSM_MAX_VERTICES) return fail(EPSM_EINVAL, "epsm_manifold_grad: K must be in 1..5");
+    if (N < 0 || (N + kBlock - 1) / kBlock > 0x7fffffffLL) return fail(EPSM_EINVAL, "epsm_manifold_grad: bad N");
     if (N == 0) return EPSM_OK;   /* empty wavefront: nothing to read or write */
     if (!cam || !verts || !dlduv || !dldp || !out_param || !out_light || !out_diffuse)
-        return fail(EPSM_EINVAL, "epsm_manifold_grad: NULL argument%s");
+        return fail(EPSM_EINVAL, "epsm_manifold_grad: NULL argument");
     if (dlduv_cols < 0 || dlduv_stride < (dlduv_cols < 2 * K ? dlduv_cols : 2 * K))
-        return fail(EPSM_EINVAL, "epsm_manifold_grad: dlduv_stride smaller than the columns to read%s");
+        return fail(EPSM_EINVAL, "epsm_manifold_grad: dlduv_stride smaller than the columns to read");
     GradArgs<float> A;
     memset(&A, 0, sizeof(A));
     A.N = N;
@@ -91,7 +102,7 @@ int epsm_manifold_grad(int variant, int64_t N, int K,
         const EpsmVertexRecord &v = verts[k];
         if (!v.p0 || !v.p1 || !v.p2 || !v.n0 || !v.n1 || !v.n2 || !v.b0 || !v.b1 || !v.eta || !v.light ||
             !v.bsdf || !v.active || !v.active_em || !v.ismesh)
-            return fail(EPSM_EINVAL, "epsm_manifold_grad: NULL pointer in a vertex record%s");
+            return fail(EPSM_EINVAL, "epsm_manifold_grad: NULL pointer in a vertex record");
         VertexPtrs<float> &o = A.v[k];
         o.p0 = (const float *) v.p0; o.p1 = (const float *) v.p1; o.p2 = (const float *) v.p2;
         o.n0 = (const float *) v.n0; o.n1 = (const float *) v.n1; o.n2 = (const float *) v.n2;
@@ -116,12 +127,7 @@ int epsm_manifold_grad(int variant, int64_t N, int K,
     else
         e = full_d ? launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, true>(K, A, dcols, s)
                    : launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, false>(K, A, dcols, s);
-    if (e != hipSuccess) {
-        if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorNoBinaryForGpu ||
-            e == hipErrorInsufficientDriver)
-            return fail(EPSM_ENODEV, "epsm_manifold_grad: %s", hipGetErrorString(e));
-        return fail(EPSM_ELAUNCH, "epsm_manifold_grad: %s", hipGetErrorString(e));
-    }
+    if (e != hipSuccess) return epsm_host::hip_fail("epsm_manifold_grad", e);
     return EPSM_OK;
 }
 

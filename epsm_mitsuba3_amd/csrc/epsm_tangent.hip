@@ -1,0 +1,110 @@
+// epsm_tangent.hip -- first-vertex tangent (include/epsm.h: epsm_first_vertex_tangent).
+//
+// Closed form of the forward-mode AD block of render_backward (epsm.py:250-272):
+// the directional derivative of the Moeller-Trumbore barycentrics
+// (include/mitsuba/render/mesh.h:343-365) along the image-space motion
+//     grad_d = (d_x - d) gx + (d_y - d) gy,
+// mapped to (b0,b1) and the hit point as src/render/mesh.cpp:698-709 does.
+// One lane per path, every input a coalesced (N,3) stream; HBM-bound:
+// 4*12 (rays) + 3*12 (triangle) + 1 (mask) in, 12 + 4*stride out per path.
+#include "epsm_common.h"
+#include "epsm_path_core.h"
+
+using namespace epsm;
+using epsm_host::fail;
+
+namespace {
+
+struct TangentArgs {
+    int64_t N;
+    int spp, res, img_width, img_channels;
+    const float *o, *d, *dx, *dy, *grad_img, *p0, *p1, *p2;
+    const uint8_t *active;
+    float *dlduv;
+    int64_t dlduv_stride;
+    float *dldp;
+    float *grad_o_sum;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void epsm_tangent_kernel(TangentArgs A) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const bool in = i < A.N;
+    V3<float> gd = zero3<float>();
+    if (in) {
+        const int64_t pix = i / A.spp;
+        const int64_t y = pix / A.res, x = pix % A.res;
+        const float *g = A.grad_img + (y * A.img_width + x) * A.img_channels;
+        const float gx = g[3], gy = g[4];
+        const V3<float> d = load3(A.d, i), dx = load3(A.dx, i), dy = load3(A.dy, i);
+        gd = (dx - d) * gx + (dy - d) * gy;                       // epsm.py:255
+        float db0 = 0.f, db1 = 0.f;
+        V3<float> dp = zero3<float>();
+        if (A.active[i]) {
+            const V3<float> o = load3(A.o, i);
+            const V3<float> p0 = load3(A.p0, i), p1 = load3(A.p1, i), p2 = load3(A.p2, i);
+            const V3<float> e1 = p1 - p0, e2 = p2 - p0;           // mesh.h:349
+            const V3<float> pvec = cross(d, e2);
+            const float inv_det = rcp_(dot(e1, pvec));
+            const V3<float> tvec = o - p0;
+            const float u = dot(tvec, pvec) * inv_det;
+            const V3<float> qvec = cross(tvec, e1);
+            const float v = dot(d, qvec) * inv_det;
+            // forward derivative along gd (ray origin fixed)
+            const V3<float> dpvec = cross(gd, e2);
+            const float ddet = dot(e1, dpvec);
+            const float du = (dot(tvec, dpvec) - u * ddet) * inv_det;
+            const float dv = (dot(gd, qvec) - v * ddet) * inv_det;
+            db1 = du;                                              // b1 = prim_uv.x  (mesh.cpp:698)
+            db0 = -du - dv;                                        // b0 = 1 - b1 - b2
+            dp = e1 * du + e2 * dv;                                // d (p0 b0 + p1 b1 + p2 b2)
+        }
+        float *row = A.dlduv + i * A.dlduv_stride;
+        row[0] = db0;
+        row[1] = db1;
+        for (int64_t c = 2; c < A.dlduv_stride; ++c) row[c] = 0.f;
+        float *q = A.dldp + 3 * i;
+        q[0] = dp.x; q[1] = dp.y; q[2] = dp.z;
+    }
+    if (A.grad_o_sum) {                                            // epsm.py:260-261: d/d ray.o = -grad_d
+        const float sx = wave_sum(-gd.x), sy = wave_sum(-gd.y), sz = wave_sum(-gd.z);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(A.grad_o_sum + 0, sx);
+            atomicAdd(A.grad_o_sum + 1, sy);
+            atomicAdd(A.grad_o_sum + 2, sz);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int epsm_first_vertex_tangent(int64_t N, int spp, int res,
+                                         const float *ray_o, const float *ray_d,
+                                         const float *ray_dx, const float *ray_dy,
+                                         const float *grad_img, int img_width, int img_channels,
+                                         const float *p0, const float *p1, const float *p2,
+                                         const uint8_t *active,
+                                         float *dlduv, int64_t dlduv_stride, float *dldp,
+                                         float *grad_o_sum, void *stream) {
+    epsm_host::err_buf()[0] = 0;
+    if (N == 0) return EPSM_OK;
+    if (N < 0 || (N + 255) / 256 > 0x7fffffffLL) return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: bad N");
+    if (spp < 1 || res < 1 || img_width < res || img_channels < 5)
+        return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: need spp>=1, res>=1, img_width>=res, img_channels>=5");
+    if ((int64_t) res * res * spp < N) return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: N exceeds res*res*spp");
+    if (!ray_o || !ray_d || !ray_dx || !ray_dy || !grad_img || !p0 || !p1 || !p2 || !active || !dlduv || !dldp)
+        return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: NULL argument");
+    if (dlduv_stride < 2) return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: dlduv_stride < 2");
+    TangentArgs A{N, spp, res, img_width, img_channels, ray_o, ray_d, ray_dx, ray_dy, grad_img, p0, p1, p2,
+                  active, dlduv, dlduv_stride, dldp, grad_o_sum};
+    hipLaunchKernelGGL(epsm_tangent_kernel, dim3((unsigned) ((N + 255) / 256)), dim3(256), 0,
+                       (hipStream_t) stream, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return epsm_host::hip_fail("epsm_first_vertex_tangent", e);
+    return EPSM_OK;
+}

@@ -97,3 +97,48 @@ class PackedRecords:
         if t.dtype == torch.uint8:
             return self._conv(t, torch.uint8)
         return self._keepalive((t.to(self.device) > 0).to(torch.uint8).contiguous())
+
+
+class EpsmScatterRecord(C.Structure):
+    """Mirror of ``struct EpsmScatterRecord`` (include/epsm.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "vidx", "mode", "bsdf_id", "dhf_dalpha", "evidx", "eb0", "eb1", "eweight")]
+
+
+MODE_VERTEX_NORMALS, MODE_FLIP_NORMALS, MODE_POS_ATTACHED, MODE_NRM_ATTACHED = 1, 2, 4, 8
+NO_INDEX = 0xFFFFFFFF
+
+
+class PackedScatter:
+    """Per-vertex addressing of the parameter buffers next to ``PackedRecords``.
+
+    ``scatter_info[k-1]`` is a dict with ``vidx (N,3) int32/uint32``, ``mode (N) uint8``
+    and optionally ``bsdf_id (N)``, ``dhf_dalpha (N,3)``, ``evidx (N,3)``, ``eb0``,
+    ``eb1``, ``eweight (N)``.  Index value -1 / 0xFFFFFFFF means "no parameter".
+    """
+
+    def __init__(self, scatter_info: Sequence[dict], device, float_dtype=torch.float32):
+        self.K = len(scatter_info)
+        self.device = torch.device(device)
+        self._keep: List[torch.Tensor] = []
+        self.records = (EpsmScatterRecord * self.K)()
+
+        def conv(t, dtype):
+            t = t.detach()
+            if t.dtype != dtype or t.device != self.device or not t.is_contiguous():
+                t = t.to(device=self.device, dtype=dtype).contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        for k, rec in enumerate(scatter_info):
+            r = self.records[k]
+            r.vidx = conv(rec["vidx"], torch.int32)
+            r.mode = conv(rec["mode"], torch.uint8)
+            if rec.get("bsdf_id") is not None and rec.get("dhf_dalpha") is not None:
+                r.bsdf_id = conv(rec["bsdf_id"], torch.int32)
+                r.dhf_dalpha = conv(rec["dhf_dalpha"], float_dtype)
+            if rec.get("evidx") is not None:
+                r.evidx = conv(rec["evidx"], torch.int32)
+                r.eb0 = conv(rec["eb0"], float_dtype)
+                r.eb1 = conv(rec["eb1"], float_dtype)
+                r.eweight = conv(rec["eweight"], float_dtype)

@@ -169,3 +169,92 @@ def path_info_to(path_info, device=None, dtype=None):
                 r[k] = v
         out.append(r)
     return out
+
+
+# ---------------------------------------------------------------------------
+# camera rays, first-hit triangles and parameter addressing (tangent / scatter)
+# ---------------------------------------------------------------------------
+def synth_camera_rays(res: int, spp: int, seed: int = 0, device="cpu", fov_deg: float = 40.0,
+                      dtype=torch.float32):
+    """Primary rays of a pinhole camera at the origin looking down -z with the
+    one-pixel offset directions of ``sample_ray_differential``
+    (src/sensors/perspective.cpp:238-279).  Paths are ordered (pixel, sample),
+    pixels row-major, as the reference reshapes them (epsm.py:250)."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(424242 + int(seed))
+    N = res * res * spp
+    pix = torch.arange(res * res, device=dev).repeat_interleave(spp)
+    py, px = (pix // res).to(dtype), (pix % res).to(dtype)
+    jit = torch.rand((N, 2), generator=gen, device=dev, dtype=dtype)
+    import math
+    scale = 2.0 * math.tan(math.radians(fov_deg) / 2.0) / res
+
+    def direction(sx, sy):
+        v = torch.stack([(sx - res / 2) * scale, -(sy - res / 2) * scale, -torch.ones_like(sx)], dim=-1)
+        return v / torch.linalg.norm(v, dim=-1, keepdim=True)
+
+    sx, sy = px + jit[:, 0], py + jit[:, 1]
+    d = direction(sx, sy)
+    dx = direction(sx + 1, sy)
+    dy = direction(sx, sy + 1)
+    o = torch.zeros((N, 3), device=dev, dtype=dtype)
+    return o, d, dx, dy
+
+
+def synth_first_hit_triangles(o, d, seed: int = 0):
+    """Triangles ``p0,p1,p2`` that the rays hit strictly inside, plus the reference
+    barycentrics ``(b0,b1)`` of the hit (b1 = u, b0 = 1-u-v; mesh.cpp:698-700)."""
+    dev, dtype, N = d.device, d.dtype, d.shape[0]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(777 + int(seed))
+    t = _u(gen, (N, 1), 2.0, 4.0, dev, dtype)
+    hit = o + t * d
+    u = _u(gen, (N, 1), 0.1, 0.4, dev, dtype)
+    v = _u(gen, (N, 1), 0.1, 0.4, dev, dtype)
+    # edges roughly perpendicular to the viewing direction, size ~0.3
+    a = torch.tensor([1.0, 0.2, 0.1], device=dev, dtype=dtype) + 0.3 * _u(gen, (N, 3), -0.5, 0.5, dev, dtype)
+    b = torch.tensor([0.1, 1.0, 0.3], device=dev, dtype=dtype) + 0.3 * _u(gen, (N, 3), -0.5, 0.5, dev, dtype)
+    e1, e2 = 0.3 * a, 0.3 * b
+    p0 = hit - u * e1 - v * e2
+    return p0, p0 + e1, p0 + e2, (1 - u - v)[:, 0], u[:, 0]
+
+
+def synth_scatter_info(n_paths: int, n_vertices: int, n_scene_vertices: int, seed: int = 0, device="cpu",
+                       n_bsdfs: int = 4, coherent: bool = True, dtype=torch.float32):
+    """Per-vertex parameter addressing (``EpsmScatterRecord`` fields).  With
+    ``coherent`` the 16 paths of a pixel group hit the same triangle at vertex 1 and
+    progressively less coherent ones deeper, like a real wavefront does."""
+    N, K, V = int(n_paths), int(n_vertices), int(n_scene_vertices)
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99991 + int(seed))
+    idx = torch.arange(N, device=dev)
+    info = []
+    for k in range(1, K + 1):
+        if coherent:
+            group = max(1, 16 >> (k - 1))
+            base = ((idx // group) * 7919 + k * 104729) % V
+            jitter = torch.randint(0, 2, (N,), generator=gen, device=dev) * (k - 1)
+            base = (base + jitter * 31) % V
+        else:
+            base = torch.randint(0, V, (N,), generator=gen, device=dev)
+        vidx = torch.stack([base, (base + 1) % V, (base + 2) % V], dim=-1).to(torch.int32)
+        r = torch.rand((N,), generator=gen, device=dev)
+        mode = torch.full((N,), 4 | 8 | 1, device=dev, dtype=torch.uint8)          # attached, vertex normals
+        mode = torch.where(r < 0.25, torch.tensor(4, device=dev, dtype=torch.uint8), mode)        # flat mesh
+        mode = torch.where((r >= 0.25) & (r < 0.35), torch.tensor(4 | 8 | 1 | 2, device=dev, dtype=torch.uint8), mode)
+        mode = torch.where((r >= 0.35) & (r < 0.40), torch.tensor(1, device=dev, dtype=torch.uint8), mode)  # detached
+        vidx = torch.where((r >= 0.40)[:, None] & (r < 0.43)[:, None], torch.full_like(vidx, -1), vidx)
+        ebase = torch.randint(0, V, (N,), generator=gen, device=dev)
+        evidx = torch.stack([ebase, (ebase + 1) % V, (ebase + 2) % V], dim=-1).to(torch.int32)
+        evidx = torch.where((torch.rand((N,), generator=gen, device=dev) < 0.5)[:, None], evidx, torch.full_like(evidx, -1))
+        info.append({
+            "vidx": vidx, "mode": mode,
+            "bsdf_id": torch.randint(-1, n_bsdfs, (N,), generator=gen, device=dev).to(torch.int32),
+            "dhf_dalpha": _u(gen, (N, 3), -1.0, 1.0, dev, dtype),
+            "evidx": evidx,
+            "eb0": _u(gen, (N,), 0.0, 0.5, dev, dtype), "eb1": _u(gen, (N,), 0.0, 0.5, dev, dtype),
+            "eweight": _u(gen, (N,), 0.0, 2.0, dev, dtype),
+        })
+    return info

@@ -107,6 +107,81 @@ int epsm_manifold_grad(int variant, int64_t N, int K,
                        float *out_param, float *out_light, float *out_diffuse,
                        void *stream);
 
+/* ---------------------------------------------------------------------------
+ * epsm_first_vertex_tangent  --  replaces the forward-mode AD block of
+ *     EPSMIntegrator.render_backward, epsm.py:238-272:
+ *         grad_d = (d_x - d) * gx + (d_y - d) * gy            (epsm.py:250-255)
+ *         set_grad(ray.d, grad_d); re-intersect; forward_to(si.p)
+ *         dlduv[:,0,0] = grad(si.b0); dlduv[:,0,1] = grad(si.b1); dldp1 = grad(si.p)
+ *     with the Moeller-Trumbore intersection of include/mitsuba/render/mesh.h:343-365
+ *     and b1 = u, b2 = v, b0 = 1-u-v, p = p0 b0 + p1 b1 + p2 b2 (src/render/mesh.cpp:698-709).
+ *
+ *   N, spp       paths are ordered (pixel, sample): pixel = n / spp, row-major
+ *                (the reference reshapes to (res,res,spp,3), epsm.py:250)
+ *   res          side of the backward sensor's film; pixel -> (y,x) = (pix / res, pix % res)
+ *   ray_o/d/dx/dy (N,3) f32  primary ray origin, direction and the two one-pixel
+ *                offset directions of sample_ray_differential
+ *   grad_img     gradient image, row-major (rows, img_width, img_channels) f32; the
+ *                top-left res x res crop is used (epsm.py:240) and channels 3,4 are
+ *                the image-space motion (gx, gy) (epsm.py:254)
+ *   p0,p1,p2     (N,3) f32 triangle of the first hit; active (N) u8 (0 -> outputs 0)
+ *   dlduv        written: row n at dlduv + n*dlduv_stride gets (d b0, d b1) in
+ *                columns 0,1; columns 2..dlduv_stride-1 are zero-filled
+ *   dldp         (N,3) written: d si.p
+ *   grad_o_sum   optional (3 floats, accumulated atomically): sum_n -grad_d, the
+ *                camera-origin gradient of epsm.py:260-261; may be NULL
+ * ------------------------------------------------------------------------- */
+int epsm_first_vertex_tangent(int64_t N, int spp, int res,
+                              const float *ray_o, const float *ray_d,
+                              const float *ray_dx, const float *ray_dy,
+                              const float *grad_img, int img_width, int img_channels,
+                              const float *p0, const float *p1, const float *p2,
+                              const uint8_t *active,
+                              float *dlduv, int64_t dlduv_stride, float *dldp,
+                              float *grad_o_sum, void *stream);
+
+/* Per-vertex addressing of the scene-parameter buffers, logged by the tracer next
+ * to EpsmVertexRecord.  Replaces the AD graph that Dr.Jit records through
+ * Mesh::vertex_position / vertex_normal gathers (include/mitsuba/render/mesh.h:94-106). */
+#define EPSM_NO_INDEX 0xFFFFFFFFu
+#define EPSM_MODE_VERTEX_NORMALS 0x1u  /* mesh has vertex normals (mesh.cpp:784-790), else flat (mesh.cpp:811-816) */
+#define EPSM_MODE_FLIP_NORMALS   0x2u  /* m_flip_normals (mesh.cpp:820-827) */
+#define EPSM_MODE_POS_ATTACHED   0x4u  /* vertex positions of this mesh receive gradients */
+#define EPSM_MODE_NRM_ATTACHED   0x8u  /* vertex normals of this mesh receive gradients */
+
+typedef struct EpsmScatterRecord {
+    const uint32_t *vidx;       /* (N,3) u32  indices of the hit triangle's vertices in the flat
+                                              (V,3) position / normal buffers; EPSM_NO_INDEX = skip */
+    const uint8_t *mode;        /* (N)   u8   EPSM_MODE_* bits of the hit mesh */
+    const uint32_t *bsdf_id;    /* (N)   u32  slot in grad_alpha, EPSM_NO_INDEX = none; may be NULL */
+    const float *dhf_dalpha;    /* (N,3) f32  d hf / d alpha of the BSDF sample (roughconductor.cpp:249-255);
+                                              may be NULL */
+    const uint32_t *evidx;      /* (N,3) u32  triangle hit by the emitter-sample shadow ray (epsm.py:622-625);
+                                              may be NULL */
+    const float *eb0, *eb1;     /* (N)   f32  barycentrics of that hit */
+    const float *eweight;       /* (N)   f32  sum_rgb(Lr_dir) (epsm.py:627) */
+} EpsmScatterRecord;
+
+/* ---------------------------------------------------------------------------
+ * epsm_scatter  --  replaces the Backward-mode replay of sample_path
+ *     (epsm.py:283-297 -> 559-562, 622-627, 644-645): the per-path gradients of
+ *     calc_grad are accumulated into the parameter-gradient buffers, i.e. the
+ *     adjoint of the vertex gathers (mesh.h:94-106) as float atomics.
+ *   per logged vertex k (iteration it = k-1):
+ *     grad_pos[vidx_j] += out_param[5it+j]                      (si.p_j * path_grad[5it+j],  :559-560)
+ *     grad_pos[vidx_j] += b_j * out_diffuse[it]                 (si_follow.p * diffuse_grad[it], :561-562)
+ *     normals:  d/dn_j of  sh_frame.n . out_param[5it+3]        (:645; mesh.cpp:784-790 or flat :729,811-816)
+ *     grad_alpha[bsdf_id] += dhf_dalpha . out_param[5it+4]      (bsdf_sample.hf * path_grad[5it+4], :645)
+ *     grad_pos[evidx_j] += eb_j * out_light[it] * eweight       (si_direct.p * light_grad[it] * sum Lr_dir, :626-627)
+ *   (for "manifold_caustic" the last vertex has no n,m entries.)
+ *   grad_pos / grad_nrm: (V,3) f32, grad_alpha: (B) f32; accumulated, not cleared.
+ * ------------------------------------------------------------------------- */
+int epsm_scatter(int variant, int64_t N, int K,
+                 const EpsmVertexRecord *verts, const EpsmScatterRecord *sc,
+                 const float *out_param, const float *out_light, const float *out_diffuse,
+                 float *grad_pos, float *grad_nrm, float *grad_alpha,
+                 int64_t V, int64_t B, void *stream);
+
 /* Human-readable text of the last failure on the calling thread ("" if none). */
 const char *epsm_last_error(void);
 

@@ -62,3 +62,55 @@ def oracle_calc_grad(variant: str, path_info, dlduv: torch.Tensor, dldp: torch.T
     if rc < 0:
         raise RuntimeError(f"oracle failed with code {rc}")
     return list(out_p.unbind(0)), list(out_l.unbind(0)), list(out_d.unbind(0)), rc
+
+
+# ---------------------------------------------------------------------------
+# tangent / scatter restatements (oracle/epsm_oracle_aux.c; "parity unpinned")
+# ---------------------------------------------------------------------------
+def _aux():
+    l = lib()
+    if not hasattr(l, "_aux_ready"):
+        l.epsm_oracle_first_vertex_tangent.restype = C.c_int
+        l.epsm_oracle_first_vertex_tangent.argtypes = [
+            C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        l.epsm_oracle_scatter.restype = C.c_int
+        l.epsm_oracle_scatter.argtypes = [
+            C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+        l._aux_ready = True
+    return l
+
+
+def oracle_first_vertex_tangent(ray_o, ray_d, ray_dx, ray_dy, grad_in, spp, res, p0, p1, p2, active, width=2):
+    f = lambda t: t.detach().to("cpu", torch.float32).contiguous()
+    o, d, dx, dy, g, q0, q1, q2 = map(f, (ray_o, ray_d, ray_dx, ray_dy, grad_in, p0, p1, p2))
+    a = (active.detach().cpu() > 0).to(torch.uint8).contiguous()
+    N = d.shape[0]
+    dlduv = torch.empty((N, 1, width), dtype=torch.float64)
+    dldp = torch.empty((N, 3), dtype=torch.float64)
+    go = torch.empty(3, dtype=torch.float64)
+    rc = _aux().epsm_oracle_first_vertex_tangent(
+        N, int(spp), int(res), o.data_ptr(), d.data_ptr(), dx.data_ptr(), dy.data_ptr(), g.data_ptr(),
+        int(g.shape[1]), int(g.shape[2]), q0.data_ptr(), q1.data_ptr(), q2.data_ptr(), a.data_ptr(),
+        dlduv.data_ptr(), width, dldp.data_ptr(), go.data_ptr())
+    assert rc == 0
+    return dlduv, dldp, go
+
+
+def oracle_scatter(variant, path_info, scatter_info, out_param, out_light, out_diffuse, V, B):
+    """Deterministic float64 accumulation; returns (grad_pos, grad_nrm, grad_alpha)."""
+    from epsm_mitsuba3_amd.records import PackedScatter
+    rec = PackedRecords(path_info, device="cpu")
+    sc = PackedScatter(scatter_info, device="cpu")
+    f = lambda t: (torch.stack(list(t)) if isinstance(t, (list, tuple)) else t).detach().to("cpu", torch.float64).contiguous()
+    op, ol, od = f(out_param), f(out_light), f(out_diffuse)
+    gp = torch.zeros((V, 3), dtype=torch.float64)
+    gn = torch.zeros((V, 3), dtype=torch.float64)
+    ga = torch.zeros((max(B, 1),), dtype=torch.float64)
+    rc = _aux().epsm_oracle_scatter(VARIANTS[variant], rec.N, rec.K, C.addressof(rec.records), C.addressof(sc.records),
+                                    op.data_ptr(), ol.data_ptr(), od.data_ptr(),
+                                    gp.data_ptr(), gn.data_ptr(), ga.data_ptr(), V, B)
+    assert rc == 0
+    return gp, gn, ga[:B]
