@@ -8,3 +8,7 @@ from .manifold_grad import calc_grad, manifold_grad_packed, OUTLIER_CLIP  # noqa
 from ._lib import EpsmError  # noqa: F401
 
 __version__ = "0.1.0"
+from .params import ParamGrads  # noqa: F401,E402
+from .integrators import (EPSMIntegrator, ManifoldIntegrator, ManifoldCausticIntegrator, PathTrace,  # noqa: F401,E402
+                          register_integrator, load_dict)
+from .synthetic_scene import SyntheticScene  # noqa: F401,E402

@@ -46,7 +46,7 @@ def _declare(lib):
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.epsm_first_vertex_tangent.restype = C.c_int
     lib.epsm_first_vertex_tangent.argtypes = [
-        C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.epsm_scatter.restype = C.c_int

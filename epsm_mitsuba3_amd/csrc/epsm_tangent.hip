@@ -16,7 +16,7 @@ using epsm_host::fail;
 namespace {
 
 struct TangentArgs {
-    int64_t N;
+    int64_t N, path_offset;
     int spp, res, img_width, img_channels;
     const float *o, *d, *dx, *dy, *grad_img, *p0, *p1, *p2;
     const uint8_t *active;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void epsm_tangent_kernel(TangentArgs A) {
     const bool in = i < A.N;
     V3<float> gd = zero3<float>();
     if (in) {
-        const int64_t pix = i / A.spp;
+        const int64_t pix = (A.path_offset + i) / A.spp;
         const int64_t y = pix / A.res, x = pix % A.res;
         const float *g = A.grad_img + (y * A.img_width + x) * A.img_channels;
         const float gx = g[3], gy = g[4];
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void epsm_tangent_kernel(TangentArgs A) {
 
 }  // namespace
 
-extern "C" int epsm_first_vertex_tangent(int64_t N, int spp, int res,
+extern "C" int epsm_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, int res,
                                          const float *ray_o, const float *ray_d,
                                          const float *ray_dx, const float *ray_dy,
                                          const float *grad_img, int img_width, int img_channels,
@@ -96,11 +96,12 @@ extern "C" int epsm_first_vertex_tangent(int64_t N, int spp, int res,
     if (N < 0 || (N + 255) / 256 > 0x7fffffffLL) return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: bad N");
     if (spp < 1 || res < 1 || img_width < res || img_channels < 5)
         return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: need spp>=1, res>=1, img_width>=res, img_channels>=5");
-    if ((int64_t) res * res * spp < N) return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: N exceeds res*res*spp");
+    if (path_offset < 0 || (int64_t) res * res * spp < path_offset + N)
+        return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: path_offset + N exceeds res*res*spp");
     if (!ray_o || !ray_d || !ray_dx || !ray_dy || !grad_img || !p0 || !p1 || !p2 || !active || !dlduv || !dldp)
         return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: NULL argument");
     if (dlduv_stride < 2) return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: dlduv_stride < 2");
-    TangentArgs A{N, spp, res, img_width, img_channels, ray_o, ray_d, ray_dx, ray_dy, grad_img, p0, p1, p2,
+    TangentArgs A{N, path_offset, spp, res, img_width, img_channels, ray_o, ray_d, ray_dx, ray_dy, grad_img, p0, p1, p2,
                   active, dlduv, dlduv_stride, dldp, grad_o_sum};
     hipLaunchKernelGGL(epsm_tangent_kernel, dim3((unsigned) ((N + 255) / 256)), dim3(256), 0,
                        (hipStream_t) stream, A);

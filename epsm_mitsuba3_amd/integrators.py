@@ -1,0 +1,148 @@
+"""The reference's integrator surface for the EPSM gradient path.
+
+Mirrors ``EPSMIntegrator`` / ``ManifoldIntegrator`` / ``ManifoldCausticIntegrator``
+(src/python/python/ad/integrators/epsm.py:12-306, 744-948, 951-1202) and the plugin
+registration the drivers use (``mi.register_integrator`` epsm.py:948,1202;
+``mi.load_dict({'type': 'manifold', 'max_depth': d})`` EPSM/optim.py:97-100).
+
+The reference's ``render_backward`` (epsm.py:84-306) is
+    trace + log paths  ->  first-vertex tangent  ->  calc_grad  ->  re-trace in
+    Backward mode so Dr.Jit scatters into the parameter gradients.
+Here the path tracer is whatever object implements ``trace_paths`` (a native
+wavefront tracer, or seeded synthetic records for the benchmark); it logs the
+vertex INDICES next to the vertex records, so the second trace is replaced by one
+scatter kernel.  Everything between the trace and the parameter gradients runs in
+three HIP launches (tangent, gradient, scatter) on the current stream.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from . import dist as _dist
+from .manifold_grad import OUTLIER_CLIP, calc_grad as _calc_grad, manifold_grad_packed
+from .params import ParamGrads
+from .records import PackedRecords, PackedScatter
+from .tangent_scatter import first_vertex_tangent, scatter
+
+
+@dataclass
+class PathTrace:
+    """What one logging trace of the backward sensor yields (epsm.py:166-181, 547, 648-654)
+    plus the parameter addressing of every logged vertex."""
+    res: int                      # film side of the backward sensor
+    spp: int
+    ray_o: torch.Tensor           # (N,3) primary rays, N = res*res*spp ordered (pixel, sample)
+    ray_d: torch.Tensor
+    ray_dx: torch.Tensor
+    ray_dy: torch.Tensor
+    path_info: List[dict]         # [{"cam"}, vertex 1, ..., vertex K]
+    scatter_info: List[dict]      # K entries (EpsmScatterRecord fields)
+    path_offset: int = 0          # first path of this shard within the full wavefront
+    n_paths_total: Optional[int] = None
+
+
+class EPSMIntegrator:
+    """Base class; ``variant`` selects the calc_grad flavour."""
+    variant: str = ""
+
+    def __init__(self, props: Optional[dict] = None):
+        props = dict(props or {})
+        max_depth = props.get("max_depth", 6)           # common.py:31-37
+        if max_depth < 0 and max_depth != -1:
+            raise Exception("\"max_depth\" must be set to -1 (infinite) or a value >= 0")
+        self.max_depth = max_depth if max_depth != -1 else 0xFFFFFFFF
+        self.rr_depth = props.get("rr_depth", 5)        # common.py:39-41
+        if self.rr_depth <= 0:
+            raise Exception("\"rr_depth\" must be set to a value greater than zero!")
+        # hard-coded in the reference (epsm.py:142,145,549,648,932-944); explicit options here
+        self.backward_sensor = props.get("backward_sensor", 2)
+        self.backward_spp = props.get("backward_spp", 8)
+        self.max_log_depth = min(props.get("max_log_depth", 5), 5)
+        self.outlier_clip = props.get("outlier_clip", OUTLIER_CLIP)
+
+    def to_string(self):
+        return f"{type(self).__name__}[max_depth = {self.max_depth}, rr_depth = {self.rr_depth}]"
+
+    __repr__ = to_string
+
+    # -- calc_grad: drop-in -------------------------------------------------
+    def calc_grad(self, path_info, dlduv, dldp, Lt=None):
+        """epsm.py:745 / 952 -- same arguments and return structure."""
+        return _calc_grad(self.variant, path_info, dlduv, dldp, Lt, clip=self.outlier_clip)
+
+    # -- primal -------------------------------------------------------------
+    def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True):
+        """epsm.py:13-82: primal image with two zero channels appended, (H,W,5); the
+        5-channel shape is what makes the driver take the EPSM branch (EPSM/optim.py:130)."""
+        if not develop:
+            raise Exception("develop=True must be specified when invoking AD integrators")
+        if not hasattr(scene, "render_primal"):
+            raise NotImplementedError("scene object has no render_primal(sensor, seed, spp, max_depth)")
+        img = scene.render_primal(sensor=sensor, seed=seed, spp=spp, max_depth=self.max_depth)
+        pad = torch.zeros(img.shape[0], img.shape[1], 2, device=img.device, dtype=img.dtype)
+        self.primal_image = torch.cat([img[..., :3], pad], dim=-1)
+        return self.primal_image
+
+    # -- backward -----------------------------------------------------------
+    def render_backward(self, scene, params: ParamGrads, grad_in: torch.Tensor,
+                        sensor=0, seed: int = 0, spp: int = 0) -> None:
+        """epsm.py:84-306.  ``sensor`` and ``spp`` are ignored exactly as the reference
+        ignores them (epsm.py:142,145): the backward pass uses ``backward_sensor`` and
+        ``backward_spp``.  Gradients are ACCUMULATED into ``params`` (as dr.backward does)."""
+        if grad_in.shape[-1] == 3:
+            raise NotImplementedError("colour-only adjoint (epsm.py:230-234) is the PRB path, not the EPSM hot path")
+        rank, world = _dist.world()
+        traces = scene.trace_paths(sensor=self.backward_sensor, seed=seed, spp=self.backward_spp,
+                                   max_depth=min(self.max_depth, 6), max_log_depth=self.max_log_depth,
+                                   rank=rank, world_size=world)
+        if isinstance(traces, PathTrace):
+            traces = [traces]
+        for trace in traces:                       # this rank's pixel/sample tiles
+            self.backward_from_trace(trace, params, grad_in)
+        _dist.allreduce_param_grads(params.flat)   # one RCCL all-reduce of the whole buffer
+
+    def backward_from_trace(self, trace: PathTrace, params: ParamGrads, grad_in: torch.Tensor):
+        dev = trace.ray_d.device
+        rec = PackedRecords(trace.path_info, device=dev)
+        sc = PackedScatter(trace.scatter_info, device=dev)
+        first = trace.path_info[1]
+        dlduv, dldp, grad_o = first_vertex_tangent(
+            trace.ray_o, trace.ray_d, trace.ray_dx, trace.ray_dy, grad_in, trace.spp, trace.res,
+            first["points"][0], first["points"][1], first["points"][2], first["active"],
+            dlduv_width=2, want_origin_grad=True, path_offset=trace.path_offset)
+        out = manifold_grad_packed(self.variant, rec, dlduv, dldp, clip=self.outlier_clip, dlduv_cols=2)
+        scatter(self.variant, rec, sc, *out, params.pos, params.nrm, params.alpha if params.B else None)
+        params.cam_origin += grad_o
+        return out
+
+
+class ManifoldIntegrator(EPSMIntegrator):
+    variant = "manifold"
+
+
+class ManifoldCausticIntegrator(EPSMIntegrator):
+    variant = "manifold_caustic"
+
+
+# -- plugin registry (mi.register_integrator / mi.load_dict) -------------------
+_REGISTRY: Dict[str, Callable[[dict], EPSMIntegrator]] = {}
+
+
+def register_integrator(name: str, constructor: Callable[[dict], EPSMIntegrator]) -> None:
+    _REGISTRY[name] = constructor
+
+
+def load_dict(d: dict) -> EPSMIntegrator:
+    d = dict(d)
+    kind = d.pop("type")
+    if kind not in _REGISTRY:
+        raise RuntimeError(f"Plugin \"{kind}\" not found")   # PluginManager error text, plugin.cpp:24-38
+    return _REGISTRY[kind](d)
+
+
+register_integrator("manifold", lambda props: ManifoldIntegrator(props))                  # epsm.py:948
+register_integrator("manifold_caustic", lambda props: ManifoldCausticIntegrator(props))   # epsm.py:1202

@@ -1,0 +1,40 @@
+"""Scene-parameter gradient buffers (what ``dr.grad(params[...])`` holds in the
+reference after ``render_backward``, epsm.py:84-306).
+
+All buffers are views into ONE flat fp32 allocation so that a multi-GPU backward
+pass needs a single RCCL all-reduce, with no packing copies.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+
+class ParamGrads:
+    """``pos (V,3)``: d/d vertex_positions; ``nrm (V,3)``: d/d vertex_normals;
+    ``alpha (B)``: d/d per-BSDF roughness; ``cam_origin (3)``: d/d ray origin
+    (epsm.py:260-261).  Vertex indices are global: meshes are concatenated and a
+    mesh's rows are ``pos[offset : offset + n_vertices]`` (see ``mesh_slices``)."""
+
+    def __init__(self, n_vertices: int, n_bsdfs: int = 0, device="cuda", mesh_slices: Optional[dict] = None):
+        self.V, self.B = int(n_vertices), int(n_bsdfs)
+        n = 6 * self.V + self.B + 3
+        self.flat = torch.zeros(n, device=device, dtype=torch.float32)
+        self.pos = self.flat[: 3 * self.V].view(self.V, 3)
+        self.nrm = self.flat[3 * self.V: 6 * self.V].view(self.V, 3)
+        self.alpha = self.flat[6 * self.V: 6 * self.V + self.B]
+        self.cam_origin = self.flat[6 * self.V + self.B:]
+        self.mesh_slices = dict(mesh_slices or {})
+
+    def zero_(self):
+        self.flat.zero_()
+        return self
+
+    def mesh_pos(self, name: str) -> torch.Tensor:
+        lo, hi = self.mesh_slices[name]
+        return self.pos[lo:hi]
+
+    def mesh_nrm(self, name: str) -> torch.Tensor:
+        lo, hi = self.mesh_slices[name]
+        return self.nrm[lo:hi]

@@ -175,16 +175,17 @@ def path_info_to(path_info, device=None, dtype=None):
 # camera rays, first-hit triangles and parameter addressing (tangent / scatter)
 # ---------------------------------------------------------------------------
 def synth_camera_rays(res: int, spp: int, seed: int = 0, device="cpu", fov_deg: float = 40.0,
-                      dtype=torch.float32):
+                      dtype=torch.float32, lo: int = 0, hi=None):
     """Primary rays of a pinhole camera at the origin looking down -z with the
     one-pixel offset directions of ``sample_ray_differential``
     (src/sensors/perspective.cpp:238-279).  Paths are ordered (pixel, sample),
     pixels row-major, as the reference reshapes them (epsm.py:250)."""
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(424242 + int(seed))
-    N = res * res * spp
-    pix = torch.arange(res * res, device=dev).repeat_interleave(spp)
+    gen.manual_seed(424242 + int(seed) + 1000003 * int(lo))
+    hi = res * res * spp if hi is None else int(hi)
+    N = hi - int(lo)
+    pix = torch.arange(int(lo), hi, device=dev) // spp
     py, px = (pix // res).to(dtype), (pix % res).to(dtype)
     jit = torch.rand((N, 2), generator=gen, device=dev, dtype=dtype)
     import math

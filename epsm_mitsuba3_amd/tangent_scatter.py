@@ -22,7 +22,8 @@ def _f32(t: torch.Tensor, dev, shape=None) -> torch.Tensor:
 
 
 def first_vertex_tangent(ray_o, ray_d, ray_dx, ray_dy, grad_in: torch.Tensor, spp: int, res: int,
-                         p0, p1, p2, active, dlduv_width: int = 2, want_origin_grad: bool = False
+                         p0, p1, p2, active, dlduv_width: int = 2, want_origin_grad: bool = False,
+                         path_offset: int = 0
                          ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """``(dlduv (N,1,width), dldp1 (N,3), grad_o (3,) | None)`` -- epsm.py:238-272.
 
@@ -46,7 +47,7 @@ def first_vertex_tangent(ray_o, ray_d, ray_dx, ray_dy, grad_in: torch.Tensor, sp
     go = torch.zeros(3, device=dev, dtype=torch.float32) if want_origin_grad else None
     with torch.cuda.device(dev):
         rc = _lib.lib().epsm_first_vertex_tangent(
-            N, int(spp), int(res), o.data_ptr(), d.data_ptr(), dx.data_ptr(), dy.data_ptr(),
+            N, int(path_offset), int(spp), int(res), o.data_ptr(), d.data_ptr(), dx.data_ptr(), dy.data_ptr(),
             g.data_ptr(), int(g.shape[1]), int(g.shape[2]), q0.data_ptr(), q1.data_ptr(), q2.data_ptr(),
             a.data_ptr(), dlduv.data_ptr(), int(dlduv_width), dldp.data_ptr(),
             go.data_ptr() if go is not None else None, torch.cuda.current_stream(dev).cuda_stream)

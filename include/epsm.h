@@ -116,8 +116,11 @@ int epsm_manifold_grad(int variant, int64_t N, int K,
  *     with the Moeller-Trumbore intersection of include/mitsuba/render/mesh.h:343-365
  *     and b1 = u, b2 = v, b0 = 1-u-v, p = p0 b0 + p1 b1 + p2 b2 (src/render/mesh.cpp:698-709).
  *
- *   N, spp       paths are ordered (pixel, sample): pixel = n / spp, row-major
- *                (the reference reshapes to (res,res,spp,3), epsm.py:250)
+ *   N, spp       paths are ordered (pixel, sample): pixel = (path_offset + n) / spp,
+ *                row-major (the reference reshapes to (res,res,spp,3), epsm.py:250);
+ *   path_offset  index of this call's first path within the whole wavefront (0 when
+ *                the wavefront is processed in one piece; tiles / GPU shards pass
+ *                their start)
  *   res          side of the backward sensor's film; pixel -> (y,x) = (pix / res, pix % res)
  *   ray_o/d/dx/dy (N,3) f32  primary ray origin, direction and the two one-pixel
  *                offset directions of sample_ray_differential
@@ -131,7 +134,7 @@ int epsm_manifold_grad(int variant, int64_t N, int K,
  *   grad_o_sum   optional (3 floats, accumulated atomically): sum_n -grad_d, the
  *                camera-origin gradient of epsm.py:260-261; may be NULL
  * ------------------------------------------------------------------------- */
-int epsm_first_vertex_tangent(int64_t N, int spp, int res,
+int epsm_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, int res,
                               const float *ray_o, const float *ray_d,
                               const float *ray_dx, const float *ray_dy,
                               const float *grad_img, int img_width, int img_channels,

@@ -72,7 +72,7 @@ def _aux():
     if not hasattr(l, "_aux_ready"):
         l.epsm_oracle_first_vertex_tangent.restype = C.c_int
         l.epsm_oracle_first_vertex_tangent.argtypes = [
-            C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
             C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
             C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         l.epsm_oracle_scatter.restype = C.c_int
@@ -83,7 +83,8 @@ def _aux():
     return l
 
 
-def oracle_first_vertex_tangent(ray_o, ray_d, ray_dx, ray_dy, grad_in, spp, res, p0, p1, p2, active, width=2):
+def oracle_first_vertex_tangent(ray_o, ray_d, ray_dx, ray_dy, grad_in, spp, res, p0, p1, p2, active, width=2,
+                                path_offset=0):
     f = lambda t: t.detach().to("cpu", torch.float32).contiguous()
     o, d, dx, dy, g, q0, q1, q2 = map(f, (ray_o, ray_d, ray_dx, ray_dy, grad_in, p0, p1, p2))
     a = (active.detach().cpu() > 0).to(torch.uint8).contiguous()
@@ -92,7 +93,7 @@ def oracle_first_vertex_tangent(ray_o, ray_d, ray_dx, ray_dy, grad_in, spp, res,
     dldp = torch.empty((N, 3), dtype=torch.float64)
     go = torch.empty(3, dtype=torch.float64)
     rc = _aux().epsm_oracle_first_vertex_tangent(
-        N, int(spp), int(res), o.data_ptr(), d.data_ptr(), dx.data_ptr(), dy.data_ptr(), g.data_ptr(),
+        N, int(path_offset), int(spp), int(res), o.data_ptr(), d.data_ptr(), dx.data_ptr(), dy.data_ptr(), g.data_ptr(),
         int(g.shape[1]), int(g.shape[2]), q0.data_ptr(), q1.data_ptr(), q2.data_ptr(), a.data_ptr(),
         dlduv.data_ptr(), width, dldp.data_ptr(), go.data_ptr())
     assert rc == 0

@@ -43,7 +43,7 @@ static inline dvec dvcross(dvec a, dvec b) {
 }
 static inline dvec dconst(const float *p) { dvec r = {dmk(p[0], 0), dmk(p[1], 0), dmk(p[2], 0)}; return r; }
 
-int epsm_oracle_first_vertex_tangent(int64_t N, int spp, int res,
+int epsm_oracle_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, int res,
                                      const float *ray_o, const float *ray_d,
                                      const float *ray_dx, const float *ray_dy,
                                      const float *grad_img, int img_width, int img_channels,
@@ -53,7 +53,7 @@ int epsm_oracle_first_vertex_tangent(int64_t N, int spp, int res,
                                      double *grad_o_sum) {
     if (grad_o_sum) grad_o_sum[0] = grad_o_sum[1] = grad_o_sum[2] = 0.0;
     for (int64_t i = 0; i < N; ++i) {
-        int64_t pix = i / spp, y = pix / res, x = pix % res;
+        int64_t pix = (path_offset + i) / spp, y = pix / res, x = pix % res;
         const float *g = grad_img + (y * img_width + x) * img_channels;
         double gx = g[3], gy = g[4];
         double gd[3];

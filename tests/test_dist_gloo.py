@@ -1,0 +1,80 @@
+"""World-size-2 test of the multi-GPU logic on CPU (gloo): tile partitioning, the
+flat parameter-gradient buffer and its single all-reduce.  The per-tile arithmetic is
+supplied by the oracle here (tests may use it); on GPUs the same orchestration calls
+the HIP kernels (tests/test_gpu_pipeline.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from epsm_mitsuba3_amd import dist as edist
+from epsm_mitsuba3_amd.params import ParamGrads
+from epsm_mitsuba3_amd.synthetic_scene import SyntheticScene
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+RES, SPP, K, V, B, TILE = 16, 8, 3, 500, 3, 512   # 2048 paths -> 4 tiles
+
+
+def _grad_image():
+    g = torch.Generator().manual_seed(3)
+    return torch.randn((RES, RES, 5), generator=g)
+
+
+def _rank_work(rank, world):
+    from _pipeline_oracle import oracle_backward
+    scene = SyntheticScene(res=RES, n_vertices=K, n_scene_vertices=V, n_bsdfs=B, profile="mixed",
+                           device="cpu", tile_paths=TILE)
+    traces = scene.trace_paths(seed=5, spp=SPP, rank=rank, world_size=world)
+    gp, gn, ga, go = oracle_backward("manifold", traces, _grad_image(), V, B)
+    params = ParamGrads(V, B, device="cpu")
+    params.pos += gp.float(); params.nrm += gn.float(); params.alpha += ga.float(); params.cam_origin += go.float()
+    return params, [t.path_offset for t in traces]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    r, w, _ = edist.init_from_env("gloo")
+    assert (r, w) == (rank, world) and edist.world() == (rank, world)
+    params, offsets = _rank_work(rank, world)
+    edist.allreduce_param_grads(params.flat)
+    q.put((rank, offsets, params.flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_partition_is_exact():
+    tiles = edist.tile_ranges(2048, 512)
+    assert tiles == [(0, 512), (512, 1024), (1024, 1536), (1536, 2048)]
+    assert edist.tile_ranges(1000, 512) == [(0, 512), (512, 1000)]
+    for world in (1, 2, 3, 8):
+        seen = sorted(t for r in range(world) for t in edist.my_tiles(11, r, world))
+        assert seen == list(range(11))
+
+
+def test_two_rank_backward_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    assert got[0][1] == [0, 1024] and got[1][1] == [512, 1536]      # round-robin tiles
+    assert torch.equal(got[0][2], got[1][2])                        # both ranks hold the sum
+    single, _ = _rank_work(0, 1)
+    assert float(single.flat.abs().max()) > 0
+    assert torch.allclose(got[0][2], single.flat, rtol=1e-5, atol=1e-7 * float(single.flat.abs().max()))
