@@ -105,18 +105,26 @@ class EPSMIntegrator:
             self.backward_from_trace(trace, params, grad_in)
         _dist.allreduce_param_grads(params.flat)   # one RCCL all-reduce of the whole buffer
 
-    def backward_from_trace(self, trace: PathTrace, params: ParamGrads, grad_in: torch.Tensor):
+    def backward_from_trace(self, trace: PathTrace, params: ParamGrads, grad_in: torch.Tensor,
+                            packed=None, out=None, mark: Optional[Callable[[str], None]] = None):
+        """Tangent -> gradient -> scatter for one tile.  ``packed`` = (PackedRecords, PackedScatter)
+        built once for records that stay resident; ``out`` = reusable output tensors; ``mark(name)`` is
+        called after each stage (bench.py records HIP events there)."""
         dev = trace.ray_d.device
-        rec = PackedRecords(trace.path_info, device=dev)
-        sc = PackedScatter(trace.scatter_info, device=dev)
+        rec, sc = packed if packed is not None else (PackedRecords(trace.path_info, device=dev),
+                                                     PackedScatter(trace.scatter_info, device=dev))
+        mark = mark or (lambda name: None)
         first = trace.path_info[1]
         dlduv, dldp, grad_o = first_vertex_tangent(
             trace.ray_o, trace.ray_d, trace.ray_dx, trace.ray_dy, grad_in, trace.spp, trace.res,
             first["points"][0], first["points"][1], first["points"][2], first["active"],
             dlduv_width=2, want_origin_grad=True, path_offset=trace.path_offset)
-        out = manifold_grad_packed(self.variant, rec, dlduv, dldp, clip=self.outlier_clip, dlduv_cols=2)
+        mark("tangent")
+        out = manifold_grad_packed(self.variant, rec, dlduv, dldp, clip=self.outlier_clip, dlduv_cols=2, out=out)
+        mark("grad")
         scatter(self.variant, rec, sc, *out, params.pos, params.nrm, params.alpha if params.B else None)
         params.cam_origin += grad_o
+        mark("scatter")
         return out
 
 
