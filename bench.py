@@ -54,7 +54,8 @@ def parse():
     ap.add_argument("--variant", default="manifold", choices=["manifold", "manifold_caustic"])
     ap.add_argument("--profile", default="bathroom")
     ap.add_argument("--scene-vertices", type=int, default=100000, help="size V of the scatter target")
-    ap.add_argument("--stages", default="tangent,grad,scatter", help="debug: subset of stages to run")
+    ap.add_argument("--two-stage", action="store_true",
+                    help="calc_grad lists + separate scatter (the reference's shape) instead of the fused kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -117,7 +118,7 @@ def main():
     N = args.res * args.res * args.spp              # paths of one gradient image, per rank
     scene = epsm.SyntheticScene(res=args.res, n_vertices=K, n_scene_vertices=V, n_bsdfs=B,
                                 profile=args.profile, device=dev, tile_paths=N)
-    integ = epsm.load_dict({"type": args.variant, "max_depth": 8})
+    integ = epsm.load_dict({"type": args.variant, "max_depth": 8, "fused": not args.two_stage})
     # this rank's wavefront: one resident tile (seeded by rank so shards differ)
     trace = scene.tile(0, 0, N, seed=rank, spp=args.spp, K=K)
     packed = (PackedRecords(trace.path_info, device=dev), PackedScatter(trace.scatter_info, device=dev))

@@ -53,6 +53,11 @@ def _declare(lib):
     lib.epsm_scatter.argtypes = [
         C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    lib.epsm_manifold_grad_scatter.restype = C.c_int
+    lib.epsm_manifold_grad_scatter.argtypes = [
+        C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_float,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     return lib
 
 

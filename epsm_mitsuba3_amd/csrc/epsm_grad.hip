@@ -42,10 +42,11 @@ template <int K, int VARIANT, bool FULL_D>
 __global__ __launch_bounds__(kBlock) void epsm_grad_kernel(GradArgs<float> A, int dcols) {
     const int64_t i = (int64_t) blockIdx.x * kBlock + threadIdx.x;
     if (i >= A.N) return;
+    const DenseOut<float> out{A, i};
     if (VARIANT == EPSM_VARIANT_MANIFOLD)
-        manifold_path<float, K, FULL_D>(A, i, dcols);
+        manifold_path<float, K, FULL_D>(A, i, dcols, out);
     else
-        caustic_path<float, K, FULL_D>(A, i, dcols);
+        caustic_path<float, K, FULL_D>(A, i, dcols, out);
 }
 
 template <int K, int VARIANT, bool FULL_D>

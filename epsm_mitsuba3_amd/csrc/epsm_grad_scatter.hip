@@ -1,0 +1,292 @@
+// epsm_grad_scatter.hip -- fused calc_grad + parameter scatter
+// (include/epsm.h: epsm_manifold_grad_scatter).
+//
+// Same per-path arithmetic as epsm_grad.hip (epsm_path_core.h), but the output
+// policy feeds every gradient row straight into the workgroup's LDS accumulator
+// (epsm_wave_scatter.h) instead of writing calc_grad's dense result lists: the
+// 84 B/vertex of (N,3) outputs and their re-read by a scatter pass never touch HBM.
+// Persistent workgroups walk contiguous 256-path chunks (neighbouring pixels -> the
+// same triangles return -> they stay in the table) and flush to HBM with float
+// atomics when the table fills and once at the end.
+#include <stdlib.h>
+#include <string.h>
+
+#include "epsm_common.h"
+#include "epsm_path_core.h"
+#include "epsm_scatter_core.h"
+#include "epsm_wave_scatter.h"
+
+using namespace epsm;
+using epsm_host::fail;
+
+namespace {
+
+constexpr int kBits = 11;                  // 2048-row table = 32 KB of LDS
+constexpr int kQueueCap = 512;             // items per wave queue: 4 x 8 KB; 64 KB per workgroup in all, 2 workgroups per CU
+constexpr int kFusedBlocks = 2048;
+
+struct FusedArgs {
+    GradArgs<float> g;
+    ScatterPtrs<float> s[kMaxVertices];
+    float *gpos, *gnrm, *galpha;
+    int64_t V, B;
+    int P, K;
+};
+
+// Output policy: rows go to the LDS table.  The clamp / NaN rule of calc_grad
+// (epsm.py:856, 932-944) is applied to each (N,3) component first, exactly as the dense
+// path stores it, then the linear map of epsm_scatter_core.h (epsm.py:559-562, 622-627,
+// 644-645) follows.  All 64 lanes call every method at the same program point (`ok` is
+// false for lanes past the end of the wavefront): rows of the hit triangle are merged
+// over runs of equal triangles before they reach LDS.
+#ifndef EPSM_FUSED_MERGE
+#define EPSM_FUSED_MERGE 0      // 0: direct LDS atomics, 1: adaptive wave-run merge first
+#endif
+
+template <int BITS> struct ScatterOut {
+    const FusedArgs &F;
+    const LdsTable<BITS> &T;
+    WaveQueue<kQueueCap> &Q;
+    int64_t i;
+    bool ok;
+
+    template <int ROWS>
+    __device__ __forceinline__ void push(bool valid, const uint32_t key[ROWS], const V3<float> val[ROWS]) const {
+        Q.reserve(T, ROWS);
+        Q.template push_rows<ROWS>(valid, key, val);
+    }
+
+    struct Tri { uint32_t vi[3]; uint32_t mode; };
+    struct Aux { uint32_t bid; V3<float> dhf; uint32_t ei[3]; float eb0, eb1, ew; };
+
+    __device__ __forceinline__ V3<float> fin(V3<float> g) const {
+        return mk3<float>(finalize(g.x, F.g.clip), finalize(g.y, F.g.clip), finalize(g.z, F.g.clip));
+    }
+    __device__ __forceinline__ bool any(bool p) const { return __ballot(p) != 0ull; }
+    // parameter addressing of vertex k, fetched ahead of the step that needs it
+    __device__ __forceinline__ Tri pre_tri(int k, bool live) const {
+        Tri t; t.vi[0] = t.vi[1] = t.vi[2] = kNoIndex; t.mode = 0;
+        if (live && ok) {
+            const ScatterPtrs<float> &s = F.s[k - 1];
+            t.mode = s.mode[i];
+            t.vi[0] = s.vidx[3 * i + 0]; t.vi[1] = s.vidx[3 * i + 1]; t.vi[2] = s.vidx[3 * i + 2];
+        }
+        return t;
+    }
+    __device__ __forceinline__ Aux pre_aux(int k, bool live) const {
+        Aux a; a.bid = kNoIndex; a.dhf = zero3<float>(); a.ei[0] = a.ei[1] = a.ei[2] = kNoIndex; a.eb0 = a.eb1 = a.ew = 0.f;
+        if (live && ok) {
+            const ScatterPtrs<float> &s = F.s[k - 1];
+            if (s.bsdf_id && s.dhf_dalpha && F.galpha) { a.bid = s.bsdf_id[i]; a.dhf = load3(s.dhf_dalpha, i); }
+            if (s.evidx) {
+                a.ei[0] = s.evidx[3 * i + 0]; a.ei[1] = s.evidx[3 * i + 1]; a.ei[2] = s.evidx[3 * i + 2];
+                a.eb0 = s.eb0[i]; a.eb1 = s.eb1[i]; a.ew = s.eweight[i];
+            }
+        }
+        return a;
+    }
+    __device__ __forceinline__ static bool tri_ok(const Tri &t, int64_t V) {
+        return t.vi[0] < (uint64_t) V && t.vi[1] < (uint64_t) V && t.vi[2] < (uint64_t) V;
+    }
+    __device__ __forceinline__ void vertex(int k, bool has_nm, V3<float> Gx, V3<float> gn, V3<float> gm, V3<float> glight,
+                                           const VCtx<float> &c, const Tri &t, const Aux &a) const {
+        // epsm.py:559,644: `iteration*5+4 < len(path_grad)` -- the caustic variant never
+        // scatters the (always zero) rows of its last vertex
+        const float b0 = c.b0, b1 = c.b1, b2 = 1.f - b0 - b1;
+        V3<float> pos[3] = {fin(Gx * b0), fin(Gx * b1), fin(Gx * b2)};       // si.p_j * path_grad[5it+j]
+        V3<float> nrm[3] = {zero3<float>(), zero3<float>(), zero3<float>()};
+        gn = fin(gn);
+        const bool idx_ok = ok && has_nm && tri_ok(t, F.V);
+        const bool pos_v = idx_ok && (t.mode & kModePos);
+        bool nrm_v = false;
+        if (idx_ok && nz3(gn)) {                                              // si_follow.sh_frame.n * path_grad[5it+3]
+            const float sgn = (t.mode & kModeFlip) ? -1.f : 1.f;
+            if (t.mode & kModeVertexNormals) {
+                if (t.mode & kModeNrm) {
+                    // logged normals are post-flip: c.n = sum_j b_j n'_j; sh = normalize(c.n)   (mesh.cpp:784-790, 820-827)
+                    const float il = rsqrt_(dot(c.n, c.n));
+                    const V3<float> sh = c.n * il;
+                    const V3<float> pg = (gn - sh * dot(sh, gn)) * (il * sgn);
+                    nrm[0] = pg * b0; nrm[1] = pg * b1; nrm[2] = pg * b2;
+                    nrm_v = true;
+                }
+            } else if (pos_v) {
+                // flat: sh = sgn normalize(cross(p1-p0, p2-p0)) with p1-p0 = e2-e1, p2-p0 = -e1   (mesh.cpp:729, 811)
+                const V3<float> d0 = c.e2 - c.e1, d1 = -c.e1;
+                const V3<float> cr = cross(d0, d1);
+                const float il = rsqrt_(dot(cr, cr));
+                const V3<float> ch = cr * il;
+                const V3<float> cb = (gn - ch * dot(ch, gn)) * (il * sgn);
+                const V3<float> d0b = cross(d1, cb), d1b = cross(cb, d0);
+                pos[1] = pos[1] + d0b; pos[2] = pos[2] + d1b; pos[0] = pos[0] - (d0b + d1b);
+            }
+        }
+        // group A: the hit triangle's position rows and normal rows (zero rows are dropped at the drain)
+        {
+            const uint32_t V32 = (uint32_t) F.V;
+            const uint32_t keys[6] = {t.vi[0], t.vi[1], t.vi[2], V32 + t.vi[0], V32 + t.vi[1], V32 + t.vi[2]};
+            const V3<float> z = zero3<float>();
+            const V3<float> vals[6] = {pos_v ? pos[0] : z, pos_v ? pos[1] : z, pos_v ? pos[2] : z,
+                                       nrm_v ? nrm[0] : z, nrm_v ? nrm[1] : z, nrm_v ? nrm[2] : z};
+            const bool any = (pos_v && (nz3(pos[0]) || nz3(pos[1]) || nz3(pos[2]))) || nrm_v;
+            push<6>(any, keys, vals);
+        }
+        // group B: bsdf_sample.hf * path_grad[5it+4]  and  si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627, 645)
+        {
+            gm = fin(gm);
+            glight = fin(glight);
+            const bool a_ok = ok && has_nm && nz3(gm) && a.bid < (uint64_t) F.B;
+            const bool e_ok = ok && nz3(glight) && a.ei[0] < (uint64_t) F.V && a.ei[1] < (uint64_t) F.V && a.ei[2] < (uint64_t) F.V;
+            const V3<float> gl = e_ok ? glight * a.ew : zero3<float>();
+            const uint32_t keys[4] = {e_ok ? a.ei[0] : 0u, e_ok ? a.ei[1] : 0u, e_ok ? a.ei[2] : 0u,
+                                      a_ok ? 2u * (uint32_t) F.V + a.bid : 0u};
+            const V3<float> vals[4] = {gl * a.eb0, gl * a.eb1, gl * (1.f - a.eb0 - a.eb1),
+                                       mk3<float>(a_ok ? dot(gm, a.dhf) : 0.f, 0.f, 0.f)};
+            push<4>(a_ok || e_ok, keys, vals);
+        }
+    }
+    // si_follow.p * diffuse_grad[it] with detached barycentrics (epsm.py:561-562); vertex it+1
+    __device__ __forceinline__ void diffuse(int idx, V3<float> g, float b0, float b1, const Tri &t) const {
+        g = fin(g);
+        const bool pos_v = ok && nz3(g) && idx + 1 <= F.K && tri_ok(t, F.V) && (t.mode & kModePos);
+        const V3<float> pos[3] = {g * b0, g * b1, g * (1.f - b0 - b1)};
+        push<3>(pos_v, t.vi, pos);
+    }
+    __device__ __forceinline__ void diffuse_first(V3<float> g) const {
+        g = fin(g);
+        Tri t = pre_tri(1, nz3(g));
+        float b0 = 0.f, b1 = 0.f;
+        if (ok && nz3(g)) { b0 = F.g.v[0].b0[i]; b1 = F.g.v[0].b1[i]; }
+        diffuse(0, g, b0, b1, t);
+    }
+    __device__ __forceinline__ void poison(int) const {
+        // Rows of a term that later turned out non-finite are already in the accumulator.
+        // This only happens for inputs on which the reference itself raises "singular
+        // matrix" or zeroes the term; the dense path reproduces the zeroing.
+    }
+};
+
+}  // namespace
+
+namespace {
+
+template <int K, int VARIANT, bool FULL_D>
+// waves-per-SIMD 2: without it hipcc budgets 128 VGPRs from the LDS-derived occupancy and spills 720 B/lane
+__global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, int dcols, int64_t chunks_per_block) {
+    constexpr int kTableSize = 1 << kBits;
+    __shared__ uint32_t s_keys[kTableSize];
+    __shared__ float s_vals[kTableSize * 3];
+    __shared__ int s_used;
+    __shared__ QItem s_queue[4][kQueueCap];
+    const LdsTable<kBits> T{s_keys, s_vals, &s_used, F.gpos, F.gnrm, F.galpha, (uint32_t) F.V};
+    WaveQueue<kQueueCap> Q{s_queue[threadIdx.x >> 6], 0};
+    T.clear();
+    // Chunk order: groups of 4 consecutive chunks (16 pixels at 64 spp share triangles),
+    // groups dealt round-robin over the workgroups so that the chip streams one contiguous
+    // window of every record array at a time (measured: same speed as one contiguous range
+    // per workgroup, but independent of how the driver places workgroups).
+    const int64_t n_chunks = (F.g.N + 255) / 256;
+    constexpr int group = 4;
+#pragma unroll 1
+    for (int64_t it = 0; it < chunks_per_block; ++it) {
+        const int64_t c = ((it / group) * gridDim.x + blockIdx.x) * group + (it % group);
+        if (c >= n_chunks) continue;
+        const int64_t i0 = c * 256 + threadIdx.x;
+        const bool ok = i0 < F.g.N;
+        const int64_t i = ok ? i0 : F.g.N - 1;    // lanes past the end recompute the last path and add nothing
+        const ScatterOut<kBits> out{F, T, Q, i, ok};
+        if (VARIANT == EPSM_VARIANT_MANIFOLD)
+            manifold_path<float, K, FULL_D>(F.g, i, dcols, out);
+        else
+            caustic_path<float, K, FULL_D>(F.g, i, dcols, out);
+        Q.drain(T);
+        if (T.crowded()) T.flush();               // workgroup-uniform census
+    }
+    T.flush();
+}
+
+template <int K, int VARIANT, bool FULL_D>
+hipError_t launch(const FusedArgs &F, int dcols, hipStream_t s) {
+    const int64_t chunks = (F.g.N + 255) / 256;
+    const int64_t blocks = chunks < kFusedBlocks ? chunks : kFusedBlocks;
+    int64_t per = (chunks + blocks - 1) / blocks;
+    per = (per + 15) / 16 * 16;              // whole groups
+    hipLaunchKernelGGL((epsm_grad_scatter_kernel<K, VARIANT, FULL_D>), dim3((unsigned) blocks), dim3(256), 0, s,
+                       F, dcols, per);
+    return hipGetLastError();
+}
+template <int VARIANT, bool FULL_D>
+hipError_t launch_k(int K, const FusedArgs &F, int dcols, hipStream_t s) {
+    switch (K) {
+        case 1: return launch<1, VARIANT, FULL_D>(F, dcols, s);
+        case 2: return launch<2, VARIANT, FULL_D>(F, dcols, s);
+        case 3: return launch<3, VARIANT, FULL_D>(F, dcols, s);
+        case 4: return launch<4, VARIANT, FULL_D>(F, dcols, s);
+        default: return launch<5, VARIANT, FULL_D>(F, dcols, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
+                                          const float *cam, const EpsmVertexRecord *verts,
+                                          const EpsmScatterRecord *sc,
+                                          const float *dlduv, int64_t dlduv_stride, int dlduv_cols,
+                                          const float *dldp, float clip,
+                                          float *grad_pos, float *grad_nrm, float *grad_alpha,
+                                          int64_t V, int64_t B, void *stream) {
+    epsm_host::err_buf()[0] = 0;
+    if (variant != EPSM_VARIANT_MANIFOLD && variant != EPSM_VARIANT_MANIFOLD_CAUSTIC)
+        return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: unknown variant");
+    if (K < 1 || K > EPSM_MAX_VERTICES) return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: K must be in 1..5");
+    if (N == 0) return EPSM_OK;
+    if (N < 0) return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: bad N");
+    if (!cam || !verts || !sc || !dlduv || !dldp || !grad_pos || !grad_nrm)
+        return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: NULL argument");
+    if (dlduv_cols < 0 || dlduv_stride < (dlduv_cols < 2 * K ? dlduv_cols : 2 * K))
+        return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: dlduv_stride smaller than the columns to read");
+    if (V < 0 || B < 0 || 2 * V + B >= 0xFFFFFFFFLL)
+        return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: bad buffer sizes (need 2V+B < 2^32-1)");
+    FusedArgs F;
+    memset(&F, 0, sizeof(F));
+    F.g.N = N;
+    F.g.cam = cam;
+    for (int k = 0; k < K; ++k) {
+        const EpsmVertexRecord &v = verts[k];
+        const EpsmScatterRecord &s = sc[k];
+        if (!v.p0 || !v.p1 || !v.p2 || !v.n0 || !v.n1 || !v.n2 || !v.b0 || !v.b1 || !v.eta || !v.light ||
+            !v.bsdf || !v.active || !v.active_em || !v.ismesh || !s.vidx || !s.mode)
+            return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: NULL pointer in a vertex / scatter record");
+        if (s.evidx && (!s.eb0 || !s.eb1 || !s.eweight))
+            return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: evidx given without eb0/eb1/eweight");
+        VertexPtrs<float> &o = F.g.v[k];
+        o.p0 = (const float *) v.p0; o.p1 = (const float *) v.p1; o.p2 = (const float *) v.p2;
+        o.n0 = (const float *) v.n0; o.n1 = (const float *) v.n1; o.n2 = (const float *) v.n2;
+        o.b0 = (const float *) v.b0; o.b1 = (const float *) v.b1; o.eta = (const float *) v.eta;
+        o.light = (const float *) v.light;
+        o.bsdf = v.bsdf; o.active = v.active; o.active_em = v.active_em; o.ismesh = v.ismesh;
+        ScatterPtrs<float> &t = F.s[k];
+        t.vidx = s.vidx; t.mode = s.mode; t.bsdf_id = s.bsdf_id; t.dhf_dalpha = s.dhf_dalpha;
+        t.evidx = s.evidx; t.eb0 = s.eb0; t.eb1 = s.eb1; t.eweight = s.eweight;
+    }
+    F.g.dlduv = dlduv;
+    F.g.dlduv_stride = dlduv_stride;
+    F.g.dldp = dldp;
+    F.g.clip = (clip > 0.0f && clip <= 3.402823466e+38f) ? clip : 3.402823466e+38f;
+    F.gpos = grad_pos; F.gnrm = grad_nrm; F.galpha = grad_alpha;
+    F.V = V; F.B = grad_alpha ? B : 0;
+    F.P = epsm_num_param_grads(variant, K);
+    F.K = K;
+    int dcols = dlduv_cols > 2 * K ? 2 * K : dlduv_cols;
+    const bool full_d = dcols > 2;
+    hipStream_t s = (hipStream_t) stream;
+    hipError_t e;
+    if (variant == EPSM_VARIANT_MANIFOLD)
+        e = full_d ? launch_k<EPSM_VARIANT_MANIFOLD, true>(K, F, dcols, s)
+                   : launch_k<EPSM_VARIANT_MANIFOLD, false>(K, F, dcols, s);
+    else
+        e = full_d ? launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, true>(K, F, dcols, s)
+                   : launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, false>(K, F, dcols, s);
+    if (e != hipSuccess) return epsm_host::hip_fail("epsm_manifold_grad_scatter", e);
+    return EPSM_OK;
+}

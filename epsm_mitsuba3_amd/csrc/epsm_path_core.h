@@ -30,6 +30,7 @@
 
 #include <stdint.h>
 #include <math.h>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #define EPSM_HD __host__ __device__ __forceinline__
@@ -37,7 +38,20 @@
 #define EPSM_HD inline __attribute__((always_inline))
 #endif
 
+#define EPSM_LAMBDA __attribute__((always_inline))
+
 namespace epsm {
+
+// Compile-time loops over the vertex index.  `#pragma unroll` is only a request: with
+// the fused output policy hipcc left the backward loop rolled, which turned the
+// per-vertex state arrays into scratch memory (720 B/lane, 10^8 extra HBM writes per
+// launch).  Recursion over an integral_constant cannot be left rolled.
+template <int I, int N, typename F> EPSM_HD void static_for_up(F &&f) {
+    if constexpr (I <= N) { f(std::integral_constant<int, I>{}); static_for_up<I + 1, N>(f); }
+}
+template <int I, typename F> EPSM_HD void static_for_down(F &&f) {
+    if constexpr (I >= 1) { f(std::integral_constant<int, I>{}); static_for_down<I - 1>(f); }
+}
 
 constexpr int kMaxVertices = 5;          // EPSM_MAX_VERTICES
 constexpr uint32_t kBsdfNull = 0x1u;     // bsdf.h:40
@@ -154,6 +168,55 @@ template <typename R> EPSM_HD void store3(R *base, int64_t slot, int64_t N, int6
     p[1] = finalize(g.y, clip);
     p[2] = finalize(g.z, clip);
 }
+
+// Output policy of the per-path functions.  DenseOut writes the reference's own
+// result arrays (calc_grad's three lists, epsm.py:946); the fused kernel plugs in a
+// policy that accumulates straight into the parameter-gradient buffers instead
+// (epsm_grad_scatter.hip), so the 84 B/vertex of dense results never touch HBM.
+//   pre_tri(k, live) / pre_aux(k, live)
+//        called at the TOP of the step that will emit vertex k, so that whatever the
+//        policy must fetch for it (parameter addressing) is in flight while the step's
+//        sweeps run -- a load issued where the gradient becomes known would be a
+//        dependent HBM round trip per vertex in a kernel with two waves per SIMD;
+//   vertex(k, has_nm, Gx, gn, gm, glight, ctx, tri, aux)
+//        d/d p_j of vertex k = b_j * Gx  (slots 5(k-1)+0..2), d/d n (slot +3), d/d m
+//        (slot +4; both only when has_nm), light_grad[k-1];
+//   diffuse(idx, g, b0, b1, tri)   diffuse_grad[idx] = position gradient of vertex idx+1,
+//        whose barycentrics / addressing are passed along;
+//   diffuse_first(g)  diffuse_grad[0] (known before anything else is computed);
+//   poison(P)         caustic only: a live term turned out non-finite after some of its
+//                     rows were already emitted -> all parameter rows are zero.
+// Every lane of a wave calls the policy at the same program points (lanes without a
+// gradient pass zeros), so a policy may use wave-wide operations.
+template <typename R> struct VCtx { R b0, b1; V3<R> n, e1, e2; };   // retained geometry of the vertex
+
+template <typename R> struct DenseOut {
+    struct Tri {};
+    struct Aux {};
+    const GradArgs<R> &A;
+    int64_t i;
+    // any(p): may the step be skipped when p is false for this lane?  Dense output never
+    // skips (zeros must be stored); the fused policy skips when p is false on the whole wave.
+    EPSM_HD bool any(bool) const { return true; }
+    EPSM_HD Tri pre_tri(int, bool) const { return Tri{}; }
+    EPSM_HD Aux pre_aux(int, bool) const { return Aux{}; }
+    EPSM_HD void vertex(int k, bool has_nm, V3<R> Gx, V3<R> gn, V3<R> gm, V3<R> glight,
+                        const VCtx<R> &c, const Tri &, const Aux &) const {
+        store3(A.out_param, 5 * (k - 1) + 0, A.N, i, Gx * c.b0, A.clip);
+        store3(A.out_param, 5 * (k - 1) + 1, A.N, i, Gx * c.b1, A.clip);
+        store3(A.out_param, 5 * (k - 1) + 2, A.N, i, Gx * (R(1) - c.b0 - c.b1), A.clip);
+        if (has_nm) {
+            store3(A.out_param, 5 * (k - 1) + 3, A.N, i, gn, A.clip);
+            store3(A.out_param, 5 * (k - 1) + 4, A.N, i, gm, A.clip);
+        }
+        store3(A.out_light, k - 1, A.N, i, glight, A.clip);
+    }
+    EPSM_HD void diffuse(int idx, V3<R> g, R, R, const Tri &) const { store3(A.out_diffuse, idx, A.N, i, g, A.clip); }
+    EPSM_HD void diffuse_first(V3<R> g) const { store3(A.out_diffuse, 0, A.N, i, g, A.clip); }
+    EPSM_HD void poison(int P) const {
+        for (int q = 0; q < P; ++q) store3(A.out_param, q, A.N, i, zero3<R>(), A.clip);
+    }
+};
 
 // ----------------------------------------------------------------------------
 // geometry of one logged vertex
@@ -305,8 +368,8 @@ template <typename R, int K> EPSM_HD Flags<K> load_flags(const GradArgs<R> &A, i
 // ============================================================================
 // "manifold"  (epsm.py:745-946)
 // ============================================================================
-template <typename R, int K, bool FULL_D>
-EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols) {
+template <typename R, int K, bool FULL_D, typename Out>
+EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols, const Out &out) {
     const Flags<K> fl = load_flags<R, K>(A, i);
 
     // term masks (epsm.py:793-802, 852-855, 916-920).  wN[id]: light-sampling
@@ -329,6 +392,9 @@ EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols) {
         }
     }
 
+    // diffuse_grad[0] = dldp where the first hit is diffuse (epsm.py:791-792)
+    out.diffuse_first(fl.diffuse[1] ? load3(A.dldp, i) : zero3<R>());
+
     // ---- pass 1: forward recursion (pivots of the continuing rows, z vectors)
     struct Keep { V3<R> x, e1, e2, n, light; R eta, b0, b1; };
     Keep kp[K + 2];
@@ -336,23 +402,36 @@ EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols) {
     V2<R> z[K + 1], zN[K + 1];
     z[0] = mk2<R>(R(0), R(0));
 
+    // Everything a vertex contributes to pass 1, fetched ONE STEP AHEAD of its use: with two
+    // waves per SIMD a load consumed in the step that issued it is a fully exposed HBM
+    // round trip (the kernel was latency-bound at 35 % VALU utilisation before this).
+    struct Raw { Geo<R> g; Nrm<R> nr; R eta; V3<R> light; };
+    auto load_raw = [&](int kk) EPSM_LAMBDA {
+        Raw r;
+        r.g = load_geo(A.v[kk - 1], i);
+        r.nr = load_nrm(A.v[kk - 1], i, r.g.b0, r.g.b1);
+        r.eta = A.v[kk - 1].eta[i];
+        r.light = load3(A.v[kk - 1].light, i);
+        return r;
+    };
     const V3<R> cam = load3(A.cam, i);
-    Geo<R> gnext;
-    if (nv >= 1) gnext = load_geo(A.v[0], i);
+    Raw rnext;
+    if (nv >= 1) rnext = load_raw(1);
     M2<R> Aup;                        // A^C_{k-1,k}: continuing row k-1, column block k
     Aup.a = Aup.b = Aup.c = Aup.d = R(0);
 
-#pragma unroll
-    for (int k = 1; k <= K; ++k) {
+    static_for_up<1, K>([&](auto kc) EPSM_LAMBDA {
+        constexpr int k = decltype(kc)::value;
         if (k <= nv) {
-            const Geo<R> g = gnext;
+            const Raw r = rnext;
+            const Geo<R> g = r.g;
+            const Nrm<R> nr = r.nr;
             kp[k].x = g.x; kp[k].e1 = g.e1; kp[k].e2 = g.e2; kp[k].b0 = g.b0; kp[k].b1 = g.b1;
             const bool has_next = (k < K) && (k + 1 <= nv);
-            if (has_next) gnext = load_geo(A.v[k < K ? k : K - 1], i);
-            const Nrm<R> nr = load_nrm(A.v[k - 1], i, g.b0, g.b1);
+            if (has_next) rnext = load_raw(k < K ? k + 1 : K);
             kp[k].n = nr.n;
-            kp[k].eta = A.v[k - 1].eta[i];
-            kp[k].light = load3(A.v[k - 1].light, i);
+            kp[k].eta = r.eta;
+            kp[k].light = r.light;
             const Frame<R> fr = make_frame(nr.n);
             const V3<R> xp = (k == 1) ? cam : kp[k - 1].x;
             const V2<R> dk = load_d<R, FULL_D>(A, i, k, dcols);
@@ -378,7 +457,8 @@ EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols) {
             }
             // continuing version (next point = x_{k+1})
             if (has_next) {
-                const HalfVec<R> h = halfvec_fwd(xp, g.x, gnext.x, fr, kp[k].eta);
+                const Geo<R> &gn_ = rnext.g;
+                const HalfVec<R> h = halfvec_fwd(xp, g.x, gn_.x, fr, kp[k].eta);
                 const Sweep<R> s0 = halfvec_rev(fr, h, R(1), R(0));
                 const Sweep<R> s1 = halfvec_rev(fr, h, R(0), R(1));
                 M2<R> Akk = madd2(block2(s0.gxc, s1.gxc, g.e1, g.e2), block2(s0.gn, s1.gn, nr.dn1, nr.dn2));
@@ -386,19 +466,23 @@ EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols) {
                 if (k > 1) S = msub(Akk, mmul(block2(s0.gxp, s1.gxp, kp[k - 1].e1, kp[k - 1].e2), T));
                 Sinv[k] = minv(S);
                 z[k] = vmul(rhs, Sinv[k]);
-                Aup = block2(s0.gxn, s1.gxn, gnext.e1, gnext.e2);
+                Aup = block2(s0.gxn, s1.gxn, gn_.e1, gn_.e2);
             }
         }
-    }
+    });
 
     // ---- pass 2: backward recursion of the adjoint seeds + seeded sweeps
-    const R clip = A.clip;
     V2<R> carry = mk2<R>(R(0), R(0));  // sum over deeper terms of their y_k
     int W = 0;                         // number of live terms with depth > k
     V3<R> GP = zero3<R>();             // d/dx_k through constraint k+1 (x_k as previous vertex)
-#pragma unroll
-    for (int k = K; k >= 1; --k) {
-        V3<R> gp0 = zero3<R>(), gp1 = gp0, gp2 = gp0, gnrm = gp0, gm = gp0, glight = gp0, gdiff = gp0;
+    typename Out::Tri tri_next = out.pre_tri(K, false);   // addressing of vertex k+1 (for diffuse_grad[k])
+    R nb0 = R(0), nb1 = R(0);
+    static_for_down<K>([&](auto kc) EPSM_LAMBDA {
+        constexpr int k = decltype(kc)::value;
+        const typename Out::Tri tri = out.pre_tri(k, k <= nv);
+        const typename Out::Aux aux = out.pre_aux(k, k <= nv);
+        V3<R> Gxk = zero3<R>(), gnrm = Gxk, gm = Gxk, glight = Gxk, gdiff = Gxk;
+        VCtx<R> ctx; ctx.b0 = ctx.b1 = R(0); ctx.n = ctx.e1 = ctx.e2 = zero3<R>();
         if (k <= nv) {
             const bool fN = wN[k] && finite2(zN[k]);
             const bool fC = wC[k] && finite2(z[k]);
@@ -417,10 +501,8 @@ EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols) {
                 const HalfVec<R> h = halfvec_fwd(xp, kp[k].x, kp[k + 1].x, fr, kp[k].eta);
                 c = halfvec_rev(fr, h, sC.x, sC.y);
             }
-            const V3<R> Gx = -(a.gxc + c.gxc + GP);
-            gp0 = Gx * kp[k].b0;
-            gp1 = Gx * kp[k].b1;
-            gp2 = Gx * (R(1) - kp[k].b0 - kp[k].b1);
+            Gxk = -(a.gxc + c.gxc + GP);
+            ctx.b0 = kp[k].b0; ctx.b1 = kp[k].b1; ctx.n = kp[k].n; ctx.e1 = kp[k].e1; ctx.e2 = kp[k].e2;
             gnrm = -(a.gn + c.gn);
             if (has_next) gm = mk3<R>(sC.x, sC.y, R(0));   // dC/dm = -I on continuing rows (epsm.py:883)
             glight = -a.gxn;
@@ -436,17 +518,10 @@ EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols) {
                 }
             }
         }
-        store3(A.out_param, 5 * (k - 1) + 0, A.N, i, gp0, clip);
-        store3(A.out_param, 5 * (k - 1) + 1, A.N, i, gp1, clip);
-        store3(A.out_param, 5 * (k - 1) + 2, A.N, i, gp2, clip);
-        store3(A.out_param, 5 * (k - 1) + 3, A.N, i, gnrm, clip);
-        store3(A.out_param, 5 * (k - 1) + 4, A.N, i, gm, clip);
-        store3(A.out_light, k - 1, A.N, i, glight, clip);
-        if (k < K) store3(A.out_diffuse, k, A.N, i, gdiff, clip);
-    }
-    // diffuse_grad[0] = dldp where the first hit is diffuse (epsm.py:791-792)
-    V3<R> d0 = fl.diffuse[1] ? load3(A.dldp, i) : zero3<R>();
-    store3(A.out_diffuse, 0, A.N, i, d0, clip);
+        if (out.any(k <= nv)) out.vertex(k, true, Gxk, gnrm, gm, glight, ctx, tri, aux);
+        if (k < K && out.any(gdiff.x != R(0) || gdiff.y != R(0) || gdiff.z != R(0))) out.diffuse(k, gdiff, nb0, nb1, tri_next);
+        tri_next = tri; nb0 = ctx.b0; nb1 = ctx.b1;
+    });
 }
 
 // ============================================================================
@@ -459,10 +534,9 @@ EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols) {
 // the pseudo-constraint wo2 of the CURRENT depth (column block id only) and
 // rows 2..id the half-vector constraints: unknowns y_2.. follow a forward
 // recursion that does not depend on the depth, y_1 closes it per depth.
-template <typename R, int K, bool FULL_D>
-EPSM_HD void caustic_path(const GradArgs<R> &A, int64_t i, int dcols) {
+template <typename R, int K, bool FULL_D, typename Out>
+EPSM_HD void caustic_path(const GradArgs<R> &A, int64_t i, int dcols, const Out &out) {
     const Flags<K> fl = load_flags<R, K>(A, i);
-    const R clip = A.clip;
     constexpr int P = 5 * K - 2;
 
     bool wP[K + 1], wD[K + 1];
@@ -483,28 +557,36 @@ EPSM_HD void caustic_path(const GradArgs<R> &A, int64_t i, int dcols) {
         }
     }
 
+    out.diffuse_first(fl.diffuse[1] ? load3(A.dldp, i) : zero3<R>());   // epsm.py:998-1000
+
     const V3<R> cam = load3(A.cam, i);
     Geo<R> gcur, gnext;
     if (nv >= 1) gnext = load_geo(A.v[0], i);
+    typename Out::Tri tri_prev = out.pre_tri(1, false), tri_cur = out.pre_tri(1, nv >= 1);
+    V3<R> n_prev = zero3<R>();
     V2<R> vprev = mk2<R>(R(0), R(0)), vcur = vprev;   // v_{k-1}, v_k   (v_1 = 0)
     V2<R> rprev = vprev;                               // r_{k-1}
     M2<R> Aup; Aup.a = Aup.b = Aup.c = Aup.d = R(0);   // A_{k-1,k}
     V3<R> xprev = cam, e1prev = zero3<R>(), e2prev = zero3<R>();
     R b0prev = R(0), b1prev = R(0);
     V3<R> Gx_prev = zero3<R>();        // -(d/dx_{k-1}) gathered so far for vertex k-1
+    V3<R> gn_prev = zero3<R>(), gm_prev = zero3<R>();
     bool poisoned = false;             // a live term turned out non-finite: zero every param gradient (nan_to_num)
 
-#pragma unroll
-    for (int k = 1; k <= K; ++k) {
+    static_for_up<1, K>([&](auto kc) EPSM_LAMBDA {
+        constexpr int k = decltype(kc)::value;
         V3<R> gnrm = zero3<R>(), gm = gnrm, gdiff = gnrm;
-        V3<R> Gx = zero3<R>();
+        V3<R> Gx = zero3<R>(), ncur = zero3<R>();
         R b0 = R(0), b1 = R(0);
         const bool live = (k < K) && (k + 1 <= nv);    // depth k has a continuing sub-path we need
+        const typename Out::Tri tri_nxt = out.pre_tri(k < K ? k + 1 : K, live);   // vertex k+1: diffuse_grad[k] now, rows later
+        const typename Out::Aux aux_prev = out.pre_aux(k >= 2 ? k - 1 : 1, k >= 2 && (k - 1) <= idstar);
         if (live) {
             gcur = gnext;
             gnext = load_geo(A.v[k < K ? k : K - 1], i);
             b0 = gcur.b0; b1 = gcur.b1;
             const Nrm<R> nr = load_nrm(A.v[k - 1], i, gcur.b0, gcur.b1);
+            ncur = nr.n;
             const R eta = A.v[k - 1].eta[i];
             const Frame<R> fr = make_frame(nr.n);
             const HalfVec<R> h = halfvec_fwd(xprev, gcur.x, gnext.x, fr, eta);
@@ -557,36 +639,26 @@ EPSM_HD void caustic_path(const GradArgs<R> &A, int64_t i, int dcols) {
             vprev = vcur;
         }
         // vertex k-1 is complete once constraint k has been swept
-        if (k >= 2) {
-            const R b2p = R(1) - b0prev - b1prev;
-            store3(A.out_param, 5 * (k - 2) + 0, A.N, i, Gx_prev * b0prev, clip);
-            store3(A.out_param, 5 * (k - 2) + 1, A.N, i, Gx_prev * b1prev, clip);
-            store3(A.out_param, 5 * (k - 2) + 2, A.N, i, Gx_prev * b2p, clip);
+        if (k >= 2 && out.any((k - 1) <= idstar)) {
+            VCtx<R> c; c.b0 = b0prev; c.b1 = b1prev; c.n = n_prev; c.e1 = e1prev; c.e2 = e2prev;
+            out.vertex(k - 1, true, Gx_prev, gn_prev, gm_prev, zero3<R>(), c, tri_prev, aux_prev);
         }
-        if (k < K) {
-            store3(A.out_param, 5 * (k - 1) + 3, A.N, i, gnrm, clip);
-            store3(A.out_param, 5 * (k - 1) + 4, A.N, i, gm, clip);
-            store3(A.out_diffuse, k, A.N, i, gdiff, clip);
-        }
-        store3(A.out_light, k - 1, A.N, i, zero3<R>(), clip);
-        Gx_prev = Gx;
+        if (k < K && out.any(live)) out.diffuse(k, gdiff, live ? gnext.b0 : R(0), live ? gnext.b1 : R(0), tri_nxt);
+        Gx_prev = Gx; gn_prev = gnrm; gm_prev = gm;
+        tri_prev = tri_cur; tri_cur = tri_nxt;
+        // geometry of vertex k, kept for its emission at step k+1 (flat-normal rows need e1,e2,n)
         if (live) {
             xprev = gcur.x; e1prev = gcur.e1; e2prev = gcur.e2;
         }
+        n_prev = ncur;
         b0prev = b0; b1prev = b1;
-    }
+    });
     // last vertex: only p0,p1,p2 are registered and no continuing row exists for it
     {
-        const R b2p = R(1) - b0prev - b1prev;
-        store3(A.out_param, 5 * (K - 1) + 0, A.N, i, Gx_prev * b0prev, clip);
-        store3(A.out_param, 5 * (K - 1) + 1, A.N, i, Gx_prev * b1prev, clip);
-        store3(A.out_param, 5 * (K - 1) + 2, A.N, i, Gx_prev * b2p, clip);
+        VCtx<R> c; c.b0 = b0prev; c.b1 = b1prev; c.n = n_prev; c.e1 = e1prev; c.e2 = e2prev;
+        out.vertex(K, false, Gx_prev, zero3<R>(), zero3<R>(), zero3<R>(), c, tri_prev, out.pre_aux(K, false));
     }
-    if (poisoned) {
-        for (int q = 0; q < P; ++q) store3(A.out_param, q, A.N, i, zero3<R>(), clip);
-    }
-    V3<R> d0 = fl.diffuse[1] ? load3(A.dldp, i) : zero3<R>();
-    store3(A.out_diffuse, 0, A.N, i, d0, clip);
+    if (poisoned) out.poison(P);
 }
 
 }  // namespace epsm

@@ -1,36 +1,81 @@
 // epsm_scatter.hip -- parameter-gradient scatter (include/epsm.h: epsm_scatter).
 //
-// One lane per path; contributions that are exactly zero (masked paths) issue
-// no atomic.  Adds are `global_atomic_add_f32` (no CAS loop on gfx950); their
-// order is not fixed, so sums differ from run to run in the last bits -- tests
-// compare against a deterministic fp64 sum with a relative tolerance.
+// One lane per path, vertices in lock step so that the items of a wave line up;
+// items are merged across the wave (epsm_wave_scatter.h) before the
+// `global_atomic_add_f32`s.  Atomic order is not fixed, so sums differ from run to
+// run in the last bits -- tests compare against a deterministic fp64 sum.
+#include <stdlib.h>
 #include <string.h>
 
 #include "epsm_common.h"
 #include "epsm_scatter_core.h"
+#include "epsm_wave_scatter.h"
 
 using namespace epsm;
 using epsm_host::fail;
 
 namespace {
 
-struct AtomicSink {
-    float *gpos, *gnrm, *galpha;
-    __device__ __forceinline__ void pos(uint32_t v, V3<float> g) const {
-        float *p = gpos + 3 * (int64_t) v;
-        atomicAdd(p + 0, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z);
-    }
-    __device__ __forceinline__ void nrm(uint32_t v, V3<float> g) const {
-        float *p = gnrm + 3 * (int64_t) v;
-        atomicAdd(p + 0, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z);
-    }
-    __device__ __forceinline__ void alpha(uint32_t b, float g) const { atomicAdd(galpha + b, g); }
-};
+struct Targets { float *gpos, *gnrm, *galpha; };
 
-__global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A, AtomicSink sink) {
-    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    if (i >= A.N) return;
-    scatter_path<float, AtomicSink>(A, i, sink);
+constexpr int kScatterBlocks = 2048;            // persistent workgroups (8 per CU by count, 2 resident by LDS)
+
+// One lane per path within a 256-path chunk; a workgroup walks a CONTIGUOUS range of
+// chunks (neighbouring pixels -> the same triangles come back -> they stay in its table).
+template <int MODE, int BITS>
+__global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A, Targets tg, int64_t chunks_per_block) {
+    constexpr int kTableSize = 1 << BITS;
+    __shared__ uint32_t s_keys[kTableSize];
+    __shared__ float s_vals[kTableSize * 3];
+    __shared__ int s_used;
+    const LdsTable<BITS> T{s_keys, s_vals, &s_used, tg.gpos, tg.gnrm, tg.galpha, (uint32_t) A.V};
+    T.clear();
+    const int64_t first = (int64_t) blockIdx.x * chunks_per_block;
+#pragma unroll 1
+    for (int64_t c = first; c < first + chunks_per_block; ++c) {
+        const int64_t i0 = c * 256 + threadIdx.x;
+        if (c * 256 >= A.N) break;
+        const bool in = i0 < A.N;
+        const int64_t i = in ? i0 : A.N - 1;      // out-of-range lanes stay in the wave (shuffles) but add nothing
+#pragma unroll 1
+        for (int it = 0; it < A.K; ++it) {
+            const VertexGrads<float> g = load_vertex_grads(A, i, it);
+            // skip the vertex for the whole wave when nobody has a gradient there (masked tails)
+            const bool live = in && (nz3(g.gp[0]) || nz3(g.gp[1]) || nz3(g.gp[2]) || nz3(g.gn) || nz3(g.gm) ||
+                                     nz3(g.glight) || nz3(g.gdiff));
+            if (__ballot(live) == 0ull) continue;
+            VertexItems<float> q;
+            if (live) {
+                q = vertex_items(A.v[it], A.s[it], i, g, A.V, A.B);
+            } else {
+                q.pos_ok = q.nrm_ok = q.alpha_ok = q.em_ok = false;
+                q.vi[0] = q.vi[1] = q.vi[2] = kNoIndex;
+                q.ei[0] = q.ei[1] = q.ei[2] = kNoIndex;
+                q.bid = kNoIndex; q.alpha = 0.f;
+                for (int j = 0; j < 3; ++j) q.pos[j] = q.nrm[j] = q.em[j] = zero3<float>();
+            }
+            const bool pos_v = live && q.pos_ok;
+            const bool nrm_v = live && q.nrm_ok && (nz3(q.nrm[0]) || nz3(q.nrm[1]) || nz3(q.nrm[2]));
+            if (MODE == 0) {
+                scatter_triangle_runs(T, 0u, pos_v, q.vi, q.pos, __ballot(pos_v) != 0ull);
+                scatter_triangle_runs(T, (uint32_t) A.V, nrm_v, q.vi, q.nrm, __ballot(nrm_v) != 0ull);
+                if (tg.galpha) scatter_scalar_hot(T, 2u * (uint32_t) A.V, live && q.alpha_ok, q.bid, q.alpha);
+                if (A.s[it].evidx) scatter_triangle_hot(T, 0u, live && q.em_ok, q.ei, q.em);
+            } else {
+                if (MODE == 1) {
+                    scatter_triangle_direct(T, 0u, pos_v, q.vi, q.pos);
+                    scatter_triangle_direct(T, (uint32_t) A.V, nrm_v, q.vi, q.nrm);
+                } else {
+                    scatter_triangle_adaptive(T, 0u, pos_v, q.vi, q.pos, MODE == 2 ? 8 : 16);
+                    scatter_triangle_adaptive(T, (uint32_t) A.V, nrm_v, q.vi, q.nrm, MODE == 2 ? 8 : 16);
+                }
+                if (tg.galpha && live && q.alpha_ok) T.add(2u * (uint32_t) A.V + q.bid, q.alpha, 0.f, 0.f);
+                if (A.s[it].evidx) scatter_triangle_direct(T, 0u, live && q.em_ok, q.ei, q.em);
+            }
+        }
+        if (T.crowded()) T.flush();               // workgroup-uniform census
+    }
+    T.flush();
 }
 
 }  // namespace
@@ -48,7 +93,9 @@ extern "C" int epsm_scatter(int variant, int64_t N, int K,
     if (N < 0 || (N + 255) / 256 > 0x7fffffffLL) return fail(EPSM_EINVAL, "epsm_scatter: bad N");
     if (!verts || !sc || !out_param || !out_light || !out_diffuse || !grad_pos)
         return fail(EPSM_EINVAL, "epsm_scatter: NULL argument");
-    if (V < 0 || B < 0 || V >= 0xFFFFFFFFLL) return fail(EPSM_EINVAL, "epsm_scatter: bad buffer sizes");
+    if (!grad_nrm) return fail(EPSM_EINVAL, "epsm_scatter: grad_nrm is NULL (pass a (V,3) buffer; it stays zero "
+                                            "when no mesh has EPSM_MODE_NRM_ATTACHED)");
+    if (V < 0 || B < 0 || 2 * V + B >= 0xFFFFFFFFLL) return fail(EPSM_EINVAL, "epsm_scatter: bad buffer sizes (need 2V+B < 2^32-1)");
     ScatterArgs<float> A;
     memset(&A, 0, sizeof(A));
     A.N = N; A.K = K; A.P = epsm_num_param_grads(variant, K);
@@ -69,11 +116,20 @@ extern "C" int epsm_scatter(int variant, int64_t N, int K,
         t.vidx = s.vidx; t.mode = s.mode; t.bsdf_id = s.bsdf_id; t.dhf_dalpha = s.dhf_dalpha;
         t.evidx = s.evidx; t.eb0 = s.eb0; t.eb1 = s.eb1; t.eweight = s.eweight;
     }
-    AtomicSink sink{grad_pos, grad_nrm, grad_alpha};
-    if (!grad_nrm) return fail(EPSM_EINVAL, "epsm_scatter: grad_nrm is NULL (pass a (V,3) buffer; it stays zero "
-                                            "when no mesh has EPSM_MODE_NRM_ATTACHED)");
-    hipLaunchKernelGGL(epsm_scatter_kernel, dim3((unsigned) ((N + 255) / 256)), dim3(256), 0,
-                       (hipStream_t) stream, A, sink);
+    Targets T{grad_pos, grad_nrm, grad_alpha};
+    const int64_t chunks = (N + 255) / 256;
+    const int64_t blocks = chunks < kScatterBlocks ? chunks : kScatterBlocks;
+    const int64_t chunks_per_block = (chunks + blocks - 1) / blocks;
+    // Defaults from the A/B on config 2 (profiles/r01_c_scatter_ab.txt): adaptive run merge, 2048-row
+    // table (4 workgroups per CU).  Tuning overrides: EPSM_SCATTER_MODE 0 runs + hot-key rounds,
+    // 1 direct LDS atomics, 2/3 adaptive (<= 8 / 16 runs); EPSM_SCATTER_BITS 10..12.
+    static const int mode = getenv("EPSM_SCATTER_MODE") ? atoi(getenv("EPSM_SCATTER_MODE")) : 3;
+    static const int bits = getenv("EPSM_SCATTER_BITS") ? atoi(getenv("EPSM_SCATTER_BITS")) : 11;
+#define EPSM_LAUNCH(M, Bt) hipLaunchKernelGGL((epsm_scatter_kernel<M, Bt>), dim3((unsigned) blocks), dim3(256), 0, (hipStream_t) stream, A, T, chunks_per_block)
+#define EPSM_BITS(M) do { if (bits == 10) EPSM_LAUNCH(M, 10); else if (bits == 11) EPSM_LAUNCH(M, 11); else EPSM_LAUNCH(M, 12); } while (0)
+    if (mode == 1) EPSM_BITS(1); else if (mode == 2) EPSM_BITS(2); else if (mode == 3) EPSM_BITS(3); else EPSM_BITS(0);
+#undef EPSM_BITS
+#undef EPSM_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_scatter", e);
     return EPSM_OK;

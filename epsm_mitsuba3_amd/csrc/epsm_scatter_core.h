@@ -4,9 +4,11 @@
 // and letting Dr.Jit differentiate  Mesh::vertex_position / vertex_normal
 // (include/mitsuba/render/mesh.h:94-106) and the BSDF sample
 // (epsm.py:283-297 -> 559-562, 622-627, 644-645) is, per logged vertex, a fixed
-// linear map of calc_grad's outputs into three flat buffers.  `Sink` adds one
-// 3-vector / scalar into a buffer: float atomics on the GPU
-// (epsm_scatter.hip), plain fp64 += in the host harness and the oracle.
+// linear map of calc_grad's outputs into three flat buffers.  `vertex_items`
+// evaluates that map for one (path, vertex): up to 3 position rows, 3 normal
+// rows, 1 alpha slot and 3 emitter-triangle rows.  How the items are summed is
+// the caller's business: float atomics after a wave-level merge on the GPU
+// (epsm_scatter.hip), plain fp64 += in the oracle.
 #pragma once
 
 #include "epsm_path_core.h"
@@ -39,79 +41,91 @@ template <typename R> EPSM_HD V3<R> load_out(const R *base, int64_t slot, int64_
     return load3(base + slot * N * 3, i);
 }
 
-template <typename R, typename Sink>
-EPSM_HD void scatter_path(const ScatterArgs<R> &A, int64_t i, Sink &sink) {
-    for (int k = 1; k <= A.K; ++k) {
-        const int it = k - 1;
-        const VertexPtrs<R> &v = A.v[it];
-        const ScatterPtrs<R> &s = A.s[it];
-        const uint32_t mode = s.mode[i];
-        uint32_t vi[3] = {s.vidx[3 * i + 0], s.vidx[3 * i + 1], s.vidx[3 * i + 2]};
-        const bool idx_ok = vi[0] < (uint64_t) A.V && vi[1] < (uint64_t) A.V && vi[2] < (uint64_t) A.V;
-        const bool pos_ok = idx_ok && (mode & kModePos);
-        const bool nrm_ok = idx_ok && (mode & kModeNrm);
-        const R b0 = v.b0[i], b1 = v.b1[i], b2 = R(1) - b0 - b1;
-        const bool has_nm = 5 * it + 4 < A.P;     // epsm.py:559,644: `iteration*5+4 < len(path_grad)`
+// The gradients calc_grad produced for vertex k of one path.
+template <typename R> struct VertexGrads {
+    V3<R> gp[3];     // d/d p0,p1,p2      out_param[5it+0..2]
+    V3<R> gn, gm;    // d/d n, d/d m      out_param[5it+3], [5it+4]
+    V3<R> glight;    // light_grad[it]
+    V3<R> gdiff;     // diffuse_grad[it]
+    bool has_nm;     // epsm.py:559,644: `iteration*5+4 < len(path_grad)`
+};
+template <typename R> EPSM_HD VertexGrads<R> load_vertex_grads(const ScatterArgs<R> &A, int64_t i, int it) {
+    VertexGrads<R> g;
+    g.has_nm = 5 * it + 4 < A.P;
+    for (int j = 0; j < 3; ++j) g.gp[j] = g.has_nm ? load_out(A.out_param, 5 * it + j, A.N, i) : zero3<R>();
+    g.gn = g.has_nm ? load_out(A.out_param, 5 * it + 3, A.N, i) : zero3<R>();
+    g.gm = g.has_nm ? load_out(A.out_param, 5 * it + 4, A.N, i) : zero3<R>();
+    g.glight = load_out(A.out_light, it, A.N, i);
+    g.gdiff = load_out(A.out_diffuse, it, A.N, i);
+    return g;
+}
 
-        // (1) si.p_j * path_grad[5it+j]                                   epsm.py:559-560
-        if (pos_ok && has_nm) {
-            for (int j = 0; j < 3; ++j) {
-                const V3<R> g = load_out(A.out_param, 5 * it + j, A.N, i);
-                if (nz3(g)) sink.pos(vi[j], g);
+template <typename R> struct VertexItems {
+    uint32_t vi[3];  bool pos_ok, nrm_ok;     // hit triangle (valid indices && attached)
+    V3<R> pos[3], nrm[3];
+    uint32_t bid;    bool alpha_ok;  R alpha;
+    uint32_t ei[3];  bool em_ok;     V3<R> em[3];
+};
+
+template <typename R>
+EPSM_HD VertexItems<R> vertex_items(const VertexPtrs<R> &v, const ScatterPtrs<R> &s, int64_t i,
+                                    const VertexGrads<R> &g, int64_t V, int64_t B) {
+    VertexItems<R> o;
+    const uint32_t mode = s.mode[i];
+    o.vi[0] = s.vidx[3 * i + 0]; o.vi[1] = s.vidx[3 * i + 1]; o.vi[2] = s.vidx[3 * i + 2];
+    const bool idx_ok = o.vi[0] < (uint64_t) V && o.vi[1] < (uint64_t) V && o.vi[2] < (uint64_t) V;
+    o.pos_ok = idx_ok && (mode & kModePos);
+    o.nrm_ok = idx_ok && (mode & kModeNrm) && (mode & kModeVertexNormals);
+    const R b0 = v.b0[i], b1 = v.b1[i], b2 = R(1) - b0 - b1;
+    // (1) si.p_j * path_grad[5it+j] (epsm.py:559-560)  +  (2) si_follow.p * diffuse_grad[it] with
+    //     detached barycentrics (epsm.py:561-562)
+    o.pos[0] = g.gp[0] + g.gdiff * b0;
+    o.pos[1] = g.gp[1] + g.gdiff * b1;
+    o.pos[2] = g.gp[2] + g.gdiff * b2;
+    o.nrm[0] = o.nrm[1] = o.nrm[2] = zero3<R>();
+    // (3) si_follow.sh_frame.n * path_grad[5it+3]  (epsm.py:644-645)
+    if (g.has_nm && nz3(g.gn)) {
+        const R sgn = (mode & kModeFlip) ? R(-1) : R(1);
+        if (mode & kModeVertexNormals) {
+            if (o.nrm_ok) {
+                // logged normals are post-flip (mesh.cpp:820-827): n' = sgn * buffer value;
+                // sh = normalize(sum b_j n'_j); d(sh.g)/d n_j = sgn b_j (g - sh (sh.g)) / |n'|
+                const V3<R> n = load3(v.n0, i) * b0 + load3(v.n1, i) * b1 + load3(v.n2, i) * b2;
+                const R il = rsqrt_(dot(n, n));
+                const V3<R> sh = n * il;
+                const V3<R> pg = (g.gn - sh * dot(sh, g.gn)) * (il * sgn);
+                o.nrm[0] = pg * b0; o.nrm[1] = pg * b1; o.nrm[2] = pg * b2;
             }
-        }
-        // (2) si_follow.p * diffuse_grad[it]   (barycentrics detached)     epsm.py:561-562
-        if (pos_ok) {
-            const V3<R> g = load_out(A.out_diffuse, it, A.N, i);
-            if (nz3(g)) { sink.pos(vi[0], g * b0); sink.pos(vi[1], g * b1); sink.pos(vi[2], g * b2); }
-        }
-        // (3) si_follow.sh_frame.n * path_grad[5it+3] + bsdf_sample.hf * path_grad[5it+4]   epsm.py:644-645
-        if (has_nm) {
-            const V3<R> gn = load_out(A.out_param, 5 * it + 3, A.N, i);
-            if (nz3(gn)) {
-                const R sgn = (mode & kModeFlip) ? R(-1) : R(1);
-                if (mode & kModeVertexNormals) {
-                    if (nrm_ok) {
-                        // logged normals are post-flip (mesh.cpp:820-827): n' = sgn * buffer value;
-                        // sh = normalize(sum b_j n'_j); d(sh.g)/d n_j = sgn b_j (g - sh (sh.g)) / |n'|
-                        const V3<R> n = load3(v.n0, i) * b0 + load3(v.n1, i) * b1 + load3(v.n2, i) * b2;
-                        const R il = rsqrt_(dot(n, n));
-                        const V3<R> sh = n * il;
-                        const V3<R> pg = (gn - sh * dot(sh, gn)) * (il * sgn);
-                        sink.nrm(vi[0], pg * b0); sink.nrm(vi[1], pg * b1); sink.nrm(vi[2], pg * b2);
-                    }
-                } else if (pos_ok) {
-                    // flat mesh: sh = sgn * normalize(cross(p1-p0, p2-p0))  (mesh.cpp:729,811)
-                    const V3<R> p0 = load3(v.p0, i), p1 = load3(v.p1, i), p2 = load3(v.p2, i);
-                    const V3<R> d0 = p1 - p0, d1 = p2 - p0;
-                    const V3<R> c = cross(d0, d1);
-                    const R il = rsqrt_(dot(c, c));
-                    const V3<R> ch = c * il;
-                    const V3<R> cb = (gn - ch * dot(ch, gn)) * (il * sgn);
-                    const V3<R> d0b = cross(d1, cb), d1b = cross(cb, d0);
-                    sink.pos(vi[1], d0b); sink.pos(vi[2], d1b); sink.pos(vi[0], -(d0b + d1b));
-                }
-            }
-            if (s.bsdf_id && s.dhf_dalpha) {
-                const uint32_t bid = s.bsdf_id[i];
-                if (bid < (uint64_t) A.B) {
-                    const V3<R> gm = load_out(A.out_param, 5 * it + 4, A.N, i);
-                    if (nz3(gm)) sink.alpha(bid, dot(gm, load3(s.dhf_dalpha, i)));
-                }
-            }
-        }
-        // (4) si_direct.p * light_grad[it] * sum(Lr_dir)                    epsm.py:622-627
-        if (s.evidx) {
-            const uint32_t e0 = s.evidx[3 * i + 0], e1 = s.evidx[3 * i + 1], e2 = s.evidx[3 * i + 2];
-            if (e0 < (uint64_t) A.V && e1 < (uint64_t) A.V && e2 < (uint64_t) A.V) {
-                const V3<R> g = load_out(A.out_light, it, A.N, i) * s.eweight[i];
-                if (nz3(g)) {
-                    const R c0 = s.eb0[i], c1 = s.eb1[i];
-                    sink.pos(e0, g * c0); sink.pos(e1, g * c1); sink.pos(e2, g * (R(1) - c0 - c1));
-                }
-            }
+        } else if (o.pos_ok) {
+            // flat mesh: sh = sgn * normalize(cross(p1-p0, p2-p0))  (mesh.cpp:729,811)
+            const V3<R> p0 = load3(v.p0, i), p1 = load3(v.p1, i), p2 = load3(v.p2, i);
+            const V3<R> d0 = p1 - p0, d1 = p2 - p0;
+            const V3<R> c = cross(d0, d1);
+            const R il = rsqrt_(dot(c, c));
+            const V3<R> ch = c * il;
+            const V3<R> cb = (g.gn - ch * dot(ch, g.gn)) * (il * sgn);
+            const V3<R> d0b = cross(d1, cb), d1b = cross(cb, d0);
+            o.pos[1] = o.pos[1] + d0b; o.pos[2] = o.pos[2] + d1b; o.pos[0] = o.pos[0] - (d0b + d1b);
         }
     }
+    // bsdf_sample.hf * path_grad[5it+4]  (epsm.py:645)
+    o.alpha_ok = false; o.alpha = R(0); o.bid = kNoIndex;
+    if (g.has_nm && s.bsdf_id && s.dhf_dalpha) {
+        o.bid = s.bsdf_id[i];
+        if (o.bid < (uint64_t) B && nz3(g.gm)) { o.alpha_ok = true; o.alpha = dot(g.gm, load3(s.dhf_dalpha, i)); }
+    }
+    // (4) si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627)
+    o.em_ok = false; o.em[0] = o.em[1] = o.em[2] = zero3<R>(); o.ei[0] = o.ei[1] = o.ei[2] = kNoIndex;
+    if (s.evidx) {
+        o.ei[0] = s.evidx[3 * i + 0]; o.ei[1] = s.evidx[3 * i + 1]; o.ei[2] = s.evidx[3 * i + 2];
+        if (o.ei[0] < (uint64_t) V && o.ei[1] < (uint64_t) V && o.ei[2] < (uint64_t) V && nz3(g.glight)) {
+            const V3<R> gl = g.glight * s.eweight[i];
+            const R c0 = s.eb0[i], c1 = s.eb1[i];
+            o.em_ok = true;
+            o.em[0] = gl * c0; o.em[1] = gl * c1; o.em[2] = gl * (R(1) - c0 - c1);
+        }
+    }
+    return o;
 }
 
 }  // namespace epsm

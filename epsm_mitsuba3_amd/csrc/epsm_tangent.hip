@@ -32,51 +32,62 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void epsm_tangent_kernel(TangentArgs A) {
-    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    const bool in = i < A.N;
-    V3<float> gd = zero3<float>();
-    if (in) {
-        const int64_t pix = (A.path_offset + i) / A.spp;
-        const int64_t y = pix / A.res, x = pix % A.res;
-        const float *g = A.grad_img + (y * A.img_width + x) * A.img_channels;
-        const float gx = g[3], gy = g[4];
-        const V3<float> d = load3(A.d, i), dx = load3(A.dx, i), dy = load3(A.dy, i);
-        gd = (dx - d) * gx + (dy - d) * gy;                       // epsm.py:255
-        float db0 = 0.f, db1 = 0.f;
-        V3<float> dp = zero3<float>();
-        if (A.active[i]) {
-            const V3<float> o = load3(A.o, i);
-            const V3<float> p0 = load3(A.p0, i), p1 = load3(A.p1, i), p2 = load3(A.p2, i);
-            const V3<float> e1 = p1 - p0, e2 = p2 - p0;           // mesh.h:349
-            const V3<float> pvec = cross(d, e2);
-            const float inv_det = rcp_(dot(e1, pvec));
-            const V3<float> tvec = o - p0;
-            const float u = dot(tvec, pvec) * inv_det;
-            const V3<float> qvec = cross(tvec, e1);
-            const float v = dot(d, qvec) * inv_det;
-            // forward derivative along gd (ray origin fixed)
-            const V3<float> dpvec = cross(gd, e2);
-            const float ddet = dot(e1, dpvec);
-            const float du = (dot(tvec, dpvec) - u * ddet) * inv_det;
-            const float dv = (dot(gd, qvec) - v * ddet) * inv_det;
-            db1 = du;                                              // b1 = prim_uv.x  (mesh.cpp:698)
-            db0 = -du - dv;                                        // b0 = 1 - b1 - b2
-            dp = e1 * du + e2 * dv;                                // d (p0 b0 + p1 b1 + p2 b2)
-        }
-        float *row = A.dlduv + i * A.dlduv_stride;
-        row[0] = db0;
-        row[1] = db1;
-        for (int64_t c = 2; c < A.dlduv_stride; ++c) row[c] = 0.f;
-        float *q = A.dldp + 3 * i;
-        q[0] = dp.x; q[1] = dp.y; q[2] = dp.z;
+__device__ __forceinline__ void tangent_one(const TangentArgs &A, int64_t i, V3<float> &gd_acc) {
+    const int64_t pix = (A.path_offset + i) / A.spp;
+    const int64_t y = pix / A.res, x = pix % A.res;
+    const float *g = A.grad_img + (y * A.img_width + x) * A.img_channels;
+    const float gx = g[3], gy = g[4];
+    const V3<float> d = load3(A.d, i), dx = load3(A.dx, i), dy = load3(A.dy, i);
+    const V3<float> gd = (dx - d) * gx + (dy - d) * gy;            // epsm.py:255
+    gd_acc = gd_acc + gd;
+    float db0 = 0.f, db1 = 0.f;
+    V3<float> dp = zero3<float>();
+    if (A.active[i]) {
+        const V3<float> o = load3(A.o, i);
+        const V3<float> p0 = load3(A.p0, i), p1 = load3(A.p1, i), p2 = load3(A.p2, i);
+        const V3<float> e1 = p1 - p0, e2 = p2 - p0;               // mesh.h:349
+        const V3<float> pvec = cross(d, e2);
+        const float inv_det = rcp_(dot(e1, pvec));
+        const V3<float> tvec = o - p0;
+        const float u = dot(tvec, pvec) * inv_det;
+        const V3<float> qvec = cross(tvec, e1);
+        const float v = dot(d, qvec) * inv_det;
+        // forward derivative along gd (ray origin fixed)
+        const V3<float> dpvec = cross(gd, e2);
+        const float ddet = dot(e1, dpvec);
+        const float du = (dot(tvec, dpvec) - u * ddet) * inv_det;
+        const float dv = (dot(gd, qvec) - v * ddet) * inv_det;
+        db1 = du;                                                  // b1 = prim_uv.x  (mesh.cpp:698)
+        db0 = -du - dv;                                            // b0 = 1 - b1 - b2
+        dp = e1 * du + e2 * dv;                                    // d (p0 b0 + p1 b1 + p2 b2)
     }
+    float *row = A.dlduv + i * A.dlduv_stride;
+    row[0] = db0;
+    row[1] = db1;
+    for (int64_t c = 2; c < A.dlduv_stride; ++c) row[c] = 0.f;
+    float *q = A.dldp + 3 * i;
+    q[0] = dp.x; q[1] = dp.y; q[2] = dp.z;
+}
+
+// Grid-stride over the paths (at most kMaxBlocks workgroups): the camera-origin
+// gradient is a sum over ALL paths into three floats, and same-address float atomics
+// serialise at the memory side (~25 ns each) -- one atomic triple per workgroup, not
+// per wave, keeps that off the critical path (10 ms -> negligible on 16.8 M paths).
+constexpr int kMaxBlocks = 4096;
+
+__global__ __launch_bounds__(256) void epsm_tangent_kernel(TangentArgs A) {
+    V3<float> acc = zero3<float>();
+    const int64_t stride = (int64_t) gridDim.x * 256;
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < A.N; i += stride) tangent_one(A, i, acc);
     if (A.grad_o_sum) {                                            // epsm.py:260-261: d/d ray.o = -grad_d
-        const float sx = wave_sum(-gd.x), sy = wave_sum(-gd.y), sz = wave_sum(-gd.z);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(A.grad_o_sum + 0, sx);
-            atomicAdd(A.grad_o_sum + 1, sy);
-            atomicAdd(A.grad_o_sum + 2, sz);
+        __shared__ float part[4][3];
+        const float sx = wave_sum(-acc.x), sy = wave_sum(-acc.y), sz = wave_sum(-acc.z);
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { part[w][0] = sx; part[w][1] = sy; part[w][2] = sz; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+            atomicAdd(A.grad_o_sum + threadIdx.x, t);
         }
     }
 }
@@ -103,7 +114,8 @@ extern "C" int epsm_first_vertex_tangent(int64_t N, int64_t path_offset, int spp
     if (dlduv_stride < 2) return fail(EPSM_EINVAL, "epsm_first_vertex_tangent: dlduv_stride < 2");
     TangentArgs A{N, path_offset, spp, res, img_width, img_channels, ray_o, ray_d, ray_dx, ray_dy, grad_img, p0, p1, p2,
                   active, dlduv, dlduv_stride, dldp, grad_o_sum};
-    hipLaunchKernelGGL(epsm_tangent_kernel, dim3((unsigned) ((N + 255) / 256)), dim3(256), 0,
+    const int64_t blocks = (N + 255) / 256 < kMaxBlocks ? (N + 255) / 256 : kMaxBlocks;
+    hipLaunchKernelGGL(epsm_tangent_kernel, dim3((unsigned) blocks), dim3(256), 0,
                        (hipStream_t) stream, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_first_vertex_tangent", e);

@@ -1,0 +1,298 @@
+// epsm_wave_scatter.h -- wave64 merge of scatter items before the float atomics.
+//
+// Global float atomics on MI355X execute at the memory side at one chip-wide
+// rate and serialise per address (MI355X_MICROARCH.md, "Global float atomics"):
+// 64 lanes adding to 64 unrelated rows, or many waves adding to the same row,
+// are an order of magnitude below the contiguous rate.  Neighbouring paths of a
+// wavefront hit the same triangle most of the time (they are samples of the
+// same / adjacent pixels), so before any atomic the items of a wave are merged:
+//   * runs of adjacent lanes with an identical key triple are summed with a
+//     segmented shuffle scan; only the last lane of a run issues the atomic;
+//   * very hot keys (the emitter triangles: every light sample of a wave may
+//     land on the same two triangles) are reduced over ALL lanes that hold
+//     them, adjacent or not (match-any loop, bounded).
+// Device-only code.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include "epsm_path_core.h"
+
+namespace epsm {
+
+struct Runs {
+    int head;        // lane index of the first lane of this lane's run
+    bool tail;       // this lane is the last of its run and the run is valid
+};
+
+__device__ __forceinline__ int lane_id() { return __lane_id(); }
+
+// Runs of adjacent lanes that are `valid` and share the same three keys.
+__device__ __forceinline__ Runs make_runs(bool valid, uint32_t k0, uint32_t k1, uint32_t k2) {
+    const int lane = lane_id();
+    const uint32_t p0 = __shfl_up(k0, 1), p1 = __shfl_up(k1, 1), p2 = __shfl_up(k2, 1);
+    const int pv = __shfl_up((int) valid, 1);
+    const bool head = (lane == 0) || !pv || !valid || p0 != k0 || p1 != k1 || p2 != k2;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    Runs r;
+    r.head = 63 - __clzll((long long) (heads & below));
+    r.tail = valid && ((lane == 63) || ((heads >> (lane + 1)) & 1ull));
+    return r;
+}
+
+// Inclusive segmented sum: after the call the tail lane of every run holds the run total.
+__device__ __forceinline__ float seg_sum(float v, int head) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(v, off);
+        if (lane - off >= head) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ V3<float> seg_sum3(V3<float> v, int head) {
+    return mk3<float>(seg_sum(v.x, head), seg_sum(v.y, head), seg_sum(v.z, head));
+}
+
+// ---------------------------------------------------------------------------
+// Workgroup-private accumulator in LDS (open addressing, linear probing).
+//
+// Same-address global float atomics serialise at ~25 ns each, so keys that the whole
+// wavefront hits (the couple of emitter triangles every light sample lands on, the
+// per-BSDF alpha slots, a big triangle seen by thousands of pixels) must not cost one
+// global atomic per wave.  A persistent workgroup sums into this table with LDS
+// atomics and flushes each live row to HBM once per fill (and once at the end).
+// Key space: row r of buffer `which` (0 pos, 1 nrm) -> which*V + r; alpha slot b -> 2V + b.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
+constexpr int kMaxProbe = 8;
+
+template <int kTableBits>
+struct LdsTable {
+    static constexpr int kTableSize = 1 << kTableBits;   // rows: 4 B key + 12 B value each
+    uint32_t *keys;      // [kTableSize]
+    float *vals;         // [kTableSize][3]
+    int *used;           // number of occupied rows
+    float *gpos, *gnrm, *galpha;
+    uint32_t V;
+
+    __device__ __forceinline__ void global_add(uint32_t key, float x, float y, float z) const {
+        float *p;
+        if (key < V) p = gpos + 3 * (int64_t) key;
+        else if (key < 2u * V) p = gnrm + 3 * (int64_t) (key - V);
+        else { if (x != 0.f) atomicAdd(galpha + (key - 2u * V), x); return; }
+        if (x != 0.f) atomicAdd(p + 0, x);
+        if (y != 0.f) atomicAdd(p + 1, y);
+        if (z != 0.f) atomicAdd(p + 2, z);
+    }
+    __device__ __forceinline__ void add(uint32_t key, float x, float y, float z) const {
+        if (x == 0.f && y == 0.f && z == 0.f) return;
+        uint32_t slot = (key * 2654435761u) >> (32 - kTableBits);
+#pragma unroll 1
+        for (int probe = 0; probe < kMaxProbe; ++probe) {
+            const uint32_t prev = atomicCAS(&keys[slot], kEmptyKey, key);
+            if (prev == kEmptyKey || prev == key) {
+                if (x != 0.f) atomicAdd(&vals[3 * slot + 0], x);
+                if (y != 0.f) atomicAdd(&vals[3 * slot + 1], y);
+                if (z != 0.f) atomicAdd(&vals[3 * slot + 2], z);
+                return;
+            }
+            slot = (slot + 1) & (kTableSize - 1);
+        }
+        global_add(key, x, y, z);          // crowded neighbourhood: go straight to HBM
+    }
+    // all threads of the workgroup; barriers inside
+    __device__ __forceinline__ void clear() const {
+        for (int e = threadIdx.x; e < kTableSize; e += blockDim.x) {
+            keys[e] = kEmptyKey; vals[3 * e] = 0.f; vals[3 * e + 1] = 0.f; vals[3 * e + 2] = 0.f;
+        }
+        if (threadIdx.x == 0) *used = 0;
+        __syncthreads();
+    }
+    // Lanes 4e..4e+2 add the x,y,z of row e in ONE wave instruction, so the three
+    // components of a row (and neighbouring rows of a 64-B line) leave as one atomic
+    // request instead of three (TCC_EA0_ATOMIC: -3x on the flush).
+    __device__ __forceinline__ void flush() const {
+        __syncthreads();
+        for (int q = threadIdx.x; q < 4 * kTableSize; q += blockDim.x) {
+            const int e = q >> 2, c = q & 3;
+            const uint32_t key = keys[e];
+            if (key != kEmptyKey && c < 3) {
+                const float v = vals[3 * e + c];
+                if (v != 0.f) {
+                    if (key < V) atomicAdd(gpos + 3 * (int64_t) key + c, v);
+                    else if (key < 2u * V) atomicAdd(gnrm + 3 * (int64_t) (key - V) + c, v);
+                    else if (c == 0) atomicAdd(galpha + (key - 2u * V), v);
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < kTableSize; e += blockDim.x) {
+            keys[e] = kEmptyKey; vals[3 * e] = 0.f; vals[3 * e + 1] = 0.f; vals[3 * e + 2] = 0.f;
+        }
+        if (threadIdx.x == 0) *used = 0;
+        __syncthreads();
+    }
+    // Workgroup-wide census of occupied rows (all threads; barriers inside).  Counting at
+    // chunk boundaries replaces a per-insertion counter, which was one hot LDS address.
+    __device__ __forceinline__ bool crowded() const {
+        __syncthreads();
+        if (threadIdx.x == 0) *used = 0;
+        __syncthreads();
+        int c = 0;
+        for (int e = threadIdx.x; e < kTableSize; e += blockDim.x) c += keys[e] != kEmptyKey;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(used, c);
+        __syncthreads();
+        return *used > kTableSize / 2;
+    }
+};
+
+template <typename Table> __device__ __forceinline__ void atomic_add3(const Table &T, uint32_t key, V3<float> g) { T.add(key, g.x, g.y, g.z); }
+
+// Sum of v over the lanes of `mask` (a ballot); every lane of the mask gets the total.
+__device__ __forceinline__ float masked_wave_sum(float v, bool in) {
+    v = in ? v : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Three rows (one triangle) per lane, merged over runs of equal triangles.
+template <typename Table> __device__ __forceinline__ void scatter_triangle_runs(const Table &buf, uint32_t base, bool valid, const uint32_t key[3],
+                                                      const V3<float> val[3], bool wave_has_any) {
+    if (!wave_has_any) return;
+    const Runs r = make_runs(valid, key[0], key[1], key[2]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const V3<float> tot = seg_sum3(valid ? val[j] : zero3<float>(), r.head);
+        if (r.tail) atomic_add3(buf, base + key[j], tot);
+    }
+}
+
+// Hot-key variant: up to `kRounds` distinct triangles are reduced over the whole wave
+// (one atomic per component per triangle per wave); what is left falls back to runs.
+template <typename Table> __device__ __forceinline__ void scatter_triangle_hot(const Table &buf, uint32_t base, bool valid, const uint32_t key[3],
+                                                     const V3<float> val[3]) {
+    constexpr int kRounds = 3;
+    bool pending = valid;
+#pragma unroll 1
+    for (int round = 0; round < kRounds; ++round) {
+        const unsigned long long pm = __ballot(pending);
+        if (pm == 0ull) return;
+        const int leader = __ffsll((long long) pm) - 1;
+        const uint32_t l0 = __shfl(key[0], leader), l1 = __shfl(key[1], leader), l2 = __shfl(key[2], leader);
+        const bool in = pending && key[0] == l0 && key[1] == l1 && key[2] == l2;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float sx = masked_wave_sum(val[j].x, in), sy = masked_wave_sum(val[j].y, in),
+                        sz = masked_wave_sum(val[j].z, in);
+            if (lane_id() == leader) atomic_add3(buf, base + key[j], mk3<float>(sx, sy, sz));
+        }
+        pending = pending && !in;
+    }
+    const bool any_left = __ballot(pending) != 0ull;
+    scatter_triangle_runs(buf, base, pending, key, val, any_left);
+}
+
+// Scalar slot (per-BSDF alpha): few distinct keys per wave -> match-any rounds, then plain atomics.
+template <typename Table> __device__ __forceinline__ void scatter_scalar_hot(const Table &buf, uint32_t base, bool valid, uint32_t key, float val) {
+    constexpr int kRounds = 4;
+    bool pending = valid;
+#pragma unroll 1
+    for (int round = 0; round < kRounds; ++round) {
+        const unsigned long long pm = __ballot(pending);
+        if (pm == 0ull) return;
+        const int leader = __ffsll((long long) pm) - 1;
+        const uint32_t lk = __shfl(key, leader);
+        const bool in = pending && key == lk;
+        const float s = masked_wave_sum(val, in);
+        if (lane_id() == leader) buf.add(base + lk, s, 0.f, 0.f);
+        pending = pending && !in;
+    }
+    if (pending) buf.add(base + key, val, 0.f, 0.f);
+}
+
+
+// Direct insertion: LDS atomics merge equal keys natively (same-address lanes serialise
+// at LDS speed), which beats shuffle scans when runs are short.
+template <typename Table> __device__ __forceinline__ void scatter_triangle_direct(const Table &buf, uint32_t base, bool valid,
+                                                                                 const uint32_t key[3], const V3<float> val[3]) {
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) atomic_add3(buf, base + key[j], val[j]);
+    }
+}
+// Adaptive: segmented scan only when the wave's runs are long enough to pay for the shuffles.
+template <typename Table> __device__ __forceinline__ void scatter_triangle_adaptive(const Table &buf, uint32_t base, bool valid,
+                                                                                   const uint32_t key[3], const V3<float> val[3],
+                                                                                   int max_runs) {
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0ull) return;
+    const Runs r = make_runs(valid, key[0], key[1], key[2]);
+    const int n_tails = __popcll(__ballot(r.tail));
+    if (n_tails > max_runs) { scatter_triangle_direct(buf, base, valid, key, val); return; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const V3<float> tot = seg_sum3(valid ? val[j] : zero3<float>(), r.head);
+        if (r.tail) atomic_add3(buf, base + key[j], tot);
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Per-wave item queue in LDS.
+//
+// Inside the gradient kernel rows become available under heavy divergence (at vertex 3
+// a few percent of the lanes hold a gradient), so inserting them into the table in place
+// issues mostly empty LDS atomics and exposes their latency in a kernel that only has
+// two waves per SIMD.  Instead every lane APPENDS its rows to a wave-private queue
+// (position = wave-uniform count + prefix popcount of the ballot: plain ds_write_b128,
+// nothing to wait for) and the wave drains the queue with all 64 lanes busy.
+// ---------------------------------------------------------------------------
+struct QItem { uint32_t key; float x, y, z; };
+
+// Out of line on purpose: the drain sits behind ~15 capacity checks per path; inlined
+// copies pushed the fused kernel past the instruction cache (70 KB of code).
+template <typename Table>
+__device__ __attribute__((noinline)) void drain_queue(const QItem *q, int n, Table T) {
+#pragma unroll 1
+    for (int idx = lane_id(); idx < n; idx += 64) {
+        const QItem it = q[idx];
+        T.add(it.key, it.x, it.y, it.z);
+    }
+}
+
+template <int CAP>
+struct WaveQueue {
+    QItem *q;          // this wave's CAP slots
+    int count;         // wave-uniform
+
+    // Every valid lane appends ROWS consecutive items (one ballot for the whole group).
+    template <int ROWS>
+    __device__ __forceinline__ void push_rows(bool valid, const uint32_t key[ROWS], const V3<float> val[ROWS]) {
+        const unsigned long long m = __ballot(valid);
+        if (m == 0ull) return;
+        const int below = __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
+        if (valid) {
+            QItem *dst = q + count + ROWS * below;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                QItem it; it.key = key[j]; it.x = val[j].x; it.y = val[j].y; it.z = val[j].z;
+                dst[j] = it;
+            }
+        }
+        count += ROWS * __popcll(m);
+    }
+    template <typename Table> __device__ __forceinline__ void drain(const Table &T) {
+        if (count > 0) drain_queue(q, count, T);
+        count = 0;
+    }
+    // room for a group of `rows` rows from all 64 lanes?
+    template <typename Table> __device__ __forceinline__ void reserve(const Table &T, int rows) {
+        if (count + 64 * rows > CAP) drain(T);
+    }
+};
+
+}  // namespace epsm

@@ -26,7 +26,7 @@ from . import dist as _dist
 from .manifold_grad import OUTLIER_CLIP, calc_grad as _calc_grad, manifold_grad_packed
 from .params import ParamGrads
 from .records import PackedRecords, PackedScatter
-from .tangent_scatter import first_vertex_tangent, scatter
+from .tangent_scatter import first_vertex_tangent, manifold_grad_scatter, scatter
 
 
 @dataclass
@@ -63,6 +63,9 @@ class EPSMIntegrator:
         self.backward_spp = props.get("backward_spp", 8)
         self.max_log_depth = min(props.get("max_log_depth", 5), 5)
         self.outlier_clip = props.get("outlier_clip", OUTLIER_CLIP)
+        # True: calc_grad and the scatter run as ONE kernel (no dense per-path gradient lists);
+        # False: the reference's two-stage shape (calc_grad lists, then scatter)
+        self.fused = props.get("fused", True)
 
     def to_string(self):
         return f"{type(self).__name__}[max_depth = {self.max_depth}, rr_depth = {self.rr_depth}]"
@@ -106,7 +109,8 @@ class EPSMIntegrator:
         _dist.allreduce_param_grads(params.flat)   # one RCCL all-reduce of the whole buffer
 
     def backward_from_trace(self, trace: PathTrace, params: ParamGrads, grad_in: torch.Tensor,
-                            packed=None, out=None, mark: Optional[Callable[[str], None]] = None):
+                            packed=None, out=None, mark: Optional[Callable[[str], None]] = None,
+                            fused: Optional[bool] = None):
         """Tangent -> gradient -> scatter for one tile.  ``packed`` = (PackedRecords, PackedScatter)
         built once for records that stay resident; ``out`` = reusable output tensors; ``mark(name)`` is
         called after each stage (bench.py records HIP events there)."""
@@ -120,6 +124,14 @@ class EPSMIntegrator:
             first["points"][0], first["points"][1], first["points"][2], first["active"],
             dlduv_width=2, want_origin_grad=True, path_offset=trace.path_offset)
         mark("tangent")
+        if self.fused if fused is None else fused:
+            # one launch: gradients go from registers into the parameter buffers
+            manifold_grad_scatter(self.variant, rec, sc, dlduv, dldp, params.pos, params.nrm,
+                                  params.alpha if params.B else None, clip=self.outlier_clip)
+            params.cam_origin += grad_o
+            mark("grad")
+            mark("scatter")
+            return None
         out = manifold_grad_packed(self.variant, rec, dlduv, dldp, clip=self.outlier_clip, dlduv_cols=2, out=out)
         mark("grad")
         scatter(self.variant, rec, sc, *out, params.pos, params.nrm, params.alpha if params.B else None)

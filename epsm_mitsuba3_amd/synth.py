@@ -222,32 +222,56 @@ def synth_first_hit_triangles(o, d, seed: int = 0):
 
 
 def synth_scatter_info(n_paths: int, n_vertices: int, n_scene_vertices: int, seed: int = 0, device="cpu",
-                       n_bsdfs: int = 4, coherent: bool = True, dtype=torch.float32):
-    """Per-vertex parameter addressing (``EpsmScatterRecord`` fields).  With
-    ``coherent`` the 16 paths of a pixel group hit the same triangle at vertex 1 and
-    progressively less coherent ones deeper, like a real wavefront does."""
+                       n_bsdfs: int = 4, coherent: bool = True, dtype=torch.float32, n_emitter_tris: int = 32,
+                       res: int = 0, spp: int = 1, path_offset: int = 0):
+    """Per-vertex parameter addressing (``EpsmScatterRecord`` fields).
+
+    Coherence model (``coherent=True``; documented in DESIGN.md 7): the scene's triangles
+    (about 2V for V vertices) are laid out on a virtual G x G grid, G = sqrt(2V); the first
+    hit of a path is the triangle under its pixel (``res`` x ``res`` film mapped onto the
+    grid, so a triangle covers (res/G)^2 pixels and all ``spp`` samples of a pixel share
+    it); every further bounce jitters the grid cell by +-2^k cells, i.e. neighbouring
+    paths keep hitting nearby triangles but spread out with depth.  Triangle t uses
+    vertex rows (t, t+1, t+G) mod V.  With ``res = 0`` paths are grouped 16 at a time
+    instead of by pixel.  ``coherent=False`` draws every triangle uniformly.
+    Emitter samples land on a small emitter mesh (``n_emitter_tris`` triangles at the end
+    of the vertex buffer; 0 = anywhere), as area lights are a handful of triangles in
+    the reference's scenes -- every wave then adds to the same few rows."""
     N, K, V = int(n_paths), int(n_vertices), int(n_scene_vertices)
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
     gen.manual_seed(99991 + int(seed))
-    idx = torch.arange(N, device=dev)
+    idx = torch.arange(N, device=dev) + int(path_offset)
+    import math
+    G = max(2, int(math.sqrt(2 * V)))
+    if res > 0:
+        pix = idx // max(1, spp)
+        cx = ((pix % res) * G) // res
+        cy = (((pix // res) % res) * G) // res
+    else:
+        grp = idx // 16
+        cx, cy = grp % G, (grp // G) % G
     info = []
     for k in range(1, K + 1):
         if coherent:
-            group = max(1, 16 >> (k - 1))
-            base = ((idx // group) * 7919 + k * 104729) % V
-            jitter = torch.randint(0, 2, (N,), generator=gen, device=dev) * (k - 1)
-            base = (base + jitter * 31) % V
+            if k > 1:
+                spread = 2 ** k
+                cx = (cx + torch.randint(-spread, spread + 1, (N,), generator=gen, device=dev)) % G
+                cy = (cy + torch.randint(-spread, spread + 1, (N,), generator=gen, device=dev)) % G
+            base = ((cy * G + cx) + k * 7) % V
         else:
             base = torch.randint(0, V, (N,), generator=gen, device=dev)
-        vidx = torch.stack([base, (base + 1) % V, (base + 2) % V], dim=-1).to(torch.int32)
+        vidx = torch.stack([base, (base + 1) % V, (base + G) % V], dim=-1).to(torch.int32)
         r = torch.rand((N,), generator=gen, device=dev)
         mode = torch.full((N,), 4 | 8 | 1, device=dev, dtype=torch.uint8)          # attached, vertex normals
         mode = torch.where(r < 0.25, torch.tensor(4, device=dev, dtype=torch.uint8), mode)        # flat mesh
         mode = torch.where((r >= 0.25) & (r < 0.35), torch.tensor(4 | 8 | 1 | 2, device=dev, dtype=torch.uint8), mode)
         mode = torch.where((r >= 0.35) & (r < 0.40), torch.tensor(1, device=dev, dtype=torch.uint8), mode)  # detached
         vidx = torch.where((r >= 0.40)[:, None] & (r < 0.43)[:, None], torch.full_like(vidx, -1), vidx)
-        ebase = torch.randint(0, V, (N,), generator=gen, device=dev)
+        if n_emitter_tris > 0 and V >= 3 * n_emitter_tris:
+            ebase = V - 3 * n_emitter_tris + 3 * torch.randint(0, n_emitter_tris, (N,), generator=gen, device=dev)
+        else:
+            ebase = torch.randint(0, V, (N,), generator=gen, device=dev)
         evidx = torch.stack([ebase, (ebase + 1) % V, (ebase + 2) % V], dim=-1).to(torch.int32)
         evidx = torch.where((torch.rand((N,), generator=gen, device=dev) < 0.5)[:, None], evidx, torch.full_like(evidx, -1))
         info.append({

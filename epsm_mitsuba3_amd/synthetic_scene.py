@@ -31,7 +31,8 @@ class SyntheticScene:
         pi[0]["cam"] = o
         pi[1]["points"][0], pi[1]["points"][1], pi[1]["points"][2] = p0, p1, p2
         pi[1]["uv"] = [b0, b1]
-        si = synth_scatter_info(n, K, self.V, seed=s, device=self.device, n_bsdfs=self.B, coherent=self.coherent)
+        si = synth_scatter_info(n, K, self.V, seed=s, device=self.device, n_bsdfs=self.B, coherent=self.coherent,
+                                res=self.res, spp=spp, path_offset=lo)
         return PathTrace(res=self.res, spp=spp, ray_o=o, ray_d=d, ray_dx=dx, ray_dy=dy, path_info=pi,
                          scatter_info=si, path_offset=lo, n_paths_total=self.res * self.res * spp)
 

@@ -80,3 +80,32 @@ def scatter(variant: str, rec: PackedRecords, sc: PackedScatter,
             grad_pos.data_ptr(), grad_nrm.data_ptr(), grad_alpha.data_ptr() if grad_alpha is not None else None,
             V, B, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "epsm_scatter")
+
+
+def manifold_grad_scatter(variant: str, rec: PackedRecords, sc: PackedScatter, dlduv: torch.Tensor,
+                          dldp: torch.Tensor, grad_pos: torch.Tensor, grad_nrm: torch.Tensor,
+                          grad_alpha: Optional[torch.Tensor] = None, clip: float = 0.1,
+                          dlduv_cols: int = 2) -> None:
+    """calc_grad + scatter fused in one launch (``epsm_manifold_grad_scatter``): the per-path
+    gradient lists are never written; results accumulate into the buffers in place."""
+    dev = rec.device
+    if dev.type != "cuda":
+        raise _lib.EpsmError("manifold_grad_scatter: records must live on the GPU (no CPU fallback)")
+    N, K = rec.N, rec.K
+    d = _f32(dlduv, dev).reshape(N, dlduv.numel() // N if N else dlduv.shape[-1])
+    p = _f32(dldp, dev, (N, 3))
+    for t in (grad_pos, grad_nrm):
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.device == dev
+    V = grad_pos.shape[0]
+    assert tuple(grad_pos.shape) == (V, 3) and tuple(grad_nrm.shape) == (V, 3)
+    B = 0
+    if grad_alpha is not None:
+        assert grad_alpha.is_contiguous() and grad_alpha.dtype == torch.float32 and grad_alpha.device == dev
+        B = grad_alpha.numel()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().epsm_manifold_grad_scatter(
+            VARIANTS[variant], N, K, rec.cam.data_ptr(), C.addressof(rec.records), C.addressof(sc.records),
+            d.data_ptr(), d.shape[1], int(dlduv_cols), p.data_ptr(), float(clip),
+            grad_pos.data_ptr(), grad_nrm.data_ptr(), grad_alpha.data_ptr() if grad_alpha is not None else None,
+            V, B, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "epsm_manifold_grad_scatter")

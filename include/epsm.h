@@ -185,6 +185,23 @@ int epsm_scatter(int variant, int64_t N, int K,
                  float *grad_pos, float *grad_nrm, float *grad_alpha,
                  int64_t V, int64_t B, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * epsm_manifold_grad_scatter  --  epsm_manifold_grad + epsm_scatter in ONE launch:
+ *     calc_grad (epsm.py:275) followed by the Backward-mode replay (epsm.py:283-297)
+ *     without materialising final_param_grad / light_grad / diffuse_grad in HBM.
+ *     Arguments as in the two calls above; results are ACCUMULATED into
+ *     grad_pos / grad_nrm (V,3) and grad_alpha (B).  This is what
+ *     EPSMIntegrator.render_backward uses; the two-call form exists for callers that
+ *     want calc_grad's lists (the drop-in of INTEGRATION.md section 1).
+ * ------------------------------------------------------------------------- */
+int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
+                               const float *cam, const EpsmVertexRecord *verts,
+                               const EpsmScatterRecord *sc,
+                               const float *dlduv, int64_t dlduv_stride, int dlduv_cols,
+                               const float *dldp, float clip,
+                               float *grad_pos, float *grad_nrm, float *grad_alpha,
+                               int64_t V, int64_t B, void *stream);
+
 /* Human-readable text of the last failure on the calling thread ("" if none). */
 const char *epsm_last_error(void);
 

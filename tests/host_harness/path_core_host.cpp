@@ -35,10 +35,11 @@ static GradArgs<R> make_args(int64_t N, int K, const void *cam, const EpsmVertex
 template <typename R, int K>
 static void run_k(int variant, bool full_d, const GradArgs<R> &A, int dcols) {
     for (int64_t i = 0; i < A.N; ++i) {
+        const DenseOut<R> out{A, i};
         if (variant == EPSM_VARIANT_MANIFOLD) {
-            if (full_d) manifold_path<R, K, true>(A, i, dcols); else manifold_path<R, K, false>(A, i, dcols);
+            if (full_d) manifold_path<R, K, true>(A, i, dcols, out); else manifold_path<R, K, false>(A, i, dcols, out);
         } else {
-            if (full_d) caustic_path<R, K, true>(A, i, dcols); else caustic_path<R, K, false>(A, i, dcols);
+            if (full_d) caustic_path<R, K, true>(A, i, dcols, out); else caustic_path<R, K, false>(A, i, dcols, out);
         }
     }
 }
