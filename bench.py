@@ -169,11 +169,37 @@ def main():
     stage_ms = {n: sum(evs[i].elapsed_time(evs[i + 1]) for evs in stage_events) / len(stage_events)
                 for i, n in enumerate(names)}
 
+    # secondary figure, outside the timed region: the stand-alone gradient kernel (calc_grad's
+    # dense lists, 32+200K B/path) -- the reference-shaped first stage of --two-stage
+    dense_ms = None
+    if rank == 0 and not args.two_stage:
+        from epsm_mitsuba3_amd.manifold_grad import manifold_grad_packed
+        d2 = torch.randn((N, 2), generator=g, device=dev) * 1e-3
+        p3 = torch.randn((N, 3), generator=g, device=dev) * 1e-3
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        manifold_grad_packed(args.variant, packed[0], d2, p3, dlduv_cols=2, out=out)
+        e0.record()
+        for _ in range(5):
+            manifold_grad_packed(args.variant, packed[0], d2, p3, dlduv_cols=2, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        dense_ms = e0.elapsed_time(e1) / 5
+
     result = None
     if rank == 0:
-        alg = algorithmic_bytes_per_path(K) * N
+        fused = not args.two_stage
+        # 32+116K B/path when the per-path gradients are never written (fused),
+        # 32+200K B/path for the stand-alone gradient kernel
+        alg = (32 + 116 * K if fused else algorithmic_bytes_per_path(K)) * N
         kernel_ms = stage_ms["grad"]
         achieved = alg / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.isfile(tfile):
+            for rec in json.load(open(tfile)):
+                if (rec["kernel"] == ("epsm_grad_scatter_kernel" if fused else "epsm_grad_kernel") and rec["paths"] == N
+                        and rec["K"] == K and rec["variant"] == args.variant and rec["profile"] == args.profile):
+                    traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
         result = {
             "metric": "manifold_paths_per_s", "value": value, "unit": "paths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -188,12 +214,21 @@ def main():
                        "sharding": f"{world} x pixel/sample-tile shard, one all-reduce of the {params.flat.numel() * 4} B "
                                    f"parameter-gradient buffer per step"},
             "stages_ms": stage_ms,
-            "grad_kernel_paths_per_s": N / (kernel_ms * 1e-3),
+            "pipeline": "fused" if fused else "two-stage",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "epsm_grad_kernel", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "epsm_grad_scatter_kernel (fused calc_grad + scatter)" if fused else "epsm_grad_kernel",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg,
+                         "algorithmic_bytes_per_path": alg // N},
         }
+        if dense_ms is not None:
+            a2 = algorithmic_bytes_per_path(K) * N
+            result["standalone_grad_kernel"] = {"kernel": "epsm_grad_kernel", "kernel_ms": dense_ms,
+                                                "paths_per_s": N / (dense_ms * 1e-3),
+                                                "achieved": a2 / (dense_ms * 1e-3) / 1e9, "unit": "GB/s",
+                                                "frac": a2 / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                "algorithmic_bytes_per_path": a2 // N,
+                                                "note": "outside the timed region; first stage of --two-stage"}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(trace.path_info, args.variant, args.cpu_seconds)
     if world > 1:
