@@ -67,9 +67,8 @@ template <int BITS> struct ScatterOut {
     __device__ __forceinline__ Tri pre_tri(int k, bool live) const {
         Tri t; t.vi[0] = t.vi[1] = t.vi[2] = kNoIndex; t.mode = 0;
         if (live && ok) {
-            const ScatterPtrs<float> &s = F.s[k - 1];
-            t.mode = s.mode[i];
-            t.vi[0] = s.vidx[3 * i + 0]; t.vi[1] = s.vidx[3 * i + 1]; t.vi[2] = s.vidx[3 * i + 2];
+            const U4 t4 = load_u4(F.s[k - 1].tri, i);
+            t.vi[0] = t4.x; t.vi[1] = t4.y; t.vi[2] = t4.z; t.mode = t4.w;
         }
         return t;
     }
@@ -77,10 +76,14 @@ template <int BITS> struct ScatterOut {
         Aux a; a.bid = kNoIndex; a.dhf = zero3<float>(); a.ei[0] = a.ei[1] = a.ei[2] = kNoIndex; a.eb0 = a.eb1 = a.ew = 0.f;
         if (live && ok) {
             const ScatterPtrs<float> &s = F.s[k - 1];
-            if (s.bsdf_id && s.dhf_dalpha && F.galpha) { a.bid = s.bsdf_id[i]; a.dhf = load3(s.dhf_dalpha, i); }
-            if (s.evidx) {
-                a.ei[0] = s.evidx[3 * i + 0]; a.ei[1] = s.evidx[3 * i + 1]; a.ei[2] = s.evidx[3 * i + 2];
-                a.eb0 = s.eb0[i]; a.eb1 = s.eb1[i]; a.ew = s.eweight[i];
+            if (s.aux && F.galpha) {
+                const U4 a4 = load_u4(s.aux, i);
+                a.bid = a4.x; a.dhf = mk3<float>(bits_to_float(a4.y), bits_to_float(a4.z), bits_to_float(a4.w));
+            }
+            if (s.emit) {
+                const U4 e4 = load_u4(s.emit, 2 * i), f4 = load_u4(s.emit, 2 * i + 1);
+                a.ei[0] = e4.x; a.ei[1] = e4.y; a.ei[2] = e4.z;
+                a.eb0 = bits_to_float(e4.w); a.eb1 = bits_to_float(f4.x); a.ew = bits_to_float(f4.y);
             }
         }
         return a;
@@ -255,10 +258,10 @@ extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
         const EpsmVertexRecord &v = verts[k];
         const EpsmScatterRecord &s = sc[k];
         if (!v.p0 || !v.p1 || !v.p2 || !v.n0 || !v.n1 || !v.n2 || !v.b0 || !v.b1 || !v.eta || !v.light ||
-            !v.bsdf || !v.active || !v.active_em || !v.ismesh || !s.vidx || !s.mode)
+            !v.bsdf || !v.active || !v.active_em || !v.ismesh || !s.tri)
             return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: NULL pointer in a vertex / scatter record");
-        if (s.evidx && (!s.eb0 || !s.eb1 || !s.eweight))
-            return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: evidx given without eb0/eb1/eweight");
+        if ((((uintptr_t) s.tri) | ((uintptr_t) s.aux) | ((uintptr_t) s.emit)) & 15)
+            return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: tri/aux/emit must be 16-byte aligned");
         VertexPtrs<float> &o = F.g.v[k];
         o.p0 = (const float *) v.p0; o.p1 = (const float *) v.p1; o.p2 = (const float *) v.p2;
         o.n0 = (const float *) v.n0; o.n1 = (const float *) v.n1; o.n2 = (const float *) v.n2;
@@ -266,8 +269,7 @@ extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
         o.light = (const float *) v.light;
         o.bsdf = v.bsdf; o.active = v.active; o.active_em = v.active_em; o.ismesh = v.ismesh;
         ScatterPtrs<float> &t = F.s[k];
-        t.vidx = s.vidx; t.mode = s.mode; t.bsdf_id = s.bsdf_id; t.dhf_dalpha = s.dhf_dalpha;
-        t.evidx = s.evidx; t.eb0 = s.eb0; t.eb1 = s.eb1; t.eweight = s.eweight;
+        t.tri = s.tri; t.aux = s.aux; t.emit = s.emit;
     }
     F.g.dlduv = dlduv;
     F.g.dlduv_stride = dlduv_stride;

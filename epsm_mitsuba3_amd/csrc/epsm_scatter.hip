@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A,
                 scatter_triangle_runs(T, 0u, pos_v, q.vi, q.pos, __ballot(pos_v) != 0ull);
                 scatter_triangle_runs(T, (uint32_t) A.V, nrm_v, q.vi, q.nrm, __ballot(nrm_v) != 0ull);
                 if (tg.galpha) scatter_scalar_hot(T, 2u * (uint32_t) A.V, live && q.alpha_ok, q.bid, q.alpha);
-                if (A.s[it].evidx) scatter_triangle_hot(T, 0u, live && q.em_ok, q.ei, q.em);
+                if (A.s[it].emit) scatter_triangle_hot(T, 0u, live && q.em_ok, q.ei, q.em);
             } else {
                 if (MODE == 1) {
                     scatter_triangle_direct(T, 0u, pos_v, q.vi, q.pos);
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A,
                     scatter_triangle_adaptive(T, (uint32_t) A.V, nrm_v, q.vi, q.nrm, MODE == 2 ? 8 : 16);
                 }
                 if (tg.galpha && live && q.alpha_ok) T.add(2u * (uint32_t) A.V + q.bid, q.alpha, 0.f, 0.f);
-                if (A.s[it].evidx) scatter_triangle_direct(T, 0u, live && q.em_ok, q.ei, q.em);
+                if (A.s[it].emit) scatter_triangle_direct(T, 0u, live && q.em_ok, q.ei, q.em);
             }
         }
         if (T.crowded()) T.flush();               // workgroup-uniform census
@@ -104,17 +104,16 @@ extern "C" int epsm_scatter(int variant, int64_t N, int K,
     for (int k = 0; k < K; ++k) {
         const EpsmVertexRecord &v = verts[k];
         const EpsmScatterRecord &s = sc[k];
-        if (!v.p0 || !v.p1 || !v.p2 || !v.n0 || !v.n1 || !v.n2 || !v.b0 || !v.b1 || !s.vidx || !s.mode)
+        if (!v.p0 || !v.p1 || !v.p2 || !v.n0 || !v.n1 || !v.n2 || !v.b0 || !v.b1 || !s.tri)
             return fail(EPSM_EINVAL, "epsm_scatter: NULL pointer in a vertex / scatter record");
-        if (s.evidx && (!s.eb0 || !s.eb1 || !s.eweight))
-            return fail(EPSM_EINVAL, "epsm_scatter: evidx given without eb0/eb1/eweight");
+        if ((((uintptr_t) s.tri) | ((uintptr_t) s.aux) | ((uintptr_t) s.emit)) & 15)
+            return fail(EPSM_EINVAL, "epsm_scatter: tri/aux/emit must be 16-byte aligned");
         VertexPtrs<float> &o = A.v[k];
         o.p0 = (const float *) v.p0; o.p1 = (const float *) v.p1; o.p2 = (const float *) v.p2;
         o.n0 = (const float *) v.n0; o.n1 = (const float *) v.n1; o.n2 = (const float *) v.n2;
         o.b0 = (const float *) v.b0; o.b1 = (const float *) v.b1;
         ScatterPtrs<float> &t = A.s[k];
-        t.vidx = s.vidx; t.mode = s.mode; t.bsdf_id = s.bsdf_id; t.dhf_dalpha = s.dhf_dalpha;
-        t.evidx = s.evidx; t.eb0 = s.eb0; t.eb1 = s.eb1; t.eweight = s.eweight;
+        t.tri = s.tri; t.aux = s.aux; t.emit = s.emit;
     }
     Targets T{grad_pos, grad_nrm, grad_alpha};
     const int64_t chunks = (N + 255) / 256;

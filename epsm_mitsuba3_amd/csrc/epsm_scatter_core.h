@@ -18,14 +18,25 @@ namespace epsm {
 constexpr uint32_t kNoIndex = 0xFFFFFFFFu;
 constexpr uint32_t kModeVertexNormals = 0x1u, kModeFlip = 0x2u, kModePos = 0x4u, kModeNrm = 0x8u;
 
+// EpsmScatterRecord (include/epsm.h): three packed arrays, one or two 16-byte loads each.
+// Float fields travel as raw bits; `R` only matters for the host harness / oracle where the
+// arrays still hold fp32.
 template <typename R> struct ScatterPtrs {
-    const uint32_t *vidx;      // (N,3)
-    const uint8_t *mode;       // (N)
-    const uint32_t *bsdf_id;   // (N) or null
-    const R *dhf_dalpha;       // (N,3) or null
-    const uint32_t *evidx;     // (N,3) or null
-    const R *eb0, *eb1, *eweight;
+    const uint32_t *tri;       // (N,4) v0,v1,v2,mode
+    const uint32_t *aux;       // (N,4) bsdf_id, dhf xyz   or null
+    const uint32_t *emit;      // (N,8) e0,e1,e2, eb0,eb1,ew, 0,0   or null
 };
+EPSM_HD float bits_to_float(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
+struct U4 { uint32_t x, y, z, w; };
+EPSM_HD U4 load_u4(const uint32_t *base, int64_t i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 v = *reinterpret_cast<const uint4 *>(base + 4 * i);
+    U4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
+#else
+    const uint32_t *p = base + 4 * i;
+    U4 o; o.x = p[0]; o.y = p[1]; o.z = p[2]; o.w = p[3]; return o;
+#endif
+}
 
 template <typename R> struct ScatterArgs {
     int64_t N;
@@ -71,8 +82,9 @@ template <typename R>
 EPSM_HD VertexItems<R> vertex_items(const VertexPtrs<R> &v, const ScatterPtrs<R> &s, int64_t i,
                                     const VertexGrads<R> &g, int64_t V, int64_t B) {
     VertexItems<R> o;
-    const uint32_t mode = s.mode[i];
-    o.vi[0] = s.vidx[3 * i + 0]; o.vi[1] = s.vidx[3 * i + 1]; o.vi[2] = s.vidx[3 * i + 2];
+    const U4 t4 = load_u4(s.tri, i);
+    const uint32_t mode = t4.w;
+    o.vi[0] = t4.x; o.vi[1] = t4.y; o.vi[2] = t4.z;
     const bool idx_ok = o.vi[0] < (uint64_t) V && o.vi[1] < (uint64_t) V && o.vi[2] < (uint64_t) V;
     o.pos_ok = idx_ok && (mode & kModePos);
     o.nrm_ok = idx_ok && (mode & kModeNrm) && (mode & kModeVertexNormals);
@@ -110,17 +122,22 @@ EPSM_HD VertexItems<R> vertex_items(const VertexPtrs<R> &v, const ScatterPtrs<R>
     }
     // bsdf_sample.hf * path_grad[5it+4]  (epsm.py:645)
     o.alpha_ok = false; o.alpha = R(0); o.bid = kNoIndex;
-    if (g.has_nm && s.bsdf_id && s.dhf_dalpha) {
-        o.bid = s.bsdf_id[i];
-        if (o.bid < (uint64_t) B && nz3(g.gm)) { o.alpha_ok = true; o.alpha = dot(g.gm, load3(s.dhf_dalpha, i)); }
+    if (g.has_nm && s.aux) {
+        const U4 a4 = load_u4(s.aux, i);
+        o.bid = a4.x;
+        if (o.bid < (uint64_t) B && nz3(g.gm)) {
+            o.alpha_ok = true;
+            o.alpha = dot(g.gm, mk3<R>(R(bits_to_float(a4.y)), R(bits_to_float(a4.z)), R(bits_to_float(a4.w))));
+        }
     }
     // (4) si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627)
     o.em_ok = false; o.em[0] = o.em[1] = o.em[2] = zero3<R>(); o.ei[0] = o.ei[1] = o.ei[2] = kNoIndex;
-    if (s.evidx) {
-        o.ei[0] = s.evidx[3 * i + 0]; o.ei[1] = s.evidx[3 * i + 1]; o.ei[2] = s.evidx[3 * i + 2];
+    if (s.emit) {
+        const U4 e4 = load_u4(s.emit, 2 * i), f4 = load_u4(s.emit, 2 * i + 1);
+        o.ei[0] = e4.x; o.ei[1] = e4.y; o.ei[2] = e4.z;
         if (o.ei[0] < (uint64_t) V && o.ei[1] < (uint64_t) V && o.ei[2] < (uint64_t) V && nz3(g.glight)) {
-            const V3<R> gl = g.glight * s.eweight[i];
-            const R c0 = s.eb0[i], c1 = s.eb1[i];
+            const V3<R> gl = g.glight * R(bits_to_float(f4.y));
+            const R c0 = R(bits_to_float(e4.w)), c1 = R(bits_to_float(f4.x));
             o.em_ok = true;
             o.em[0] = gl * c0; o.em[1] = gl * c1; o.em[2] = gl * (R(1) - c0 - c1);
         }

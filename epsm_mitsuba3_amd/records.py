@@ -101,44 +101,47 @@ class PackedRecords:
 
 class EpsmScatterRecord(C.Structure):
     """Mirror of ``struct EpsmScatterRecord`` (include/epsm.h)."""
-    _fields_ = [(n, C.c_void_p) for n in (
-        "vidx", "mode", "bsdf_id", "dhf_dalpha", "evidx", "eb0", "eb1", "eweight")]
+    _fields_ = [(n, C.c_void_p) for n in ("tri", "aux", "emit")]
 
 
 MODE_VERTEX_NORMALS, MODE_FLIP_NORMALS, MODE_POS_ATTACHED, MODE_NRM_ATTACHED = 1, 2, 4, 8
 NO_INDEX = 0xFFFFFFFF
 
 
-class PackedScatter:
-    """Per-vertex addressing of the parameter buffers next to ``PackedRecords``.
+def pack_scatter_vertex(rec: dict, device, float_dtype=torch.float32) -> dict:
+    """One logged vertex's parameter addressing -> the three packed int32 arrays of
+    ``EpsmScatterRecord``: ``tri (N,4) = [v0,v1,v2,mode]``, ``aux (N,4) = [bsdf_id, dhf xyz bits]``,
+    ``emit (N,8) = [e0,e1,e2, eb0,eb1,eweight bits, 0,0]``.  Accepts either the packed keys or the
+    loose ones (``vidx, mode, bsdf_id, dhf_dalpha, evidx, eb0, eb1, eweight``)."""
+    dev = torch.device(device)
+    if "tri" in rec:
+        out = {"tri": rec["tri"], "aux": rec.get("aux"), "emit": rec.get("emit")}
+    else:
+        i32 = lambda t: t.detach().to(dev).to(torch.int32)
+        bits = lambda t: t.detach().to(dev).to(torch.float32).contiguous().view(torch.int32)
+        tri = torch.cat([i32(rec["vidx"]).reshape(-1, 3), i32(rec["mode"]).reshape(-1, 1)], dim=1)
+        out = {"tri": tri, "aux": None, "emit": None}
+        if rec.get("bsdf_id") is not None and rec.get("dhf_dalpha") is not None:
+            out["aux"] = torch.cat([i32(rec["bsdf_id"]).reshape(-1, 1), bits(rec["dhf_dalpha"]).reshape(-1, 3)], dim=1)
+        if rec.get("evidx") is not None:
+            n = tri.shape[0]
+            out["emit"] = torch.cat([i32(rec["evidx"]).reshape(-1, 3), bits(rec["eb0"]).reshape(-1, 1),
+                                     bits(rec["eb1"]).reshape(-1, 1), bits(rec["eweight"]).reshape(-1, 1),
+                                     torch.zeros((n, 2), dtype=torch.int32, device=dev)], dim=1)
+    return {k: (None if v is None else v.detach().to(device=dev, dtype=torch.int32).contiguous()) for k, v in out.items()}
 
-    ``scatter_info[k-1]`` is a dict with ``vidx (N,3) int32/uint32``, ``mode (N) uint8``
-    and optionally ``bsdf_id (N)``, ``dhf_dalpha (N,3)``, ``evidx (N,3)``, ``eb0``,
-    ``eb1``, ``eweight (N)``.  Index value -1 / 0xFFFFFFFF means "no parameter".
-    """
+
+class PackedScatter:
+    """Per-vertex addressing of the parameter buffers next to ``PackedRecords``; keeps the packed
+    tensors alive next to the ctypes array.  ``scatter_info[k-1]``: see ``pack_scatter_vertex``."""
 
     def __init__(self, scatter_info: Sequence[dict], device, float_dtype=torch.float32):
         self.K = len(scatter_info)
         self.device = torch.device(device)
-        self._keep: List[torch.Tensor] = []
+        self.packed = [pack_scatter_vertex(rec, self.device, float_dtype) for rec in scatter_info]
         self.records = (EpsmScatterRecord * self.K)()
-
-        def conv(t, dtype):
-            t = t.detach()
-            if t.dtype != dtype or t.device != self.device or not t.is_contiguous():
-                t = t.to(device=self.device, dtype=dtype).contiguous()
-            self._keep.append(t)
-            return t.data_ptr()
-
-        for k, rec in enumerate(scatter_info):
+        for k, p in enumerate(self.packed):
             r = self.records[k]
-            r.vidx = conv(rec["vidx"], torch.int32)
-            r.mode = conv(rec["mode"], torch.uint8)
-            if rec.get("bsdf_id") is not None and rec.get("dhf_dalpha") is not None:
-                r.bsdf_id = conv(rec["bsdf_id"], torch.int32)
-                r.dhf_dalpha = conv(rec["dhf_dalpha"], float_dtype)
-            if rec.get("evidx") is not None:
-                r.evidx = conv(rec["evidx"], torch.int32)
-                r.eb0 = conv(rec["eb0"], float_dtype)
-                r.eb1 = conv(rec["eb1"], float_dtype)
-                r.eweight = conv(rec["eweight"], float_dtype)
+            r.tri = p["tri"].data_ptr()
+            r.aux = p["aux"].data_ptr() if p["aux"] is not None else None
+            r.emit = p["emit"].data_ptr() if p["emit"] is not None else None

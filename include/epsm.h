@@ -153,16 +153,15 @@ int epsm_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, int res,
 #define EPSM_MODE_NRM_ATTACHED   0x8u  /* vertex normals of this mesh receive gradients */
 
 typedef struct EpsmScatterRecord {
-    const uint32_t *vidx;       /* (N,3) u32  indices of the hit triangle's vertices in the flat
-                                              (V,3) position / normal buffers; EPSM_NO_INDEX = skip */
-    const uint8_t *mode;        /* (N)   u8   EPSM_MODE_* bits of the hit mesh */
-    const uint32_t *bsdf_id;    /* (N)   u32  slot in grad_alpha, EPSM_NO_INDEX = none; may be NULL */
-    const float *dhf_dalpha;    /* (N,3) f32  d hf / d alpha of the BSDF sample (roughconductor.cpp:249-255);
-                                              may be NULL */
-    const uint32_t *evidx;      /* (N,3) u32  triangle hit by the emitter-sample shadow ray (epsm.py:622-625);
-                                              may be NULL */
-    const float *eb0, *eb1;     /* (N)   f32  barycentrics of that hit */
-    const float *eweight;       /* (N)   f32  sum_rgb(Lr_dir) (epsm.py:627) */
+    const uint32_t *tri;    /* (N,4) u32  [v0, v1, v2, mode]: rows of the hit triangle's vertices in the flat (V,3)
+                                          position / normal buffers (EPSM_NO_INDEX = skip) and the EPSM_MODE_* bits
+                                          of the hit mesh; one 16-byte load per path */
+    const uint32_t *aux;    /* (N,4)      [bsdf_id u32, d hf / d alpha as 3 x f32 bits]: slot in grad_alpha
+                                          (EPSM_NO_INDEX = none) and the derivative of the sampled microfacet normal
+                                          w.r.t. the BSDF's alpha (roughconductor.cpp:249-255); may be NULL */
+    const uint32_t *emit;   /* (N,8)      [e0, e1, e2 u32, eb0, eb1, eweight f32, 0, 0]: triangle hit by the
+                                          emitter-sample shadow ray (epsm.py:622-625), its barycentrics and
+                                          sum_rgb(Lr_dir) (epsm.py:627); may be NULL */
 } EpsmScatterRecord;
 
 /* ---------------------------------------------------------------------------
@@ -171,6 +170,8 @@ typedef struct EpsmScatterRecord {
  *     calc_grad are accumulated into the parameter-gradient buffers, i.e. the
  *     adjoint of the vertex gathers (mesh.h:94-106) as float atomics.
  *   per logged vertex k (iteration it = k-1):
+ *     (vidx = tri[0..2], evidx = emit[0..2], eb = emit[3..4], eweight = emit[5], bsdf_id = aux[0],
+ *      dhf_dalpha = aux[1..3])
  *     grad_pos[vidx_j] += out_param[5it+j]                      (si.p_j * path_grad[5it+j],  :559-560)
  *     grad_pos[vidx_j] += b_j * out_diffuse[it]                 (si_follow.p * diffuse_grad[it], :561-562)
  *     normals:  d/dn_j of  sh_frame.n . out_param[5it+3]        (:645; mesh.cpp:784-790 or flat :729,811-816)

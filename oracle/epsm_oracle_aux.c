@@ -105,8 +105,8 @@ int epsm_oracle_scatter(int variant, int64_t N, int K,
         for (int it = 0; it < K; ++it) {
             const EpsmVertexRecord *v = &verts[it];
             const EpsmScatterRecord *s = &sc[it];
-            const uint32_t mode = s->mode[i];
-            const uint32_t *vi = s->vidx + 3 * i;
+            const uint32_t mode = s->tri[4 * i + 3];
+            const uint32_t *vi = s->tri + 4 * i;
             const int idx_ok = vi[0] < (uint64_t) V && vi[1] < (uint64_t) V && vi[2] < (uint64_t) V;
             const double b0 = ((const float *) v->b0)[i], b1 = ((const float *) v->b1)[i], b2 = 1.0 - b0 - b1;
             const double bw[3] = {b0, b1, b2};
@@ -150,20 +150,21 @@ int epsm_oracle_scatter(int variant, int64_t N, int K,
                     for (int a = 0; a < 3; ++a) neg[a] = -(d0b[a] + d1b[a]);
                     add3(grad_pos, vi[1], d0b, 1.0); add3(grad_pos, vi[2], d1b, 1.0); add3(grad_pos, vi[0], neg, 1.0);
                 }
-                if (s->bsdf_id && s->dhf_dalpha && grad_alpha) {
-                    uint32_t bid = s->bsdf_id[i];
+                if (s->aux && grad_alpha) {
+                    uint32_t bid = s->aux[4 * i];
                     if (bid < (uint64_t) B) {
                         const double *gm = out_param + ((int64_t) (5 * it + 4) * N + i) * 3;
-                        const float *dh = s->dhf_dalpha + 3 * i;
+                        const float *dh = (const float *) (s->aux + 4 * i + 1);
                         grad_alpha[bid] += gm[0] * dh[0] + gm[1] * dh[1] + gm[2] * dh[2];
                     }
                 }
             }
             /* epsm.py:622-627 */
-            if (s->evidx) {
-                const uint32_t *e = s->evidx + 3 * i;
+            if (s->emit) {
+                const uint32_t *e = s->emit + 8 * i;
+                const float *ef = (const float *) (s->emit + 8 * i + 3);
                 if (e[0] < (uint64_t) V && e[1] < (uint64_t) V && e[2] < (uint64_t) V) {
-                    double c0 = s->eb0[i], c1 = s->eb1[i], w = s->eweight[i];
+                    double c0 = ef[0], c1 = ef[1], w = ef[2];
                     const double *g = out_light + ((int64_t) it * N + i) * 3;
                     add3(grad_pos, e[0], g, w * c0); add3(grad_pos, e[1], g, w * c1); add3(grad_pos, e[2], g, w * (1.0 - c0 - c1));
                 }
