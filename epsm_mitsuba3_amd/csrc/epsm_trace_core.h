@@ -1,0 +1,674 @@
+// epsm_trace_core.h -- per-path code of the wavefront tracer (include/epsm_trace.h).
+//
+// Restates, for triangle meshes and the plugin set the EPSM experiments use
+// (EPSM/exp/*.py: obj/ply/rectangle, diffuse, roughconductor, dielectric, twosided,
+// area, point, perspective, hdrfilm + gaussian, independent), the unidirectional path
+// tracer with emitter sampling + MIS of EPSMIntegrator.sample_path (epsm.py:503-742)
+// including its vertex log (epsm.py:547, 648-654).  Reference lines are cited at each
+// step.  Plain C++ (fp32), compiled by hipcc for gfx950 and by g++ for the host harness.
+#pragma once
+
+#include "epsm_path_core.h"
+#include "epsm_scatter_core.h"
+#include "../../include/epsm_trace.h"
+
+namespace epsm {
+
+typedef V3<float> F3;
+EPSM_HD F3 f3(float x, float y, float z) { return mk3<float>(x, y, z); }
+EPSM_HD F3 ld3(const float *p) { return f3(p[0], p[1], p[2]); }
+EPSM_HD F3 mul3(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+EPSM_HD float max3(F3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
+EPSM_HD float safe_sqrt(float x) { return sqrtf(fmaxf(x, 0.f)); }
+EPSM_HD float sqr(float x) { return x * x; }
+EPSM_HD F3 normalize3(F3 v) { return v * (1.f / sqrtf(dot(v, v))); }
+EPSM_HD float mulsign(float x, float s) { return s < 0.f ? -x : x; }   // x * sign(s), sign(+-0) by bit in drjit; 0 -> +
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.31830988618379067154f;
+constexpr float kEps = 5.9604644775390625e-8f;          // numeric_limits<float>::epsilon()/2  (math.h Epsilon)
+constexpr float kRayEps = kEps * 1500.f;                // math::RayEpsilon
+constexpr float kShadowEps = kRayEps * 10.f;            // math::ShadowEpsilon
+constexpr float kInf = 3.402823466e+38f;
+
+// BSDF flag words (include/mitsuba/render/bsdf.h:31-101)
+constexpr uint32_t kFlDiffuseRefl = 0x2, kFlGlossyRefl = 0x8, kFlDeltaRefl = 0x20, kFlDeltaTrans = 0x40,
+                   kFlNonSymmetric = 0x4000, kFlFront = 0x8000, kFlBack = 0x10000;
+constexpr uint32_t kFlSmooth = 0x2 | 0x4 | 0x8 | 0x10;  // Diffuse | Glossy
+constexpr uint32_t kFlDelta = 0x1 | 0x20 | 0x40;        // Null | DeltaReflection | DeltaTransmission
+
+// ---------------------------------------------------------------------------
+// sampler: independent (PCG32) seeded through TEA  (src/render/sampler.cpp:115-134)
+// ---------------------------------------------------------------------------
+struct Pcg32 {
+    uint64_t state, inc;
+    EPSM_HD uint32_t next_u32() {
+        const uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        const uint32_t xorshifted = (uint32_t) (((old >> 18u) ^ old) >> 27u);
+        const uint32_t rot = (uint32_t) (old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+    }
+    EPSM_HD float next_1d() {
+        union { uint32_t u; float f; } c;
+        c.u = (next_u32() >> 9) | 0x3f800000u;
+        return c.f - 1.f;
+    }
+};
+EPSM_HD void sample_tea_32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1) {
+    uint32_t sum = 0;
+    for (int i = 0; i < 4; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    o0 = v0; o1 = v1;
+}
+EPSM_HD Pcg32 seed_sampler(uint32_t seed, uint32_t wavefront_index) {
+    uint32_t v0, v1;
+    sample_tea_32(seed, wavefront_index, v0, v1);       // sampler.cpp:127
+    Pcg32 r;                                             // m_rng.seed(1, v0, v1)
+    r.state = 0; r.inc = ((uint64_t) v1 << 1) | 1u;
+    r.next_u32();
+    r.state += (uint64_t) v0;
+    r.next_u32();
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// warps (include/mitsuba/core/warp.h)
+// ---------------------------------------------------------------------------
+EPSM_HD void square_to_uniform_disk_concentric(float u, float v, float &ox, float &oy) {
+    const float x = 2.f * u - 1.f, y = 2.f * v - 1.f;
+    const bool is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
+    const float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * kPi * rp / r;
+    if (q13) phi = 0.5f * kPi - phi;
+    if (is_zero) phi = 0.f;
+    ox = r * cosf(phi); oy = r * sinf(phi);
+}
+EPSM_HD F3 square_to_cosine_hemisphere(float u, float v) {
+    float x, y;
+    square_to_uniform_disk_concentric(u, v, x, y);
+    return f3(x, y, safe_sqrt(1.f - x * x - y * y));
+}
+EPSM_HD void square_to_uniform_triangle(float u, float v, float &bx, float &by) {
+    const float t = safe_sqrt(1.f - u);
+    bx = 1.f - t; by = t * v;
+}
+// coordinate_system (include/mitsuba/core/vector.h, Duff et al.)
+EPSM_HD void coordinate_system(F3 n, F3 &s, F3 &t) {
+    const float sign = n.z >= 0.f ? 1.f : -1.f, a = -1.f / (sign + n.z), b = n.x * n.y * a;
+    s = f3(mulsign(n.x * n.x * a, n.z) + 1.f, mulsign(b, n.z), mulsign(-n.x, n.z));
+    t = f3(b, n.y * n.y * a + sign, -n.y);
+}
+
+// ---------------------------------------------------------------------------
+// ray / triangle / BVH
+// ---------------------------------------------------------------------------
+struct Ray { F3 o, d; float maxt; };
+
+// Moeller-Trumbore (include/mitsuba/render/mesh.h:343-365)
+EPSM_HD bool moeller_trumbore(const Ray &r, F3 p0, F3 p1, F3 p2, float &t, float &u, float &v) {
+    const F3 e1 = p1 - p0, e2 = p2 - p0;
+    const F3 pvec = cross(r.d, e2);
+    const float inv_det = 1.f / dot(e1, pvec);
+    const F3 tvec = r.o - p0;
+    u = dot(tvec, pvec) * inv_det;
+    const F3 qvec = cross(tvec, e1);
+    v = dot(r.d, qvec) * inv_det;
+    t = dot(e2, qvec) * inv_det;
+    return u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t <= r.maxt;
+}
+EPSM_HD bool hit_box(const EpsmBvhNode &n, F3 o, F3 inv_d, float maxt) {
+    float t0 = 0.f, t1 = maxt;
+    const float lo[3] = {n.lo[0], n.lo[1], n.lo[2]}, hi[3] = {n.hi[0], n.hi[1], n.hi[2]};
+    const float oo[3] = {o.x, o.y, o.z}, id[3] = {inv_d.x, inv_d.y, inv_d.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float ta = (lo[a] - oo[a]) * id[a], tb = (hi[a] - oo[a]) * id[a];
+        if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; }
+        t0 = fmaxf(t0, ta); t1 = fminf(t1, tb * 1.0000004f);
+    }
+    return t0 <= t1;
+}
+struct TriHit { bool hit; uint32_t tri; float t, u, v; };
+
+template <bool ANY_HIT>
+EPSM_HD TriHit intersect(const EpsmScene &S, Ray r) {
+    TriHit best; best.hit = false; best.tri = 0; best.t = r.maxt; best.u = best.v = 0.f;
+    if (S.n_nodes <= 0) return best;
+    const F3 inv_d = f3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+    uint32_t stack[48];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const EpsmBvhNode n = S.bvh[stack[--sp]];
+        if (!hit_box(n, r.o, inv_d, r.maxt)) continue;
+        if (n.count > 0) {
+            for (uint32_t e = n.left_or_first; e < n.left_or_first + n.count; ++e) {
+                const uint32_t q = S.prim_index[e];
+                const uint32_t *iv = S.tri + 3 * (int64_t) q;
+                float t, u, v;
+                if (moeller_trumbore(r, ld3(S.positions + 3 * (int64_t) iv[0]), ld3(S.positions + 3 * (int64_t) iv[1]),
+                                     ld3(S.positions + 3 * (int64_t) iv[2]), t, u, v)) {
+                    best.hit = true; best.tri = q; best.t = t; best.u = u; best.v = v;
+                    r.maxt = t;
+                    if (ANY_HIT) return best;
+                }
+            }
+        } else if (sp + 2 <= 48) {
+            stack[sp++] = n.left_or_first;
+            stack[sp++] = n.left_or_first + 1;
+        }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------
+// surface interaction (src/render/mesh.cpp:632-892 incl. the EPSM fields :712-720, 784-827)
+// ---------------------------------------------------------------------------
+struct SurfHit {
+    bool valid;
+    float t;
+    uint32_t tri, mesh, vi[3], mesh_flags;
+    int32_t bsdf, emitter;
+    float b0, b1, b2;                 // weights of p0,p1,p2: b1 = u, b2 = v, b0 = 1-u-v (mesh.cpp:698-700)
+    F3 p, n, shn, fs, ft;             // position, geometric normal, shading frame (s, t, n)
+    F3 p0, p1, p2, n0, n1, n2;        // logged triangle (normals post-flip, flat: n0=n1=n2=n)
+    F3 wi;                            // -ray.d in the shading frame
+};
+EPSM_HD F3 to_local(const SurfHit &h, F3 v) { return f3(dot(v, h.fs), dot(v, h.ft), dot(v, h.shn)); }
+EPSM_HD F3 to_world(const SurfHit &h, F3 v) { return h.fs * v.x + h.ft * v.y + h.shn * v.z; }
+
+EPSM_HD SurfHit surface_interaction(const EpsmScene &S, const Ray &r, const TriHit &th) {
+    SurfHit h;
+    h.valid = th.hit;
+    h.t = th.hit ? th.t : kInf;
+    h.tri = th.tri; h.mesh = 0; h.mesh_flags = 0; h.bsdf = -1; h.emitter = -1;
+    h.vi[0] = h.vi[1] = h.vi[2] = kNoIndex;
+    h.b0 = h.b1 = h.b2 = 0.f;
+    h.p = h.n = h.shn = h.fs = h.ft = h.wi = zero3<float>();
+    h.p0 = h.p1 = h.p2 = h.n0 = h.n1 = h.n2 = zero3<float>();
+    if (!th.hit) return h;
+    const uint32_t *iv = S.tri + 3 * (int64_t) th.tri;
+    h.vi[0] = iv[0]; h.vi[1] = iv[1]; h.vi[2] = iv[2];
+    h.mesh = S.tri_mesh[th.tri];
+    const EpsmMesh m = S.meshes[h.mesh];
+    h.mesh_flags = m.flags; h.bsdf = m.bsdf; h.emitter = m.emitter;
+    h.p0 = ld3(S.positions + 3 * (int64_t) iv[0]);
+    h.p1 = ld3(S.positions + 3 * (int64_t) iv[1]);
+    h.p2 = ld3(S.positions + 3 * (int64_t) iv[2]);
+    h.b1 = th.u; h.b2 = th.v; h.b0 = 1.f - th.u - th.v;
+    h.p = h.p0 * h.b0 + h.p1 * h.b1 + h.p2 * h.b2;                       // mesh.cpp:709
+    h.n = normalize3(cross(h.p1 - h.p0, h.p2 - h.p0));                   // mesh.cpp:729
+    if (m.flags & EPSM_MESH_VERTEX_NORMALS) {                           // mesh.cpp:784-790
+        h.n0 = ld3(S.normals + 3 * (int64_t) iv[0]);
+        h.n1 = ld3(S.normals + 3 * (int64_t) iv[1]);
+        h.n2 = ld3(S.normals + 3 * (int64_t) iv[2]);
+        h.shn = normalize3(h.n0 * h.b0 + h.n1 * h.b1 + h.n2 * h.b2);
+    } else {                                                            // mesh.cpp:811-816
+        h.shn = h.n; h.n0 = h.n1 = h.n2 = h.n;
+    }
+    if (m.flags & EPSM_MESH_FLIP_NORMALS) {                             // mesh.cpp:820-827
+        h.n = -h.n; h.shn = -h.shn; h.n0 = -h.n0; h.n1 = -h.n1; h.n2 = -h.n2;
+    }
+    // SurfaceInteraction::initialize_sh_frame with dp_du from coordinate_system(n) (mesh.cpp:734)
+    F3 dpdu, dpdv;
+    coordinate_system(h.n, dpdu, dpdv);
+    h.fs = normalize3(dpdu - h.shn * dot(h.shn, dpdu));
+    h.ft = cross(h.shn, h.fs);
+    h.wi = to_local(h, -r.d);
+    return h;
+}
+// Interaction::offset_p / spawn_ray / spawn_ray_to (include/mitsuba/render/interaction.h)
+EPSM_HD F3 offset_p(const SurfHit &h, F3 d) {
+    float mag = (1.f + fmaxf(fabsf(h.p.x), fmaxf(fabsf(h.p.y), fabsf(h.p.z)))) * kRayEps;
+    mag = mulsign(mag, dot(h.n, d));
+    return h.p + h.n * mag;
+}
+EPSM_HD Ray spawn_ray(const SurfHit &h, F3 d) { Ray r; r.o = offset_p(h, d); r.d = d; r.maxt = kInf; return r; }
+EPSM_HD Ray spawn_ray_to(const SurfHit &h, F3 target, float &dist) {
+    Ray r;
+    r.o = offset_p(h, target - h.p);
+    F3 d = target - r.o;
+    dist = sqrtf(dot(d, d));
+    r.d = d * (1.f / dist);
+    r.maxt = dist * (1.f - kShadowEps);
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Fresnel (include/mitsuba/render/fresnel.h:34-72, 92-117)
+// ---------------------------------------------------------------------------
+EPSM_HD void fresnel(float cos_i, float eta, float &r, float &cos_t, float &eta_it, float &eta_ti) {
+    const bool outside = cos_i >= 0.f;
+    const float rcp_eta = 1.f / eta;
+    eta_it = outside ? eta : rcp_eta;
+    eta_ti = outside ? rcp_eta : eta;
+    const float cos_t_sqr = 1.f - (1.f - cos_i * cos_i) * eta_ti * eta_ti;
+    const float ci = fabsf(cos_i), ct = safe_sqrt(cos_t_sqr);
+    const bool index_matched = eta == 1.f, special = index_matched || ci == 0.f;
+    const float a_s = (ci - eta_it * ct) / (ci + eta_it * ct);
+    const float a_p = (ct - eta_it * ci) / (ct + eta_it * ci);
+    r = 0.5f * (a_s * a_s + a_p * a_p);
+    if (special) r = index_matched ? 0.f : 1.f;
+    cos_t = cos_i >= 0.f ? -ct : ct;                                     // mulsign_neg
+}
+EPSM_HD float fresnel_conductor(float cos_i, float eta_r, float eta_i) {
+    const float c2 = cos_i * cos_i, s2 = 1.f - c2, s4 = s2 * s2;
+    const float temp_1 = eta_r * eta_r - eta_i * eta_i - s2;
+    const float a_2_pb_2 = safe_sqrt(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r);
+    const float a = safe_sqrt(0.5f * (a_2_pb_2 + temp_1));
+    const float term_1 = a_2_pb_2 + c2, term_2 = 2.f * cos_i * a;
+    const float r_s = (term_1 - term_2) / (term_1 + term_2);
+    const float term_3 = a_2_pb_2 * c2 + s4, term_4 = term_2 * s2;
+    const float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return 0.5f * (r_s + r_p);
+}
+EPSM_HD F3 fresnel_conductor3(float cos_i, const EpsmBsdf &b) {
+    return f3(fresnel_conductor(cos_i, b.eta[0], b.k[0]), fresnel_conductor(cos_i, b.eta[1], b.k[1]),
+              fresnel_conductor(cos_i, b.eta[2], b.k[2]));
+}
+
+// ---------------------------------------------------------------------------
+// microfacet distribution (include/mitsuba/render/microfacet.h, isotropic)
+// ---------------------------------------------------------------------------
+EPSM_HD float mf_eval(const EpsmBsdf &b, F3 m) {
+    const float a = b.alpha, ct = m.z, ct2 = ct * ct;
+    float result;
+    if (b.distr == EPSM_DISTR_BECKMANN)
+        result = expf(-(sqr(m.x / a) + sqr(m.y / a)) / ct2) / (kPi * a * a * sqr(ct2));
+    else
+        result = 1.f / (kPi * a * a * sqr(sqr(m.x / a) + sqr(m.y / a) + sqr(m.z)));
+    return result * ct > 1e-20f ? result : 0.f;
+}
+EPSM_HD float mf_smith_g1(const EpsmBsdf &b, F3 v, F3 m) {
+    const float xy_alpha_2 = sqr(b.alpha * v.x) + sqr(b.alpha * v.y), tan2 = xy_alpha_2 / sqr(v.z);
+    float result;
+    if (b.distr == EPSM_DISTR_BECKMANN) {
+        const float a = 1.f / sqrtf(tan2), a2 = a * a;
+        result = a >= 1.6f ? 1.f : (3.535f * a + 2.181f * a2) / (1.f + 2.276f * a + 2.577f * a2);
+    } else {
+        result = 2.f / (1.f + sqrtf(1.f + tan2));
+    }
+    if (xy_alpha_2 == 0.f) result = 1.f;
+    if (dot(v, m) * v.z <= 0.f) result = 0.f;
+    return result;
+}
+EPSM_HD float mf_pdf(const EpsmBsdf &b, F3 wi, F3 m) {
+    float result = mf_eval(b, m);
+    if (b.sample_visible) result *= mf_smith_g1(b, wi, m) * fabsf(dot(wi, m)) / wi.z;
+    else result *= m.z;
+    return result;
+}
+// The fork forces the D*cos sampling branch (`if (true)`, microfacet.h) whatever sample_visible says.
+// Also returns d m / d alpha (tan(theta_m) is proportional to alpha for both distributions).
+EPSM_HD F3 mf_sample(const EpsmBsdf &b, float u, float v, float &pdf, F3 &dm_dalpha) {
+    const float phi = 2.f * kPi * v, sin_phi = sinf(phi), cos_phi = cosf(phi);
+    const float alpha_2 = b.alpha * b.alpha;
+    float cos_theta, cos_theta_2;
+    if (b.distr == EPSM_DISTR_BECKMANN) {
+        cos_theta = 1.f / sqrtf(1.f - alpha_2 * logf(1.f - u));
+        cos_theta_2 = cos_theta * cos_theta;
+        const float c3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+        pdf = (1.f - u) / (kPi * alpha_2 * c3);
+    } else {
+        const float tan2 = alpha_2 * u / (1.f - u);
+        cos_theta = 1.f / sqrtf(1.f + tan2);
+        cos_theta_2 = cos_theta * cos_theta;
+        const float temp = 1.f + tan2 / alpha_2, c3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+        pdf = 1.f / (kPi * alpha_2 * c3 * temp * temp);
+    }
+    const float sin_theta = sqrtf(1.f - cos_theta_2);
+    const float dtheta = sin_theta * cos_theta / b.alpha;
+    dm_dalpha = f3(cos_phi * cos_theta, sin_phi * cos_theta, -sin_theta) * dtheta;
+    return f3(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
+}
+
+// ---------------------------------------------------------------------------
+// BSDFs in the local frame
+// ---------------------------------------------------------------------------
+struct BsdfSample { F3 wo, weight, hf, dhf; float pdf, eta; uint32_t sampled_type; bool valid; };
+
+EPSM_HD uint32_t bsdf_flags(const EpsmBsdf &b) {
+    uint32_t f;
+    switch (b.type) {
+        case EPSM_BSDF_DIFFUSE_T: f = kFlDiffuseRefl | kFlFront; break;                       // diffuse.cpp
+        case EPSM_BSDF_CONDUCTOR_T: f = kFlDeltaRefl | kFlFront; break;                       // conductor.cpp
+        case EPSM_BSDF_ROUGHCONDUCTOR_T: f = kFlGlossyRefl | kFlFront; break;                 // roughconductor.cpp
+        default: f = kFlDeltaRefl | kFlDeltaTrans | kFlFront | kFlBack | kFlNonSymmetric; break;   // dielectric.cpp
+    }
+    if (b.twosided) f |= kFlBack;                                                             // twosided.cpp
+    return f;
+}
+EPSM_HD F3 reflect_local(F3 wi) { return f3(-wi.x, -wi.y, wi.z); }
+EPSM_HD F3 reflect_about(F3 wi, F3 m) { return m * (2.f * dot(wi, m)) - wi; }
+
+EPSM_HD BsdfSample bsdf_sample(const EpsmBsdf &b, F3 wi_in, float s1, float s2x, float s2y, bool active) {
+    BsdfSample o;
+    o.wo = o.weight = o.hf = o.dhf = zero3<float>(); o.pdf = 0.f; o.eta = 0.f; o.sampled_type = 0; o.valid = false;
+    if (!active) return o;
+    F3 wi = wi_in;
+    const bool flipped = b.twosided && wi.z < 0.f;                         // twosided.cpp: evaluate the front BSDF mirrored
+    if (flipped) wi.z = -wi.z;
+    const float cti = wi.z;
+    const F3 R = ld3(b.reflectance);
+    switch (b.type) {
+        case EPSM_BSDF_DIFFUSE_T: {                                       // diffuse.cpp:126-150
+            if (cti <= 0.f) return o;
+            o.wo = square_to_cosine_hemisphere(s2x, s2y);
+            o.pdf = o.wo.z * kInvPi;
+            o.eta = 1.f; o.sampled_type = kFlDiffuseRefl;
+            o.weight = R;
+            o.valid = o.pdf > 0.f;
+        } break;
+        case EPSM_BSDF_CONDUCTOR_T: {                                     // conductor.cpp:235-270
+            if (cti <= 0.f) return o;
+            o.wo = reflect_local(wi); o.pdf = 1.f; o.eta = 1.f; o.sampled_type = kFlDeltaRefl;
+            o.weight = mul3(fresnel_conductor3(cti, b), R);
+            o.valid = true;
+        } break;
+        case EPSM_BSDF_ROUGHCONDUCTOR_T: {                                // roughconductor.cpp:225-300
+            if (cti <= 0.f) return o;
+            float pdf; F3 dm;
+            const F3 m = mf_sample(b, s2x, s2y, pdf, dm);
+            o.wo = reflect_about(wi, m);
+            o.eta = 1.f; o.sampled_type = kFlGlossyRefl;
+            o.hf = m; o.dhf = dm;                                         // bs.hf = m  (:255)
+            if (!(pdf != 0.f && o.wo.z > 0.f)) { o.hf = m; return o; }
+            float w;
+            if (b.sample_visible) w = mf_smith_g1(b, o.wo, m);
+            else w = mf_smith_g1(b, wi, m) * mf_smith_g1(b, o.wo, m) * dot(wi, m) / (cti * m.z);
+            o.pdf = pdf / (4.f * dot(o.wo, m));
+            o.weight = mul3(fresnel_conductor3(dot(wi, m), b), R) * w;
+            o.valid = true;
+        } break;
+        default: {                                                        // dielectric.cpp:250-330
+            const float eta = b.int_ior / b.ext_ior;
+            float r_i, cos_t, eta_it, eta_ti;
+            fresnel(wi_in.z, eta, r_i, cos_t, eta_it, eta_ti);
+            const bool selected_r = s1 <= r_i;
+            o.pdf = selected_r ? r_i : 1.f - r_i;
+            o.sampled_type = selected_r ? kFlDeltaRefl : kFlDeltaTrans;
+            o.wo = selected_r ? reflect_local(wi_in) : f3(-eta_ti * wi_in.x, -eta_ti * wi_in.y, cos_t);
+            o.eta = selected_r ? 1.f : eta_it;
+            o.weight = selected_r ? R : f3(1.f, 1.f, 1.f) * (eta_ti * eta_ti);   // radiance transport: * sqr(eta_ti)
+            o.valid = o.pdf > 0.f;
+            return o;                                                     // never two-sided
+        }
+    }
+    if (flipped) { o.wo.z = -o.wo.z; }
+    return o;
+}
+// value (incl. cosine) and pdf for a given direction (eval_pdf)
+EPSM_HD void bsdf_eval_pdf(const EpsmBsdf &b, F3 wi, F3 wo, F3 &value, float &pdf) {
+    value = zero3<float>(); pdf = 0.f;
+    if (b.twosided && wi.z < 0.f) { wi.z = -wi.z; wo.z = -wo.z; }
+    const float cti = wi.z, cto = wo.z;
+    if (!(cti > 0.f && cto > 0.f)) return;
+    if (b.type == EPSM_BSDF_DIFFUSE_T) {                                  // diffuse.cpp:152-190
+        value = ld3(b.reflectance) * (kInvPi * cto);
+        pdf = cto * kInvPi;
+    } else if (b.type == EPSM_BSDF_ROUGHCONDUCTOR_T) {                    // roughconductor.cpp:302-400
+        const F3 H = normalize3(wi + wo);
+        const float D = mf_eval(b, H);
+        if (D == 0.f) return;
+        const float G = mf_smith_g1(b, wi, H) * mf_smith_g1(b, wo, H);
+        const float result = D * G / (4.f * cti);
+        value = mul3(fresnel_conductor3(dot(wi, H), b), ld3(b.reflectance)) * result;
+        pdf = mf_pdf(b, wi, H) / (4.f * dot(wo, H));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// emitters (src/emitters/area.cpp, point.cpp; src/render/scene.cpp:226-300; src/render/mesh.cpp sample_position)
+// ---------------------------------------------------------------------------
+struct EmitterSample {
+    F3 p, n, d, weight;              // ds.p, ds.n, ds.d, radiance / pdf (already zero when occluded / facing away)
+    float pdf, dist;
+    bool delta, valid;
+    uint32_t vi[3]; float b0, b1;    // triangle + barycentrics of the sampled point (parameter addressing)
+};
+EPSM_HD F3 emitter_normal(const EpsmScene &S, const EpsmMesh &m, const uint32_t *iv, float w0, float w1, float w2, F3 q0, F3 q1, F3 q2) {
+    F3 n = normalize3(cross(q1 - q0, q2 - q0));
+    if (m.flags & EPSM_MESH_VERTEX_NORMALS)
+        n = normalize3(ld3(S.normals + 3 * (int64_t) iv[0]) * w0 + ld3(S.normals + 3 * (int64_t) iv[1]) * w1 +
+                       ld3(S.normals + 3 * (int64_t) iv[2]) * w2);
+    if (m.flags & EPSM_MESH_FLIP_NORMALS) n = -n;
+    return n;
+}
+EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit &ref, float u, float v, bool active) {
+    EmitterSample e;
+    e.p = e.n = e.d = e.weight = zero3<float>(); e.pdf = 0.f; e.dist = 0.f; e.delta = false; e.valid = false;
+    e.vi[0] = e.vi[1] = e.vi[2] = kNoIndex; e.b0 = e.b1 = 0.f;
+    if (!active || S.n_emitters <= 0) return e;
+    // scene.cpp:233-246: uniform emitter choice, the sample is re-used
+    const int count = S.n_emitters;
+    int index = 0;
+    float emitter_weight = 1.f;
+    if (count > 1) {
+        index = (int) fminf(u * (float) count, (float) (count - 1));
+        u = (u - index / (float) count) * count;
+        emitter_weight = (float) count;
+    }
+    const EpsmEmitter em = S.emitters[index];
+    F3 radiance = ld3(em.radiance);
+    if (em.type == EPSM_EMITTER_POINT) {                                  // point.cpp:96-115
+        e.p = ld3(em.position);
+        F3 d = e.p - ref.p;
+        const float dist2 = dot(d, d);
+        e.dist = sqrtf(dist2); e.d = d * (1.f / e.dist);
+        e.pdf = 1.f; e.delta = true; e.n = zero3<float>();
+        e.weight = radiance * (1.f / dist2);
+    } else {                                                              // area.cpp:117-146 + Mesh::sample_position
+        const EpsmMesh m = S.meshes[em.mesh];
+        // triangle by area (sample_reuse on sample.y in Mitsuba; here on v), binary search in the CDF
+        const float *cdf = S.emitter_cdf + m.cdf_begin;
+        uint32_t lo = 0, hi = m.tri_count - 1;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] < v) lo = mid + 1; else hi = mid; }
+        const float c0 = lo > 0 ? cdf[lo - 1] : 0.f, c1 = cdf[lo];
+        v = c1 > c0 ? (v - c0) / (c1 - c0) : 0.f;
+        const uint32_t t = m.tri_begin + lo;
+        const uint32_t *iv = S.tri + 3 * (int64_t) t;
+        const F3 q0 = ld3(S.positions + 3 * (int64_t) iv[0]), q1 = ld3(S.positions + 3 * (int64_t) iv[1]),
+                 q2 = ld3(S.positions + 3 * (int64_t) iv[2]);
+        float bx, by;
+        square_to_uniform_triangle(u, v, bx, by);
+        const float w0 = 1.f - bx - by;
+        e.p = q0 * w0 + q1 * bx + q2 * by;
+        e.n = emitter_normal(S, m, iv, w0, bx, by, q0, q1, q2);
+        e.vi[0] = iv[0]; e.vi[1] = iv[1]; e.vi[2] = iv[2]; e.b0 = w0; e.b1 = bx;
+        F3 d = e.p - ref.p;
+        const float dist2 = dot(d, d);
+        e.dist = sqrtf(dist2); e.d = d * (1.f / e.dist);
+        const float dp = fabsf(dot(e.d, e.n));
+        e.pdf = dp != 0.f ? (1.f / m.area) * dist2 / dp : 0.f;           // shape.cpp sample_direction
+        const bool facing = dot(e.d, e.n) < 0.f && e.pdf != 0.f;          // area.cpp:129
+        e.weight = facing ? radiance * (1.f / e.pdf) : zero3<float>();
+        if (!facing) e.pdf = 0.f;
+    }
+    e.pdf /= emitter_weight;                                              // scene.cpp:262-266
+    e.weight = e.weight * emitter_weight;
+    e.valid = e.pdf != 0.f;
+    if (e.valid) {                                                        // scene.cpp:270-275 test_visibility
+        float dist;
+        const Ray sr = spawn_ray_to(ref, e.p, dist);
+        if (intersect<true>(S, sr).hit) e.weight = zero3<float>();
+    }
+    return e;
+}
+// pdf of having sampled the point `h` on an emitter from `ref` (scene.cpp pdf_emitter_direction)
+EPSM_HD float pdf_emitter_direction(const EpsmScene &S, F3 ref_p, const SurfHit &h) {
+    if (h.emitter < 0) return 0.f;
+    const EpsmMesh m = S.meshes[h.mesh];
+    F3 d = h.p - ref_p;
+    const float dist2 = dot(d, d);
+    d = d * (1.f / sqrtf(dist2));
+    const float dp = fabsf(dot(d, h.shn));                                // DirectionSample(si): n = si.sh_frame.n
+    float pdf = dp != 0.f ? (1.f / m.area) * dist2 / dp : 0.f;
+    if (S.n_emitters > 1) pdf /= (float) S.n_emitters;
+    return pdf;
+}
+EPSM_HD float mis_weight(float pdf_a, float pdf_b) {                      // common.py:1224-1230
+    const float a2 = pdf_a * pdf_a;
+    return pdf_a > 0.f ? a2 / (pdf_b * pdf_b + a2) : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// camera (src/sensors/perspective.cpp:238-279) and sample_rays (common.py:291-422)
+// ---------------------------------------------------------------------------
+EPSM_HD F3 xform_point(const float *m, F3 p) {                            // 4x4 row-major, with perspective divide
+    const float x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+                z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11], w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    const float iw = 1.f / w;
+    return f3(x * iw, y * iw, z * iw);
+}
+EPSM_HD F3 xform_vec34(const float *m, F3 v) {
+    return f3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+struct PrimaryRay { Ray ray; F3 dx, dy; float px, py; };
+EPSM_HD PrimaryRay sample_primary_ray(const EpsmSensor &C, int64_t wavefront_index, int spp, Pcg32 &rng) {
+    // common.py:320-335: idx // spp -> pixel, pos = pixel + next_2d()
+    const int64_t pix = wavefront_index / spp;
+    const int py = (int) (pix / C.width), px = (int) (pix - (int64_t) py * C.width);
+    const float jx = rng.next_1d(), jy = rng.next_1d();
+    PrimaryRay o;
+    o.px = px + jx; o.py = py + jy;
+    const float sx = o.px / C.width, sy = o.py / C.height;
+    const F3 near_p = xform_point(C.sample_to_camera, f3(sx, sy, 0.f));   // perspective.cpp:255-258
+    const F3 d = normalize3(near_p);
+    const float *W = C.to_world;                                          // 3x4
+    const F3 origin = f3(W[3], W[7], W[11]);
+    const F3 dw = xform_vec34(W, d);
+    const float inv_z = 1.f / d.z, near_t = C.near_clip * inv_z, far_t = C.far_clip * inv_z;
+    o.ray.o = origin + dw * near_t;                                       // perspective.cpp:266-270
+    o.ray.d = dw;
+    o.ray.maxt = far_t - near_t;
+    o.dx = xform_vec34(W, normalize3(near_p + ld3(C.dx)));               // perspective.cpp:274-275
+    o.dy = xform_vec34(W, normalize3(near_p + ld3(C.dy)));
+    return o;
+}
+
+// ---------------------------------------------------------------------------
+// the path (epsm.py:503-742)
+// ---------------------------------------------------------------------------
+EPSM_HD void st3(float *base, int64_t i, F3 v) { if (base) { base[3 * i] = v.x; base[3 * i + 1] = v.y; base[3 * i + 2] = v.z; } }
+EPSM_HD uint32_t f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+
+struct TraceArgs {
+    EpsmScene S;
+    EpsmSensor C;
+    uint32_t seed;
+    int spp, max_depth, rr_depth, K_log;
+    int64_t path_offset, N;
+    float *ray_o, *ray_d, *ray_dx, *ray_dy, *film_pos, *radiance;
+    uint8_t *valid;
+    EpsmRecordOut rec[kMaxVertices];
+};
+
+EPSM_HD void write_record(const EpsmRecordOut &R, int64_t i, bool active, const SurfHit &h, uint32_t flags,
+                          const EmitterSample &es, bool active_em, const BsdfSample &bs, float eweight, int32_t alpha_slot) {
+    const bool mesh = h.valid && (h.mesh_flags & EPSM_MESH_IS_MESH);
+    const F3 z = zero3<float>();
+    // analytic shapes leave the EPSM fields zero and ismesh = 0 (interaction.h:221-224 zero-initialised)
+    st3(R.p0, i, mesh ? h.p0 : z); st3(R.p1, i, mesh ? h.p1 : z); st3(R.p2, i, mesh ? h.p2 : z); st3(R.p, i, h.p);
+    st3(R.n0, i, mesh ? h.n0 : z); st3(R.n1, i, mesh ? h.n1 : z); st3(R.n2, i, mesh ? h.n2 : z); st3(R.normal, i, h.shn);
+    R.b0[i] = mesh ? h.b0 : 0.f; R.b1[i] = mesh ? h.b1 : 0.f;
+    R.eta[i] = bs.eta;
+    st3(R.hf, i, bs.hf); st3(R.light, i, es.p);
+    R.bsdf[i] = flags;
+    R.active[i] = active ? 1 : 0; R.active_em[i] = active_em ? 1 : 0; R.ismesh[i] = mesh ? 1 : 0;
+    uint32_t *t = R.tri + 4 * i;
+    t[0] = mesh ? h.vi[0] : kNoIndex; t[1] = mesh ? h.vi[1] : kNoIndex; t[2] = mesh ? h.vi[2] : kNoIndex;
+    t[3] = h.mesh_flags & 0xFu;
+    uint32_t *a = R.aux + 4 * i;
+    a[0] = alpha_slot >= 0 ? (uint32_t) alpha_slot : kNoIndex; a[1] = f2u(bs.dhf.x); a[2] = f2u(bs.dhf.y); a[3] = f2u(bs.dhf.z);
+    uint32_t *e = R.emit + 8 * i;
+    e[0] = es.vi[0]; e[1] = es.vi[1]; e[2] = es.vi[2]; e[3] = f2u(es.b0); e[4] = f2u(es.b1); e[5] = f2u(eweight); e[6] = 0; e[7] = 0;
+}
+
+EPSM_HD void trace_one_path(const TraceArgs &A, int64_t i) {
+    const EpsmScene &S = A.S;
+    const int64_t widx = A.path_offset + i;
+    Pcg32 rng = seed_sampler(A.seed, (uint32_t) widx);                    // common.py:475 sampler.seed(seed, wavefront_size)
+    const PrimaryRay pr = sample_primary_ray(A.C, widx, A.spp, rng);
+    st3(A.ray_o, i, pr.ray.o); st3(A.ray_d, i, pr.ray.d); st3(A.ray_dx, i, pr.dx); st3(A.ray_dy, i, pr.dy);
+    if (A.film_pos) { A.film_pos[2 * i] = pr.px; A.film_pos[2 * i + 1] = pr.py; }
+
+    Ray ray = pr.ray;
+    F3 L = zero3<float>(), beta = f3(1.f, 1.f, 1.f);
+    float eta = 1.f;
+    int depth = 0;
+    bool active = true;
+    F3 prev_p = zero3<float>();
+    float prev_bsdf_pdf = 1.f;
+    bool prev_bsdf_delta = true;
+    const int max_depth = A.max_depth < 6 ? A.max_depth : 6;              // epsm.py:549
+
+    for (int iteration = 0; iteration < max_depth; ++iteration) {         // epsm.py:551 (lanes stay in the loop, masked)
+        TriHit th; th.hit = false; th.tri = 0; th.t = kInf; th.u = th.v = 0.f;
+        if (active) th = intersect<false>(S, ray);
+        const SurfHit si = surface_interaction(S, ray, th);               // epsm.py:556-558
+        EpsmBsdf bsdf;
+        bsdf.type = EPSM_BSDF_DIFFUSE_T; bsdf.twosided = 0; bsdf.distr = 0; bsdf.sample_visible = 1; bsdf.alpha = 0.1f;
+        bsdf.reflectance[0] = bsdf.reflectance[1] = bsdf.reflectance[2] = 0.f;
+        bsdf.eta[0] = bsdf.eta[1] = bsdf.eta[2] = 0.f; bsdf.k[0] = bsdf.k[1] = bsdf.k[2] = 1.f;
+        bsdf.int_ior = 1.5046f; bsdf.ext_ior = 1.000277f; bsdf.alpha_slot = -1; bsdf.pad = 0;
+        uint32_t flags = 0;
+        if (si.valid && si.bsdf >= 0) { bsdf = S.bsdfs[si.bsdf]; flags = bsdf_flags(bsdf); }
+
+        // ---- direct emission, MIS against the emitter sample of the previous bounce (epsm.py:569-577)
+        F3 Le = zero3<float>();
+        if (si.valid && si.emitter >= 0 && si.wi.z > 0.f) {                // area.cpp eval: front side only
+            const float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction(S, prev_p, si);
+            const float mis = mis_weight(prev_bsdf_pdf, em_pdf);
+            Le = mul3(beta, ld3(S.emitters[si.emitter].radiance)) * mis;
+        }
+        // ---- emitter sampling (epsm.py:582-605)
+        bool active_next = (depth + 1 < A.max_depth) && si.valid;
+        bool active_em = active_next && (flags & kFlSmooth);
+        const float e1 = rng.next_1d(), e2 = rng.next_1d();              // sampler.next_2d()
+        const EmitterSample es = sample_emitter_direction(S, si, e1, e2, active_em);
+        active_em = active_em && es.pdf != 0.f;                           // :590
+        F3 Lr_dir = zero3<float>();
+        if (active_em) {
+            const F3 wo = to_local(si, es.d);
+            F3 bval; float bpdf;
+            bsdf_eval_pdf(bsdf, si.wi, wo, bval, bpdf);
+            const float mis_em = es.delta ? 1.f : mis_weight(es.pdf, bpdf);
+            Lr_dir = mul3(mul3(beta, bval), es.weight) * mis_em;          // :605
+        }
+        // ---- BSDF sampling: once detached, once attached with fresh numbers (epsm.py:633-643)
+        rng.next_1d(); rng.next_1d(); rng.next_1d();
+        const float s1 = rng.next_1d(), s2x = rng.next_1d(), s2y = rng.next_1d();
+        const BsdfSample bs = bsdf_sample(bsdf, si.wi, s1, s2x, s2y, active_next);
+        // ---- log (epsm.py:648-654)
+        if (iteration < A.K_log)
+            write_record(A.rec[iteration], i, active && si.valid, si, flags, es, active_em, bs,
+                         Lr_dir.x + Lr_dir.y + Lr_dir.z, bsdf.alpha_slot);
+        // ---- update (epsm.py:658-683)
+        if (active) L = L + Le + Lr_dir;
+        const F3 wo_world = to_world(si, bs.wo);
+        ray = spawn_ray(si, wo_world);
+        eta *= bs.valid ? bs.eta : 1.f;
+        beta = bs.valid ? mul3(beta, bs.weight) : zero3<float>();
+        prev_p = si.p;
+        prev_bsdf_pdf = bs.pdf;
+        prev_bsdf_delta = (bs.sampled_type & kFlDelta) != 0;
+        const float beta_max = max3(beta);
+        active_next = active_next && beta_max != 0.f;
+        const float rr_prob = fminf(beta_max * eta * eta, 0.95f);
+        const bool rr_active = depth >= A.rr_depth;
+        if (rr_active) beta = beta * (1.f / rr_prob);
+        const bool rr_continue = rng.next_1d() < rr_prob;
+        active_next = active_next && (!rr_active || rr_continue);
+        if (si.valid && active) depth += 1;                               // :734
+        active = active && active_next;                                   // :735
+    }
+    // bounces never reached are logged as inactive zeros
+    st3(A.radiance, i, L);
+    if (A.valid) A.valid[i] = depth != 0;
+}
+
+}  // namespace epsm

@@ -1,0 +1,554 @@
+"""Scene description for the native tracer: the subset of ``mi.load_dict`` that the EPSM
+experiments use (EPSM/exp/*.py): ``obj`` / inline meshes / ``rectangle``, ``diffuse``,
+``conductor``, ``roughconductor``, ``dielectric``, ``twosided``, ``area`` / ``point`` emitters,
+``perspective`` sensors with ``hdrfilm`` (+ ``box`` / ``gaussian`` rfilter) and an
+``independent`` sampler.  Geometry is flattened into the arrays of ``EpsmScene``
+(include/epsm_trace.h); a median-split BVH is built on the host with numpy.
+
+    scene = Scene.from_dict({...})                       # mi.load_dict shape
+    scene.attach("glass", positions=True)                # dr.enable_grad(params['glass.vertex_positions'])
+    params = scene.param_grads()                          # ParamGrads over the concatenated vertex buffers
+    img = integrator.render(scene, sensor=1, seed=0, spp=16)
+    integrator.render_backward(scene, params, grad_in, seed=0)
+    scene.set_vertex_positions("glass", new_positions)    # params.update()
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import dist as _dist
+from .params import ParamGrads
+
+MESH_VERTEX_NORMALS, MESH_FLIP_NORMALS, MESH_POS_ATTACHED, MESH_NRM_ATTACHED, MESH_IS_MESH = 1, 2, 4, 8, 16
+BSDF_TYPES = {"diffuse": 0, "conductor": 1, "roughconductor": 2, "dielectric": 3}
+
+# complex IORs at R,G,B for the `material` names the experiments use (approximate: Mitsuba
+# integrates measured spectra, data files that are not in the reference tree)
+CONDUCTORS = {
+    "none": ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)),
+    "Al": ((1.657460, 0.880369, 0.521229), (9.223869, 6.269523, 4.837001)),
+    "Cu": ((0.200438, 0.924033, 1.102212), (3.912949, 2.452848, 2.142188)),
+    "Au": ((0.143119, 0.374957, 1.442479), (3.983160, 2.385721, 1.603215)),
+    "Ag": ((0.155265, 0.116723, 0.138342), (4.828427, 3.122499, 2.147038)),
+}
+IOR = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "bk7": 1.5046, "glass": 1.5046, "diamond": 2.419}
+
+
+# ---------------------------------------------------------------------------- ctypes mirrors
+class EpsmMesh(C.Structure):
+    _fields_ = [("tri_begin", C.c_uint32), ("tri_count", C.c_uint32), ("flags", C.c_uint32), ("bsdf", C.c_int32),
+                ("emitter", C.c_int32), ("area", C.c_float), ("cdf_begin", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class EpsmBsdf(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("twosided", C.c_uint32), ("distr", C.c_uint32), ("sample_visible", C.c_uint32),
+                ("reflectance", C.c_float * 3), ("alpha", C.c_float), ("eta", C.c_float * 3), ("k", C.c_float * 3),
+                ("int_ior", C.c_float), ("ext_ior", C.c_float), ("alpha_slot", C.c_int32), ("pad", C.c_uint32)]
+
+
+class EpsmEmitter(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("mesh", C.c_int32), ("radiance", C.c_float * 3), ("position", C.c_float * 3)]
+
+
+class EpsmSensor(C.Structure):
+    _fields_ = [("to_world", C.c_float * 12), ("sample_to_camera", C.c_float * 16), ("dx", C.c_float * 3),
+                ("dy", C.c_float * 3), ("near_clip", C.c_float), ("far_clip", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class EpsmSceneC(C.Structure):
+    _fields_ = [("positions", C.c_void_p), ("normals", C.c_void_p), ("tri", C.c_void_p), ("tri_mesh", C.c_void_p),
+                ("meshes", C.c_void_p), ("n_meshes", C.c_int32), ("bsdfs", C.c_void_p), ("n_bsdfs", C.c_int32),
+                ("emitters", C.c_void_p), ("n_emitters", C.c_int32), ("emitter_cdf", C.c_void_p),
+                ("bvh", C.c_void_p), ("n_nodes", C.c_int32), ("prim_index", C.c_void_p),
+                ("n_vertices", C.c_int64), ("n_triangles", C.c_int64)]
+
+
+class EpsmRecordOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "p0", "p1", "p2", "p", "n0", "n1", "n2", "normal", "b0", "b1", "eta", "hf", "light",
+        "bsdf", "active", "active_em", "ismesh", "tri", "aux", "emit")]
+
+
+# ---------------------------------------------------------------------------- transforms
+def look_at(origin, target, up) -> np.ndarray:
+    """Transform4f.look_at: camera space +z is the viewing direction."""
+    o, t, u = (np.asarray(v, dtype=np.float64) for v in (origin, target, up))
+    d = (t - o) / np.linalg.norm(t - o)
+    left = np.cross(u, d); left /= np.linalg.norm(left)
+    new_up = np.cross(d, left)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = left, new_up, d, o
+    return m
+
+
+def translate(v) -> np.ndarray:
+    m = np.eye(4); m[:3, 3] = v; return m
+
+
+def scale(v) -> np.ndarray:
+    v = np.broadcast_to(np.asarray(v, dtype=np.float64), (3,))
+    return np.diag([v[0], v[1], v[2], 1.0])
+
+
+def rotate(axis, angle_deg) -> np.ndarray:
+    a = np.asarray(axis, dtype=np.float64); a = a / np.linalg.norm(a)
+    th = math.radians(angle_deg); c, s = math.cos(th), math.sin(th)
+    x, y, z = a
+    r = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
+                  [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
+                  [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
+    m = np.eye(4); m[:3, :3] = r; return m
+
+
+def perspective_projection(width: int, height: int, fov_x_deg: float, near: float, far: float) -> np.ndarray:
+    """camera_to_sample (include/mitsuba/core/transform.h perspective_projection, no crop)."""
+    aspect = width / height
+    recip = 1.0 / (far - near)
+    cot = 1.0 / math.tan(math.radians(fov_x_deg * 0.5))
+    persp = np.array([[cot, 0, 0, 0], [0, cot, 0, 0], [0, 0, far * recip, -near * far * recip], [0, 0, 1, 0]], dtype=np.float64)
+    return scale([-0.5, -0.5 * aspect, 1.0]) @ translate([-1.0, -1.0 / aspect, 0.0]) @ persp
+
+
+def _xform_point(m, p):
+    q = m @ np.array([p[0], p[1], p[2], 1.0])
+    return q[:3] / q[3]
+
+
+# ---------------------------------------------------------------------------- meshes
+def load_obj(path: str):
+    """Minimal Wavefront OBJ reader: v / vn / f (triangulated fans), vertices merged per (v, vn) pair."""
+    vs, vns, key_to_idx, out_v, out_n, faces = [], [], {}, [], [], []
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                vs.append([float(x) for x in t[1:4]])
+            elif t[0] == "vn":
+                vns.append([float(x) for x in t[1:4]])
+            elif t[0] == "f":
+                idx = []
+                for tok in t[1:]:
+                    parts = tok.split("/")
+                    vi = int(parts[0]); vi = vi - 1 if vi > 0 else len(vs) + vi
+                    ni = None
+                    if len(parts) >= 3 and parts[2]:
+                        ni = int(parts[2]); ni = ni - 1 if ni > 0 else len(vns) + ni
+                    key = (vi, ni)
+                    if key not in key_to_idx:
+                        key_to_idx[key] = len(out_v)
+                        out_v.append(vs[vi]); out_n.append(vns[ni] if ni is not None else [0.0, 0.0, 0.0])
+                    idx.append(key_to_idx[key])
+                for j in range(1, len(idx) - 1):
+                    faces.append([idx[0], idx[j], idx[j + 1]])
+    v = np.asarray(out_v, dtype=np.float64).reshape(-1, 3)
+    n = np.asarray(out_n, dtype=np.float64).reshape(-1, 3)
+    has_n = len(vns) > 0
+    return v, (n if has_n else None), np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+
+
+def vertex_normals(v: np.ndarray, f: np.ndarray) -> np.ndarray:
+    """Angle-weighted vertex normals (Mesh::recompute_vertex_normals, src/render/mesh.cpp)."""
+    n = np.zeros_like(v)
+    p = v[f]
+    for i in range(3):
+        d0 = p[:, (i + 1) % 3] - p[:, i]; d1 = p[:, (i + 2) % 3] - p[:, i]
+        fn = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+        ln = np.linalg.norm(fn, axis=1, keepdims=True)
+        fn = np.where(ln > 0, fn / np.maximum(ln, 1e-30), 0)
+        cosang = np.sum(d0 * d1, 1) / np.maximum(np.linalg.norm(d0, axis=1) * np.linalg.norm(d1, axis=1), 1e-30)
+        ang = np.arccos(np.clip(cosang, -1, 1))
+        np.add.at(n, f[:, i], fn * ang[:, None])
+    ln = np.linalg.norm(n, axis=1, keepdims=True)
+    return np.where(ln > 0, n / np.maximum(ln, 1e-30), np.array([0.0, 0.0, 1.0]))
+
+
+class Mesh:
+    def __init__(self, name, v, f, n=None, bsdf=0, emitter=-1, flip_normals=False, is_mesh=True, face_normals=False):
+        self.name = name
+        self.v = np.asarray(v, dtype=np.float64).reshape(-1, 3)
+        self.f = np.asarray(f, dtype=np.int64).reshape(-1, 3)
+        self.face_normals = face_normals
+        self.has_normals = (not face_normals)
+        self.n = None
+        if self.has_normals:
+            self.n = np.asarray(n, dtype=np.float64).reshape(-1, 3) if n is not None else vertex_normals(self.v, self.f)
+        self.bsdf, self.emitter = bsdf, emitter
+        self.flip_normals, self.is_mesh = flip_normals, is_mesh
+        self.pos_attached = self.nrm_attached = False
+
+    def flags(self) -> int:
+        return ((MESH_VERTEX_NORMALS if self.has_normals else 0) | (MESH_FLIP_NORMALS if self.flip_normals else 0) |
+                (MESH_POS_ATTACHED if self.pos_attached else 0) | (MESH_NRM_ATTACHED if self.nrm_attached else 0) |
+                (MESH_IS_MESH if self.is_mesh else 0))
+
+
+# ---------------------------------------------------------------------------- BVH
+def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = 4):
+    """Median-split BVH over triangle centroids.  Returns (nodes (n,8) float32 view-compatible, prim_index)."""
+    T = tri.shape[0]
+    p = pos[tri]                                   # (T,3,3)
+    lo_t, hi_t = p.min(axis=1), p.max(axis=1)
+    cen = 0.5 * (lo_t + hi_t)
+    order = np.arange(T, dtype=np.int64)
+    nodes: List[list] = []
+
+    def new_node():
+        nodes.append(None); return len(nodes) - 1
+
+    root = new_node()
+    stack = [(root, 0, T)]
+    while stack:
+        ni, a, b = stack.pop()
+        ids = order[a:b]
+        lo, hi = lo_t[ids].min(axis=0), hi_t[ids].max(axis=0)
+        if b - a <= leaf_size:
+            nodes[ni] = (lo, a, hi, b - a)
+            continue
+        c = cen[ids]
+        ext = c.max(axis=0) - c.min(axis=0)
+        ax = int(np.argmax(ext))
+        mid = (b - a) // 2
+        part = np.argpartition(c[:, ax], mid)
+        order[a:b] = ids[part]
+        left = new_node(); right = new_node()
+        assert right == left + 1
+        nodes[ni] = (lo, left, hi, 0)
+        stack.append((left, a, a + mid)); stack.append((right, a + mid, b))
+    arr = np.zeros((len(nodes), 8), dtype=np.float32)
+    iarr = arr.view(np.uint32)
+    for i, (lo, first, hi, cnt) in enumerate(nodes):
+        arr[i, 0:3] = lo - 1e-6 * (1 + np.abs(lo)); iarr[i, 3] = first
+        arr[i, 4:7] = hi + 1e-6 * (1 + np.abs(hi)); iarr[i, 7] = cnt
+    return arr, order.astype(np.uint32)
+
+
+# ---------------------------------------------------------------------------- scene
+def _rgb(x, default):
+    if x is None:
+        return np.array(default, dtype=np.float32)
+    if isinstance(x, dict):
+        x = x.get("value", default)
+    a = np.asarray(x, dtype=np.float32).reshape(-1)
+    return np.repeat(a, 3) if a.size == 1 else a[:3]
+
+
+def _ior(x, default):
+    if x is None:
+        return default
+    return IOR[x] if isinstance(x, str) else float(x)
+
+
+class Sensor:
+    def __init__(self, d: dict):
+        film = next((v for v in d.values() if isinstance(v, dict) and v.get("type") == "hdrfilm"), {})
+        sampler = next((v for v in d.values() if isinstance(v, dict) and v.get("type") == "independent"), {})
+        self.width, self.height = int(film.get("width", 768)), int(film.get("height", 576))
+        rf = film.get("rfilter", {"type": "gaussian"})
+        self.rfilter = {"box": 0, "gaussian": 1}[rf.get("type", "gaussian")]
+        self.spp = int(sampler.get("sample_count", 4))
+        self.fov = float(d.get("fov", 45.0))
+        self.near, self.far = float(d.get("near_clip", 1e-2)), float(d.get("far_clip", 1e4))
+        self.to_world = np.asarray(d.get("to_world", np.eye(4)), dtype=np.float64)
+
+    def c_struct(self) -> EpsmSensor:
+        s = EpsmSensor()
+        c2s = perspective_projection(self.width, self.height, self.fov, self.near, self.far)
+        s2c = np.linalg.inv(c2s)
+        s.to_world[:] = self.to_world[:3, :].astype(np.float32).reshape(-1).tolist()
+        s.sample_to_camera[:] = s2c.astype(np.float32).reshape(-1).tolist()
+        p0 = _xform_point(s2c, [0, 0, 0])
+        s.dx[:] = (_xform_point(s2c, [1.0 / self.width, 0, 0]) - p0).astype(np.float32).tolist()    # perspective.cpp:178-182
+        s.dy[:] = (_xform_point(s2c, [0, 1.0 / self.height, 0]) - p0).astype(np.float32).tolist()
+        s.near_clip, s.far_clip, s.width, s.height = self.near, self.far, self.width, self.height
+        return s
+
+
+class Scene:
+    """Flattened scene + device buffers.  Implements the tracer protocol the integrators use:
+    ``trace_paths`` (records for the backward pass) and ``render_primal``."""
+
+    def __init__(self, meshes: Sequence[Mesh], bsdfs: Sequence[dict], emitters: Sequence[dict],
+                 sensors: Sequence[Sensor], device="cuda", bsdf_names: Optional[Sequence[str]] = None,
+                 tile_paths: int = _dist.TILE_PATHS):
+        self.meshes, self.bsdf_desc, self.emitter_desc, self.sensors = list(meshes), list(bsdfs), list(emitters), list(sensors)
+        self.bsdf_names = list(bsdf_names or [f"bsdf{i}" for i in range(len(bsdfs))])
+        self.device = torch.device(device)
+        self.tile_paths = tile_paths
+        self.alpha_slots: Dict[int, int] = {}
+        self.rr_depth = 5
+        # test hook: tests/host_harness compiles the tracer's per-path code for the CPU and plugs
+        # its entry points in here; the product path (None) is the HIP library and needs a GPU
+        self._backend = None
+        self._upload()
+
+    # -- construction from the reference's dict shape ---------------------------------------
+    @staticmethod
+    def from_dict(d: dict, device="cuda", base_dir: str = ".") -> "Scene":
+        assert d.get("type") == "scene"
+        bsdfs, bsdf_names, named = [], [], {}
+
+        def parse_bsdf(b: dict) -> dict:
+            t = b["type"]
+            if t == "twosided":
+                inner = next(v for v in b.values() if isinstance(v, dict) and "type" in v)
+                out = parse_bsdf(inner); out["twosided"] = 1
+                return out
+            o = dict(type=BSDF_TYPES[t], twosided=0, distr=0, sample_visible=1, reflectance=_rgb(None, [1, 1, 1]),
+                     alpha=0.1, eta=np.zeros(3, np.float32), k=np.ones(3, np.float32), int_ior=1.5046, ext_ior=1.000277)
+            if t == "diffuse":
+                o["reflectance"] = _rgb(b.get("reflectance"), [0.5, 0.5, 0.5])
+            elif t in ("conductor", "roughconductor"):
+                mat = b.get("material", "Cu")
+                if "eta" in b or "k" in b:
+                    o["eta"], o["k"] = _rgb(b.get("eta"), [0, 0, 0]), _rgb(b.get("k"), [1, 1, 1])
+                else:
+                    e, k = CONDUCTORS[mat]
+                    o["eta"], o["k"] = np.array(e, np.float32), np.array(k, np.float32)
+                o["reflectance"] = _rgb(b.get("specular_reflectance"), [1, 1, 1])
+                if t == "roughconductor":
+                    o["distr"] = {"beckmann": 0, "ggx": 1}[b.get("distribution", "beckmann")]
+                    a = b.get("alpha", 0.1)
+                    o["alpha"] = float(a["value"] if isinstance(a, dict) else a)
+                    o["sample_visible"] = 1 if b.get("sample_visible", True) else 0
+            elif t == "dielectric":
+                o["int_ior"], o["ext_ior"] = _ior(b.get("int_ior"), 1.5046), _ior(b.get("ext_ior"), 1.000277)
+                o["reflectance"] = _rgb(b.get("specular_reflectance"), [1, 1, 1])
+            return o
+
+        def add_bsdf(name, b):
+            bsdfs.append(parse_bsdf(b)); bsdf_names.append(name)
+            return len(bsdfs) - 1
+
+        for key, val in d.items():
+            if isinstance(val, dict) and val.get("type") in list(BSDF_TYPES) + ["twosided"]:
+                named[val.get("id", key)] = add_bsdf(key, val)
+                named[key] = named[val.get("id", key)]
+        default_bsdf = None
+        meshes, emitters, sensors = [], [], []
+        for key, val in d.items():
+            if not isinstance(val, dict):
+                continue
+            t = val.get("type")
+            if t == "perspective":
+                sensors.append(Sensor(val))
+            elif t == "point":
+                emitters.append(dict(type=1, mesh=-1, radiance=_rgb(val.get("intensity"), [1, 1, 1]),
+                                     position=np.asarray(val.get("position", [0, 0, 0]), np.float32)))
+            elif t in ("obj", "mesh", "rectangle"):
+                tw = np.asarray(val.get("to_world", np.eye(4)), dtype=np.float64)
+                if t == "obj":
+                    v, n, f = load_obj(os.path.join(base_dir, val["filename"]))
+                elif t == "mesh":
+                    v, f = np.asarray(val["vertices"], np.float64), np.asarray(val["faces"], np.int64)
+                    n = np.asarray(val["normals"], np.float64) if "normals" in val else None
+                else:
+                    v = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float64)
+                    f = np.array([[0, 1, 2], [0, 2, 3]], np.int64); n = None
+                v = (tw[:3, :3] @ v.T).T + tw[:3, 3]
+                if n is not None:
+                    nt = np.linalg.inv(tw[:3, :3]).T
+                    n = (nt @ n.T).T; n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-30)
+                bsdf_id, emitter_id = None, -1
+                for k2, v2 in val.items():
+                    if not isinstance(v2, dict):
+                        continue
+                    if v2.get("type") == "ref":
+                        bsdf_id = named[v2["id"]]
+                    elif v2.get("type") in list(BSDF_TYPES) + ["twosided"]:
+                        bsdf_id = add_bsdf(f"{key}.{k2}", v2)
+                    elif v2.get("type") == "area":
+                        emitters.append(dict(type=0, mesh=len(meshes), radiance=_rgb(v2.get("radiance"), [1, 1, 1]),
+                                             position=np.zeros(3, np.float32)))
+                        emitter_id = len(emitters) - 1
+                if bsdf_id is None:
+                    if default_bsdf is None:
+                        default_bsdf = add_bsdf("__default_diffuse", {"type": "diffuse"})
+                    bsdf_id = default_bsdf
+                face_normals = bool(val.get("face_normals", False)) or t == "rectangle"
+                meshes.append(Mesh(key, v, f, n, bsdf=bsdf_id, emitter=emitter_id,
+                                   flip_normals=bool(val.get("flip_normals", False)), is_mesh=(t != "rectangle"),
+                                   face_normals=face_normals))
+        return Scene(meshes, bsdfs, emitters, sensors, device=device, bsdf_names=bsdf_names)
+
+    # -- parameters ----------------------------------------------------------------------------
+    def mesh(self, name: str) -> Mesh:
+        return next(m for m in self.meshes if m.name == name)
+
+    def attach(self, mesh_name: str, positions: bool = True, normals: bool = False):
+        """``dr.enable_grad(params['<mesh>.vertex_positions' / '.vertex_normals'])``."""
+        m = self.mesh(mesh_name)
+        m.pos_attached, m.nrm_attached = positions, normals
+        self._upload()
+
+    def attach_alpha(self, bsdf_name: str) -> int:
+        i = self.bsdf_names.index(bsdf_name)
+        self.alpha_slots.setdefault(i, len(self.alpha_slots))
+        self._upload()
+        return self.alpha_slots[i]
+
+    def set_alpha(self, bsdf_name: str, alpha: float):
+        self.bsdf_desc[self.bsdf_names.index(bsdf_name)]["alpha"] = float(alpha)
+        self._upload()
+
+    def set_vertex_positions(self, mesh_name: str, v):
+        """``params['<mesh>.vertex_positions'] = v; params.update()`` (normals are recomputed like
+        Mesh::parameters_changed does, the BVH is rebuilt)."""
+        m = self.mesh(mesh_name)
+        m.v = np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float64).reshape(-1, 3)
+        if m.has_normals:
+            m.n = vertex_normals(m.v, m.f)
+        self._upload()
+
+    def vertex_positions(self, mesh_name: str) -> torch.Tensor:
+        lo, hi = self.mesh_slices[mesh_name]
+        return self.positions[lo:hi]
+
+    def param_grads(self) -> ParamGrads:
+        return ParamGrads(self.V, len(self.alpha_slots), device=self.device, mesh_slices=self.mesh_slices)
+
+    # -- upload ----------------------------------------------------------------------------------
+    def _upload(self):
+        dev = self.device
+        pos, nrm, tri, tri_mesh, cdf = [], [], [], [], []
+        self.mesh_slices = {}
+        mesh_c = (EpsmMesh * max(1, len(self.meshes)))()
+        voff = toff = coff = 0
+        for mi_, m in enumerate(self.meshes):
+            nv, nt = m.v.shape[0], m.f.shape[0]
+            self.mesh_slices[m.name] = (voff, voff + nv)
+            pos.append(m.v); nrm.append(m.n if m.n is not None else np.zeros_like(m.v))
+            tri.append(m.f + voff); tri_mesh.append(np.full(nt, mi_, np.uint32))
+            p = m.v[m.f]
+            areas = 0.5 * np.linalg.norm(np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), axis=1)
+            c = mesh_c[mi_]
+            c.tri_begin, c.tri_count, c.flags, c.bsdf, c.emitter = toff, nt, m.flags(), m.bsdf, m.emitter
+            c.area, c.cdf_begin = float(areas.sum()), coff
+            cdf.append(np.cumsum(areas) / max(areas.sum(), 1e-30))
+            voff += nv; toff += nt; coff += nt
+        self.V, self.T = voff, toff
+        P = np.concatenate(pos) if pos else np.zeros((0, 3))
+        TRI = np.concatenate(tri) if tri else np.zeros((0, 3), np.int64)
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        self.positions = f32(P)
+        self.normals = f32(np.concatenate(nrm) if nrm else np.zeros((0, 3)))
+        self.tri = torch.from_numpy(np.ascontiguousarray(TRI, dtype=np.int32)).to(dev)
+        self.tri_mesh = torch.from_numpy(np.ascontiguousarray(np.concatenate(tri_mesh) if tri_mesh else np.zeros(0), dtype=np.int32)).to(dev)
+        self.emitter_cdf = f32(np.concatenate(cdf) if cdf else np.zeros(1))
+        nodes, prim = build_bvh(P, TRI) if self.T > 0 else (np.zeros((0, 8), np.float32), np.zeros(0, np.uint32))
+        self.bvh = torch.from_numpy(nodes).to(dev)
+        self.prim_index = torch.from_numpy(prim.astype(np.int32)).to(dev)
+        bs = (EpsmBsdf * max(1, len(self.bsdf_desc)))()
+        for i, b in enumerate(self.bsdf_desc):
+            c = bs[i]
+            c.type, c.twosided, c.distr, c.sample_visible = b["type"], b["twosided"], b["distr"], b["sample_visible"]
+            c.reflectance[:] = [float(x) for x in b["reflectance"]]
+            c.alpha = float(b["alpha"])
+            c.eta[:] = [float(x) for x in b["eta"]]; c.k[:] = [float(x) for x in b["k"]]
+            c.int_ior, c.ext_ior = float(b["int_ior"]), float(b["ext_ior"])
+            c.alpha_slot = self.alpha_slots.get(i, -1)
+        em = (EpsmEmitter * max(1, len(self.emitter_desc)))()
+        for i, e in enumerate(self.emitter_desc):
+            c = em[i]
+            c.type, c.mesh = e["type"], e["mesh"]
+            c.radiance[:] = [float(x) for x in e["radiance"]]; c.position[:] = [float(x) for x in e["position"]]
+        as_dev = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self._mesh_buf, self._bsdf_buf, self._em_buf = as_dev(mesh_c), as_dev(bs), as_dev(em)
+        s = EpsmSceneC()
+        s.positions, s.normals = self.positions.data_ptr(), self.normals.data_ptr()
+        s.tri, s.tri_mesh = self.tri.data_ptr(), self.tri_mesh.data_ptr()
+        s.meshes, s.n_meshes = self._mesh_buf.data_ptr(), len(self.meshes)
+        s.bsdfs, s.n_bsdfs = self._bsdf_buf.data_ptr(), len(self.bsdf_desc)
+        s.emitters, s.n_emitters = self._em_buf.data_ptr(), len(self.emitter_desc)
+        s.emitter_cdf = self.emitter_cdf.data_ptr()
+        s.bvh, s.n_nodes, s.prim_index = self.bvh.data_ptr(), int(nodes.shape[0]), self.prim_index.data_ptr()
+        s.n_vertices, s.n_triangles = self.V, self.T
+        self.c_scene = s
+
+    # -- tracing ---------------------------------------------------------------------------------
+    def _trace(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int,
+               want_radiance: bool = True):
+        from .integrators import PathTrace
+        dev = self.device
+        if dev.type != "cuda" and self._backend is None:
+            raise _lib.EpsmError("the tracer runs on the GPU only (no CPU fallback)")
+        lib = self._backend if self._backend is not None else _lib.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+        sensor = self.sensors[sensor_index]
+        n = hi - lo
+        f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        ray = [f(n, 3) for _ in range(4)]
+        film_pos, radiance = f(n, 2), f(n, 3)
+        valid = torch.empty(n, device=dev, dtype=torch.uint8)
+        recs = (EpsmRecordOut * max(1, K))()
+        info, sinfo, keep = [{"cam": ray[0]}], [], []
+        for k in range(K):
+            t = {name: f(n, 3) for name in ("p0", "p1", "p2", "p", "n0", "n1", "n2", "normal", "hf", "light")}
+            t.update({name: f(n) for name in ("b0", "b1", "eta")})
+            t["bsdf"] = torch.empty(n, device=dev, dtype=torch.int32)
+            for name in ("active", "active_em", "ismesh"):
+                t[name] = torch.empty(n, device=dev, dtype=torch.uint8)
+            t["tri"] = torch.empty((n, 4), device=dev, dtype=torch.int32)
+            t["aux"] = torch.empty((n, 4), device=dev, dtype=torch.int32)
+            t["emit"] = torch.empty((n, 8), device=dev, dtype=torch.int32)
+            for name, _ in EpsmRecordOut._fields_:
+                setattr(recs[k], name, t[name].data_ptr())
+            keep.append(t)
+            info.append({"it": k, "active": t["active"], "bsdf": t["bsdf"], "ismesh": t["ismesh"], "light": t["light"],
+                         "active_em": t["active_em"], "points": [t["p0"], t["p1"], t["p2"], t["p"]],
+                         "uv": [t["b0"], t["b1"]], "normal": t["normal"], "normals": [t["n0"], t["n1"], t["n2"]],
+                         "eta": t["eta"], "hf": t["hf"]})
+            sinfo.append({"tri": t["tri"], "aux": t["aux"] if self.alpha_slots else None, "emit": t["emit"]})
+        cs = sensor.c_struct()
+        rc = lib.epsm_trace_paths(
+            C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
+            C.c_int64(lo), C.c_int64(n), K, C.c_void_p(ray[0].data_ptr()), C.c_void_p(ray[1].data_ptr()),
+            C.c_void_p(ray[2].data_ptr()), C.c_void_p(ray[3].data_ptr()),
+            C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()), C.c_void_p(valid.data_ptr()),
+            C.c_void_p(C.addressof(recs)), C.c_void_p(stream))
+        if rc != 0:
+            _lib.check(rc, "epsm_trace_paths") if self._backend is None else (_ for _ in ()).throw(RuntimeError(f"host tracer rc={rc}"))
+        tr = PathTrace(res=sensor.width, spp=spp, ray_o=ray[0], ray_d=ray[1], ray_dx=ray[2], ray_dy=ray[3],
+                       path_info=info, scatter_info=sinfo, path_offset=lo,
+                       n_paths_total=sensor.width * sensor.height * spp)
+        tr.film_pos, tr.radiance, tr.valid = film_pos, radiance, valid
+        return tr
+
+    def trace_paths(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1):
+        """This rank's tiles of the backward wavefront of ``sensors[sensor]`` (epsm.py:142-181)."""
+        s = self.sensors[min(sensor, len(self.sensors) - 1)]
+        if s.width != s.height:
+            raise ValueError("the EPSM backward pass assumes a square film (epsm.py:239)")
+        K = min(max_log_depth, max_depth, 5)
+        n_total = s.width * s.height * spp
+        tiles = _dist.tile_ranges(n_total, self.tile_paths)
+        si = min(sensor, len(self.sensors) - 1)
+        return [self._trace(si, seed, spp, max_depth, K, *tiles[t]) for t in _dist.my_tiles(len(tiles), rank, world_size)]
+
+    def render_primal(self, sensor=0, seed=0, spp=0, max_depth=6) -> torch.Tensor:
+        """(H,W,3) image: sample_rays + path tracing + film splat / develop (epsm.py:13-76)."""
+        si = min(sensor, len(self.sensors) - 1)
+        s = self.sensors[si]
+        spp = spp or s.spp
+        n_total = s.width * s.height * spp
+        accum = torch.zeros((s.height, s.width, 4), device=self.device, dtype=torch.float32)
+        lib = self._backend if self._backend is not None else _lib.lib()
+        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+        for lo, hi in _dist.tile_ranges(n_total, self.tile_paths):
+            tr = self._trace(si, seed, spp, max_depth, 0, lo, hi)
+            rc = lib.epsm_film_splat(C.c_int64(hi - lo), C.c_void_p(tr.film_pos.data_ptr()), C.c_void_p(tr.radiance.data_ptr()),
+                                     s.width, s.height, s.rfilter, C.c_void_p(accum.data_ptr()), C.c_void_p(stream))
+            assert rc == 0, "epsm_film_splat failed"
+        img = torch.empty((s.height, s.width, 3), device=self.device, dtype=torch.float32)
+        rc = lib.epsm_film_develop(s.width, s.height, C.c_void_p(accum.data_ptr()), C.c_void_p(img.data_ptr()), C.c_void_p(stream))
+        assert rc == 0, "epsm_film_develop failed"
+        return img

@@ -1,0 +1,142 @@
+/*
+ * epsm_trace.h -- C ABI of the wavefront path tracer that PRODUCES the EPSM path records.
+ *
+ * Replaces, for triangle-mesh scenes, what the reference obtains from Mitsuba 3 + Dr.Jit:
+ *   EPSMIntegrator.sample_path (Primal, log_path=True)   epsm.py:503-742   (records: :547, :648-654)
+ *   ADIntegrator.prepare / sample_rays                    common.py:291-480 (PCG32 + TEA seeding:
+ *                                                         src/render/sampler.cpp:115-134)
+ *   PerspectiveCamera::sample_ray_differential            src/sensors/perspective.cpp:238-279
+ *   Mesh::compute_surface_interaction (EPSM fields)       src/render/mesh.cpp:632-892
+ *   diffuse / conductor / roughconductor / dielectric     src/bsdfs/{...}.cpp (+ the fork's BSDFSample3::hf,
+ *                                                         roughconductor.cpp:255, and its forced
+ *                                                         non-visible microfacet sampling, microfacet.h `if (true)`)
+ *   area / point emitters, Scene::sample_emitter_direction src/emitters/{area,point}.cpp, src/render/scene.cpp:226-300
+ *   film splat (box / gaussian) for the primal image      src/render/imageblock.cpp, src/rfilters/gaussian.cpp
+ *
+ * One lane = one path; bounces run in lock step inside ONE launch (no per-bounce host sync,
+ * no .torch() round trips); every logged vertex is written in the record layout of epsm.h
+ * together with the parameter addressing (EpsmScatterRecord), so the reference's second,
+ * Backward-mode trace is not needed.
+ *
+ * PARITY UNPINNED: Mitsuba/Dr.Jit can be neither built nor imported here and the reference
+ * has no test for these functions; they are pinned by analytic
+ * known-answer tests (tests/test_tracer_*.py).
+ */
+#ifndef EPSM_TRACE_H
+#define EPSM_TRACE_H
+
+#include <stdint.h>
+#include "epsm.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mesh flags (the low four match EPSM_MODE_*) */
+#define EPSM_MESH_VERTEX_NORMALS 0x1u
+#define EPSM_MESH_FLIP_NORMALS   0x2u
+#define EPSM_MESH_POS_ATTACHED   0x4u
+#define EPSM_MESH_NRM_ATTACHED   0x8u
+#define EPSM_MESH_IS_MESH        0x10u   /* 0: tessellated analytic shape (rectangle): si.ismesh stays 0 */
+
+enum { EPSM_BSDF_DIFFUSE_T = 0, EPSM_BSDF_CONDUCTOR_T = 1, EPSM_BSDF_ROUGHCONDUCTOR_T = 2, EPSM_BSDF_DIELECTRIC_T = 3 };
+enum { EPSM_DISTR_BECKMANN = 0, EPSM_DISTR_GGX = 1 };
+enum { EPSM_EMITTER_AREA = 0, EPSM_EMITTER_POINT = 1 };
+enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
+
+typedef struct EpsmMesh {
+    uint32_t tri_begin, tri_count;   /* this mesh's range in the triangle arrays */
+    uint32_t flags;                  /* EPSM_MESH_* */
+    int32_t bsdf;                    /* index into bsdfs */
+    int32_t emitter;                 /* index into emitters, -1 = none */
+    float area;                      /* total surface area (emitter sampling pdf) */
+    uint32_t cdf_begin;              /* first entry of this mesh's triangle-area CDF in emitter_cdf (tri_count entries) */
+    uint32_t pad;
+} EpsmMesh;
+
+typedef struct EpsmBsdf {
+    uint32_t type;                   /* EPSM_BSDF_*_T */
+    uint32_t twosided;
+    uint32_t distr;                  /* EPSM_DISTR_* (roughconductor) */
+    uint32_t sample_visible;         /* roughconductor: selects the weight/pdf formulas (roughconductor.cpp:258-262) */
+    float reflectance[3];            /* diffuse reflectance / specular_reflectance */
+    float alpha;                     /* roughconductor roughness */
+    float eta[3], k[3];              /* conductor complex IOR; eta = 0,k = 1 is the '100 % reflecting mirror' */
+    float int_ior, ext_ior;          /* dielectric */
+    int32_t alpha_slot;              /* slot of this BSDF's alpha in grad_alpha, -1 = not optimised */
+    uint32_t pad;
+} EpsmBsdf;
+
+typedef struct EpsmEmitter {
+    uint32_t type;                   /* EPSM_EMITTER_* */
+    int32_t mesh;                    /* area: emitting mesh */
+    float radiance[3];               /* area: radiance; point: intensity */
+    float position[3];               /* point */
+} EpsmEmitter;
+
+typedef struct EpsmBvhNode {         /* 32 bytes */
+    float lo[3]; uint32_t left_or_first;   /* inner: left child (right = left+1); leaf: first triangle */
+    float hi[3]; uint32_t count;           /* 0 = inner node */
+} EpsmBvhNode;
+
+typedef struct EpsmSensor {
+    float to_world[12];              /* 3x4 row-major camera-to-world (rotation | translation) */
+    float sample_to_camera[16];      /* 4x4 row-major, perspective.cpp:171-176 */
+    float dx[3], dy[3];              /* position differentials on the near plane, perspective.cpp:178-182 */
+    float near_clip, far_clip;
+    int32_t width, height;
+} EpsmSensor;
+
+typedef struct EpsmScene {           /* host struct holding DEVICE pointers */
+    const float *positions;          /* (V,3) world space */
+    const float *normals;            /* (V,3) (zero rows for meshes without vertex normals) */
+    const uint32_t *tri;             /* (T,3) rows of the triangle's vertices in positions/normals, mesh by mesh */
+    const uint32_t *tri_mesh;        /* (T)   owning mesh */
+    const EpsmMesh *meshes;          int32_t n_meshes;
+    const EpsmBsdf *bsdfs;           int32_t n_bsdfs;
+    const EpsmEmitter *emitters;     int32_t n_emitters;
+    const float *emitter_cdf;        /* concatenated normalised area CDFs of the emitting meshes */
+    const EpsmBvhNode *bvh;          int32_t n_nodes;
+    const uint32_t *prim_index;      /* leaf entries: BVH order -> triangle id (triangles stay mesh-contiguous) */
+    int64_t n_vertices, n_triangles;
+} EpsmScene;
+
+/* Writable twin of EpsmVertexRecord + EpsmScatterRecord for one logged bounce. */
+typedef struct EpsmRecordOut {
+    float *p0, *p1, *p2, *p;         /* (N,3) */
+    float *n0, *n1, *n2, *normal;    /* (N,3) */
+    float *b0, *b1, *eta;            /* (N) */
+    float *hf, *light;               /* (N,3) */
+    uint32_t *bsdf;                  /* (N) */
+    uint8_t *active, *active_em, *ismesh;  /* (N) */
+    uint32_t *tri, *aux, *emit;      /* (N,4) (N,4) (N,8): EpsmScatterRecord */
+} EpsmRecordOut;
+
+/* ---------------------------------------------------------------------------
+ * epsm_trace_paths -- sample_rays + sample_path(Primal, log_path=True) for paths
+ *   [path_offset, path_offset + N) of the wavefront  width*height*spp  (ordered pixel-major,
+ *   then sample: common.py:320-330).
+ *   seed, spp, max_depth, rr_depth   as in ADIntegrator (common.py:28-43, 424-480)
+ *   K_log                            bounces to log (<= 5, epsm.py:648)
+ *   ray_o/d/dx/dy (N,3), film_pos (N,2), radiance (N,3), valid (N) u8: outputs (any may be NULL
+ *                                    except ray_*); radiance = L of epsm.py:658, valid = depth != 0
+ *   recs                             K_log records to fill (all fields written for every path)
+ * ------------------------------------------------------------------------- */
+int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor,
+                     uint32_t seed, int spp, int max_depth, int rr_depth,
+                     int64_t path_offset, int64_t N, int K_log,
+                     float *ray_o, float *ray_d, float *ray_dx, float *ray_dy,
+                     float *film_pos, float *radiance, uint8_t *valid,
+                     const EpsmRecordOut *recs, void *stream);
+
+/* epsm_film_splat -- ImageBlock::put + weight division (film.develop): accumulates
+ * radiance with the reconstruction filter into accum (height,width,4) [r,g,b,w] (atomics);
+ * epsm_film_develop divides into image (height,width,3). */
+int epsm_film_splat(int64_t N, const float *film_pos, const float *radiance, int width, int height,
+                    int rfilter, float *accum, void *stream);
+int epsm_film_develop(int width, int height, const float *accum, float *image, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,59 @@
+"""Small analytic scenes + the host-harness backend of the tracer (test infrastructure)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+from epsm_mitsuba3_amd import scene as S
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_harness")
+_SO = os.path.join(_DIR, "libtrace_host.so")
+_lib = None
+
+
+def host_tracer():
+    global _lib
+    if _lib is None:
+        src = os.path.join(_DIR, "trace_host.cpp")
+        hdr = os.path.join(_DIR, "..", "..", "epsm_mitsuba3_amd", "csrc", "epsm_trace_core.h")
+        if (not os.path.isfile(_SO)) or any(os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr)):
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wno-unknown-pragmas",
+                            "-ffp-contract=off", "-o", _SO, src], check=True)
+        _lib = C.CDLL(_SO)
+        for n in ("epsm_trace_paths", "epsm_film_splat", "epsm_film_develop"):
+            getattr(_lib, n).restype = C.c_int
+    return _lib
+
+
+def on_host(scene: S.Scene) -> S.Scene:
+    scene._backend = host_tracer()
+    return scene
+
+
+def quad(z=0.0, half=1.0, up=True):
+    v = np.array([[-half, -half, z], [half, -half, z], [half, half, z], [-half, half, z]], float)
+    f = np.array([[0, 1, 2], [0, 2, 3]]) if up else np.array([[0, 2, 1], [0, 3, 2]])
+    return v, f
+
+
+def sensor(origin, target, up=(0, 1, 0), fov=40, res=16, spp=4, rfilter="box", near=0.01, far=100.0):
+    return {"type": "perspective", "fov": fov, "near_clip": near, "far_clip": far,
+            "to_world": S.look_at(origin, target, up),
+            "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": rfilter}},
+            "sampler": {"type": "independent", "sample_count": spp}}
+
+
+def floor_and_light(radiance=50.0, light_half=0.05, height=2.0, reflectance=0.6, res=16, bsdf=None, device="cpu"):
+    """Diffuse floor z=0 (normal +z), small square light at z=height facing down, camera looking at the origin."""
+    fv, ff = quad(0.0, 3.0, up=True)
+    lv, lf = quad(height, light_half, up=False)          # normal -z
+    d = {"type": "scene",
+         "cam": sensor([0.0, -2.0, 1.5], [0, 0, 0], up=(0, 0, 1), res=res),
+         "floor": {"type": "mesh", "vertices": fv, "faces": ff, "face_normals": True,
+                   "bsdf": bsdf or {"type": "diffuse", "reflectance": {"type": "rgb", "value": [reflectance] * 3}}},
+         "light": {"type": "mesh", "vertices": lv, "faces": lf, "face_normals": True,
+                   "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0, 0, 0]}},
+                   "emitter": {"type": "area", "radiance": {"type": "rgb", "value": radiance}}}}
+    return S.Scene.from_dict(d, device=device)

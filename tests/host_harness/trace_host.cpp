@@ -1,0 +1,59 @@
+// TEST HARNESS ONLY: compiles the tracer's per-path code (epsm_trace_core.h) for the host CPU so
+// that the analytic known-answer tests of tests/test_tracer_*.py run without a GPU.  Same entry
+// point names as the product library; host pointers.  Not shipped, not a fallback.
+#include <math.h>
+#include <string.h>
+#include "../../epsm_mitsuba3_amd/csrc/epsm_trace_core.h"
+
+using namespace epsm;
+
+extern "C" int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor, uint32_t seed, int spp, int max_depth,
+                                int rr_depth, int64_t path_offset, int64_t N, int K_log, float *ray_o, float *ray_d,
+                                float *ray_dx, float *ray_dy, float *film_pos, float *radiance, uint8_t *valid,
+                                const EpsmRecordOut *recs, void *) {
+    TraceArgs A;
+    memset(&A, 0, sizeof(A));
+    A.S = *scene; A.C = *sensor;
+    A.seed = seed; A.spp = spp; A.max_depth = max_depth; A.rr_depth = rr_depth; A.K_log = K_log;
+    A.path_offset = path_offset; A.N = N;
+    A.ray_o = ray_o; A.ray_d = ray_d; A.ray_dx = ray_dx; A.ray_dy = ray_dy;
+    A.film_pos = film_pos; A.radiance = radiance; A.valid = valid;
+    for (int k = 0; k < K_log; ++k) A.rec[k] = recs[k];
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < N; ++i) trace_one_path(A, i);
+    return 0;
+}
+
+extern "C" int epsm_film_splat(int64_t N, const float *pos, const float *rad, int W, int H, int rfilter, float *accum, void *) {
+    for (int64_t i = 0; i < N; ++i) {
+        const float px = pos[2 * i], py = pos[2 * i + 1];
+        if (rfilter == EPSM_RFILTER_BOX) {
+            const int x = (int) floorf(px), y = (int) floorf(py);
+            if (x < 0 || y < 0 || x >= W || y >= H) continue;
+            float *a = accum + 4 * ((int64_t) y * W + x);
+            a[0] += rad[3 * i]; a[1] += rad[3 * i + 1]; a[2] += rad[3 * i + 2]; a[3] += 1.f;
+            continue;
+        }
+        const float radius = 2.f, alpha = -1.f / (2.f * 0.5f * 0.5f), bias = expf(alpha * radius * radius);
+        const int x0 = (int) ceilf(px - radius - 0.5f), x1 = (int) floorf(px + radius - 0.5f);
+        const int y0 = (int) ceilf(py - radius - 0.5f), y1 = (int) floorf(py + radius - 0.5f);
+        for (int y = y0; y <= y1; ++y) {
+            if (y < 0 || y >= H) continue;
+            const float dy = (y + 0.5f) - py, wy = fmaxf(0.f, expf(alpha * dy * dy) - bias);
+            for (int x = x0; x <= x1; ++x) {
+                if (x < 0 || x >= W) continue;
+                const float dx = (x + 0.5f) - px, w = wy * fmaxf(0.f, expf(alpha * dx * dx) - bias);
+                float *a = accum + 4 * ((int64_t) y * W + x);
+                a[0] += rad[3 * i] * w; a[1] += rad[3 * i + 1] * w; a[2] += rad[3 * i + 2] * w; a[3] += w;
+            }
+        }
+    }
+    return 0;
+}
+extern "C" int epsm_film_develop(int W, int H, const float *accum, float *image, void *) {
+    for (int64_t i = 0; i < (int64_t) W * H; ++i) {
+        const float w = accum[4 * i + 3], iw = w != 0.f ? 1.f / w : 0.f;
+        image[3 * i] = accum[4 * i] * iw; image[3 * i + 1] = accum[4 * i + 1] * iw; image[3 * i + 2] = accum[4 * i + 2] * iw;
+    }
+    return 0;
+}
