@@ -10,9 +10,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "epsm.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(epsm_[a-z0-9_]+)\s*\(", text)))
+    syms = set()
+    for name in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not name.endswith(".h"):
+            continue
+        text = open(os.path.join(ROOT, "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"\b(epsm_[a-z0-9_]+)\s*\(", text))
+    return sorted(syms)
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +30,7 @@ def lib():
 
 def test_header_declares_something():
     syms = declared_symbols()
-    assert "epsm_manifold_grad" in syms and len(syms) >= 4
+    assert "epsm_manifold_grad" in syms and "epsm_trace_paths" in syms and len(syms) >= 10
 
 
 def test_every_declared_symbol_is_exported(lib):
@@ -63,3 +68,22 @@ def test_vertex_record_layout_matches_header():
         names += [n.strip(" *") for n in decl.split(",")]
     assert names == [f[0] for f in EpsmVertexRecord._fields_]
     assert C.sizeof(EpsmVertexRecord) == 8 * len(names)
+
+
+def test_trace_structs_match_header_sizes():
+    """ctypes mirrors of include/epsm_trace.h keep the C layout (compiled with gcc and compared)."""
+    import subprocess, tempfile, textwrap
+    from epsm_mitsuba3_amd import scene as S
+    src = textwrap.dedent("""
+        #include <stdio.h>
+        #include "epsm_trace.h"
+        int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(EpsmMesh), sizeof(EpsmBsdf), sizeof(EpsmEmitter),
+                                sizeof(EpsmBvhNode), sizeof(EpsmSensor), sizeof(EpsmScene), sizeof(EpsmRecordOut)); return 0; }
+    """)
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(td, "t"), os.path.join(td, "t.c")], check=True)
+        sizes = [int(x) for x in subprocess.run([os.path.join(td, "t")], capture_output=True, text=True, check=True).stdout.split()]
+    mine = [C.sizeof(S.EpsmMesh), C.sizeof(S.EpsmBsdf), C.sizeof(S.EpsmEmitter), 32, C.sizeof(S.EpsmSensor),
+            C.sizeof(S.EpsmSceneC), C.sizeof(S.EpsmRecordOut)]
+    assert sizes == mine, (sizes, mine)
