@@ -1,0 +1,70 @@
+"""Outer optimisation loop in the shape of EPSM/optim.py:36-165:
+
+    python -m epsm_mitsuba3_amd.optim METHOD EXP        # METHOD: manifold | manifold_caustic (| *_hybrid)
+
+render (H,W,5) -> tone-map + resize to ``match_res`` -> Sinkhorn matcher -> 5-channel gradient image tiled
+back to the film size (optim.py:130-135) -> ``render_backward`` -> chain rule into the optimised leaves
+-> NaN scrub (optim.py:143-154) -> Adam step (torch, as the reference's optim_human.py does).
+The ``*_hybrid`` second phase (prb_reparam after ``thres`` iterations, optim.py:87-94,113-119) is not
+built: a hybrid METHOD runs its manifold phase only and says so.
+"""
+from __future__ import annotations
+
+import importlib
+import sys
+
+import torch
+import torch.nn.functional as F
+
+from . import load_dict
+from .matcher import Matcher
+
+
+def to_ldr(img: torch.Tensor) -> torch.Tensor:
+    """mi.util.convert_to_bitmap + /255 (optim.py:121,131): linear -> sRGB, clamp, 8-bit quantisation."""
+    x = img.clamp(0, 1)
+    srgb = torch.where(x <= 0.0031308, 12.92 * x, 1.055 * x.clamp_min(1e-12).pow(1 / 2.4) - 0.055)
+    return torch.round(srgb.clamp(0, 1) * 255) / 255
+
+
+def resize(img: torch.Tensor, res: int) -> torch.Tensor:
+    """cv2.resize(img, (res,res)) -- bilinear, no anti-aliasing."""
+    return F.interpolate(img.permute(2, 0, 1)[None], size=(res, res), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+
+
+def run(method: str, exp: str, device="cuda", iterations=None, lr=0.02, log=print):
+    tasks = importlib.import_module(f"epsm_mitsuba3_amd.exp.{exp}")
+    if method.endswith("hybrid"):
+        method = method[:-7]
+        log("hybrid: the prb_reparam phase is not built; running the manifold phase for all iterations")
+    scene = tasks.load_scene(device)
+    integrator = load_dict({"type": method, "max_depth": tasks.max_depth})
+    sensor_id = 1 if method.startswith("manifold") else 0                      # optim.py:103-106
+    gt = tasks.gt_scene(device).render_primal(sensor=0, seed=0, spp=512, max_depth=tasks.max_depth)
+    gt_low = resize(to_ldr(gt), tasks.match_res)                               # optim.py:66
+    matcher = Matcher(tasks.match_res, device)
+    opt, apply_transformation, backward, output = tasks.optim_settings(scene)
+    optimizer = torch.optim.Adam(list(opt.values()), lr=lr)
+    params = scene.param_grads()
+    history = [output(opt)]
+    rep = tasks.resolution // tasks.match_res
+    for it in range(iterations or tasks.it):
+        apply_transformation(scene, opt)                                        # optim.py:112
+        img = integrator.render(scene, sensor=sensor_id, seed=it, spp=tasks.spp)             # (H,W,5)
+        render_low = resize(to_ldr(img[..., :3]), tasks.match_res)
+        grad_ = matcher.match_Sinkhorn(render_low.reshape(-1, 3), gt_low.reshape(-1, 3))
+        grad = grad_.reshape(tasks.match_res, tasks.match_res, 5).repeat(rep, rep, 1)         # optim.py:133-135
+        params.zero_()
+        integrator.render_backward(scene, params, grad, sensor=sensor_id, seed=it, spp=tasks.spp)   # dr.backward(img*grad)
+        backward(opt, params)
+        for p in opt.values():                                                  # optim.py:143-154
+            if p.grad is not None:
+                p.grad = torch.nan_to_num(p.grad, nan=0.0, posinf=0.0, neginf=0.0)
+        optimizer.step()
+        history.append(output(opt))
+        log(f"Iteration {it:02d}: error={history[-1]:.5f}")
+    return history, opt
+
+
+if __name__ == "__main__":
+    run(sys.argv[1], sys.argv[2])

@@ -1,0 +1,14 @@
+"""End to end: the outer loop (EPSM/optim.py shape) recovers the translation of an area light from the
+position of its highlight on a specular plate (the `li` parameters of EPSM/exp/highlight.py) -- exercises
+tracer, tangent, fused gradient/scatter (through the emitter rows, epsm.py:622-627), matcher and Adam
+together and pins the SIGN conventions along the whole chain."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_plate_translation_is_recovered():
+    from epsm_mitsuba3_amd.optim import run
+    hist, opt = run("manifold", "plate", iterations=45, lr=0.03, log=lambda s: None)
+    assert hist[0] > 0.7
+    assert min(hist[-10:]) < 0.25 * hist[0], hist
