@@ -32,6 +32,12 @@ def resize(img: torch.Tensor, res: int) -> torch.Tensor:
     return F.interpolate(img.permute(2, 0, 1)[None], size=(res, res), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
 
 
+def chain_vertex_grads(vertices: torch.Tensor, vertex_grad: torch.Tensor) -> None:
+    """EPSM/optim_human.py:118-121: per-vertex position gradients chained into whatever torch module
+    produced the vertices (SMPL there): ``loss = sum(verts * grad); loss.backward()``."""
+    (vertices * vertex_grad.detach().to(vertices.device, vertices.dtype)).sum().backward()
+
+
 def run(method: str, exp: str, device="cuda", iterations=None, lr=0.02, log=print):
     tasks = importlib.import_module(f"epsm_mitsuba3_amd.exp.{exp}")
     if method.endswith("hybrid"):

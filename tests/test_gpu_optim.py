@@ -12,3 +12,12 @@ def test_plate_translation_is_recovered():
     hist, opt = run("manifold", "plate", iterations=45, lr=0.03, log=lambda s: None)
     assert hist[0] > 0.7
     assert min(hist[-10:]) < 0.25 * hist[0], hist
+
+
+def test_caustic_light_translation_is_recovered():
+    """manifold_caustic: camera -> diffuse floor -> glass slab (two refractions) -> area light; the light's
+    gradient arrives through diffuse_grad of the chain's end point (epsm.py:1178-1184)."""
+    from epsm_mitsuba3_amd.optim import run
+    hist, opt = run("manifold_caustic", "slab", iterations=45, lr=0.03, log=lambda s: None)
+    assert hist[0] > 0.55
+    assert min(hist[-15:]) < 0.35 * hist[0], hist
