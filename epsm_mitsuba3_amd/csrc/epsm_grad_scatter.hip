@@ -39,6 +39,9 @@ struct FusedArgs {
 // 644-645) follows.  All 64 lanes call every method at the same program point (`ok` is
 // false for lanes past the end of the wavefront): rows of the hit triangle are merged
 // over runs of equal triangles before they reach LDS.
+// fewer lanes than this: the DPP sums (VALU, the kernel's bottleneck) cost more than the LDS atomics they save
+// (measured on the bathroom / specular / pool profiles: 4, 8, 16, 32 for the triangle rows)
+constexpr int kMinMergeLanes = 16, kMinMergeLanesAlpha = 4;
 #ifndef EPSM_FUSED_MERGE
 #define EPSM_FUSED_MERGE 0      // 0: direct LDS atomics, 1: adaptive wave-run merge first
 #endif
@@ -54,6 +57,45 @@ template <int BITS> struct ScatterOut {
     __device__ __forceinline__ void push(bool valid, const uint32_t key[ROWS], const V3<float> val[ROWS]) const {
         Q.reserve(T, ROWS);
         Q.template push_rows<ROWS>(valid, key, val);
+    }
+
+    // Lanes whose rows go to the SAME three parameter rows (the samples of one pixel at the first hit, the
+    // two triangles of an area light, one BSDF's alpha) are summed over the wave with DPP adds and the first
+    // of them alone carries the sum on: the LDS table then sees one row instead of up to 64 same-address
+    // atomics, which it executes one after the other.  Up to ROUNDS distinct targets per call; a round that
+    // would merge fewer than kMinMergeLanes lanes ends the search.
+    template <int ROWS, int ROUNDS>
+    __device__ __forceinline__ void merge_equal(bool &any, const uint32_t id[3], V3<float> vals[ROWS], int live_rows = ROWS) const {
+        constexpr int kMin = ROWS == 1 ? kMinMergeLanesAlpha : kMinMergeLanes;
+        unsigned long long pending = __ballot(any);
+#pragma unroll 1
+        for (int round = 0; round < ROUNDS; ++round) {
+            if (__popcll(pending) < kMin) return;
+            const int leader = __ffsll((long long) pending) - 1;
+            const uint32_t l0 = (uint32_t) __builtin_amdgcn_readlane((int) id[0], leader),
+                           l1 = (uint32_t) __builtin_amdgcn_readlane((int) id[1], leader),
+                           l2 = (uint32_t) __builtin_amdgcn_readlane((int) id[2], leader);
+            const bool mine = any && id[0] == l0 && id[1] == l1 && id[2] == l2;
+            const unsigned long long mm = __ballot(mine);
+            pending &= ~mm;
+            if (__popcll(mm) < kMin) return;                             // incoherent wave: stop searching
+            const bool carrier = lane_id() == leader;
+            if (ROWS == 1) {
+                vals[0].x = merge_row1(vals[0].x, mine, carrier);        // alpha rows carry one component
+            } else {
+#pragma unroll
+                for (int j = 0; j + 2 < ROWS; j += 3) {
+                    if (j >= live_rows) break;                           // wave-uniform: rows nobody has
+                    Rows3 r = {{vals[j].x, vals[j].y, vals[j].z, vals[j + 1].x, vals[j + 1].y, vals[j + 1].z,
+                                vals[j + 2].x, vals[j + 2].y, vals[j + 2].z}};
+                    r = merge_rows3(r, mine, carrier);
+                    vals[j] = mk3<float>(r.v[0], r.v[1], r.v[2]);
+                    vals[j + 1] = mk3<float>(r.v[3], r.v[4], r.v[5]);
+                    vals[j + 2] = mk3<float>(r.v[6], r.v[7], r.v[8]);
+                }
+            }
+            if (mine && !carrier) any = false;
+        }
     }
 
     struct Tri { uint32_t vi[3]; uint32_t mode; };
@@ -127,11 +169,13 @@ template <int BITS> struct ScatterOut {
         // group A: the hit triangle's position rows and normal rows (zero rows are dropped at the drain)
         {
             const uint32_t V32 = (uint32_t) F.V;
-            const uint32_t keys[6] = {t.vi[0], t.vi[1], t.vi[2], V32 + t.vi[0], V32 + t.vi[1], V32 + t.vi[2]};
             const V3<float> z = zero3<float>();
-            const V3<float> vals[6] = {pos_v ? pos[0] : z, pos_v ? pos[1] : z, pos_v ? pos[2] : z,
-                                       nrm_v ? nrm[0] : z, nrm_v ? nrm[1] : z, nrm_v ? nrm[2] : z};
-            const bool any = (pos_v && (nz3(pos[0]) || nz3(pos[1]) || nz3(pos[2]))) || nrm_v;
+            V3<float> vals[6] = {pos_v ? pos[0] : z, pos_v ? pos[1] : z, pos_v ? pos[2] : z,
+                                 nrm_v ? nrm[0] : z, nrm_v ? nrm[1] : z, nrm_v ? nrm[2] : z};
+            bool any = (pos_v && (nz3(pos[0]) || nz3(pos[1]) || nz3(pos[2]))) || nrm_v;
+            const uint32_t tri[3] = {t.vi[0], t.vi[1], t.vi[2]};
+            merge_equal<6, 2>(any, tri, vals, __ballot(nrm_v) != 0ull ? 6 : 3);
+            const uint32_t keys[6] = {tri[0], tri[1], tri[2], V32 + tri[0], V32 + tri[1], V32 + tri[2]};
             push<6>(any, keys, vals);
         }
         // group B: bsdf_sample.hf * path_grad[5it+4]  and  si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627, 645)
@@ -143,16 +187,21 @@ template <int BITS> struct ScatterOut {
             const V3<float> gl = e_ok ? glight * a.ew : zero3<float>();
             const uint32_t keys[4] = {e_ok ? a.ei[0] : 0u, e_ok ? a.ei[1] : 0u, e_ok ? a.ei[2] : 0u,
                                       a_ok ? 2u * (uint32_t) F.V + a.bid : 0u};
-            const V3<float> vals[4] = {gl * a.eb0, gl * a.eb1, gl * (1.f - a.eb0 - a.eb1),
-                                       mk3<float>(a_ok ? dot(gm, a.dhf) : 0.f, 0.f, 0.f)};
-            push<4>(a_ok || e_ok, keys, vals);
+            V3<float> vals[4] = {gl * a.eb0, gl * a.eb1, gl * (1.f - a.eb0 - a.eb1),
+                                 mk3<float>(a_ok ? dot(gm, a.dhf) : 0.f, 0.f, 0.f)};
+            bool e_any = e_ok, a_any = a_ok;
+            merge_equal<3, 2>(e_any, keys, vals);                       // area lights are a handful of triangles
+            const uint32_t aid[3] = {keys[3], 0u, 0u};
+            merge_equal<1, 4>(a_any, aid, vals + 3);                    // a handful of materials
+            push<4>(a_any || e_any, keys, vals);
         }
     }
     // si_follow.p * diffuse_grad[it] with detached barycentrics (epsm.py:561-562); vertex it+1
     __device__ __forceinline__ void diffuse(int idx, V3<float> g, float b0, float b1, const Tri &t) const {
         g = fin(g);
-        const bool pos_v = ok && nz3(g) && idx + 1 <= F.K && tri_ok(t, F.V) && (t.mode & kModePos);
-        const V3<float> pos[3] = {g * b0, g * b1, g * (1.f - b0 - b1)};
+        bool pos_v = ok && nz3(g) && idx + 1 <= F.K && tri_ok(t, F.V) && (t.mode & kModePos);
+        V3<float> pos[3] = {g * b0, g * b1, g * (1.f - b0 - b1)};
+        merge_equal<3, 2>(pos_v, t.vi, pos);
         push<3>(pos_v, t.vi, pos);
     }
     __device__ __forceinline__ void diffuse_first(V3<float> g) const {
@@ -203,7 +252,9 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
         else
             caustic_path<float, K, FULL_D>(F.g, i, dcols, out);
         Q.drain(T);
-        if (T.crowded()) T.flush();               // workgroup-uniform census
+        // workgroup-uniform census (three barriers) once per group of chunks; a table that fills up in
+        // between sends the overflow straight to HBM (LdsTable::add)
+        if ((it % group) == group - 1 && T.crowded()) T.flush();
     }
     T.flush();
 }

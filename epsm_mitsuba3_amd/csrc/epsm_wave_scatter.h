@@ -159,6 +159,44 @@ __device__ __forceinline__ float masked_wave_sum(float v, bool in) {
     return v;
 }
 
+// Sum over the wave with DPP adds only (no LDS crossbar): quad swaps, half-row and row mirrors
+// give every lane its 16-lane row total, row_bcast15 / row_bcast31 chain the rows; lane 63 ends up
+// with the wave total.  Lanes that must not contribute pass 0.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_total_lane63(float v) {
+    v = dpp_add<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);    // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);    // row_mirror
+    v = dpp_add<0x142, 0xa>(v);    // row_bcast15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);    // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ V3<float> wave_total_lane63(V3<float> v) {
+    return mk3<float>(wave_total_lane63(v.x), wave_total_lane63(v.y), wave_total_lane63(v.z));
+}
+
+// Three rows of one merge round: lanes with `mine` are summed, the carrier lane receives the totals, the
+// other merged lanes are zeroed.  Out of line: it is used ~20 times per kernel and the fused kernel has to
+// stay inside the instruction cache.
+struct Rows3 { float v[9]; };
+__device__ __attribute__((noinline)) Rows3 merge_rows3(Rows3 r, bool mine, bool carrier) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const float tot = lane63(wave_total_lane63(mine ? r.v[c] : 0.f));
+        r.v[c] = carrier ? tot : (mine ? 0.f : r.v[c]);
+    }
+    return r;
+}
+__device__ __attribute__((noinline)) float merge_row1(float v, bool mine, bool carrier) {
+    const float tot = lane63(wave_total_lane63(mine ? v : 0.f));
+    return carrier ? tot : (mine ? 0.f : v);
+}
+
 // Three rows (one triangle) per lane, merged over runs of equal triangles.
 template <typename Table> __device__ __forceinline__ void scatter_triangle_runs(const Table &buf, uint32_t base, bool valid, const uint32_t key[3],
                                                       const V3<float> val[3], bool wave_has_any) {

@@ -13,10 +13,11 @@ def test_render_backward_matches_oracle_pipeline(kind, profile, fused):
     import epsm_mitsuba3_amd as epsm
     from _pipeline_oracle import oracle_backward
     dev = torch.device("cuda", 0)
-    res, spp, K, V, B = 32, 8, 4, 3000, 4
+    res, spp, K, V, B = 32, 8, 4, 3000, 4       # 8 spp = the reference's backward wavefront (epsm.py:145)
     scene = epsm.SyntheticScene(res=res, n_vertices=K, n_scene_vertices=V, n_bsdfs=B, profile=profile,
                                 device=dev, tile_paths=3000)
     integ = epsm.load_dict({"type": kind, "max_depth": 8, "fused": fused})
+    integ.backward_spp = spp
     assert isinstance(integ, epsm.EPSMIntegrator) and integ.variant == kind and integ.fused == fused
     g = torch.Generator().manual_seed(11)
     grad_in = (torch.randn((res * 2, res * 2, 5), generator=g) * 1e-3).to(dev)   # tiled image; the crop is used
@@ -24,18 +25,59 @@ def test_render_backward_matches_oracle_pipeline(kind, profile, fused):
     integ.render_backward(scene, params, grad_in, sensor=1, seed=7, spp=64)      # sensor/spp ignored (epsm.py:142,145)
     torch.cuda.synchronize()
     traces = scene.trace_paths(seed=7, spp=integ.backward_spp)
-    assert len(traces) == 3 and traces[1].path_offset == 3000
-    gp, gn, ga, go = oracle_backward(kind, traces, grad_in.cpu(), V, B)
-    for mine, ref, name in ((params.pos, gp, "pos"), (params.nrm, gn, "nrm"), (params.alpha, ga, "alpha"),
-                            (params.cam_origin, go, "cam")):
+    assert len(traces) == -(-res * res * spp // 3000) and traces[1].path_offset == 3000
+    gp, gn, ga, go, allow = oracle_backward(kind, traces, grad_in.cpu(), V, B, straddle_band=0.02)
+    for mine, ref, slack, name in ((params.pos, gp, allow[0], "pos"), (params.nrm, gn, allow[1], "nrm"),
+                                   (params.alpha, ga, allow[2], "alpha"), (params.cam_origin, go, 0.0, "cam")):
         m = float(ref.abs().max())
         assert m > 0, name
-        # end-to-end fp32 chain + clamp straddlers + atomic order: 1 % of the buffer's magnitude
-        assert float((mine.cpu().double() - ref).abs().max()) <= 1e-2 * m, name
+        # end-to-end fp32 chain + atomic order: 1 % of the buffer's magnitude, plus the weight of the per-path
+        # components within 2 % of the outlier threshold (fp32 and fp64 may zero different ones) and of
+        # the ill-conditioned paths on which the fp32 oracle itself leaves the fp64 one
+        assert bool(((mine.cpu().double() - ref).abs() <= 1e-2 * m + slack).all()), name
+        if name in ("pos", "nrm"):
+            assert float(slack.sum() / ref.abs().sum()) < 0.1, name      # the allowance is the exception, not the rule
     # accumulation: a second backward doubles the gradients (dr.backward accumulates)
     before = params.flat.clone()
     integ.render_backward(scene, params, grad_in, seed=7)
     assert torch.allclose(params.flat, 2 * before, rtol=1e-3, atol=1e-6 * float(before.abs().max()))
+
+
+@pytest.mark.parametrize("res,spp,V", [(32, 8, 3000), (12, 64, 300), (16, 256, 120)])
+@pytest.mark.parametrize("kind,profile", [("manifold", "bathroom"), ("manifold", "mixed"), ("manifold_caustic", "pool")])
+def test_fused_matches_oracle_scatter_of_dense_gradients(kind, profile, res, spp, V):
+    """The fused kernel against calc_grad's lists (dense HIP kernel, per-path parity in test_gpu_parity.py)
+    summed by the float64 scatter oracle: isolates the accumulation -- wave-level DPP merge, LDS table,
+    flush -- from the conditioning of the per-path systems.  At 64 / 256 spp on a coarse mesh a wave holds
+    one first-hit triangle (every lane merges) and a few per later bounce (leader rounds)."""
+    import epsm_mitsuba3_amd as epsm
+    from epsm_mitsuba3_amd.records import PackedRecords, PackedScatter
+    from epsm_mitsuba3_amd.synth import path_info_to
+    from oracle.binding import oracle_scatter
+    dev = torch.device("cuda", 0)
+    K, B = 5, 4
+    scene = epsm.SyntheticScene(res=res, n_vertices=K, n_scene_vertices=V, n_bsdfs=B, profile=profile,
+                                device=dev, tile_paths=5000)
+    g = torch.Generator().manual_seed(5)
+    grad_in = (torch.randn((res, res, 5), generator=g) * 1e-3).to(dev)
+    fused = epsm.load_dict({"type": kind, "max_depth": 8, "fused": True})
+    dense = epsm.load_dict({"type": kind, "max_depth": 8, "fused": False})
+    params = epsm.ParamGrads(V, B, device=dev)
+    ref = [torch.zeros((V, 3), dtype=torch.float64), torch.zeros((V, 3), dtype=torch.float64),
+           torch.zeros((B,), dtype=torch.float64)]
+    scratch = epsm.ParamGrads(V, B, device=dev)
+    for tr in scene.trace_paths(seed=3, spp=spp):
+        fused.backward_from_trace(tr, params, grad_in)
+        lists = dense.backward_from_trace(tr, scratch, grad_in)
+        pi = path_info_to(tr.path_info, device="cpu")
+        si = [{k: v.cpu() for k, v in r.items()} for r in tr.scatter_info]
+        for acc, part in zip(ref, oracle_scatter(kind, pi, si, *[t.cpu() for t in lists], V, B)):
+            acc += part
+    torch.cuda.synchronize()
+    for mine, want, name in ((params.pos, ref[0], "pos"), (params.nrm, ref[1], "nrm"), (params.alpha, ref[2], "alpha")):
+        m = float(want.abs().max())
+        assert m > 0, name
+        assert float((mine.cpu().double() - want).abs().max()) <= 2e-4 * m, name      # fp32 summation order only
 
 
 def test_unknown_plugin_and_bad_props():
@@ -46,13 +88,15 @@ def test_unknown_plugin_and_bad_props():
         epsm.load_dict({"type": "manifold", "max_depth": -3})
 
 
+@pytest.mark.parametrize("res,spp,V", [(512, 8, 50000), (128, 64, 2000)])
 @pytest.mark.parametrize("kind,profile", [("manifold", "bathroom"), ("manifold", "specular"), ("manifold_caustic", "pool")])
-def test_fused_equals_two_stage_at_scale(kind, profile):
-    """2^21 paths: the fused kernel and calc_grad -> scatter accumulate the same sums (the
-    only difference is the order of float additions)."""
+def test_fused_equals_two_stage_at_scale(kind, profile, res, spp, V):
+    """2^21 / 2^20 paths: the fused kernel and calc_grad -> scatter accumulate the same sums (the
+    only difference is the order of float additions).  At 64 spp on a coarse mesh every wave of the
+    fused kernel holds one or two triangles per bounce: its wave-level merge (DPP sums) does the adding."""
     import epsm_mitsuba3_amd as epsm
     dev = torch.device("cuda", 0)
-    res, spp, K, V, B = 512, 8, 5, 50000, 4
+    K, B = 5, 4
     scene = epsm.SyntheticScene(res=res, n_vertices=K, n_scene_vertices=V, n_bsdfs=B, profile=profile,
                                 device=dev, tile_paths=res * res * spp)
     g = torch.Generator().manual_seed(2)
@@ -60,6 +104,7 @@ def test_fused_equals_two_stage_at_scale(kind, profile):
     bufs = []
     for fused in (True, False):
         integ = epsm.load_dict({"type": kind, "max_depth": 8, "fused": fused})
+        integ.backward_spp = spp
         params = epsm.ParamGrads(V, B, device=dev)
         integ.render_backward(scene, params, grad_in, seed=1)
         torch.cuda.synchronize()
