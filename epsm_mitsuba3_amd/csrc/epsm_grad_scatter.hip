@@ -33,6 +33,22 @@ struct FusedArgs {
     int P, K;
 };
 
+// The 85 array pointers of a K = 5 launch are 170 SGPRs: kept as kernel arguments the compiler hoists them
+// out of the persistent loop and spills ~240 of them into VGPR lanes (a v_readlane per use: ~10 % of the
+// kernel's VALU instructions).  The workgroup copies them to LDS once; the path code reads the few it
+// needs per vertex with ds_read_b64 into VGPR pairs that die with the loads they feed.
+struct PtrTable {
+    VertexPtrs<float> v[kMaxVertices];
+    ScatterPtrs<float> s[kMaxVertices];
+};
+struct LdsArgs {
+    int64_t N;
+    const float *cam, *dlduv, *dldp;
+    int64_t dlduv_stride;
+    const PtrTable *tab;             // LDS
+    __device__ __forceinline__ const VertexPtrs<float> &vtx(int k) const { return tab->v[k]; }
+};
+
 // Output policy: rows go to the LDS table.  The clamp / NaN rule of calc_grad
 // (epsm.py:856, 932-944) is applied to each (N,3) component first, exactly as the dense
 // path stores it, then the linear map of epsm_scatter_core.h (epsm.py:559-562, 622-627,
@@ -48,6 +64,7 @@ constexpr int kMinMergeLanes = 16, kMinMergeLanesAlpha = 4;
 
 template <int BITS> struct ScatterOut {
     const FusedArgs &F;
+    const PtrTable &P;
     const LdsTable<BITS> &T;
     WaveQueue<kQueueCap> &Q;
     int64_t i;
@@ -109,7 +126,7 @@ template <int BITS> struct ScatterOut {
     __device__ __forceinline__ Tri pre_tri(int k, bool live) const {
         Tri t; t.vi[0] = t.vi[1] = t.vi[2] = kNoIndex; t.mode = 0;
         if (live && ok) {
-            const U4 t4 = load_u4(F.s[k - 1].tri, i);
+            const U4 t4 = load_u4(P.s[k - 1].tri, i);
             t.vi[0] = t4.x; t.vi[1] = t4.y; t.vi[2] = t4.z; t.mode = t4.w;
         }
         return t;
@@ -117,7 +134,7 @@ template <int BITS> struct ScatterOut {
     __device__ __forceinline__ Aux pre_aux(int k, bool live) const {
         Aux a; a.bid = kNoIndex; a.dhf = zero3<float>(); a.ei[0] = a.ei[1] = a.ei[2] = kNoIndex; a.eb0 = a.eb1 = a.ew = 0.f;
         if (live && ok) {
-            const ScatterPtrs<float> &s = F.s[k - 1];
+            const ScatterPtrs<float> &s = P.s[k - 1];
             if (s.aux && F.galpha) {
                 const U4 a4 = load_u4(s.aux, i);
                 a.bid = a4.x; a.dhf = mk3<float>(bits_to_float(a4.y), bits_to_float(a4.z), bits_to_float(a4.w));
@@ -208,7 +225,7 @@ template <int BITS> struct ScatterOut {
         g = fin(g);
         Tri t = pre_tri(1, nz3(g));
         float b0 = 0.f, b1 = 0.f;
-        if (ok && nz3(g)) { b0 = F.g.v[0].b0[i]; b1 = F.g.v[0].b1[i]; }
+        if (ok && nz3(g)) { b0 = P.v[0].b0[i]; b1 = P.v[0].b1[i]; }
         diffuse(0, g, b0, b1, t);
     }
     __device__ __forceinline__ void poison(int) const {
@@ -230,9 +247,12 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
     __shared__ float s_vals[kTableSize * 3];
     __shared__ int s_used;
     __shared__ QItem s_queue[4][kQueueCap];
+    __shared__ PtrTable s_ptrs;
     const LdsTable<kBits> T{s_keys, s_vals, &s_used, F.gpos, F.gnrm, F.galpha, (uint32_t) F.V};
     WaveQueue<kQueueCap> Q{s_queue[threadIdx.x >> 6], 0};
-    T.clear();
+    if (threadIdx.x < K) { s_ptrs.v[threadIdx.x] = F.g.v[threadIdx.x]; s_ptrs.s[threadIdx.x] = F.s[threadIdx.x]; }
+    const LdsArgs A{F.g.N, F.g.cam, F.g.dlduv, F.g.dldp, F.g.dlduv_stride, &s_ptrs};
+    T.clear();                                   // ends with a barrier: the table of pointers is visible too
     // Chunk order: groups of 4 consecutive chunks (16 pixels at 64 spp share triangles),
     // groups dealt round-robin over the workgroups so that the chip streams one contiguous
     // window of every record array at a time (measured: same speed as one contiguous range
@@ -246,11 +266,11 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
         const int64_t i0 = c * 256 + threadIdx.x;
         const bool ok = i0 < F.g.N;
         const int64_t i = ok ? i0 : F.g.N - 1;    // lanes past the end recompute the last path and add nothing
-        const ScatterOut<kBits> out{F, T, Q, i, ok};
+        const ScatterOut<kBits> out{F, s_ptrs, T, Q, i, ok};
         if (VARIANT == EPSM_VARIANT_MANIFOLD)
-            manifold_path<float, K, FULL_D>(F.g, i, dcols, out);
+            manifold_path<float, K, FULL_D>(A, i, dcols, out);
         else
-            caustic_path<float, K, FULL_D>(F.g, i, dcols, out);
+            caustic_path<float, K, FULL_D>(A, i, dcols, out);
         Q.drain(T);
         // workgroup-uniform census (three barriers) once per group of chunks; a table that fills up in
         // between sends the overflow straight to HBM (LdsTable::add)

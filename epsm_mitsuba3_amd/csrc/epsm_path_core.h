@@ -146,6 +146,7 @@ template <typename R> struct GradArgs {
     R *out_param;            // (P,N,3)
     R *out_light;            // (K,N,3)
     R *out_diffuse;          // (K,N,3)
+    EPSM_HD const VertexPtrs<R> &vtx(int k) const { return v[k]; }
 };
 
 template <typename R> EPSM_HD V3<R> load3(const R *base, int64_t i) {
@@ -334,7 +335,7 @@ template <typename R> EPSM_HD M2<R> block2(V3<R> g0, V3<R> g1, V3<R> e1, V3<R> e
 }
 template <typename R> EPSM_HD M2<R> madd2(M2<R> p, M2<R> q) { M2<R> r; r.a = p.a + q.a; r.b = p.b + q.b; r.c = p.c + q.c; r.d = p.d + q.d; return r; }
 
-template <typename R, bool FULL_D> EPSM_HD V2<R> load_d(const GradArgs<R> &A, int64_t i, int k /*1-based*/, int dcols) {
+template <typename R, bool FULL_D, typename Args> EPSM_HD V2<R> load_d(const Args &A, int64_t i, int k /*1-based*/, int dcols) {
     if (!FULL_D && k > 1) return mk2<R>(R(0), R(0));
     const R *row = A.dlduv + i * A.dlduv_stride;
     int c = 2 * (k - 1);
@@ -349,16 +350,16 @@ template <typename R, bool FULL_D> EPSM_HD V2<R> load_d(const GradArgs<R> &A, in
 template <int K> struct Flags {
     bool diffuse[K + 2], null_[K + 2], active[K + 2], active_em[K + 2], mesh[K + 2];
 };
-template <typename R, int K> EPSM_HD Flags<K> load_flags(const GradArgs<R> &A, int64_t i) {
+template <typename R, int K, typename Args> EPSM_HD Flags<K> load_flags(const Args &A, int64_t i) {
     Flags<K> f;
 #pragma unroll
     for (int k = 1; k <= K; ++k) {
-        uint32_t b = A.v[k - 1].bsdf[i];
+        uint32_t b = A.vtx(k - 1).bsdf[i];
         f.diffuse[k] = (b & kBsdfDiffuse) != 0;
         f.null_[k] = (b & kBsdfNull) != 0;
-        f.active[k] = A.v[k - 1].active[i] != 0;
-        f.active_em[k] = A.v[k - 1].active_em[i] != 0;
-        f.mesh[k] = A.v[k - 1].ismesh[i] != 0;
+        f.active[k] = A.vtx(k - 1).active[i] != 0;
+        f.active_em[k] = A.vtx(k - 1).active_em[i] != 0;
+        f.mesh[k] = A.vtx(k - 1).ismesh[i] != 0;
     }
     f.diffuse[0] = f.null_[0] = f.active[0] = f.active_em[0] = f.mesh[0] = false;
     f.diffuse[K + 1] = f.null_[K + 1] = f.active[K + 1] = f.active_em[K + 1] = f.mesh[K + 1] = false;
@@ -368,8 +369,8 @@ template <typename R, int K> EPSM_HD Flags<K> load_flags(const GradArgs<R> &A, i
 // ============================================================================
 // "manifold"  (epsm.py:745-946)
 // ============================================================================
-template <typename R, int K, bool FULL_D, typename Out>
-EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols, const Out &out) {
+template <typename R, int K, bool FULL_D, typename Out, typename Args>
+EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) {
     const Flags<K> fl = load_flags<R, K>(A, i);
 
     // term masks (epsm.py:793-802, 852-855, 916-920).  wN[id]: light-sampling
@@ -408,10 +409,10 @@ EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols, const Out
     struct Raw { Geo<R> g; Nrm<R> nr; R eta; V3<R> light; };
     auto load_raw = [&](int kk) EPSM_LAMBDA {
         Raw r;
-        r.g = load_geo(A.v[kk - 1], i);
-        r.nr = load_nrm(A.v[kk - 1], i, r.g.b0, r.g.b1);
-        r.eta = A.v[kk - 1].eta[i];
-        r.light = load3(A.v[kk - 1].light, i);
+        r.g = load_geo(A.vtx(kk - 1), i);
+        r.nr = load_nrm(A.vtx(kk - 1), i, r.g.b0, r.g.b1);
+        r.eta = A.vtx(kk - 1).eta[i];
+        r.light = load3(A.vtx(kk - 1).light, i);
         return r;
     };
     const V3<R> cam = load3(A.cam, i);
@@ -534,8 +535,8 @@ EPSM_HD void manifold_path(const GradArgs<R> &A, int64_t i, int dcols, const Out
 // the pseudo-constraint wo2 of the CURRENT depth (column block id only) and
 // rows 2..id the half-vector constraints: unknowns y_2.. follow a forward
 // recursion that does not depend on the depth, y_1 closes it per depth.
-template <typename R, int K, bool FULL_D, typename Out>
-EPSM_HD void caustic_path(const GradArgs<R> &A, int64_t i, int dcols, const Out &out) {
+template <typename R, int K, bool FULL_D, typename Out, typename Args>
+EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
     const Flags<K> fl = load_flags<R, K>(A, i);
     constexpr int P = 5 * K - 2;
 
@@ -561,7 +562,7 @@ EPSM_HD void caustic_path(const GradArgs<R> &A, int64_t i, int dcols, const Out 
 
     const V3<R> cam = load3(A.cam, i);
     Geo<R> gcur, gnext;
-    if (nv >= 1) gnext = load_geo(A.v[0], i);
+    if (nv >= 1) gnext = load_geo(A.vtx(0), i);
     typename Out::Tri tri_prev = out.pre_tri(1, false), tri_cur = out.pre_tri(1, nv >= 1);
     V3<R> n_prev = zero3<R>();
     V2<R> vprev = mk2<R>(R(0), R(0)), vcur = vprev;   // v_{k-1}, v_k   (v_1 = 0)
@@ -583,11 +584,11 @@ EPSM_HD void caustic_path(const GradArgs<R> &A, int64_t i, int dcols, const Out 
         const typename Out::Aux aux_prev = out.pre_aux(k >= 2 ? k - 1 : 1, k >= 2 && (k - 1) <= idstar);
         if (live) {
             gcur = gnext;
-            gnext = load_geo(A.v[k < K ? k : K - 1], i);
+            gnext = load_geo(A.vtx(k < K ? k : K - 1), i);
             b0 = gcur.b0; b1 = gcur.b1;
-            const Nrm<R> nr = load_nrm(A.v[k - 1], i, gcur.b0, gcur.b1);
+            const Nrm<R> nr = load_nrm(A.vtx(k - 1), i, gcur.b0, gcur.b1);
             ncur = nr.n;
-            const R eta = A.v[k - 1].eta[i];
+            const R eta = A.vtx(k - 1).eta[i];
             const Frame<R> fr = make_frame(nr.n);
             const HalfVec<R> h = halfvec_fwd(xprev, gcur.x, gnext.x, fr, eta);
             const V2<R> dk = load_d<R, FULL_D>(A, i, k, dcols);
