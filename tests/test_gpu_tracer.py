@@ -81,3 +81,34 @@ def test_primal_render_and_backward_on_a_scene():
     sc.set_vertex_positions("plate", v)
     img2 = integ.render(sc, sensor=1, seed=0, spp=16)
     assert float((img2 - img).abs().mean()) > 1e-4
+
+
+@pytest.mark.parametrize("rfilter", [1, 0])                      # EPSM_RFILTER_GAUSSIAN, EPSM_RFILTER_BOX
+@pytest.mark.parametrize("res,spp,n_cut", [(24, 64, 0), (24, 128, 0), (32, 16, 0), (40, 8, 0), (33, 5, 0), (24, 64, 37), (16, 0, 0)])
+def test_film_splat_matches_host(res, spp, n_cut, rfilter):
+    """epsm_film_splat against the serial host loop of tests/host_harness (ImageBlock::put restated twice,
+    independently): pixel-major wavefronts at 64 / 128 / 16 / 8 spp take the wave-level sums over 64 / 16 / 8
+    lanes, 5 spp, a ragged tail and positions all over the film (spp = 0 here) the lane-by-lane path."""
+    import ctypes as C
+    from _scenes import host_tracer
+    from epsm_mitsuba3_amd import _lib
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(res * 1000 + spp)
+    if spp:
+        n = res * res * spp - n_cut
+        pix = torch.arange(res * res * spp)[:n] // spp
+        pos = torch.stack([(pix % res).float(), (pix // res).float()], dim=1) + torch.rand((n, 2), generator=g)
+    else:
+        n = 5000
+        pos = torch.rand((n, 2), generator=g) * (res + 6) - 3.0           # some samples off the film
+    rad = torch.rand((n, 3), generator=g) * 3.0
+    want = torch.zeros((res, res, 4))
+    assert host_tracer().epsm_film_splat(C.c_int64(n), C.c_void_p(pos.data_ptr()), C.c_void_p(rad.data_ptr()), res, res,
+                                         rfilter, C.c_void_p(want.data_ptr()), None) == 0
+    got = torch.zeros((res, res, 4), device=dev)
+    pd, rd = pos.to(dev), rad.to(dev)
+    assert _lib.lib().epsm_film_splat(C.c_int64(n), C.c_void_p(pd.data_ptr()), C.c_void_p(rd.data_ptr()), res, res, rfilter,
+                                      C.c_void_p(got.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) == 0
+    torch.cuda.synchronize()
+    assert float(want.abs().max()) > 0
+    assert torch.allclose(got.cpu(), want, rtol=2e-4, atol=2e-4 * float(want.abs().max()))
