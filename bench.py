@@ -4,19 +4,21 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one backward pass of the hot path over one wavefront of synthetic path
-records that are already resident in HBM: first-vertex tangent -> per-path
-constraint Jacobian + block solve + adjoint gradients (``epsm_manifold_grad``) ->
-scatter into the parameter-gradient buffer (+ one RCCL all-reduce of that buffer
-when N > 1).  At N=1 the workload is BASELINE.json ``configs[1]``: bathroom,
+records that are already resident in HBM: zero the parameter-gradient buffer ->
+first-vertex tangent -> per-path constraint Jacobian + block solve + adjoint
+gradients + scatter into the parameter-gradient buffer (one fused launch,
+``epsm_manifold_grad_scatter``; ``--two-stage``: ``epsm_manifold_grad`` then
+``epsm_scatter``, the reference's shape) -> one RCCL all-reduce of that buffer
+when N > 1.  At N=1 the workload is BASELINE.json ``configs[1]``: bathroom,
 ``manifold``, 512x512 @ 64 spp -> 16 777 216 paths, 5 logged vertices each
 (SURVEY.md 8d).  With N>1 every rank processes its own wavefront of that size
 (weak scaling: pixel/sample tiles of a larger image sharded over the GPUs).
 
 Prints ONE JSON line (rank 0).  ``value`` = paths/s over all ranks for the whole
 step; ``grad_image_ms`` = wall-clock of the step; ``roofline`` prices the dominant
-kernel (the gradient kernel) against the 8 TB/s HBM peak using the ALGORITHMIC
-bytes (32 + 200*K per path) and its own launch time measured with HIP
-events on the launch stream; ``cpu_baseline`` times oracle/ (the C restatement of
+kernel (the fused gradient+scatter kernel) against the 8 TB/s HBM peak using the
+ALGORITHMIC bytes (32 + 116*K per path fused, 32 + 200*K stand-alone)
+and its own launch time measured with HIP events on the launch stream; ``cpu_baseline`` times oracle/ (the C restatement of
 the reference's calc_grad) on this box's host cores on a bounded sample of the same
 records.
 """
@@ -138,6 +140,7 @@ def main():
         def mark(name):
             if record:
                 e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+        params.flat.zero_()                      # every backward pass starts from dr.grad == 0 (optim.py: per iteration)
         integ.backward_from_trace(trace, params, grad_in, packed=packed, out=out, mark=mark)
         edist.allreduce_param_grads(params.flat)
         mark("allreduce")

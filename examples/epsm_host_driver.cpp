@@ -1,0 +1,258 @@
+// epsm_host_driver.cpp -- a C++ host that drives the hot path through the C ABI alone (include/epsm.h):
+// no Python, no torch.  It is the shape of what a C++ integrator plugin of the reference would do in
+// render_backward (epsm.py:84-306) once the path records are on the device:
+//
+//     epsm_first_vertex_tangent  ->  epsm_manifold_grad_scatter            (one fused launch)
+//                                ->  epsm_manifold_grad -> epsm_scatter    (the reference's two stages)
+//
+// and it checks that both routes accumulate the same parameter gradients, that the error convention of
+// the ABI holds (status codes + epsm_last_error), and prints the rate of each stage.
+//
+// Records are synthetic (the generator of SURVEY.md 8d, restated for the host): triangles around zig-zagging
+// centres, bathroom-like diffuse placement, 10 % termination per bounce; parameter addressing on a coherent
+// grid as in epsm_mitsuba3_amd/synth.py.
+//
+//   hipcc -O2 -std=c++17 --offload-arch=gfx950 -Iinclude examples/epsm_host_driver.cpp \
+//         -Lepsm_mitsuba3_amd -lepsm_hip -Wl,-rpath,'$ORIGIN/../../epsm_mitsuba3_amd' -o examples/build/epsm_host_driver
+//   examples/build/epsm_host_driver [paths=1048576] [K=5] [variant=0|1] [V=100000]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "epsm.h"
+
+namespace {
+
+#define HIP_OK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e_)); std::exit(2); } \
+    } while (0)
+#define EPSM_CALL(call)                                                                                \
+    do {                                                                                               \
+        int rc_ = (call);                                                                              \
+        if (rc_ != EPSM_OK) { std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, epsm_last_error()); std::exit(3); } \
+    } while (0)
+
+struct Rng {                       // splitmix64: one stream per array, reproducible across hosts
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed) {}
+    uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+    float uni() { return (float) ((next() >> 40) * (1.0 / 16777216.0)); }          // [0,1)
+    float uni(float lo, float hi) { return lo + (hi - lo) * uni(); }
+    float gauss() { const float u = std::fmax(uni(), 1e-7f), v = uni(); return std::sqrt(-2.f * std::log(u)) * std::cos(6.2831853f * v); }
+};
+
+template <typename T> struct DeviceArray {
+    T *ptr = nullptr;
+    size_t n = 0;
+    DeviceArray() = default;
+    explicit DeviceArray(const std::vector<T> &h) { upload(h); }
+    explicit DeviceArray(size_t count) : n(count) { HIP_OK(hipMalloc(&ptr, count * sizeof(T))); HIP_OK(hipMemset(ptr, 0, count * sizeof(T))); }
+    DeviceArray(const DeviceArray &) = delete;
+    DeviceArray &operator=(const DeviceArray &) = delete;
+    DeviceArray(DeviceArray &&o) noexcept : ptr(o.ptr), n(o.n) { o.ptr = nullptr; }
+    ~DeviceArray() { if (ptr) (void) hipFree(ptr); }
+    void upload(const std::vector<T> &h) {
+        n = h.size();
+        HIP_OK(hipMalloc(&ptr, n * sizeof(T)));
+        HIP_OK(hipMemcpy(ptr, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    }
+    std::vector<T> download() const { std::vector<T> h(n); HIP_OK(hipMemcpy(h.data(), ptr, n * sizeof(T), hipMemcpyDeviceToHost)); return h; }
+    void zero() { HIP_OK(hipMemset(ptr, 0, n * sizeof(T))); }
+};
+
+constexpr uint32_t kFlagsDiffuse = 0x2u | 0x8000u, kFlagsRough = 0x8u | 0x8000u,
+                   kFlagsDielectric = 0x20u | 0x40u | 0x8000u | 0x10000u | 0x4000u;      // bsdf.h:40-101
+
+struct VertexArrays {               // one logged vertex, device side
+    DeviceArray<float> p[3], n[3], b0, b1, eta, hf, light;
+    DeviceArray<uint32_t> bsdf, tri, aux, emit;
+    DeviceArray<uint8_t> active, active_em, ismesh;
+};
+
+void normalize3(float *v) { const float l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= l; v[1] /= l; v[2] /= l; }
+
+// SURVEY.md 8d generator for vertex k (1-based); `alive` carries the termination state along the path.
+VertexArrays make_vertex(int64_t N, int k, int64_t V, int res, int spp, std::vector<uint8_t> &alive, uint64_t seed) {
+    Rng r(seed * 1000003ull + (uint64_t) k);
+    std::vector<float> p[3], nn[3], b0(N), b1(N), eta(N), hf(3 * N), light(3 * N);
+    std::vector<uint32_t> bsdf(N), tri(4 * N), aux(4 * N), emit(8 * N);
+    std::vector<uint8_t> act(N), act_em(N), ismesh(N);
+    for (auto &a : p) a.resize(3 * N);
+    for (auto &a : nn) a.resize(3 * N);
+    const float centre[3] = {1.6f * ((k % 2) * 2 - 1) * 0.5f, 0.35f * k, 2.5f - 2.0f * (k % 2)};
+    const int64_t G = (int64_t) std::fmax(2.0, std::floor(std::sqrt(2.0 * (double) V)));
+    const int64_t n_emit_tris = 32;
+    for (int64_t i = 0; i < N; ++i) {
+        for (int j = 0; j < 3; ++j)
+            for (int c = 0; c < 3; ++c) p[j][3 * i + c] = centre[c] + r.uni(-0.5f, 0.5f);
+        for (int j = 0; j < 3; ++j) {
+            float v[3] = {0.1f + 0.2f * r.uni(-0.5f, 0.5f), 0.2f + 0.2f * r.uni(-0.5f, 0.5f), 1.0f + 0.2f * r.uni(-0.5f, 0.5f)};
+            normalize3(v);
+            std::memcpy(&nn[j][3 * i], v, sizeof(v));
+        }
+        b0[i] = r.uni(0.f, 0.5f); b1[i] = r.uni(0.f, 0.5f);
+        const bool diffuse = r.uni() < (k == 1 ? 0.3f : 0.6f);
+        const bool refr = r.uni() < 0.2f, enter = r.uni() < 0.5f;
+        eta[i] = diffuse ? 1.f : (refr ? (enter ? 1.5f : 1.f / 1.5f) : 1.f);
+        bsdf[i] = diffuse ? kFlagsDiffuse : (refr ? kFlagsDielectric : kFlagsRough);
+        const bool rough = bsdf[i] == kFlagsRough;      // only roughconductor exports hf (roughconductor.cpp:255)
+        hf[3 * i] = rough ? 0.05f * r.uni(-0.5f, 0.5f) : 0.f; hf[3 * i + 1] = rough ? 0.05f * r.uni(-0.5f, 0.5f) : 0.f;
+        hf[3 * i + 2] = rough ? 1.f : 0.f;
+        light[3 * i] = r.uni(); light[3 * i + 1] = 4.f + r.uni(); light[3 * i + 2] = 4.f + r.uni();
+        if (k > 1 && r.uni() < 0.1f) alive[i] = 0;
+        act[i] = alive[i];
+        act_em[i] = alive[i] && r.uni() >= 0.1f;
+        ismesh[i] = r.uni() >= 0.02f;
+        // addressing: the film is mapped onto a G x G grid of triangles; bounces jitter the cell by +-2^k
+        const int64_t pix = i / spp, px = pix % res, py = (pix / res) % res;
+        int64_t cx = px * G / res, cy = py * G / res;
+        if (k > 1) {
+            const int64_t spread = 1ll << k;
+            cx = ((cx + (int64_t) (r.next() % (2 * spread + 1)) - spread) % G + G) % G;
+            cy = ((cy + (int64_t) (r.next() % (2 * spread + 1)) - spread) % G + G) % G;
+        }
+        const uint32_t base = (uint32_t) (((cy * G + cx) + k * 7) % V);
+        tri[4 * i] = base; tri[4 * i + 1] = (uint32_t) ((base + 1) % V); tri[4 * i + 2] = (uint32_t) ((base + G) % V);
+        tri[4 * i + 3] = EPSM_MODE_POS_ATTACHED | EPSM_MODE_NRM_ATTACHED | EPSM_MODE_VERTEX_NORMALS;
+        aux[4 * i] = (uint32_t) (r.next() % 4);
+        for (int c = 0; c < 3; ++c) { const float d = r.uni(-1.f, 1.f); std::memcpy(&aux[4 * i + 1 + c], &d, 4); }
+        const uint32_t eb = (uint32_t) (V - 3 * n_emit_tris + 3 * (int64_t) (r.next() % n_emit_tris));
+        const float e0 = r.uni(0.f, 0.5f), e1 = r.uni(0.f, 0.5f), ew = r.uni(0.f, 2.f);
+        emit[8 * i] = eb; emit[8 * i + 1] = eb + 1; emit[8 * i + 2] = eb + 2;
+        std::memcpy(&emit[8 * i + 3], &e0, 4); std::memcpy(&emit[8 * i + 4], &e1, 4); std::memcpy(&emit[8 * i + 5], &ew, 4);
+        emit[8 * i + 6] = emit[8 * i + 7] = 0;
+    }
+    VertexArrays v;
+    for (int j = 0; j < 3; ++j) { v.p[j].upload(p[j]); v.n[j].upload(nn[j]); }
+    v.b0.upload(b0); v.b1.upload(b1); v.eta.upload(eta); v.hf.upload(hf); v.light.upload(light);
+    v.bsdf.upload(bsdf); v.tri.upload(tri); v.aux.upload(aux); v.emit.upload(emit);
+    v.active.upload(act); v.active_em.upload(act_em); v.ismesh.upload(ismesh);
+    return v;
+}
+
+double max_abs(const std::vector<float> &a) { double m = 0; for (float x : a) m = std::fmax(m, std::fabs((double) x)); return m; }
+double max_diff(const std::vector<float> &a, const std::vector<float> &b) {
+    double m = 0; for (size_t i = 0; i < a.size(); ++i) m = std::fmax(m, std::fabs((double) a[i] - (double) b[i])); return m;
+}
+
+struct Timer {
+    hipEvent_t a, b;
+    Timer() { HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); }
+    ~Timer() { (void) hipEventDestroy(a); (void) hipEventDestroy(b); }
+    void start() { HIP_OK(hipEventRecord(a, nullptr)); }
+    float stop_ms() { HIP_OK(hipEventRecord(b, nullptr)); HIP_OK(hipEventSynchronize(b)); float ms = 0; HIP_OK(hipEventElapsedTime(&ms, a, b)); return ms; }
+};
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    const int64_t N = argc > 1 ? std::atoll(argv[1]) : (1ll << 20);
+    const int K = argc > 2 ? std::atoi(argv[2]) : 5;
+    const int variant = argc > 3 ? std::atoi(argv[3]) : EPSM_VARIANT_MANIFOLD;
+    const int64_t V = argc > 4 ? std::atoll(argv[4]) : 100000, B = 4;
+    const int spp = 64;
+    int res = 1; while ((int64_t) res * res * spp < N) ++res;
+    if (epsm_abi_version() != EPSM_ABI_VERSION) { std::fprintf(stderr, "ABI mismatch\n"); return 1; }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) { std::fprintf(stderr, "no HIP device\n"); return 1; }
+    HIP_OK(hipSetDevice(0));
+
+    // ---- the error convention first: a bad call returns a status, sets the message, launches nothing
+    {
+        const int rc = epsm_manifold_grad(variant, 16, 9, nullptr, nullptr, nullptr, 2, 2, nullptr, 0.1f, nullptr, nullptr, nullptr, nullptr);
+        if (rc != EPSM_EINVAL || std::strlen(epsm_last_error()) == 0) { std::fprintf(stderr, "error convention broken (rc %d)\n", rc); return 1; }
+        if (epsm_num_param_grads(EPSM_VARIANT_MANIFOLD, 5) != 25 || epsm_num_param_grads(EPSM_VARIANT_MANIFOLD_CAUSTIC, 5) != 23) return 1;
+    }
+
+    // ---- records of one wavefront, resident on the device
+    std::vector<uint8_t> alive(N, 1);
+    std::vector<VertexArrays> verts;
+    for (int k = 1; k <= K; ++k) verts.push_back(make_vertex(N, k, V, res, spp, alive, 42));
+    std::vector<EpsmVertexRecord> vrec(K);
+    std::vector<EpsmScatterRecord> srec(K);
+    for (int k = 0; k < K; ++k) {
+        const VertexArrays &v = verts[k];
+        vrec[k] = EpsmVertexRecord{v.p[0].ptr, v.p[1].ptr, v.p[2].ptr, v.n[0].ptr, v.n[1].ptr, v.n[2].ptr, v.b0.ptr, v.b1.ptr,
+                                   v.eta.ptr, v.hf.ptr, v.light.ptr, v.bsdf.ptr, v.active.ptr, v.active_em.ptr, v.ismesh.ptr};
+        srec[k] = EpsmScatterRecord{v.tri.ptr, v.aux.ptr, v.emit.ptr};
+    }
+    Rng r(7);
+    std::vector<float> cam(3 * N), ray_o(3 * N), ray_d(3 * N), ray_dx(3 * N), ray_dy(3 * N), grad_img((size_t) res * res * 5);
+    for (auto &g : grad_img) g = 1e-3f * r.gauss();
+    {
+        // rays through the first hit (so that the tangent kernel sees a real intersection), pixel footprint ~1e-3
+        std::vector<float> p0 = verts[0].p[0].download(), p1 = verts[0].p[1].download(), p2 = verts[0].p[2].download();
+        std::vector<float> b0 = verts[0].b0.download(), b1 = verts[0].b1.download();
+        for (int64_t i = 0; i < N; ++i) {
+            float x[3], d[3];
+            for (int c = 0; c < 3; ++c) {
+                x[c] = p0[3 * i + c] * b0[i] + p1[3 * i + c] * b1[i] + p2[3 * i + c] * (1.f - b0[i] - b1[i]);
+                cam[3 * i + c] = ray_o[3 * i + c] = c == 2 ? 5.f : 0.f;
+                d[c] = x[c] - ray_o[3 * i + c];
+            }
+            normalize3(d);
+            float dx[3] = {d[0] + 1e-3f, d[1], d[2]}, dy[3] = {d[0], d[1] + 1e-3f, d[2]};
+            normalize3(dx); normalize3(dy);
+            std::memcpy(&ray_d[3 * i], d, 12); std::memcpy(&ray_dx[3 * i], dx, 12); std::memcpy(&ray_dy[3 * i], dy, 12);
+        }
+    }
+    DeviceArray<float> d_cam(cam), d_o(ray_o), d_d(ray_d), d_dx(ray_dx), d_dy(ray_dy), d_img(grad_img);
+    DeviceArray<float> dlduv(2 * N), dldp(3 * N), grad_o(3);
+    const int P = epsm_num_param_grads(variant, K);
+    DeviceArray<float> out_p((size_t) P * N * 3), out_l((size_t) K * N * 3), out_d((size_t) K * N * 3);
+    DeviceArray<float> pos_a(3 * V), nrm_a(3 * V), alpha_a(B), pos_b(3 * V), nrm_b(3 * V), alpha_b(B);
+
+    Timer t;
+    // ---- first-vertex tangent (epsm.py:250-272)
+    EPSM_CALL(epsm_first_vertex_tangent(N, 0, spp, res, d_o.ptr, d_d.ptr, d_dx.ptr, d_dy.ptr, d_img.ptr, res, 5,
+                                        verts[0].p[0].ptr, verts[0].p[1].ptr, verts[0].p[2].ptr, verts[0].active.ptr,
+                                        dlduv.ptr, 2, dldp.ptr, grad_o.ptr, nullptr));
+    t.start();
+    EPSM_CALL(epsm_first_vertex_tangent(N, 0, spp, res, d_o.ptr, d_d.ptr, d_dx.ptr, d_dy.ptr, d_img.ptr, res, 5,
+                                        verts[0].p[0].ptr, verts[0].p[1].ptr, verts[0].p[2].ptr, verts[0].active.ptr,
+                                        dlduv.ptr, 2, dldp.ptr, grad_o.ptr, nullptr));
+    const float ms_tangent = t.stop_ms();
+
+    // ---- the reference's two stages: calc_grad (epsm.py:745 / 952), then the scatter (epsm.py:559-562, 622-627, 644-645)
+    float ms_grad = 0, ms_scatter = 0, ms_fused = 0;
+    for (int rep = 0; rep < 2; ++rep) {            // first round warms up (code objects, clocks)
+        pos_a.zero(); nrm_a.zero(); alpha_a.zero(); pos_b.zero(); nrm_b.zero(); alpha_b.zero();
+        t.start();
+        EPSM_CALL(epsm_manifold_grad(variant, N, K, d_cam.ptr, vrec.data(), dlduv.ptr, 2, 2, dldp.ptr, 0.1f,
+                                     out_p.ptr, out_l.ptr, out_d.ptr, nullptr));
+        ms_grad = t.stop_ms();
+        t.start();
+        EPSM_CALL(epsm_scatter(variant, N, K, vrec.data(), srec.data(), out_p.ptr, out_l.ptr, out_d.ptr,
+                               pos_a.ptr, nrm_a.ptr, alpha_a.ptr, V, B, nullptr));
+        ms_scatter = t.stop_ms();
+        // ---- the same in one launch; calc_grad's lists are never written
+        t.start();
+        EPSM_CALL(epsm_manifold_grad_scatter(variant, N, K, d_cam.ptr, vrec.data(), srec.data(), dlduv.ptr, 2, 2, dldp.ptr, 0.1f,
+                                             pos_b.ptr, nrm_b.ptr, alpha_b.ptr, V, B, nullptr));
+        ms_fused = t.stop_ms();
+    }
+    HIP_OK(hipDeviceSynchronize());
+
+    const std::vector<float> pa = pos_a.download(), pb = pos_b.download(), na = nrm_a.download(), nb = nrm_b.download(),
+                             aa = alpha_a.download(), ab = alpha_b.download(), uv = dlduv.download();
+    const double mp = max_abs(pa), mn = max_abs(na), ma = max_abs(aa);
+    const double ep = max_diff(pa, pb), en = max_diff(na, nb), ea = max_diff(aa, ab);
+    std::printf("epsm_host_driver: N=%lld K=%d variant=%d V=%lld (res %d @ %d spp)\n", (long long) N, K, variant, (long long) V, res, spp);
+    std::printf("  tangent        %8.3f ms  %7.2f Gpaths/s   max|dlduv| %.3g\n", ms_tangent, N / ms_tangent * 1e-6, max_abs(uv));
+    std::printf("  calc_grad      %8.3f ms  %7.2f Gpaths/s\n", ms_grad, N / ms_grad * 1e-6);
+    std::printf("  scatter        %8.3f ms\n", ms_scatter);
+    std::printf("  fused          %8.3f ms  %7.2f Gpaths/s   (two stages: %.3f ms)\n", ms_fused, N / ms_fused * 1e-6, ms_grad + ms_scatter);
+    std::printf("  fused vs two-stage: pos %.3g / %.3g  nrm %.3g / %.3g  alpha %.3g / %.3g  (max |diff| / max |value|)\n", ep, mp, en, mn, ea, ma);
+    // (K = 1 has no continuing rows, hence no alpha gradient: only the position buffer must be non-zero)
+    const bool ok = mp > 0 && max_abs(uv) > 0 && ep <= 2e-4 * mp && en <= 2e-4 * mn + 1e-30 && ea <= 2e-4 * ma + 1e-30;
+    std::printf("%s\n", ok ? "OK" : "MISMATCH");
+    return ok ? 0 : 1;
+}

@@ -87,3 +87,16 @@ def test_trace_structs_match_header_sizes():
     mine = [C.sizeof(S.EpsmMesh), C.sizeof(S.EpsmBsdf), C.sizeof(S.EpsmEmitter), 32, C.sizeof(S.EpsmSensor),
             C.sizeof(S.EpsmSceneC), C.sizeof(S.EpsmRecordOut)]
     assert sizes == mine, (sizes, mine)
+
+
+def test_cxx_host_driver_builds_and_reports_missing_device():
+    """examples/epsm_host_driver.cpp compiles against include/epsm.h, links the product library and, without
+    a GPU, fails loudly at its device check (exit status 1) instead of computing anything on the host."""
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "-s"], check=True)
+    exe = os.path.join(ROOT, "examples", "build", "epsm_host_driver")
+    assert os.path.isfile(exe)
+    import torch
+    if torch.cuda.device_count() == 0:
+        r = subprocess.run([exe, "1000", "2"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "no HIP device" in r.stderr

@@ -1,0 +1,25 @@
+"""The C++ host driver (examples/epsm_host_driver.cpp) drives tangent -> calc_grad -> scatter and the fused
+launch through the C ABI alone -- no Python, no torch in the process -- and checks both routes against each
+other on the device; this test runs the binary that __graft_entry__.build() produced."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "build", "epsm_host_driver")
+
+
+def _exe():
+    if not os.path.isfile(EXE):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "-s"], check=True)
+    return EXE
+
+
+@pytest.mark.parametrize("n,K,variant", [(200000, 5, 0), (65536, 3, 1), (1000, 1, 0)])
+def test_cxx_host_driver(n, K, variant):
+    r = subprocess.run([_exe(), str(n), str(K), str(variant), "20000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("OK")
