@@ -58,6 +58,11 @@ def parse():
     ap.add_argument("--scene-vertices", type=int, default=100000, help="size V of the scatter target")
     ap.add_argument("--two-stage", action="store_true",
                     help="calc_grad lists + separate scatter (the reference's shape) instead of the fused kernel")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="preset of BASELINE.json configs[n-1] (0: the flags above; the default flags ARE config 2)")
+    ap.add_argument("--slabs", type=int, default=1,
+                    help="wavefronts larger than one resident slab: the resident records are processed this many "
+                         "times per step (configs 3, 4: 1024x1024 @ 256 spp = 16 slabs of 2^24 paths)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -98,9 +103,24 @@ def cpu_baseline(path_info, variant, target_s):
                       f"oracle/epsm_oracle.c fp32 + OpenMP, {dt1:.2f} s"}
 
 
+CONFIGS = {
+    # n: (label, variant, profile, res, spp, K, V, slabs of the wavefront when it is run on ONE GPU)
+    1: ("configs[0]: single glass-sphere caustic, manifold_caustic, 64x64 @ 4 spp", "manifold_caustic", "caustic", 64, 4, 4, 7829, 1),
+    2: ("configs[1]: bathroom, manifold, 512x512 @ 64 spp", "manifold", "bathroom", 512, 64, 5, 100000, 1),
+    3: ("configs[2]: pool caustic, manifold_caustic, 1024x1024 @ 256 spp (16 slabs of 2^24 paths)", "manifold_caustic", "pool", 512, 64, 5, 100000, 16),
+    4: ("configs[3]: bathroom, manifold (hybrid phase 1), 1024x1024 @ 256 spp sharded over the ranks", "manifold", "bathroom", 512, 64, 5, 100000, 16),
+    5: ("configs[4]: human, manifold, 256x256 @ 8 spp, K=2, 7829-vertex mesh", "manifold", "bathroom", 256, 8, 2, 7829, 1),
+}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    label = "BASELINE.json configs[1]"
+    if args.config:
+        label, args.variant, args.profile, args.res, args.spp, args.vertices, args.scene_vertices, args.slabs = CONFIGS[args.config]
+        if args.config == 4:
+            args.slabs = max(1, args.slabs // world)          # strong scaling of ONE 1024x1024 @ 256 spp image
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -134,13 +154,15 @@ def main():
 
     def step(record=False):
         evs = [torch.cuda.Event(enable_timing=True)] if record else None
-        if record:
-            evs[0].record()
 
         def mark(name):
             if record:
                 e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
         params.flat.zero_()                      # every backward pass starts from dr.grad == 0 (optim.py: per iteration)
+        for _ in range(args.slabs - 1):          # earlier slabs of a wavefront that is larger than the resident one
+            integ.backward_from_trace(trace, params, grad_in, packed=packed, out=out)
+        if record:
+            evs[0].record()                      # per-stage times are those of the step's last slab
         integ.backward_from_trace(trace, params, grad_in, packed=packed, out=out, mark=mark)
         edist.allreduce_param_grads(params.flat)
         mark("allreduce")
@@ -166,7 +188,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * N * args.steps / elapsed
+    value = world * N * args.slabs * args.steps / elapsed
 
     names = ["tangent", "grad", "scatter", "allreduce"]
     stage_ms = {n: sum(evs[i].elapsed_time(evs[i + 1]) for evs in stage_events) / len(stage_events)
@@ -207,12 +229,12 @@ def main():
             "metric": "manifold_paths_per_s", "value": value, "unit": "paths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "grad_image_ms": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.config == 4 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"bathroom-like synthetic path records, {args.variant}, "
-                                   f"{args.res}x{args.res} @ {args.spp} spp = {N} paths/GPU, K={K} logged vertices "
-                                   f"(BASELINE.json configs[1]); scatter target V={V} vertices",
-                       "variant": args.variant, "profile": args.profile, "paths_per_gpu": N, "vertices": K,
+            "config": {"workload": f"{args.profile}-like synthetic path records, {args.variant}, "
+                                   f"{args.res}x{args.res} @ {args.spp} spp = {N} resident paths/GPU x {args.slabs} slab(s) "
+                                   f"per step, K={K} logged vertices ({label}); scatter target V={V} vertices",
+                       "variant": args.variant, "profile": args.profile, "paths_per_gpu": N * args.slabs, "vertices": K,
                        "scene_vertices": V,
                        "sharding": f"{world} x pixel/sample-tile shard, one all-reduce of the {params.flat.numel() * 4} B "
                                    f"parameter-gradient buffer per step"},
