@@ -58,9 +58,6 @@ struct LdsArgs {
 // fewer lanes than this: the DPP sums (VALU, the kernel's bottleneck) cost more than the LDS atomics they save
 // (measured on the bathroom / specular / pool profiles: 4, 8, 16, 32 for the triangle rows)
 constexpr int kMinMergeLanes = 16, kMinMergeLanesAlpha = 4;
-#ifndef EPSM_FUSED_MERGE
-#define EPSM_FUSED_MERGE 0      // 0: direct LDS atomics, 1: adaptive wave-run merge first
-#endif
 
 template <int BITS> struct ScatterOut {
     const FusedArgs &F;

@@ -119,16 +119,9 @@ extern "C" int epsm_scatter(int variant, int64_t N, int K,
     const int64_t chunks = (N + 255) / 256;
     const int64_t blocks = chunks < kScatterBlocks ? chunks : kScatterBlocks;
     const int64_t chunks_per_block = (chunks + blocks - 1) / blocks;
-    // Defaults from the A/B on config 2 (profiles/r01_c_scatter_ab.txt): adaptive run merge, 2048-row
-    // table (4 workgroups per CU).  Tuning overrides: EPSM_SCATTER_MODE 0 runs + hot-key rounds,
-    // 1 direct LDS atomics, 2/3 adaptive (<= 8 / 16 runs); EPSM_SCATTER_BITS 10..12.
-    static const int mode = getenv("EPSM_SCATTER_MODE") ? atoi(getenv("EPSM_SCATTER_MODE")) : 3;
-    static const int bits = getenv("EPSM_SCATTER_BITS") ? atoi(getenv("EPSM_SCATTER_BITS")) : 11;
-#define EPSM_LAUNCH(M, Bt) hipLaunchKernelGGL((epsm_scatter_kernel<M, Bt>), dim3((unsigned) blocks), dim3(256), 0, (hipStream_t) stream, A, T, chunks_per_block)
-#define EPSM_BITS(M) do { if (bits == 10) EPSM_LAUNCH(M, 10); else if (bits == 11) EPSM_LAUNCH(M, 11); else EPSM_LAUNCH(M, 12); } while (0)
-    if (mode == 1) EPSM_BITS(1); else if (mode == 2) EPSM_BITS(2); else if (mode == 3) EPSM_BITS(3); else EPSM_BITS(0);
-#undef EPSM_BITS
-#undef EPSM_LAUNCH
+    // Adaptive run merge (<= 16 runs per wave), 2048-row table (4 workgroups per CU): the winner of the A/B on
+    // config 2 over {runs + hot-key rounds, direct LDS atomics, adaptive 8 / 16} x {1024, 2048, 4096 rows}.
+    hipLaunchKernelGGL((epsm_scatter_kernel<3, 11>), dim3((unsigned) blocks), dim3(256), 0, (hipStream_t) stream, A, T, chunks_per_block);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_scatter", e);
     return EPSM_OK;

@@ -261,6 +261,9 @@ class Sensor:
         self.to_world = np.asarray(d.get("to_world", np.eye(4)), dtype=np.float64)
 
     def c_struct(self) -> EpsmSensor:
+        key = (self.width, self.height, self.fov, self.near, self.far, self.to_world.tobytes())
+        if getattr(self, "_c_key", None) == key:
+            return self._c_struct
         s = EpsmSensor()
         c2s = perspective_projection(self.width, self.height, self.fov, self.near, self.far)
         s2c = np.linalg.inv(c2s)
@@ -270,6 +273,7 @@ class Sensor:
         s.dx[:] = (_xform_point(s2c, [1.0 / self.width, 0, 0]) - p0).astype(np.float32).tolist()    # perspective.cpp:178-182
         s.dy[:] = (_xform_point(s2c, [0, 1.0 / self.height, 0]) - p0).astype(np.float32).tolist()
         s.near_clip, s.far_clip, s.width, s.height = self.near, self.far, self.width, self.height
+        self._c_key, self._c_struct = key, s
         return s
 
 
@@ -485,24 +489,30 @@ class Scene:
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
         sensor = self.sensors[sensor_index]
         n = hi - lo
-        f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
-        ray = [f(n, 3) for _ in range(4)]
-        film_pos, radiance = f(n, 2), f(n, 3)
-        valid = torch.empty(n, device=dev, dtype=torch.uint8)
+        # One allocation per element type, carved into the per-vertex arrays with unbind(): ~10 tensor
+        # constructions per tile instead of ~25 per logged vertex (the Python side of a 2^20-path tile was
+        # as long as its kernel).  Arrays of consecutive vertices end up N elements apart.
+        Kk = max(K, 0)
+        v3 = torch.empty((5 + 10 * Kk, n, 3), device=dev, dtype=torch.float32).unbind(0)
+        ray, radiance = list(v3[:4]), v3[4]
+        film_pos = torch.empty((n, 2), device=dev, dtype=torch.float32)
+        u8 = torch.empty((1 + 3 * Kk, n), device=dev, dtype=torch.uint8).unbind(0)
+        valid = u8[0]
         recs = (EpsmRecordOut * max(1, K))()
-        info, sinfo, keep = [{"cam": ray[0]}], [], []
+        info, sinfo = [{"cam": ray[0]}], []
+        if K > 0:
+            f1 = torch.empty((3 * K, n), device=dev, dtype=torch.float32).unbind(0)
+            bsdf = torch.empty((K, n), device=dev, dtype=torch.int32).unbind(0)
+            quad = torch.empty((2 * K, n, 4), device=dev, dtype=torch.int32).unbind(0)
+            emit = torch.empty((K, n, 8), device=dev, dtype=torch.int32).unbind(0)
         for k in range(K):
-            t = {name: f(n, 3) for name in ("p0", "p1", "p2", "p", "n0", "n1", "n2", "normal", "hf", "light")}
-            t.update({name: f(n) for name in ("b0", "b1", "eta")})
-            t["bsdf"] = torch.empty(n, device=dev, dtype=torch.int32)
-            for name in ("active", "active_em", "ismesh"):
-                t[name] = torch.empty(n, device=dev, dtype=torch.uint8)
-            t["tri"] = torch.empty((n, 4), device=dev, dtype=torch.int32)
-            t["aux"] = torch.empty((n, 4), device=dev, dtype=torch.int32)
-            t["emit"] = torch.empty((n, 8), device=dev, dtype=torch.int32)
+            t = dict(zip(("p0", "p1", "p2", "p", "n0", "n1", "n2", "normal", "hf", "light"), v3[5 + 10 * k: 15 + 10 * k]))
+            t.update(zip(("b0", "b1", "eta"), f1[3 * k: 3 * k + 3]))
+            t.update(zip(("active", "active_em", "ismesh"), u8[1 + 3 * k: 4 + 3 * k]))
+            t["bsdf"], t["tri"], t["aux"], t["emit"] = bsdf[k], quad[2 * k], quad[2 * k + 1], emit[k]
+            r = recs[k]
             for name, _ in EpsmRecordOut._fields_:
-                setattr(recs[k], name, t[name].data_ptr())
-            keep.append(t)
+                setattr(r, name, t[name].data_ptr())
             info.append({"it": k, "active": t["active"], "bsdf": t["bsdf"], "ismesh": t["ismesh"], "light": t["light"],
                          "active_em": t["active_em"], "points": [t["p0"], t["p1"], t["p2"], t["p"]],
                          "uv": [t["b0"], t["b1"]], "normal": t["normal"], "normals": [t["n0"], t["n1"], t["n2"]],

@@ -11,10 +11,14 @@ tasks.resolution, tasks.spp, tasks.match_res = res, spp, res // 2
 scene = tasks.load_scene(dev)
 scene.attach("light", positions=True); scene.attach("plate", positions=True)
 integ = epsm.load_dict({"type": "manifold", "max_depth": 4})
-def timed(fn, n=3):
-    fn(); torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(n): fn()
-    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
+def timed(fn, n=5):
+    # median of n wall-clock repetitions (the first repetitions may still grow the caching allocator's pool)
+    fn(); fn(); out = []
+    for _ in range(n):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        fn()
+        torch.cuda.synchronize(); out.append((time.perf_counter() - t) * 1e3)
+    return sorted(out)[n // 2]
 N = res * res * spp
 ms = timed(lambda: scene.render_primal(sensor=1, seed=0, spp=spp, max_depth=4))
 print(f"primal render {res}x{res}@{spp}: {ms:.2f} ms  ({N/ms/1e3:.1f} Mpaths/s)")

@@ -1,6 +1,5 @@
 # A/B: fused vs two-stage on a few profiles
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-export EPSM_SCATTER_MODE=3 EPSM_SCATTER_BITS=11
 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
 for extra in "" "--two-stage" "--profile specular" "--profile specular --two-stage" "--variant manifold_caustic --profile pool" "--variant manifold_caustic --profile pool --two-stage"; do
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline $extra 2>/dev/null | tail -1 | python -c "

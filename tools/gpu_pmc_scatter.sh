@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-export EPSM_SCATTER_MODE=3 EPSM_SCATTER_BITS=11
 for prof in bathroom specular; do
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile $prof"
 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum --kernel-include-regex "epsm" --output-format csv -d gpurun_out/r1j_pmc_f1_$prof -- $B > gpurun_out/r1j_pmc1.log 2>&1
