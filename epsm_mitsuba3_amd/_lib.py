@@ -15,6 +15,7 @@ import subprocess
 import torch  # noqa: F401  (must be loaded before libepsm_hip.so, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2          # EPSM_ABI_VERSION of include/epsm.h
 LIB_PATH = os.path.join(_HERE, os.environ.get("EPSM_LIB_NAME", "libepsm_hip.so"))   # EPSM_LIB_NAME: A/B builds
 _lib = None
 
@@ -72,7 +73,7 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or make -C epsm_mitsuba3_amd/csrc). There is no CPU fallback.")
         _lib = _declare(C.CDLL(LIB_PATH))
-        if _lib.epsm_abi_version() != 1:
+        if _lib.epsm_abi_version() != ABI_VERSION:
             raise EpsmError("libepsm_hip.so ABI version mismatch")
     return _lib
 

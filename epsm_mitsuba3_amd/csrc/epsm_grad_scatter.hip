@@ -224,6 +224,12 @@ template <int BITS> struct ScatterOut {
         float b0 = 0.f, b1 = 0.f;
         if (ok && nz3(g)) { b0 = P.v[0].b0[i]; b1 = P.v[0].b1[i]; }
         diffuse(0, g, b0, b1, t);
+        // occluder of the first vertex's emitter sample: si_direct.p * diffuse_grad[0] * dis (epsm.py:609-620)
+        if (P.s[0].shadow) {
+            ShadowItems<float> sh = shadow_items<float>(P.s[0].shadow, i, ok ? g : zero3<float>(), F.V);
+            merge_equal<3, 2>(sh.ok, sh.si, sh.val);
+            push<3>(sh.ok, sh.si, sh.val);
+        }
     }
     __device__ __forceinline__ void poison(int) const {
         // Rows of a term that later turned out non-finite are already in the accumulator.
@@ -328,8 +334,8 @@ extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
         if (!v.p0 || !v.p1 || !v.p2 || !v.n0 || !v.n1 || !v.n2 || !v.b0 || !v.b1 || !v.eta || !v.light ||
             !v.bsdf || !v.active || !v.active_em || !v.ismesh || !s.tri)
             return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: NULL pointer in a vertex / scatter record");
-        if ((((uintptr_t) s.tri) | ((uintptr_t) s.aux) | ((uintptr_t) s.emit)) & 15)
-            return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: tri/aux/emit must be 16-byte aligned");
+        if ((((uintptr_t) s.tri) | ((uintptr_t) s.aux) | ((uintptr_t) s.emit) | ((uintptr_t) s.shadow)) & 15)
+            return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: tri/aux/emit/shadow must be 16-byte aligned");
         VertexPtrs<float> &o = F.g.v[k];
         o.p0 = (const float *) v.p0; o.p1 = (const float *) v.p1; o.p2 = (const float *) v.p2;
         o.n0 = (const float *) v.n0; o.n1 = (const float *) v.n1; o.n2 = (const float *) v.n2;
@@ -338,6 +344,7 @@ extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
         o.bsdf = v.bsdf; o.active = v.active; o.active_em = v.active_em; o.ismesh = v.ismesh;
         ScatterPtrs<float> &t = F.s[k];
         t.tri = s.tri; t.aux = s.aux; t.emit = s.emit;
+        t.shadow = k == 0 ? s.shadow : nullptr;       // epsm.py:610: `iteration == 0`
     }
     F.g.dlduv = dlduv;
     F.g.dlduv_stride = dlduv_stride;

@@ -48,11 +48,12 @@ __global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A,
             if (live) {
                 q = vertex_items(A.v[it], A.s[it], i, g, A.V, A.B);
             } else {
-                q.pos_ok = q.nrm_ok = q.alpha_ok = q.em_ok = false;
+                q.pos_ok = q.nrm_ok = q.alpha_ok = q.em_ok = q.sh_ok = false;
+                q.si[0] = q.si[1] = q.si[2] = kNoIndex;
                 q.vi[0] = q.vi[1] = q.vi[2] = kNoIndex;
                 q.ei[0] = q.ei[1] = q.ei[2] = kNoIndex;
                 q.bid = kNoIndex; q.alpha = 0.f;
-                for (int j = 0; j < 3; ++j) q.pos[j] = q.nrm[j] = q.em[j] = zero3<float>();
+                for (int j = 0; j < 3; ++j) q.pos[j] = q.nrm[j] = q.em[j] = q.sh[j] = zero3<float>();
             }
             const bool pos_v = live && q.pos_ok;
             const bool nrm_v = live && q.nrm_ok && (nz3(q.nrm[0]) || nz3(q.nrm[1]) || nz3(q.nrm[2]));
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A,
                 scatter_triangle_runs(T, (uint32_t) A.V, nrm_v, q.vi, q.nrm, __ballot(nrm_v) != 0ull);
                 if (tg.galpha) scatter_scalar_hot(T, 2u * (uint32_t) A.V, live && q.alpha_ok, q.bid, q.alpha);
                 if (A.s[it].emit) scatter_triangle_hot(T, 0u, live && q.em_ok, q.ei, q.em);
+                if (A.s[it].shadow) scatter_triangle_runs(T, 0u, live && q.sh_ok, q.si, q.sh, __ballot(live && q.sh_ok) != 0ull);
             } else {
                 if (MODE == 1) {
                     scatter_triangle_direct(T, 0u, pos_v, q.vi, q.pos);
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A,
                 }
                 if (tg.galpha && live && q.alpha_ok) T.add(2u * (uint32_t) A.V + q.bid, q.alpha, 0.f, 0.f);
                 if (A.s[it].emit) scatter_triangle_direct(T, 0u, live && q.em_ok, q.ei, q.em);
+                if (A.s[it].shadow) scatter_triangle_adaptive(T, 0u, live && q.sh_ok, q.si, q.sh, MODE == 2 ? 8 : 16);
             }
         }
         if (T.crowded()) T.flush();               // workgroup-uniform census
@@ -106,14 +109,15 @@ extern "C" int epsm_scatter(int variant, int64_t N, int K,
         const EpsmScatterRecord &s = sc[k];
         if (!v.p0 || !v.p1 || !v.p2 || !v.n0 || !v.n1 || !v.n2 || !v.b0 || !v.b1 || !s.tri)
             return fail(EPSM_EINVAL, "epsm_scatter: NULL pointer in a vertex / scatter record");
-        if ((((uintptr_t) s.tri) | ((uintptr_t) s.aux) | ((uintptr_t) s.emit)) & 15)
-            return fail(EPSM_EINVAL, "epsm_scatter: tri/aux/emit must be 16-byte aligned");
+        if ((((uintptr_t) s.tri) | ((uintptr_t) s.aux) | ((uintptr_t) s.emit) | ((uintptr_t) s.shadow)) & 15)
+            return fail(EPSM_EINVAL, "epsm_scatter: tri/aux/emit/shadow must be 16-byte aligned");
         VertexPtrs<float> &o = A.v[k];
         o.p0 = (const float *) v.p0; o.p1 = (const float *) v.p1; o.p2 = (const float *) v.p2;
         o.n0 = (const float *) v.n0; o.n1 = (const float *) v.n1; o.n2 = (const float *) v.n2;
         o.b0 = (const float *) v.b0; o.b1 = (const float *) v.b1;
         ScatterPtrs<float> &t = A.s[k];
         t.tri = s.tri; t.aux = s.aux; t.emit = s.emit;
+        t.shadow = k == 0 ? s.shadow : nullptr;       // epsm.py:610: `iteration == 0`
     }
     Targets T{grad_pos, grad_nrm, grad_alpha};
     const int64_t chunks = (N + 255) / 256;

@@ -25,6 +25,7 @@ template <typename R> struct ScatterPtrs {
     const uint32_t *tri;       // (N,4) v0,v1,v2,mode
     const uint32_t *aux;       // (N,4) bsdf_id, dhf xyz   or null
     const uint32_t *emit;      // (N,8) e0,e1,e2, eb0,eb1,ew, 0,0   or null
+    const uint32_t *shadow;    // (N,8) s0,s1,s2, sb0,sb1,dis, mode,0   or null; first vertex only
 };
 EPSM_HD float bits_to_float(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
 struct U4 { uint32_t x, y, z, w; };
@@ -76,7 +77,27 @@ template <typename R> struct VertexItems {
     V3<R> pos[3], nrm[3];
     uint32_t bid;    bool alpha_ok;  R alpha;
     uint32_t ei[3];  bool em_ok;     V3<R> em[3];
+    uint32_t si[3];  bool sh_ok;     V3<R> sh[3];     // occluder of the first vertex's emitter sample (epsm.py:609-620)
 };
+
+// Occluder term: si_direct.p * diffuse_grad[0] * dis with detached barycentrics (epsm.py:609-620).
+template <typename R> struct ShadowItems { uint32_t si[3]; bool ok; V3<R> val[3]; };
+template <typename R>
+EPSM_HD ShadowItems<R> shadow_items(const uint32_t *shadow, int64_t i, V3<R> gdiff, int64_t V) {
+    ShadowItems<R> o;
+    o.ok = false; o.si[0] = o.si[1] = o.si[2] = kNoIndex; o.val[0] = o.val[1] = o.val[2] = zero3<R>();
+    if (!shadow || !nz3(gdiff)) return o;
+    const U4 a = load_u4(shadow, 2 * i), b = load_u4(shadow, 2 * i + 1);
+    o.si[0] = a.x; o.si[1] = a.y; o.si[2] = a.z;
+    const R c0 = R(bits_to_float(a.w)), c1 = R(bits_to_float(b.x)), dis = R(bits_to_float(b.y));
+    const uint32_t mode = b.z;
+    if (o.si[0] < (uint64_t) V && o.si[1] < (uint64_t) V && o.si[2] < (uint64_t) V && (mode & kModePos) && dis != R(0)) {
+        o.ok = true;
+        const V3<R> g = gdiff * dis;
+        o.val[0] = g * c0; o.val[1] = g * c1; o.val[2] = g * (R(1) - c0 - c1);
+    }
+    return o;
+}
 
 template <typename R>
 EPSM_HD VertexItems<R> vertex_items(const VertexPtrs<R> &v, const ScatterPtrs<R> &s, int64_t i,
@@ -142,6 +163,10 @@ EPSM_HD VertexItems<R> vertex_items(const VertexPtrs<R> &v, const ScatterPtrs<R>
             o.em[0] = gl * c0; o.em[1] = gl * c1; o.em[2] = gl * (R(1) - c0 - c1);
         }
     }
+    // (5) occluder of the emitter sample of the first vertex (epsm.py:609-620)
+    const ShadowItems<R> sh = shadow_items<R>(s.shadow, i, g.gdiff, V);
+    o.sh_ok = sh.ok;
+    for (int j = 0; j < 3; ++j) { o.si[j] = sh.si[j]; o.sh[j] = sh.val[j]; }
     return o;
 }
 

@@ -639,6 +639,27 @@ EPSM_HD void trace_one_path(const TraceArgs &A, int64_t i) {
             const float mis_em = es.delta ? 1.f : mis_weight(es.pdf, bpdf);
             Lr_dir = mul3(mul3(beta, bval), es.weight) * mis_em;          // :605
         }
+        // ---- occluder of the first vertex's emitter sample (epsm.py:609-620; integrators with max_depth <= 3):
+        //      closest hit of the ray towards the sample, NO maximum distance, as scene.ray_intersect(si.spawn_ray(ds.d))
+        if (iteration == 0 && A.K_log > 0 && A.rec[0].shadow) {
+            uint32_t w[8] = {kNoIndex, kNoIndex, kNoIndex, 0u, 0u, 0u, 0u, 0u};
+            if (A.max_depth <= 3 && active_em) {
+                const Ray sr = spawn_ray(si, es.d);
+                const TriHit oh = intersect<false>(S, sr);
+                if (oh.hit) {
+                    const SurfHit occ = surface_interaction(S, sr, oh);
+                    if (occ.mesh_flags & EPSM_MESH_IS_MESH) {
+                        const F3 a = es.p - occ.p, b = es.p - si.p;
+                        float dis = sqrtf(dot(a, a)) / sqrtf(dot(b, b));             // :614
+                        if (!(dis >= 0.01f)) dis = 0.f;                              // :615
+                        w[0] = occ.vi[0]; w[1] = occ.vi[1]; w[2] = occ.vi[2];
+                        w[3] = f2u(occ.b0); w[4] = f2u(occ.b1); w[5] = f2u(dis); w[6] = occ.mesh_flags & 0xFu;
+                    }
+                }
+            }
+            uint32_t *o = A.rec[0].shadow + 8 * i;
+            for (int j = 0; j < 8; ++j) o[j] = w[j];
+        }
         // ---- BSDF sampling: once detached, once attached with fresh numbers (epsm.py:633-643)
         rng.next_1d(); rng.next_1d(); rng.next_1d();
         const float s1 = rng.next_1d(), s2x = rng.next_1d(), s2y = rng.next_1d();

@@ -101,7 +101,7 @@ class PackedRecords:
 
 class EpsmScatterRecord(C.Structure):
     """Mirror of ``struct EpsmScatterRecord`` (include/epsm.h)."""
-    _fields_ = [(n, C.c_void_p) for n in ("tri", "aux", "emit")]
+    _fields_ = [(n, C.c_void_p) for n in ("tri", "aux", "emit", "shadow")]
 
 
 MODE_VERTEX_NORMALS, MODE_FLIP_NORMALS, MODE_POS_ATTACHED, MODE_NRM_ATTACHED = 1, 2, 4, 8
@@ -111,16 +111,22 @@ NO_INDEX = 0xFFFFFFFF
 def pack_scatter_vertex(rec: dict, device, float_dtype=torch.float32) -> dict:
     """One logged vertex's parameter addressing -> the three packed int32 arrays of
     ``EpsmScatterRecord``: ``tri (N,4) = [v0,v1,v2,mode]``, ``aux (N,4) = [bsdf_id, dhf xyz bits]``,
-    ``emit (N,8) = [e0,e1,e2, eb0,eb1,eweight bits, 0,0]``.  Accepts either the packed keys or the
-    loose ones (``vidx, mode, bsdf_id, dhf_dalpha, evidx, eb0, eb1, eweight``)."""
+    ``emit (N,8) = [e0,e1,e2, eb0,eb1,eweight bits, 0,0]``, and (first vertex, ``max_depth <= 3`` only)
+    ``shadow (N,8) = [s0,s1,s2, sb0,sb1,dis bits, mode, 0]``.  Accepts either the packed keys or the
+    loose ones (``vidx, mode, bsdf_id, dhf_dalpha, evidx, eb0, eb1, eweight, svidx, sb0, sb1, sdis, smode``)."""
     dev = torch.device(device)
     if "tri" in rec:
-        out = {"tri": rec["tri"], "aux": rec.get("aux"), "emit": rec.get("emit")}
+        out = {"tri": rec["tri"], "aux": rec.get("aux"), "emit": rec.get("emit"), "shadow": rec.get("shadow")}
     else:
         i32 = lambda t: t.detach().to(dev).to(torch.int32)
         bits = lambda t: t.detach().to(dev).to(torch.float32).contiguous().view(torch.int32)
         tri = torch.cat([i32(rec["vidx"]).reshape(-1, 3), i32(rec["mode"]).reshape(-1, 1)], dim=1)
-        out = {"tri": tri, "aux": None, "emit": None}
+        out = {"tri": tri, "aux": None, "emit": None, "shadow": None}
+        if rec.get("svidx") is not None:
+            n = tri.shape[0]
+            out["shadow"] = torch.cat([i32(rec["svidx"]).reshape(-1, 3), bits(rec["sb0"]).reshape(-1, 1),
+                                       bits(rec["sb1"]).reshape(-1, 1), bits(rec["sdis"]).reshape(-1, 1),
+                                       i32(rec["smode"]).reshape(-1, 1), torch.zeros((n, 1), dtype=torch.int32, device=dev)], dim=1)
         if rec.get("bsdf_id") is not None and rec.get("dhf_dalpha") is not None:
             out["aux"] = torch.cat([i32(rec["bsdf_id"]).reshape(-1, 1), bits(rec["dhf_dalpha"]).reshape(-1, 3)], dim=1)
         if rec.get("evidx") is not None:
@@ -145,3 +151,4 @@ class PackedScatter:
             r.tri = p["tri"].data_ptr()
             r.aux = p["aux"].data_ptr() if p["aux"] is not None else None
             r.emit = p["emit"].data_ptr() if p["emit"] is not None else None
+            r.shadow = p["shadow"].data_ptr() if p.get("shadow") is not None else None

@@ -74,7 +74,7 @@ class EpsmSceneC(C.Structure):
 class EpsmRecordOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "p0", "p1", "p2", "p", "n0", "n1", "n2", "normal", "b0", "b1", "eta", "hf", "light",
-        "bsdf", "active", "active_em", "ismesh", "tri", "aux", "emit")]
+        "bsdf", "active", "active_em", "ismesh", "tri", "aux", "emit", "shadow")]
 
 
 # ---------------------------------------------------------------------------- transforms
@@ -504,20 +504,23 @@ class Scene:
             f1 = torch.empty((3 * K, n), device=dev, dtype=torch.float32).unbind(0)
             bsdf = torch.empty((K, n), device=dev, dtype=torch.int32).unbind(0)
             quad = torch.empty((2 * K, n, 4), device=dev, dtype=torch.int32).unbind(0)
-            emit = torch.empty((K, n, 8), device=dev, dtype=torch.int32).unbind(0)
+            # + the occluder record of the first vertex (integrators with max_depth <= 3, epsm.py:609-620)
+            want_shadow = max_depth <= 3
+            emit = torch.empty((K + (1 if want_shadow else 0), n, 8), device=dev, dtype=torch.int32).unbind(0)
         for k in range(K):
             t = dict(zip(("p0", "p1", "p2", "p", "n0", "n1", "n2", "normal", "hf", "light"), v3[5 + 10 * k: 15 + 10 * k]))
             t.update(zip(("b0", "b1", "eta"), f1[3 * k: 3 * k + 3]))
             t.update(zip(("active", "active_em", "ismesh"), u8[1 + 3 * k: 4 + 3 * k]))
             t["bsdf"], t["tri"], t["aux"], t["emit"] = bsdf[k], quad[2 * k], quad[2 * k + 1], emit[k]
+            shadow = emit[K] if (k == 0 and want_shadow) else None
             r = recs[k]
             for name, _ in EpsmRecordOut._fields_:
-                setattr(r, name, t[name].data_ptr())
+                setattr(r, name, t[name].data_ptr() if name != "shadow" else (shadow.data_ptr() if shadow is not None else None))
             info.append({"it": k, "active": t["active"], "bsdf": t["bsdf"], "ismesh": t["ismesh"], "light": t["light"],
                          "active_em": t["active_em"], "points": [t["p0"], t["p1"], t["p2"], t["p"]],
                          "uv": [t["b0"], t["b1"]], "normal": t["normal"], "normals": [t["n0"], t["n1"], t["n2"]],
                          "eta": t["eta"], "hf": t["hf"]})
-            sinfo.append({"tri": t["tri"], "aux": t["aux"] if self.alpha_slots else None, "emit": t["emit"]})
+            sinfo.append({"tri": t["tri"], "aux": t["aux"] if self.alpha_slots else None, "emit": t["emit"], "shadow": shadow})
         cs = sensor.c_struct()
         rc = lib.epsm_trace_paths(
             C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),

@@ -223,7 +223,7 @@ def synth_first_hit_triangles(o, d, seed: int = 0):
 
 def synth_scatter_info(n_paths: int, n_vertices: int, n_scene_vertices: int, seed: int = 0, device="cpu",
                        n_bsdfs: int = 4, coherent: bool = True, dtype=torch.float32, n_emitter_tris: int = 32,
-                       res: int = 0, spp: int = 1, path_offset: int = 0):
+                       res: int = 0, spp: int = 1, path_offset: int = 0, shadow: bool = False):
     """Per-vertex parameter addressing (``EpsmScatterRecord`` fields).
 
     Coherence model (``coherent=True``; documented in DESIGN.md 7): the scene's triangles
@@ -236,7 +236,9 @@ def synth_scatter_info(n_paths: int, n_vertices: int, n_scene_vertices: int, see
     instead of by pixel.  ``coherent=False`` draws every triangle uniformly.
     Emitter samples land on a small emitter mesh (``n_emitter_tris`` triangles at the end
     of the vertex buffer; 0 = anywhere), as area lights are a handful of triangles in
-    the reference's scenes -- every wave then adds to the same few rows."""
+    the reference's scenes -- every wave then adds to the same few rows.
+    ``shadow=True`` adds the occluder record of the first vertex (epsm.py:609-620, integrators with
+    max_depth <= 3): a triangle near the first hit's cell, dis in [0, 0.9) with 30 % zeros, 10 % detached."""
     N, K, V = int(n_paths), int(n_vertices), int(n_scene_vertices)
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
@@ -274,7 +276,18 @@ def synth_scatter_info(n_paths: int, n_vertices: int, n_scene_vertices: int, see
             ebase = torch.randint(0, V, (N,), generator=gen, device=dev)
         evidx = torch.stack([ebase, (ebase + 1) % V, (ebase + 2) % V], dim=-1).to(torch.int32)
         evidx = torch.where((torch.rand((N,), generator=gen, device=dev) < 0.5)[:, None], evidx, torch.full_like(evidx, -1))
+        extra = {}
+        if shadow and k == 1:
+            sbase = (base + 11 + torch.randint(0, 3, (N,), generator=gen, device=dev)) % V
+            svidx = torch.stack([sbase, (sbase + 1) % V, (sbase + G) % V], dim=-1).to(torch.int32)
+            svidx = torch.where((torch.rand((N,), generator=gen, device=dev) < 0.05)[:, None], torch.full_like(svidx, -1), svidx)
+            sdis = _u(gen, (N,), 0.0, 0.9, dev, dtype)
+            sdis = torch.where(torch.rand((N,), generator=gen, device=dev) < 0.3, torch.zeros_like(sdis), sdis)
+            smode = torch.where(torch.rand((N,), generator=gen, device=dev) < 0.1, 1, 4 | 8 | 1).to(torch.int32)
+            extra = {"svidx": svidx, "sb0": _u(gen, (N,), 0.0, 0.5, dev, dtype), "sb1": _u(gen, (N,), 0.0, 0.5, dev, dtype),
+                     "sdis": sdis, "smode": smode}
         info.append({
+            **extra,
             "vidx": vidx, "mode": mode,
             "bsdf_id": torch.randint(-1, n_bsdfs, (N,), generator=gen, device=dev).to(torch.int32),
             "dhf_dalpha": _u(gen, (N, 3), -1.0, 1.0, dev, dtype),

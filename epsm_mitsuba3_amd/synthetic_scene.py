@@ -15,12 +15,14 @@ from .synth import synth_camera_rays, synth_first_hit_triangles, synth_path_info
 
 class SyntheticScene:
     def __init__(self, res: int = 128, n_vertices: int = 5, n_scene_vertices: int = 7829, n_bsdfs: int = 4,
-                 profile: str = "bathroom", device="cuda", coherent: bool = True, tile_paths: int = _dist.TILE_PATHS):
+                 profile: str = "bathroom", device="cuda", coherent: bool = True, tile_paths: int = _dist.TILE_PATHS,
+                 shadow_term: bool = True):
         self.res, self.K, self.V, self.B = res, n_vertices, n_scene_vertices, n_bsdfs
         self.profile, self.device, self.coherent = profile, torch.device(device), coherent
         self.tile_paths = tile_paths
+        self.shadow_term = shadow_term       # log the occluder record when max_depth <= 3 (epsm.py:609-620)
 
-    def tile(self, t: int, lo: int, hi: int, seed: int, spp: int, K: int) -> PathTrace:
+    def tile(self, t: int, lo: int, hi: int, seed: int, spp: int, K: int, shadow: bool = False) -> PathTrace:
         """Tile t = paths [lo, hi) of the wavefront; its content depends only on (seed, t),
         so any rank regenerates the same tile."""
         n = hi - lo
@@ -32,7 +34,7 @@ class SyntheticScene:
         pi[1]["points"][0], pi[1]["points"][1], pi[1]["points"][2] = p0, p1, p2
         pi[1]["uv"] = [b0, b1]
         si = synth_scatter_info(n, K, self.V, seed=s, device=self.device, n_bsdfs=self.B, coherent=self.coherent,
-                                res=self.res, spp=spp, path_offset=lo)
+                                res=self.res, spp=spp, path_offset=lo, shadow=shadow)
         return PathTrace(res=self.res, spp=spp, ray_o=o, ray_d=d, ray_dx=dx, ray_dy=dy, path_info=pi,
                          scatter_info=si, path_offset=lo, n_paths_total=self.res * self.res * spp)
 
@@ -42,4 +44,5 @@ class SyntheticScene:
         K = min(self.K, max_log_depth, max_depth)
         n_total = self.res * self.res * spp
         tiles = _dist.tile_ranges(n_total, self.tile_paths)
-        return [self.tile(t, *tiles[t], seed, spp, K) for t in _dist.my_tiles(len(tiles), rank, world_size)]
+        shadow = self.shadow_term and max_depth <= 3
+        return [self.tile(t, *tiles[t], seed, spp, K, shadow) for t in _dist.my_tiles(len(tiles), rank, world_size)]

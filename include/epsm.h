@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EPSM_ABI_VERSION 1
+#define EPSM_ABI_VERSION 2
 
 /* BSDF flag bits tested by the hot path (include/mitsuba/render/bsdf.h:40-46,101). */
 #define EPSM_BSDF_NULL     0x1u
@@ -162,6 +162,13 @@ typedef struct EpsmScatterRecord {
     const uint32_t *emit;   /* (N,8)      [e0, e1, e2 u32, eb0, eb1, eweight f32, 0, 0]: triangle hit by the
                                           emitter-sample shadow ray (epsm.py:622-625), its barycentrics and
                                           sum_rgb(Lr_dir) (epsm.py:627); may be NULL */
+    const uint32_t *shadow; /* (N,8)      [s0, s1, s2 u32, sb0, sb1, dis f32, mode u32, 0]: read for the FIRST logged
+                                          vertex only (sc[0]).  The occluder term of epsm.py:609-620 (integrators with
+                                          max_depth <= 3): first surface hit by the ray from the first vertex towards
+                                          its emitter sample (closest hit, no maximum distance), its barycentrics,
+                                          dis = |ds.p - hit| / |ds.p - si.p| (0 when < 0.01, :614-615) and the
+                                          EPSM_MODE_* bits of the hit mesh; that triangle receives
+                                          diffuse_grad[0] * dis * barycentric (:616-618).  May be NULL */
 } EpsmScatterRecord;
 
 /* ---------------------------------------------------------------------------

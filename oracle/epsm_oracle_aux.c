@@ -159,6 +159,16 @@ int epsm_oracle_scatter(int variant, int64_t N, int K,
                     }
                 }
             }
+            /* epsm.py:609-620: occluder of the first vertex's emitter sample receives diffuse_grad[0] * dis */
+            if (it == 0 && s->shadow) {
+                const uint32_t *h = s->shadow + 8 * i;
+                const float *hf = (const float *) (s->shadow + 8 * i + 3);
+                if (h[0] < (uint64_t) V && h[1] < (uint64_t) V && h[2] < (uint64_t) V && (h[6] & EPSM_MODE_POS_ATTACHED)) {
+                    double c0 = hf[0], c1 = hf[1], dis = hf[2];
+                    const double *g = out_diffuse + ((int64_t) 0 * N + i) * 3;
+                    add3(grad_pos, h[0], g, dis * c0); add3(grad_pos, h[1], g, dis * c1); add3(grad_pos, h[2], g, dis * (1.0 - c0 - c1));
+                }
+            }
             /* epsm.py:622-627 */
             if (s->emit) {
                 const uint32_t *e = s->emit + 8 * i;

@@ -21,3 +21,12 @@ def test_caustic_light_translation_is_recovered():
     hist, opt = run("manifold_caustic", "slab", iterations=45, lr=0.03, log=lambda s: None)
     assert hist[0] > 0.55
     assert min(hist[-15:]) < 0.35 * hist[0], hist
+
+
+def test_shadow_occluder_translation_is_recovered():
+    """max_depth = 2, everything diffuse: the only gradient path is the occluder term of epsm.py:609-620
+    (first hit = floor point in or near the shadow, occluder = closest hit towards the emitter sample)."""
+    from epsm_mitsuba3_amd.optim import run
+    hist, opt = run("manifold", "shadow", iterations=45, lr=0.03, log=lambda s: None)
+    assert hist[0] > 0.55
+    assert min(hist[-15:]) < 0.35 * hist[0], hist

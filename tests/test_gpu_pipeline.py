@@ -43,13 +43,14 @@ def test_render_backward_matches_oracle_pipeline(kind, profile, fused):
     assert torch.allclose(params.flat, 2 * before, rtol=1e-3, atol=1e-6 * float(before.abs().max()))
 
 
-@pytest.mark.parametrize("res,spp,V", [(32, 8, 3000), (12, 64, 300), (16, 256, 120)])
+@pytest.mark.parametrize("res,spp,V,max_depth", [(32, 8, 3000, 8), (12, 64, 300, 8), (16, 256, 120, 8), (32, 8, 3000, 3), (12, 64, 300, 3)])
 @pytest.mark.parametrize("kind,profile", [("manifold", "bathroom"), ("manifold", "mixed"), ("manifold_caustic", "pool")])
-def test_fused_matches_oracle_scatter_of_dense_gradients(kind, profile, res, spp, V):
+def test_fused_matches_oracle_scatter_of_dense_gradients(kind, profile, res, spp, V, max_depth):
     """The fused kernel against calc_grad's lists (dense HIP kernel, per-path parity in test_gpu_parity.py)
     summed by the float64 scatter oracle: isolates the accumulation -- wave-level DPP merge, LDS table,
     flush -- from the conditioning of the per-path systems.  At 64 / 256 spp on a coarse mesh a wave holds
-    one first-hit triangle (every lane merges) and a few per later bounce (leader rounds)."""
+    one first-hit triangle (every lane merges) and a few per later bounce (leader rounds).  max_depth = 3 adds
+    the occluder record of the first vertex (epsm.py:609-620) to the trace."""
     import epsm_mitsuba3_amd as epsm
     from epsm_mitsuba3_amd.records import PackedRecords, PackedScatter
     from epsm_mitsuba3_amd.synth import path_info_to
@@ -66,7 +67,9 @@ def test_fused_matches_oracle_scatter_of_dense_gradients(kind, profile, res, spp
     ref = [torch.zeros((V, 3), dtype=torch.float64), torch.zeros((V, 3), dtype=torch.float64),
            torch.zeros((B,), dtype=torch.float64)]
     scratch = epsm.ParamGrads(V, B, device=dev)
-    for tr in scene.trace_paths(seed=3, spp=spp):
+    traces = scene.trace_paths(seed=3, spp=spp, max_depth=max_depth)
+    assert (traces[0].scatter_info[0].get("svidx") is not None) == (max_depth <= 3)
+    for tr in traces:
         fused.backward_from_trace(tr, params, grad_in)
         lists = dense.backward_from_trace(tr, scratch, grad_in)
         pi = path_info_to(tr.path_info, device="cpu")

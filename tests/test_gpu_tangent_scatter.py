@@ -53,7 +53,7 @@ def test_scatter_matches_oracle(variant, V, coherent, dev):
     N, K, B = 30000, 4, 5
     profile = "mixed"
     pi, dlduv, dldp = synth_path_info(N, K, seed=9, profile=profile, tangent_scale=1e-4)
-    si = synth_scatter_info(N, K, V, seed=9, n_bsdfs=B, coherent=coherent)
+    si = synth_scatter_info(N, K, V, seed=9, n_bsdfs=B, coherent=coherent, shadow=True)      # + occluder record (epsm.py:609-620)
     rec = PackedRecords(path_info_to(pi, device=dev), device=dev)
     sc = PackedScatter(si, device=dev)
     out = manifold_grad_packed(variant, rec, dlduv.to(dev), dldp.to(dev), dlduv_cols=2)

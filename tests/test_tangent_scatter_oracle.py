@@ -108,6 +108,13 @@ def _autograd_scatter(variant, pi, si, fp, lg, dg, V, B):
                 ep = [pos_attached[ev[j]] for j in range(3)]
                 direct_p = ep[0] * c0 + ep[1] * c1 + ep[2] * (1 - c0 - c1)
                 loss = loss + (direct_p * (lg[it][n].double() * s["eweight"][n].double())).sum()   # epsm.py:626-627
+            if it == 0 and "svidx" in s:                              # epsm.py:609-620 (max_depth <= 3)
+                sv = s["svidx"][n].long()
+                if ((sv >= 0) & (sv < V)).all() and (int(s["smode"][n]) & 4):
+                    c0, c1 = s["sb0"][n].double(), s["sb1"][n].double()
+                    sp = [pos_attached[sv[j]] for j in range(3)]
+                    occluder_p = sp[0] * c0 + sp[1] * c1 + sp[2] * (1 - c0 - c1)                  # FollowShape: b detached
+                    loss = loss + (occluder_p * dg[0][n].double() * s["sdis"][n].double()).sum()   # :617
     gp, gn_, ga = torch.autograd.grad(loss, [pos_attached, nrm_attached, alpha], allow_unused=True)
     z = lambda t, like: torch.zeros_like(like) if t is None else t
     return z(gp, pos_attached), z(gn_, nrm_attached), z(ga, alpha)[:B]
@@ -117,7 +124,7 @@ def _autograd_scatter(variant, pi, si, fp, lg, dg, V, B):
 def test_scatter_matches_autograd_of_reference_losses(variant):
     N, K, V, B = 160, 3, 40, 3
     pi, dlduv, dldp = synth_path_info(N, K, seed=3, profile="mixed", tangent_scale=1e-4)
-    si = synth_scatter_info(N, K, V, seed=3, n_bsdfs=B)
+    si = synth_scatter_info(N, K, V, seed=3, n_bsdfs=B, shadow=True)
     fp, lg, dg, _ = oracle_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float64)
     # dense random "gradients" exercise every branch, not only the unmasked paths
     g = torch.Generator().manual_seed(0)

@@ -189,3 +189,52 @@ def test_records_feed_the_gradient_oracle():
     fp, lg, dg, _ = oracle_calc_grad("manifold", tr.path_info, dlduv, torch.zeros((N, 3)), dtype=torch.float64)
     g = torch.stack(fp)
     assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+
+
+def test_occluder_record_of_the_first_vertex():
+    """epsm.py:609-620 (integrators with max_depth <= 3): the closest hit of the ray from the first vertex
+    towards its emitter sample is logged with its barycentrics and dis = |ds.p - hit| / |ds.p - si.p|."""
+    fv, ff = quad(0.0, 3.0, up=True)
+    ov, of = quad(1.0, 0.4, up=True)                           # occluder plate at z = 1 above the origin
+    lv, lf = quad(3.0, 0.05, up=False)                         # small light at z = 3
+    d = {"type": "scene", "cam": sensor([0.0, -2.5, 2.0], [0, 0, 0], up=(0, 0, 1), res=16, spp=16),
+         "floor": {"type": "mesh", "vertices": fv, "faces": ff, "face_normals": True, "bsdf": {"type": "diffuse"}},
+         "plate": {"type": "mesh", "vertices": ov, "faces": of, "face_normals": True,
+                   "bsdf": {"type": "twosided", "bsdf": {"type": "diffuse"}}},
+         "light": {"type": "mesh", "vertices": lv, "faces": lf, "face_normals": True,
+                   "emitter": {"type": "area", "radiance": {"type": "rgb", "value": 30.0}}}}
+    sc = on_host(S.Scene.from_dict(d, device="cpu"))
+    sc.attach("plate", positions=True)
+    n = 16 * 16 * 16
+    assert sc._trace(0, seed=2, spp=16, max_depth=4, K=2, lo=0, hi=n).scatter_info[0]["shadow"] is None   # max_depth > 3
+    tr = sc._trace(0, seed=2, spp=16, max_depth=3, K=2, lo=0, hi=n)
+    sh = tr.scatter_info[0]["shadow"]
+    assert sh is not None and tr.scatter_info[1].get("shadow") is None
+    v1 = tr.path_info[1]
+    x = v1["points"][3]
+    on_floor = (v1["active"] > 0) & (x[:, 2].abs() < 1e-5) & (v1["active_em"] > 0)
+    tri, fl = sh[:, :3].long(), sh[:, 3:6].contiguous().view(torch.float32)
+    plo, phi = sc.mesh_slices["plate"]
+    llo, lhi = sc.mesh_slices["light"]
+    hit_plate = on_floor & ((tri >= plo) & (tri < phi)).all(1)
+    hit_light = on_floor & ((tri >= llo) & (tri < lhi)).all(1)
+    assert int(hit_plate.sum()) > 50 and int(hit_light.sum()) > 50
+    # the ray towards the light ends on one of the two (samples on the light's very edge may slip past it)
+    assert float((hit_plate | hit_light)[on_floor].double().mean()) > 0.98
+    # unoccluded: the hit is the emitter sample itself, dis ~ 0 -> 0 (:615)
+    assert bool((fl[hit_light, 2] == 0).all())
+    # occluded: the hit lies on the plate (z = 1) on the segment floor point -> light sample, dis = 2/3 here
+    verts = sc.vertex_positions("plate").double()
+    c0, c1 = fl[hit_plate, 0].double(), fl[hit_plate, 1].double()
+    t = tri[hit_plate] - plo
+    p = verts[t[:, 0]] * c0[:, None] + verts[t[:, 1]] * c1[:, None] + verts[t[:, 2]] * (1 - c0 - c1)[:, None]
+    lp, xp = v1["light"][hit_plate].double(), x[hit_plate].double()
+    assert torch.allclose(p[:, 2], torch.ones_like(p[:, 2]), atol=1e-5)
+    s = (p - xp).norm(dim=1) / (lp - xp).norm(dim=1)
+    assert torch.allclose(xp + (lp - xp) * s[:, None], p, atol=1e-4)
+    assert torch.allclose(fl[hit_plate, 2].double(), (lp - p).norm(dim=1) / (lp - xp).norm(dim=1), atol=1e-5)
+    assert torch.allclose(fl[hit_plate, 2], torch.full((int(hit_plate.sum()),), 2.0 / 3.0), atol=0.02)
+    assert bool((sh[hit_plate, 6] == 4).all())                         # the plate is a flat mesh with attached positions
+    # paths without a usable emitter sample carry no occluder
+    dead = ~((v1["active"] > 0) & (v1["active_em"] > 0))
+    assert bool((sh[dead, 0] == -1).all()) and bool((fl[dead, 2] == 0).all())
