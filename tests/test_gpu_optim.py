@@ -30,3 +30,13 @@ def test_shadow_occluder_translation_is_recovered():
     hist, opt = run("manifold", "shadow", iterations=45, lr=0.03, log=lambda s: None)
     assert hist[0] > 0.55
     assert min(hist[-15:]) < 0.35 * hist[0], hist
+
+
+def test_human_pose_is_recovered_through_per_vertex_gradients():
+    """Config 5 (optim_human.py): vertices come from a torch module (three-bone skinned tube standing in for
+    SMPL); the per-vertex gradients of the `human` mesh are chained into its pose with sum(verts * grad).backward()
+    -- first-hit term on the figure itself plus the occluder term of its shadow (max_depth = 3)."""
+    from epsm_mitsuba3_amd.optim import run
+    hist, opt = run("manifold", "human", iterations=80, lr=0.03, log=lambda s: None)
+    assert hist[0] > 0.6
+    assert min(hist[-15:]) < 0.35 * hist[0], hist
