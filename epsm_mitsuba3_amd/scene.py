@@ -547,8 +547,11 @@ class Scene:
         si = min(sensor, len(self.sensors) - 1)
         return [self._trace(si, seed, spp, max_depth, K, *tiles[t]) for t in _dist.my_tiles(len(tiles), rank, world_size)]
 
-    def render_primal(self, sensor=0, seed=0, spp=0, max_depth=6) -> torch.Tensor:
-        """(H,W,3) image: sample_rays + path tracing + film splat / develop (epsm.py:13-76)."""
+    def render_primal(self, sensor=0, seed=0, spp=0, max_depth=6, rank=None, world_size=None) -> torch.Tensor:
+        """(H,W,3) image: sample_rays + path tracing + film splat / develop (epsm.py:13-76).  With more than
+        one rank (default: the initialised process group) every rank traces its round-robin share of the tiles
+        and the film accumulator [r,g,b,w] is summed with one all-reduce before the weight division (SURVEY 8e:
+        the film is the only shared state of the primal pass), so all ranks return the same image."""
         si = min(sensor, len(self.sensors) - 1)
         s = self.sensors[si]
         spp = spp or s.spp
@@ -556,11 +559,17 @@ class Scene:
         accum = torch.zeros((s.height, s.width, 4), device=self.device, dtype=torch.float32)
         lib = self._backend if self._backend is not None else _lib.lib()
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
-        for lo, hi in _dist.tile_ranges(n_total, self.tile_paths):
+        if rank is None or world_size is None:
+            rank, world_size = _dist.world()
+        tiles = _dist.tile_ranges(n_total, self.tile_paths)
+        for t in _dist.my_tiles(len(tiles), rank, world_size):
+            lo, hi = tiles[t]
             tr = self._trace(si, seed, spp, max_depth, 0, lo, hi)
             rc = lib.epsm_film_splat(C.c_int64(hi - lo), C.c_void_p(tr.film_pos.data_ptr()), C.c_void_p(tr.radiance.data_ptr()),
                                      s.width, s.height, s.rfilter, C.c_void_p(accum.data_ptr()), C.c_void_p(stream))
             assert rc == 0, "epsm_film_splat failed"
+        if world_size > 1:
+            _dist.allreduce_param_grads(accum)
         img = torch.empty((s.height, s.width, 3), device=self.device, dtype=torch.float32)
         rc = lib.epsm_film_develop(s.width, s.height, C.c_void_p(accum.data_ptr()), C.c_void_p(img.data_ptr()), C.c_void_p(stream))
         assert rc == 0, "epsm_film_develop failed"

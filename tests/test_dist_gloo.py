@@ -78,3 +78,42 @@ def test_two_rank_backward_matches_single_process():
     single, _ = _rank_work(0, 1)
     assert float(single.flat.abs().max()) > 0
     assert torch.allclose(got[0][2], single.flat, rtol=1e-5, atol=1e-7 * float(single.flat.abs().max()))
+
+
+def _render_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _scenes import floor_and_light, on_host
+    edist.init_from_env("gloo")
+    sc = on_host(floor_and_light(res=16, device="cpu"))
+    sc.tile_paths = 256                                  # 16*16*4 = 1024 paths -> 4 tiles, 2 per rank
+    img = sc.render_primal(sensor=0, seed=4, spp=4, max_depth=3)       # rank / world from the process group
+    q.put((rank, img.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_primal_render_matches_single_process():
+    """The primal pass shards its tiles over the ranks and all-reduces the film accumulator [r,g,b,w]
+    before the weight division: every rank ends up with the single-process image (host tracer here)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _scenes import floor_and_light, on_host
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_render_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sc = on_host(floor_and_light(res=16, device="cpu"))
+    sc.tile_paths = 256
+    single = sc.render_primal(sensor=0, seed=4, spp=4, max_depth=3)
+    assert float(single.max()) > 0
+    assert torch.equal(got[0][1], got[1][1])
+    assert torch.allclose(got[0][1], single, rtol=1e-5, atol=1e-6)
