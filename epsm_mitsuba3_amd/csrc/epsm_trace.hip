@@ -10,9 +10,10 @@ using epsm_host::fail;
 namespace {
 
 __global__ __launch_bounds__(128) void epsm_trace_kernel(TraceArgs A) {
+    __shared__ uint32_t s_stack[kBvhStack * 128];        // traversal stacks: one LDS column per path (16 KB)
     const int64_t i = (int64_t) blockIdx.x * 128 + threadIdx.x;
     if (i >= A.N) return;
-    trace_one_path(A, i);
+    trace_one_path(A, i, BvhStack{s_stack + threadIdx.x, 128});
 }
 
 // ImageBlock::put (src/render/imageblock.cpp) with the reconstruction filter evaluated
@@ -143,7 +144,7 @@ extern "C" int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor
     if (!ray_o || !ray_d || !ray_dx || !ray_dy || (K_log > 0 && !recs))
         return fail(EPSM_EINVAL, "epsm_trace_paths: NULL output");
     if (scene->n_triangles > 0 && (!scene->positions || !scene->normals || !scene->tri || !scene->tri_mesh ||
-                                   !scene->meshes || !scene->bsdfs || !scene->bvh || !scene->prim_index))
+                                   !scene->meshes || !scene->bsdfs || !scene->bvh || !scene->prim_index || !scene->tri_verts))
         return fail(EPSM_EINVAL, "epsm_trace_paths: NULL scene array");
     if (scene->n_emitters > 0 && !scene->emitters) return fail(EPSM_EINVAL, "epsm_trace_paths: NULL emitters");
     TraceArgs A;

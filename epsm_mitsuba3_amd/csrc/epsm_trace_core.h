@@ -120,9 +120,9 @@ EPSM_HD bool moeller_trumbore(const Ray &r, F3 p0, F3 p1, F3 p2, float &t, float
     t = dot(e2, qvec) * inv_det;
     return u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t <= r.maxt;
 }
-EPSM_HD bool hit_box(const EpsmBvhNode &n, F3 o, F3 inv_d, float maxt) {
+// slab test; `tnear` is the entry distance (used to visit the nearer child first)
+EPSM_HD bool hit_box(const float *lo, const float *hi, F3 o, F3 inv_d, float maxt, float &tnear) {
     float t0 = 0.f, t1 = maxt;
-    const float lo[3] = {n.lo[0], n.lo[1], n.lo[2]}, hi[3] = {n.hi[0], n.hi[1], n.hi[2]};
     const float oo[3] = {o.x, o.y, o.z}, id[3] = {inv_d.x, inv_d.y, inv_d.z};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -130,38 +130,59 @@ EPSM_HD bool hit_box(const EpsmBvhNode &n, F3 o, F3 inv_d, float maxt) {
         if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; }
         t0 = fmaxf(t0, ta); t1 = fminf(t1, tb * 1.0000004f);
     }
+    tnear = t0;
     return t0 <= t1;
 }
 struct TriHit { bool hit; uint32_t tri; float t, u, v; };
 
+// Traversal stack of one path: entry k lives at base[k * stride] (LDS on the GPU: one column per thread,
+// conflict-free; a local array on the host).  Depth of the tree <= kBvhStack.
+constexpr int kBvhStack = 32;
+struct BvhStack { uint32_t *base; int stride; };
+
+// Ordered traversal of the two-wide BVH: one 64-byte node holds both children's boxes, leaf children are
+// intersected on the spot, of two inner children the nearer is followed and the farther pushed.
 template <bool ANY_HIT>
-EPSM_HD TriHit intersect(const EpsmScene &S, Ray r) {
+EPSM_HD TriHit intersect(const EpsmScene &S, Ray r, const BvhStack &st) {
     TriHit best; best.hit = false; best.tri = 0; best.t = r.maxt; best.u = best.v = 0.f;
     if (S.n_nodes <= 0) return best;
     const F3 inv_d = f3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
-    uint32_t stack[48];
-    int sp = 0;
-    stack[sp++] = 0;
-    while (sp > 0) {
-        const EpsmBvhNode n = S.bvh[stack[--sp]];
-        if (!hit_box(n, r.o, inv_d, r.maxt)) continue;
-        if (n.count > 0) {
-            for (uint32_t e = n.left_or_first; e < n.left_or_first + n.count; ++e) {
-                const uint32_t q = S.prim_index[e];
-                const uint32_t *iv = S.tri + 3 * (int64_t) q;
-                float t, u, v;
-                if (moeller_trumbore(r, ld3(S.positions + 3 * (int64_t) iv[0]), ld3(S.positions + 3 * (int64_t) iv[1]),
-                                     ld3(S.positions + 3 * (int64_t) iv[2]), t, u, v)) {
-                    best.hit = true; best.tri = q; best.t = t; best.u = u; best.v = v;
-                    r.maxt = t;
-                    if (ANY_HIT) return best;
-                }
+    int32_t best_e = -1;
+    auto leaf = [&](int32_t first, int32_t count) {
+        for (int32_t e = first; e < first + count; ++e) {
+            const float *q = S.tri_verts + 9 * (int64_t) e;
+            float t, u, v;
+            if (moeller_trumbore(r, ld3(q), ld3(q + 3), ld3(q + 6), t, u, v)) {
+                best.hit = true; best_e = e; best.t = t; best.u = u; best.v = v;
+                r.maxt = t;
+                if (ANY_HIT) return;
             }
-        } else if (sp + 2 <= 48) {
-            stack[sp++] = n.left_or_first;
-            stack[sp++] = n.left_or_first + 1;
+        }
+    };
+    int32_t node = 0;
+    int sp = 0;
+    for (;;) {
+        const EpsmBvhNode n = S.bvh[node];
+        float t0, t1;
+        bool h0 = hit_box(n.lo0, n.hi0, r.o, inv_d, r.maxt, t0), h1 = hit_box(n.lo1, n.hi1, r.o, inv_d, r.maxt, t1);
+        if (h0 && n.n0 > 0) { leaf(n.c0, n.n0); h0 = false; if (ANY_HIT && best.hit) break; }
+        if (h1 && n.n1 > 0) { if (t1 <= r.maxt) leaf(n.c1, n.n1); h1 = false; if (ANY_HIT && best.hit) break; }
+        // a leaf hit may have shortened the ray; an absent child (c = -1) is never followed
+        h0 = h0 && t0 <= r.maxt && n.c0 >= 0; h1 = h1 && t1 <= r.maxt && n.c1 >= 0;
+        if (h0 && h1) {
+            const bool first0 = t0 <= t1;
+            if (sp < kBvhStack) st.base[(sp++) * st.stride] = (uint32_t) (first0 ? n.c1 : n.c0);
+            node = first0 ? n.c0 : n.c1;
+        } else if (h0) {
+            node = n.c0;
+        } else if (h1) {
+            node = n.c1;
+        } else {
+            if (sp == 0) break;
+            node = (int32_t) st.base[(--sp) * st.stride];
         }
     }
+    if (best.hit) best.tri = S.prim_index[best_e];
     return best;
 }
 
@@ -438,7 +459,8 @@ EPSM_HD F3 emitter_normal(const EpsmScene &S, const EpsmMesh &m, const uint32_t 
     if (m.flags & EPSM_MESH_FLIP_NORMALS) n = -n;
     return n;
 }
-EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit &ref, float u, float v, bool active) {
+EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit &ref, float u, float v, bool active,
+                                               const BvhStack &st) {
     EmitterSample e;
     e.p = e.n = e.d = e.weight = zero3<float>(); e.pdf = 0.f; e.dist = 0.f; e.delta = false; e.valid = false;
     e.vi[0] = e.vi[1] = e.vi[2] = kNoIndex; e.b0 = e.b1 = 0.f;
@@ -494,7 +516,7 @@ EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit
     if (e.valid) {                                                        // scene.cpp:270-275 test_visibility
         float dist;
         const Ray sr = spawn_ray_to(ref, e.p, dist);
-        if (intersect<true>(S, sr).hit) e.weight = zero3<float>();
+        if (intersect<true>(S, sr, st).hit) e.weight = zero3<float>();
     }
     return e;
 }
@@ -588,7 +610,7 @@ EPSM_HD void write_record(const EpsmRecordOut &R, int64_t i, bool active, const 
     e[0] = es.vi[0]; e[1] = es.vi[1]; e[2] = es.vi[2]; e[3] = f2u(es.b0); e[4] = f2u(es.b1); e[5] = f2u(eweight); e[6] = 0; e[7] = 0;
 }
 
-EPSM_HD void trace_one_path(const TraceArgs &A, int64_t i) {
+EPSM_HD void trace_one_path(const TraceArgs &A, int64_t i, const BvhStack &st) {
     const EpsmScene &S = A.S;
     const int64_t widx = A.path_offset + i;
     Pcg32 rng = seed_sampler(A.seed, (uint32_t) widx);                    // common.py:475 sampler.seed(seed, wavefront_size)
@@ -608,7 +630,7 @@ EPSM_HD void trace_one_path(const TraceArgs &A, int64_t i) {
 
     for (int iteration = 0; iteration < max_depth; ++iteration) {         // epsm.py:551 (lanes stay in the loop, masked)
         TriHit th; th.hit = false; th.tri = 0; th.t = kInf; th.u = th.v = 0.f;
-        if (active) th = intersect<false>(S, ray);
+        if (active) th = intersect<false>(S, ray, st);
         const SurfHit si = surface_interaction(S, ray, th);               // epsm.py:556-558
         EpsmBsdf bsdf;
         bsdf.type = EPSM_BSDF_DIFFUSE_T; bsdf.twosided = 0; bsdf.distr = 0; bsdf.sample_visible = 1; bsdf.alpha = 0.1f;
@@ -629,7 +651,7 @@ EPSM_HD void trace_one_path(const TraceArgs &A, int64_t i) {
         bool active_next = (depth + 1 < A.max_depth) && si.valid;
         bool active_em = active_next && (flags & kFlSmooth);
         const float e1 = rng.next_1d(), e2 = rng.next_1d();              // sampler.next_2d()
-        const EmitterSample es = sample_emitter_direction(S, si, e1, e2, active_em);
+        const EmitterSample es = sample_emitter_direction(S, si, e1, e2, active_em, st);
         active_em = active_em && es.pdf != 0.f;                           // :590
         F3 Lr_dir = zero3<float>();
         if (active_em) {
@@ -645,7 +667,7 @@ EPSM_HD void trace_one_path(const TraceArgs &A, int64_t i) {
             uint32_t w[8] = {kNoIndex, kNoIndex, kNoIndex, 0u, 0u, 0u, 0u, 0u};
             if (A.max_depth <= 3 && active_em) {
                 const Ray sr = spawn_ray(si, es.d);
-                const TriHit oh = intersect<false>(S, sr);
+                const TriHit oh = intersect<false>(S, sr, st);
                 if (oh.hit) {
                     const SurfHit occ = surface_interaction(S, sr, oh);
                     if (occ.mesh_flags & EPSM_MESH_IS_MESH) {

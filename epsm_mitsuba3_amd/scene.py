@@ -67,7 +67,7 @@ class EpsmSceneC(C.Structure):
     _fields_ = [("positions", C.c_void_p), ("normals", C.c_void_p), ("tri", C.c_void_p), ("tri_mesh", C.c_void_p),
                 ("meshes", C.c_void_p), ("n_meshes", C.c_int32), ("bsdfs", C.c_void_p), ("n_bsdfs", C.c_int32),
                 ("emitters", C.c_void_p), ("n_emitters", C.c_int32), ("emitter_cdf", C.c_void_p),
-                ("bvh", C.c_void_p), ("n_nodes", C.c_int32), ("prim_index", C.c_void_p),
+                ("bvh", C.c_void_p), ("n_nodes", C.c_int32), ("prim_index", C.c_void_p), ("tri_verts", C.c_void_p),
                 ("n_vertices", C.c_int64), ("n_triangles", C.c_int64)]
 
 
@@ -172,6 +172,21 @@ def vertex_normals(v: np.ndarray, f: np.ndarray) -> np.ndarray:
     return np.where(ln > 0, n / np.maximum(ln, 1e-30), np.array([0.0, 0.0, 1.0]))
 
 
+def vertex_normals_torch(v: torch.Tensor, f: torch.Tensor) -> torch.Tensor:
+    """``vertex_normals`` on the device (same angle weighting), for ``Scene.set_vertex_positions``."""
+    p = v[f]                                                      # (T,3,3)
+    fn = torch.linalg.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    fn = fn / fn.norm(dim=1, keepdim=True).clamp_min(1e-30)
+    n = torch.zeros_like(v)
+    for i in range(3):
+        d0 = p[:, (i + 1) % 3] - p[:, i]; d1 = p[:, (i + 2) % 3] - p[:, i]
+        cosang = (d0 * d1).sum(1) / (d0.norm(dim=1) * d1.norm(dim=1)).clamp_min(1e-30)
+        n.index_add_(0, f[:, i], fn * torch.acos(cosang.clamp(-1, 1))[:, None])
+    ln = n.norm(dim=1, keepdim=True)
+    up = torch.tensor([0.0, 0.0, 1.0], device=v.device, dtype=v.dtype)
+    return torch.where(ln > 0, n / ln.clamp_min(1e-30), up)
+
+
 class Mesh:
     def __init__(self, name, v, f, n=None, bsdf=0, emitter=-1, flip_normals=False, is_mesh=True, face_normals=False):
         self.name = name
@@ -193,43 +208,110 @@ class Mesh:
 
 
 # ---------------------------------------------------------------------------- BVH
-def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = 4):
-    """Median-split BVH over triangle centroids.  Returns (nodes (n,8) float32 view-compatible, prim_index)."""
+LEAF_SIZE = 4
+
+
+def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE):
+    """Median-split BVH over triangle centroids, emitted as two-wide nodes (``EpsmBvhNode``: the boxes of both
+    children in one 64-byte record, leaf children embedded).  Returns a dict:
+
+      nodes        (n,16) float32; columns 12..15 hold c0,c1,n0,n1 as int32 bits
+      order        (T,)   triangle ids in leaf order (``prim_index``)
+      leaf_node / leaf_slot / leaf_tris   which (node, child slot) is a leaf and its triangles as rows of
+                   leaf-ordered indices, padded to ``leaf_size`` by repetition          -> refit step 1
+      levels       [(node, slot, child), ...] inner child slots grouped by depth, deepest first -> refit step 2
+    """
     T = tri.shape[0]
     p = pos[tri]                                   # (T,3,3)
     lo_t, hi_t = p.min(axis=1), p.max(axis=1)
     cen = 0.5 * (lo_t + hi_t)
     order = np.arange(T, dtype=np.int64)
-    nodes: List[list] = []
-
-    def new_node():
-        nodes.append(None); return len(nodes) - 1
-
-    root = new_node()
-    stack = [(root, 0, T)]
+    # binary tree first: node = [a, b, left, right] over order[a:b]; leaves have left = -1
+    tree: List[list] = [[0, T, -1, -1]]
+    stack = [0]
     while stack:
-        ni, a, b = stack.pop()
-        ids = order[a:b]
-        lo, hi = lo_t[ids].min(axis=0), hi_t[ids].max(axis=0)
+        ni = stack.pop()
+        a, b = tree[ni][0], tree[ni][1]
         if b - a <= leaf_size:
-            nodes[ni] = (lo, a, hi, b - a)
             continue
+        ids = order[a:b]
         c = cen[ids]
-        ext = c.max(axis=0) - c.min(axis=0)
-        ax = int(np.argmax(ext))
+        ax = int(np.argmax(c.max(axis=0) - c.min(axis=0)))
         mid = (b - a) // 2
-        part = np.argpartition(c[:, ax], mid)
-        order[a:b] = ids[part]
-        left = new_node(); right = new_node()
-        assert right == left + 1
-        nodes[ni] = (lo, left, hi, 0)
-        stack.append((left, a, a + mid)); stack.append((right, a + mid, b))
-    arr = np.zeros((len(nodes), 8), dtype=np.float32)
-    iarr = arr.view(np.uint32)
-    for i, (lo, first, hi, cnt) in enumerate(nodes):
-        arr[i, 0:3] = lo - 1e-6 * (1 + np.abs(lo)); iarr[i, 3] = first
-        arr[i, 4:7] = hi + 1e-6 * (1 + np.abs(hi)); iarr[i, 7] = cnt
-    return arr, order.astype(np.uint32)
+        order[a:b] = ids[np.argpartition(c[:, ax], mid)]
+        tree[ni][2], tree[ni][3] = len(tree), len(tree) + 1
+        tree.append([a, a + mid, -1, -1]); tree.append([a + mid, b, -1, -1])
+        stack += [tree[ni][2], tree[ni][3]]
+    # wide nodes = the inner nodes of the binary tree (a single-leaf scene gets one node with an absent child)
+    inner = [i for i, t in enumerate(tree) if t[2] >= 0]
+    wide_of = {bi: wi for wi, bi in enumerate(inner)}
+    n = max(1, len(inner))
+    nodes = np.zeros((n, 16), dtype=np.float32)
+    inodes = nodes.view(np.int32)
+    nodes[:, 0:3] = nodes[:, 6:9] = np.inf; nodes[:, 3:6] = nodes[:, 9:12] = -np.inf
+    inodes[:, 12:14] = -1
+    leaf_node, leaf_slot, leaf_tris = [], [], []
+    depth = np.zeros(n, dtype=np.int64)
+    per_level: Dict[int, list] = {}
+
+    def put_child(wi, slot, bi):
+        a, b, left, _ = tree[bi]
+        if left < 0:
+            inodes[wi, 12 + slot], inodes[wi, 14 + slot] = a, b - a
+            leaf_node.append(wi); leaf_slot.append(slot)
+            leaf_tris.append([a + min(j, b - a - 1) for j in range(leaf_size)])
+        else:
+            ci = wide_of[bi]
+            inodes[wi, 12 + slot], inodes[wi, 14 + slot] = ci, 0
+            depth[ci] = depth[wi] + 1
+            per_level.setdefault(int(depth[wi]), []).append((wi, slot, ci))
+
+    if not inner:
+        put_child(0, 0, 0)
+    for bi in inner:                               # parents precede children in `tree`, hence in `inner`
+        put_child(wide_of[bi], 0, tree[bi][2]); put_child(wide_of[bi], 1, tree[bi][3])
+    if int(depth.max(initial=0)) + 1 > 31:
+        raise ValueError("BVH deeper than the traversal stack (kBvhStack)")
+    levels = [np.asarray(per_level[d], dtype=np.int64).reshape(-1, 3) for d in sorted(per_level, reverse=True)]
+    return {"nodes": nodes, "order": order.astype(np.int64),
+            "leaf_node": np.asarray(leaf_node, np.int64), "leaf_slot": np.asarray(leaf_slot, np.int64),
+            "leaf_tris": np.asarray(leaf_tris, np.int64).reshape(-1, leaf_size), "levels": levels}
+
+
+class DeviceBvh:
+    """The BVH on the device + its refit: after the vertices moved, the boxes are recomputed bottom-up with a
+    handful of torch gathers (leaf slots from the triangles, then one level of inner slots after the other);
+    the topology of the build is kept (``params.update()`` per optimisation step must not cost a rebuild)."""
+
+    def __init__(self, plan: dict, device):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.nodes = t(plan["nodes"])                              # (n,16) float32
+        self.order = t(plan["order"])
+        self.prim_index = self.order.to(torch.int32)
+        self.leaf_node, self.leaf_slot, self.leaf_tris = t(plan["leaf_node"]), t(plan["leaf_slot"]), t(plan["leaf_tris"])
+        self.levels = [(t(l[:, 0]), t(l[:, 1]), t(l[:, 2])) for l in plan["levels"]]
+        self._cols = torch.arange(3, device=device)
+        self.tri_verts = None
+
+    def _write(self, node, slot, lo, hi):
+        c = (slot * 6).unsqueeze(1) + self._cols
+        self.nodes[node.unsqueeze(1), c] = lo
+        self.nodes[node.unsqueeze(1), c + 3] = hi
+
+    def refit(self, positions: torch.Tensor, tri: torch.Tensor):
+        """positions (V,3) f32, tri (T,3) int -> tri_verts (T,9) in leaf order and fresh boxes."""
+        tv = positions[tri.long()[self.order]]                     # (T,3,3)
+        if self.tri_verts is None:
+            self.tri_verts = tv.reshape(-1, 9).contiguous()
+        else:
+            self.tri_verts.copy_(tv.reshape(-1, 9))                # in place: the scene struct keeps its pointer
+        if self.leaf_node.numel():
+            g = tv[self.leaf_tris]                                 # (L, leaf, 3, 3)
+            lo, hi = g.amin(dim=(1, 2)), g.amax(dim=(1, 2))
+            self._write(self.leaf_node, self.leaf_slot, lo - 1e-6 * (1 + lo.abs()), hi + 1e-6 * (1 + hi.abs()))
+        for node, slot, child in self.levels:
+            cb = self.nodes[child]
+            self._write(node, slot, torch.minimum(cb[:, 0:3], cb[:, 6:9]), torch.maximum(cb[:, 3:6], cb[:, 9:12]))
 
 
 # ---------------------------------------------------------------------------- scene
@@ -405,13 +487,36 @@ class Scene:
         self._upload()
 
     def set_vertex_positions(self, mesh_name: str, v):
-        """``params['<mesh>.vertex_positions'] = v; params.update()`` (normals are recomputed like
-        Mesh::parameters_changed does, the BVH is rebuilt)."""
+        """``params['<mesh>.vertex_positions'] = v; params.update()``: everything stays on the device -- the
+        rows of the flat position buffer are overwritten, vertex normals are recomputed like
+        Mesh::parameters_changed does, the BVH is refitted (same topology, fresh boxes).  Only an emitting
+        mesh (its area / sampling CDF change) goes through the full host-side upload."""
         m = self.mesh(mesh_name)
-        m.v = np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float64).reshape(-1, 3)
+        lo, hi = self.mesh_slices[mesh_name]
+        if m.emitter >= 0 or self.bvh is None:
+            m.v = np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float64).reshape(-1, 3)
+            if m.has_normals:
+                m.n = vertex_normals(m.v, m.f)
+            self._upload()
+            return
+        v_t = torch.as_tensor(v, dtype=torch.float32, device=self.device).detach().reshape(-1, 3)
+        if v_t.shape[0] != hi - lo:
+            raise ValueError(f"{mesh_name}: expected {hi - lo} vertices, got {v_t.shape[0]}")
+        self.positions[lo:hi] = v_t
+        m.host_stale = True                                   # m.v / m.n are refreshed when the host needs them
         if m.has_normals:
-            m.n = vertex_normals(m.v, m.f)
-        self._upload()
+            t0, t1 = self.mesh_tri_slices[mesh_name]
+            self.normals[lo:hi] = vertex_normals_torch(v_t, self.tri[t0:t1].long() - lo)
+        self.bvh.refit(self.positions, self.tri)
+
+    def _sync_host_meshes(self):
+        for m in self.meshes:
+            if getattr(m, "host_stale", False):
+                lo, hi = self.mesh_slices[m.name]
+                m.v = self.positions[lo:hi].detach().cpu().double().numpy()
+                if m.has_normals:
+                    m.n = self.normals[lo:hi].detach().cpu().double().numpy()
+                m.host_stale = False
 
     def vertex_positions(self, mesh_name: str) -> torch.Tensor:
         lo, hi = self.mesh_slices[mesh_name]
@@ -423,13 +528,16 @@ class Scene:
     # -- upload ----------------------------------------------------------------------------------
     def _upload(self):
         dev = self.device
+        if getattr(self, "positions", None) is not None:
+            self._sync_host_meshes()
         pos, nrm, tri, tri_mesh, cdf = [], [], [], [], []
-        self.mesh_slices = {}
+        self.mesh_slices, self.mesh_tri_slices = {}, {}
         mesh_c = (EpsmMesh * max(1, len(self.meshes)))()
         voff = toff = coff = 0
         for mi_, m in enumerate(self.meshes):
             nv, nt = m.v.shape[0], m.f.shape[0]
             self.mesh_slices[m.name] = (voff, voff + nv)
+            self.mesh_tri_slices[m.name] = (toff, toff + nt)
             pos.append(m.v); nrm.append(m.n if m.n is not None else np.zeros_like(m.v))
             tri.append(m.f + voff); tri_mesh.append(np.full(nt, mi_, np.uint32))
             p = m.v[m.f]
@@ -448,9 +556,10 @@ class Scene:
         self.tri = torch.from_numpy(np.ascontiguousarray(TRI, dtype=np.int32)).to(dev)
         self.tri_mesh = torch.from_numpy(np.ascontiguousarray(np.concatenate(tri_mesh) if tri_mesh else np.zeros(0), dtype=np.int32)).to(dev)
         self.emitter_cdf = f32(np.concatenate(cdf) if cdf else np.zeros(1))
-        nodes, prim = build_bvh(P, TRI) if self.T > 0 else (np.zeros((0, 8), np.float32), np.zeros(0, np.uint32))
-        self.bvh = torch.from_numpy(nodes).to(dev)
-        self.prim_index = torch.from_numpy(prim.astype(np.int32)).to(dev)
+        self.bvh = None
+        if self.T > 0:
+            self.bvh = DeviceBvh(build_bvh(P, TRI), dev)
+            self.bvh.refit(self.positions, self.tri)
         bs = (EpsmBsdf * max(1, len(self.bsdf_desc)))()
         for i, b in enumerate(self.bsdf_desc):
             c = bs[i]
@@ -474,7 +583,9 @@ class Scene:
         s.bsdfs, s.n_bsdfs = self._bsdf_buf.data_ptr(), len(self.bsdf_desc)
         s.emitters, s.n_emitters = self._em_buf.data_ptr(), len(self.emitter_desc)
         s.emitter_cdf = self.emitter_cdf.data_ptr()
-        s.bvh, s.n_nodes, s.prim_index = self.bvh.data_ptr(), int(nodes.shape[0]), self.prim_index.data_ptr()
+        if self.bvh is not None:
+            s.bvh, s.n_nodes = self.bvh.nodes.data_ptr(), int(self.bvh.nodes.shape[0])
+            s.prim_index, s.tri_verts = self.bvh.prim_index.data_ptr(), self.bvh.tri_verts.data_ptr()
         s.n_vertices, s.n_triangles = self.V, self.T
         self.c_scene = s
 

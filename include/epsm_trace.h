@@ -74,9 +74,12 @@ typedef struct EpsmEmitter {
     float position[3];               /* point */
 } EpsmEmitter;
 
-typedef struct EpsmBvhNode {         /* 32 bytes */
-    float lo[3]; uint32_t left_or_first;   /* inner: left child (right = left+1); leaf: first triangle */
-    float hi[3]; uint32_t count;           /* 0 = inner node */
+typedef struct EpsmBvhNode {         /* 64 bytes: one load brings the boxes of BOTH children */
+    float lo0[3], hi0[3];            /* child 0 */
+    float lo1[3], hi1[3];            /* child 1 */
+    int32_t c0, c1;                  /* inner child: node index; leaf child: first triangle in tri_verts / prim_index */
+    int32_t n0, n1;                  /* number of triangles of a leaf child, 0 = inner child; an absent child has
+                                        n = 0, c = -1 and an inverted box */
 } EpsmBvhNode;
 
 typedef struct EpsmSensor {
@@ -96,8 +99,9 @@ typedef struct EpsmScene {           /* host struct holding DEVICE pointers */
     const EpsmBsdf *bsdfs;           int32_t n_bsdfs;
     const EpsmEmitter *emitters;     int32_t n_emitters;
     const float *emitter_cdf;        /* concatenated normalised area CDFs of the emitting meshes */
-    const EpsmBvhNode *bvh;          int32_t n_nodes;
+    const EpsmBvhNode *bvh;          int32_t n_nodes;   /* node 0 is the root; depth <= 31 */
     const uint32_t *prim_index;      /* leaf entries: BVH order -> triangle id (triangles stay mesh-contiguous) */
+    const float *tri_verts;          /* (T,9) p0,p1,p2 of the triangles in BVH (leaf) order */
     int64_t n_vertices, n_triangles;
 } EpsmScene;
 

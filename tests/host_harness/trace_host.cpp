@@ -20,7 +20,10 @@ extern "C" int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor
     A.film_pos = film_pos; A.radiance = radiance; A.valid = valid;
     for (int k = 0; k < K_log; ++k) A.rec[k] = recs[k];
 #pragma omp parallel for schedule(dynamic, 256)
-    for (int64_t i = 0; i < N; ++i) trace_one_path(A, i);
+    for (int64_t i = 0; i < N; ++i) {
+        uint32_t stack[kBvhStack];
+        trace_one_path(A, i, BvhStack{stack, 1});
+    }
     return 0;
 }
 

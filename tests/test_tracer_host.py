@@ -238,3 +238,46 @@ def test_occluder_record_of_the_first_vertex():
     # paths without a usable emitter sample carry no occluder
     dead = ~((v1["active"] > 0) & (v1["active_em"] > 0))
     assert bool((sh[dead, 0] == -1).all()) and bool((fl[dead, 2] == 0).all())
+
+
+def test_vertex_update_refits_the_bvh_and_recomputes_normals():
+    """params.update(): `set_vertex_positions` overwrites the rows of the flat buffers on the device, recomputes
+    the vertex normals and refits the BVH (same topology); tracing then sees exactly what a scene built from
+    the moved vertices sees."""
+    from epsm_mitsuba3_amd.exp.human import SkinnedTube
+    m = SkinnedTube("cpu", rings=12, sectors=10)
+    fv, ff = quad(0.0, 4.0, up=True)
+    lv, lf = quad(5.0, 0.3, up=False)
+
+    def scene(verts):
+        d = {"type": "scene", "cam": sensor([0.5, -4.0, 2.5], [0, 0, 1.0], up=(0, 0, 1), fov=45, res=24, spp=4),
+             "floor": {"type": "mesh", "vertices": fv, "faces": ff, "face_normals": True, "bsdf": {"type": "diffuse"}},
+             "tube": {"type": "mesh", "vertices": verts, "faces": m.faces, "bsdf": {"type": "diffuse"}},      # vertex normals
+             "light": {"type": "mesh", "vertices": lv, "faces": lf, "face_normals": True,
+                       "emitter": {"type": "area", "radiance": {"type": "rgb", "value": 20.0}}}}
+        return on_host(S.Scene.from_dict(d, device="cpu"))
+
+    v0 = m.gen_mesh(torch.zeros(1, 6))[0]
+    v1 = m.gen_mesh(torch.tensor([[0.0, 0.5, 0.0, 0.3, -0.4, 0.0]]))[0] + torch.tensor([0.3, 0.2, 0.0])
+    moved = scene(v0.numpy().astype(np.float64))
+    nodes_before = moved.bvh.nodes.clone()
+    moved.set_vertex_positions("tube", v1)
+    assert not torch.equal(moved.bvh.nodes[:, :12], nodes_before[:, :12])                  # boxes changed,
+    assert torch.equal(moved.bvh.nodes[:, 12:].view(torch.int32), nodes_before[:, 12:].view(torch.int32))   # topology kept
+    fresh = scene(v1.numpy().astype(np.float64))
+    lo, hi = fresh.mesh_slices["tube"]
+    assert torch.allclose(moved.positions, fresh.positions, atol=1e-6)
+    assert torch.allclose(moved.normals[lo:hi], fresh.normals[lo:hi], atol=1e-4)
+    n = 24 * 24 * 4
+    a = moved._trace(0, seed=3, spp=4, max_depth=3, K=2, lo=0, hi=n)
+    b = fresh._trace(0, seed=3, spp=4, max_depth=3, K=2, lo=0, hi=n)
+    on_tube = (a.path_info[1]["active"] > 0) & (a.scatter_info[0]["tri"][:, 0] >= lo) & (a.scatter_info[0]["tri"][:, 0] < hi)
+    assert int(on_tube.sum()) > 100
+    assert torch.equal(a.path_info[1]["active"], b.path_info[1]["active"])
+    assert torch.allclose(a.path_info[1]["points"][3], b.path_info[1]["points"][3], atol=1e-5)
+    assert torch.allclose(a.path_info[1]["normal"], b.path_info[1]["normal"], atol=1e-4)
+    assert torch.equal(a.scatter_info[0]["tri"], b.scatter_info[0]["tri"])
+    assert torch.allclose(a.radiance, b.radiance, rtol=1e-4, atol=1e-5)
+    # the host copy of the mesh follows when it is needed again (attach -> full upload)
+    moved.attach("tube", positions=True)
+    assert np.allclose(moved.mesh("tube").v, v1.numpy(), atol=1e-6)
