@@ -22,7 +22,7 @@ constexpr int kScatterBlocks = 2048;            // persistent workgroups (8 per 
 
 // One lane per path within a 256-path chunk; a workgroup walks a CONTIGUOUS range of
 // chunks (neighbouring pixels -> the same triangles come back -> they stay in its table).
-template <int MODE, int BITS>
+template <int BITS>
 __global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A, Targets tg, int64_t chunks_per_block) {
     constexpr int kTableSize = 1 << BITS;
     __shared__ uint32_t s_keys[kTableSize];
@@ -57,24 +57,12 @@ __global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A,
             }
             const bool pos_v = live && q.pos_ok;
             const bool nrm_v = live && q.nrm_ok && (nz3(q.nrm[0]) || nz3(q.nrm[1]) || nz3(q.nrm[2]));
-            if (MODE == 0) {
-                scatter_triangle_runs(T, 0u, pos_v, q.vi, q.pos, __ballot(pos_v) != 0ull);
-                scatter_triangle_runs(T, (uint32_t) A.V, nrm_v, q.vi, q.nrm, __ballot(nrm_v) != 0ull);
-                if (tg.galpha) scatter_scalar_hot(T, 2u * (uint32_t) A.V, live && q.alpha_ok, q.bid, q.alpha);
-                if (A.s[it].emit) scatter_triangle_hot(T, 0u, live && q.em_ok, q.ei, q.em);
-                if (A.s[it].shadow) scatter_triangle_runs(T, 0u, live && q.sh_ok, q.si, q.sh, __ballot(live && q.sh_ok) != 0ull);
-            } else {
-                if (MODE == 1) {
-                    scatter_triangle_direct(T, 0u, pos_v, q.vi, q.pos);
-                    scatter_triangle_direct(T, (uint32_t) A.V, nrm_v, q.vi, q.nrm);
-                } else {
-                    scatter_triangle_adaptive(T, 0u, pos_v, q.vi, q.pos, MODE == 2 ? 8 : 16);
-                    scatter_triangle_adaptive(T, (uint32_t) A.V, nrm_v, q.vi, q.nrm, MODE == 2 ? 8 : 16);
-                }
-                if (tg.galpha && live && q.alpha_ok) T.add(2u * (uint32_t) A.V + q.bid, q.alpha, 0.f, 0.f);
-                if (A.s[it].emit) scatter_triangle_direct(T, 0u, live && q.em_ok, q.ei, q.em);
-                if (A.s[it].shadow) scatter_triangle_adaptive(T, 0u, live && q.sh_ok, q.si, q.sh, MODE == 2 ? 8 : 16);
-            }
+            // rows of the hit triangle: segmented scan when the wave has <= 16 runs, else straight into the table
+            scatter_triangle_adaptive(T, 0u, pos_v, q.vi, q.pos, 16);
+            scatter_triangle_adaptive(T, (uint32_t) A.V, nrm_v, q.vi, q.nrm, 16);
+            if (tg.galpha && live && q.alpha_ok) T.add(2u * (uint32_t) A.V + q.bid, q.alpha, 0.f, 0.f);
+            if (A.s[it].emit) scatter_triangle_direct(T, 0u, live && q.em_ok, q.ei, q.em);
+            if (A.s[it].shadow) scatter_triangle_adaptive(T, 0u, live && q.sh_ok, q.si, q.sh, 16);
         }
         if (T.crowded()) T.flush();               // workgroup-uniform census
     }
@@ -125,7 +113,7 @@ extern "C" int epsm_scatter(int variant, int64_t N, int K,
     const int64_t chunks_per_block = (chunks + blocks - 1) / blocks;
     // Adaptive run merge (<= 16 runs per wave), 2048-row table (4 workgroups per CU): the winner of the A/B on
     // config 2 over {runs + hot-key rounds, direct LDS atomics, adaptive 8 / 16} x {1024, 2048, 4096 rows}.
-    hipLaunchKernelGGL((epsm_scatter_kernel<3, 11>), dim3((unsigned) blocks), dim3(256), 0, (hipStream_t) stream, A, T, chunks_per_block);
+    hipLaunchKernelGGL((epsm_scatter_kernel<11>), dim3((unsigned) blocks), dim3(256), 0, (hipStream_t) stream, A, T, chunks_per_block);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_scatter", e);
     return EPSM_OK;

@@ -6,11 +6,13 @@
 // are an order of magnitude below the contiguous rate.  Neighbouring paths of a
 // wavefront hit the same triangle most of the time (they are samples of the
 // same / adjacent pixels), so before any atomic the items of a wave are merged:
-//   * runs of adjacent lanes with an identical key triple are summed with a
-//     segmented shuffle scan; only the last lane of a run issues the atomic;
-//   * very hot keys (the emitter triangles: every light sample of a wave may
-//     land on the same two triangles) are reduced over ALL lanes that hold
-//     them, adjacent or not (match-any loop, bounded).
+//   * stand-alone scatter kernel: runs of adjacent lanes with an identical key
+//     triple are summed with a segmented shuffle scan when the wave has few
+//     runs; only the last lane of a run issues the atomic;
+//   * fused kernel: lanes with the same target (one pixel's samples on the first
+//     triangle, the couple of emitter triangles, a BSDF's alpha slot), adjacent
+//     or not, are summed with DPP adds in bounded leader rounds
+//     (ScatterOut::merge_equal, epsm_grad_scatter.hip).
 // Device-only code.
 #pragma once
 
@@ -151,14 +153,6 @@ struct LdsTable {
 
 template <typename Table> __device__ __forceinline__ void atomic_add3(const Table &T, uint32_t key, V3<float> g) { T.add(key, g.x, g.y, g.z); }
 
-// Sum of v over the lanes of `mask` (a ballot); every lane of the mask gets the total.
-__device__ __forceinline__ float masked_wave_sum(float v, bool in) {
-    v = in ? v : 0.f;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
 // Sum over the wave with DPP adds only (no LDS crossbar): quad swaps, half-row and row mirrors
 // give every lane its 16-lane row total, row_bcast15 / row_bcast31 chain the rows; lane 63 ends up
 // with the wave total.  Lanes that must not contribute pass 0.  All 64 lanes must be active.
@@ -196,62 +190,6 @@ __device__ __attribute__((noinline)) float merge_row1(float v, bool mine, bool c
     const float tot = lane63(wave_total_lane63(mine ? v : 0.f));
     return carrier ? tot : (mine ? 0.f : v);
 }
-
-// Three rows (one triangle) per lane, merged over runs of equal triangles.
-template <typename Table> __device__ __forceinline__ void scatter_triangle_runs(const Table &buf, uint32_t base, bool valid, const uint32_t key[3],
-                                                      const V3<float> val[3], bool wave_has_any) {
-    if (!wave_has_any) return;
-    const Runs r = make_runs(valid, key[0], key[1], key[2]);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const V3<float> tot = seg_sum3(valid ? val[j] : zero3<float>(), r.head);
-        if (r.tail) atomic_add3(buf, base + key[j], tot);
-    }
-}
-
-// Hot-key variant: up to `kRounds` distinct triangles are reduced over the whole wave
-// (one atomic per component per triangle per wave); what is left falls back to runs.
-template <typename Table> __device__ __forceinline__ void scatter_triangle_hot(const Table &buf, uint32_t base, bool valid, const uint32_t key[3],
-                                                     const V3<float> val[3]) {
-    constexpr int kRounds = 3;
-    bool pending = valid;
-#pragma unroll 1
-    for (int round = 0; round < kRounds; ++round) {
-        const unsigned long long pm = __ballot(pending);
-        if (pm == 0ull) return;
-        const int leader = __ffsll((long long) pm) - 1;
-        const uint32_t l0 = __shfl(key[0], leader), l1 = __shfl(key[1], leader), l2 = __shfl(key[2], leader);
-        const bool in = pending && key[0] == l0 && key[1] == l1 && key[2] == l2;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float sx = masked_wave_sum(val[j].x, in), sy = masked_wave_sum(val[j].y, in),
-                        sz = masked_wave_sum(val[j].z, in);
-            if (lane_id() == leader) atomic_add3(buf, base + key[j], mk3<float>(sx, sy, sz));
-        }
-        pending = pending && !in;
-    }
-    const bool any_left = __ballot(pending) != 0ull;
-    scatter_triangle_runs(buf, base, pending, key, val, any_left);
-}
-
-// Scalar slot (per-BSDF alpha): few distinct keys per wave -> match-any rounds, then plain atomics.
-template <typename Table> __device__ __forceinline__ void scatter_scalar_hot(const Table &buf, uint32_t base, bool valid, uint32_t key, float val) {
-    constexpr int kRounds = 4;
-    bool pending = valid;
-#pragma unroll 1
-    for (int round = 0; round < kRounds; ++round) {
-        const unsigned long long pm = __ballot(pending);
-        if (pm == 0ull) return;
-        const int leader = __ffsll((long long) pm) - 1;
-        const uint32_t lk = __shfl(key, leader);
-        const bool in = pending && key == lk;
-        const float s = masked_wave_sum(val, in);
-        if (lane_id() == leader) buf.add(base + lk, s, 0.f, 0.f);
-        pending = pending && !in;
-    }
-    if (pending) buf.add(base + key, val, 0.f, 0.f);
-}
-
 
 // Direct insertion: LDS atomics merge equal keys natively (same-address lanes serialise
 // at LDS speed), which beats shuffle scans when runs are short.
