@@ -138,17 +138,27 @@ struct TriHit { bool hit; uint32_t tri; float t, u, v; };
 // Traversal stack of one path: entry k lives at base[k * stride] (LDS on the GPU: one column per thread,
 // conflict-free; a local array on the host).  Depth of the tree <= kBvhStack.
 constexpr int kBvhStack = 32;
+constexpr int32_t kBvhNone = 0x7fffffff;
 struct BvhStack { uint32_t *base; int stride; };
 
 // Ordered traversal of the two-wide BVH: one 64-byte node holds both children's boxes, leaf children are
 // intersected on the spot, of two inner children the nearer is followed and the farther pushed.
+#ifdef EPSM_BVH_STATS
+static long g_bvh_nodes = 0, g_bvh_tris = 0, g_bvh_rays = 0;
+#endif
 template <bool ANY_HIT>
 EPSM_HD TriHit intersect(const EpsmScene &S, Ray r, const BvhStack &st) {
+#ifdef EPSM_BVH_STATS
+    __atomic_fetch_add(&g_bvh_rays, 1, __ATOMIC_RELAXED);
+#endif
     TriHit best; best.hit = false; best.tri = 0; best.t = r.maxt; best.u = best.v = 0.f;
     if (S.n_nodes <= 0) return best;
     const F3 inv_d = f3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
     int32_t best_e = -1;
     auto leaf = [&](int32_t first, int32_t count) {
+#ifdef EPSM_BVH_STATS
+        __atomic_fetch_add(&g_bvh_tris, count, __ATOMIC_RELAXED);
+#endif
         for (int32_t e = first; e < first + count; ++e) {
             const float *q = S.tri_verts + 9 * (int64_t) e;
             float t, u, v;
@@ -159,28 +169,38 @@ EPSM_HD TriHit intersect(const EpsmScene &S, Ray r, const BvhStack &st) {
             }
         }
     };
-    int32_t node = 0;
+    // while-while traversal: descend through inner nodes until the current reference is a leaf, then intersect
+    // that leaf's triangles -- the lanes of a wave run the (long) triangle code together instead of each one
+    // in the middle of its own descent.  A reference is a node index (>= 0), a leaf ~((first << 3) | count)
+    // (< 0) or kBvhNone.
+    int32_t cur = 0;
     int sp = 0;
     for (;;) {
-        const EpsmBvhNode n = S.bvh[node];
-        float t0, t1;
-        bool h0 = hit_box(n.lo0, n.hi0, r.o, inv_d, r.maxt, t0), h1 = hit_box(n.lo1, n.hi1, r.o, inv_d, r.maxt, t1);
-        if (h0 && n.n0 > 0) { leaf(n.c0, n.n0); h0 = false; if (ANY_HIT && best.hit) break; }
-        if (h1 && n.n1 > 0) { if (t1 <= r.maxt) leaf(n.c1, n.n1); h1 = false; if (ANY_HIT && best.hit) break; }
-        // a leaf hit may have shortened the ray; an absent child (c = -1) is never followed
-        h0 = h0 && t0 <= r.maxt && n.c0 >= 0; h1 = h1 && t1 <= r.maxt && n.c1 >= 0;
-        if (h0 && h1) {
-            const bool first0 = t0 <= t1;
-            if (sp < kBvhStack) st.base[(sp++) * st.stride] = (uint32_t) (first0 ? n.c1 : n.c0);
-            node = first0 ? n.c0 : n.c1;
-        } else if (h0) {
-            node = n.c0;
-        } else if (h1) {
-            node = n.c1;
-        } else {
-            if (sp == 0) break;
-            node = (int32_t) st.base[(--sp) * st.stride];
+        while (cur >= 0 && cur != kBvhNone) {
+#ifdef EPSM_BVH_STATS
+            __atomic_fetch_add(&g_bvh_nodes, 1, __ATOMIC_RELAXED);
+#endif
+            const EpsmBvhNode n = S.bvh[cur];
+            float t0, t1;
+            const bool h0 = n.c0 != kBvhNone && hit_box(n.lo0, n.hi0, r.o, inv_d, r.maxt, t0);
+            const bool h1 = n.c1 != kBvhNone && hit_box(n.lo1, n.hi1, r.o, inv_d, r.maxt, t1);
+            if (h0 && h1) {
+                const bool first0 = t0 <= t1;
+                if (sp < kBvhStack) st.base[(sp++) * st.stride] = (uint32_t) (first0 ? n.c1 : n.c0);
+                cur = first0 ? n.c0 : n.c1;
+            } else if (h0) {
+                cur = n.c0;
+            } else if (h1) {
+                cur = n.c1;
+            } else {
+                cur = sp > 0 ? (int32_t) st.base[(--sp) * st.stride] : kBvhNone;
+            }
         }
+        if (cur == kBvhNone) break;
+        const uint32_t ref = ~(uint32_t) cur;
+        leaf((int32_t) (ref >> 3), (int32_t) (ref & 7u));
+        if (ANY_HIT && best.hit) break;
+        cur = sp > 0 ? (int32_t) st.base[(--sp) * st.stride] : kBvhNone;
     }
     if (best.hit) best.tri = S.prim_index[best_e];
     return best;

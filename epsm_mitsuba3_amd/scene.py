@@ -215,7 +215,7 @@ def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE):
     """Median-split BVH over triangle centroids, emitted as two-wide nodes (``EpsmBvhNode``: the boxes of both
     children in one 64-byte record, leaf children embedded).  Returns a dict:
 
-      nodes        (n,16) float32; columns 12..15 hold c0,c1,n0,n1 as int32 bits
+      nodes        (n,16) float32; columns 12..15 hold c0,c1 (child references) and n0,n1 as int32 bits
       order        (T,)   triangle ids in leaf order (``prim_index``)
       leaf_node / leaf_slot / leaf_tris   which (node, child slot) is a leaf and its triangles as rows of
                    leaf-ordered indices, padded to ``leaf_size`` by repetition          -> refit step 1
@@ -249,7 +249,7 @@ def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE):
     nodes = np.zeros((n, 16), dtype=np.float32)
     inodes = nodes.view(np.int32)
     nodes[:, 0:3] = nodes[:, 6:9] = np.inf; nodes[:, 3:6] = nodes[:, 9:12] = -np.inf
-    inodes[:, 12:14] = -1
+    inodes[:, 12:14] = 0x7fffffff                  # absent child
     leaf_node, leaf_slot, leaf_tris = [], [], []
     depth = np.zeros(n, dtype=np.int64)
     per_level: Dict[int, list] = {}
@@ -257,7 +257,7 @@ def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE):
     def put_child(wi, slot, bi):
         a, b, left, _ = tree[bi]
         if left < 0:
-            inodes[wi, 12 + slot], inodes[wi, 14 + slot] = a, b - a
+            inodes[wi, 12 + slot], inodes[wi, 14 + slot] = ~((a << 3) | (b - a)), b - a     # leaf reference
             leaf_node.append(wi); leaf_slot.append(slot)
             leaf_tris.append([a + min(j, b - a - 1) for j in range(leaf_size)])
         else:

@@ -77,9 +77,10 @@ typedef struct EpsmEmitter {
 typedef struct EpsmBvhNode {         /* 64 bytes: one load brings the boxes of BOTH children */
     float lo0[3], hi0[3];            /* child 0 */
     float lo1[3], hi1[3];            /* child 1 */
-    int32_t c0, c1;                  /* inner child: node index; leaf child: first triangle in tri_verts / prim_index */
-    int32_t n0, n1;                  /* number of triangles of a leaf child, 0 = inner child; an absent child has
-                                        n = 0, c = -1 and an inverted box */
+    int32_t c0, c1;                  /* child reference: >= 0 node index; < 0 leaf ~((first << 3) | count) with `first`
+                                        the leaf's first triangle in tri_verts / prim_index and count <= 7;
+                                        0x7fffffff = absent */
+    int32_t n0, n1;                  /* build-side copy of the leaf counts (0 = inner); not read by the traversal */
 } EpsmBvhNode;
 
 typedef struct EpsmSensor {

@@ -2,6 +2,6 @@
 set -e
 cd "$(dirname "$0")/../epsm_mitsuba3_amd/csrc"
 make -s
-F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=fast -fno-slp-vectorize -Wall -Wno-unused-function"
+F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=fast -fno-slp-vectorize -Wall -Wno-unused-function -mllvm -amdgpu-sched-strategy=max-ilp"
 /opt/rocm/bin/hipcc $F $2 -c -o build/epsm_grad_scatter_$1.o epsm_grad_scatter.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libepsm_$1.so build/epsm_grad.o build/epsm_tangent.o build/epsm_scatter.o build/epsm_grad_scatter_$1.o build/epsm_trace.o
