@@ -211,8 +211,43 @@ class Mesh:
 LEAF_SIZE = 4
 
 
-def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE):
-    """Median-split BVH over triangle centroids, emitted as two-wide nodes (``EpsmBvhNode``: the boxes of both
+def _sah_split(cen: np.ndarray, lo: np.ndarray, hi: np.ndarray, bins: int = 16):
+    """Best binned surface-area-heuristic plane over the three axes for the triangles (centroids ``cen``, boxes
+    ``lo``/``hi``) of one node.  Returns the boolean mask of the left side or None (degenerate extent)."""
+    n = cen.shape[0]
+    cmin, cmax = cen.min(axis=0), cen.max(axis=0)
+    best = (np.inf, None)
+    for ax in range(3):
+        ext = cmax[ax] - cmin[ax]
+        if not ext > 0:
+            continue
+        b = np.minimum(((cen[:, ax] - cmin[ax]) * (bins / ext)).astype(np.int64), bins - 1)
+        cnt = np.bincount(b, minlength=bins)
+        blo = np.full((bins, 3), np.inf); bhi = np.full((bins, 3), -np.inf)
+        order = np.argsort(b, kind="stable")
+        starts = np.searchsorted(b[order], np.arange(bins))
+        nz = cnt > 0
+        blo[nz] = np.minimum.reduceat(lo[order], starts[nz], axis=0)
+        bhi[nz] = np.maximum.reduceat(hi[order], starts[nz], axis=0)
+        llo, lhi = np.minimum.accumulate(blo, axis=0), np.maximum.accumulate(bhi, axis=0)
+        rlo, rhi = np.minimum.accumulate(blo[::-1], axis=0)[::-1], np.maximum.accumulate(bhi[::-1], axis=0)[::-1]
+        nl = np.cumsum(cnt)
+
+        def area(l, h):
+            d = np.maximum(h - l, 0.0)
+            return d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]
+        # plane k separates bins [0..k] from [k+1..]
+        with np.errstate(invalid="ignore"):
+            cost = area(llo[:-1], lhi[:-1]) * nl[:-1] + area(rlo[1:], rhi[1:]) * (n - nl[:-1])
+        cost = np.where((nl[:-1] > 0) & (nl[:-1] < n), cost, np.inf)
+        k = int(np.argmin(cost))
+        if cost[k] < best[0]:
+            best = (cost[k], b <= k)
+    return best[1]
+
+
+def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE, sah_min: int = 24):
+    """Binned-SAH BVH (16 bins per axis; nodes of <= ``sah_min`` triangles: median split), emitted as two-wide nodes (``EpsmBvhNode``: the boxes of both
     children in one 64-byte record, leaf children embedded).  Returns a dict:
 
       nodes        (n,16) float32; columns 12..15 hold c0,c1 (child references) and n0,n1 as int32 bits
@@ -228,6 +263,7 @@ def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE):
     order = np.arange(T, dtype=np.int64)
     # binary tree first: node = [a, b, left, right] over order[a:b]; leaves have left = -1
     tree: List[list] = [[0, T, -1, -1]]
+    tdepth = [0]
     stack = [0]
     while stack:
         ni = stack.pop()
@@ -236,11 +272,20 @@ def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE):
             continue
         ids = order[a:b]
         c = cen[ids]
-        ax = int(np.argmax(c.max(axis=0) - c.min(axis=0)))
-        mid = (b - a) // 2
-        order[a:b] = ids[np.argpartition(c[:, ax], mid)]
+        mid = None
+        if b - a > sah_min and tdepth[ni] < 20:    # deep SAH chains fall back to halving: depth stays <= kBvhStack
+            split = _sah_split(c, lo_t[ids], hi_t[ids])
+            if split is not None:
+                left_mask = split
+                mid = int(left_mask.sum())
+                order[a:b] = np.concatenate([ids[left_mask], ids[~left_mask]])
+        if mid is None:                            # small node or no useful plane: median of the widest axis
+            ax = int(np.argmax(c.max(axis=0) - c.min(axis=0)))
+            mid = (b - a) // 2
+            order[a:b] = ids[np.argpartition(c[:, ax], mid)]
         tree[ni][2], tree[ni][3] = len(tree), len(tree) + 1
         tree.append([a, a + mid, -1, -1]); tree.append([a + mid, b, -1, -1])
+        tdepth += [tdepth[ni] + 1, tdepth[ni] + 1]
         stack += [tree[ni][2], tree[ni][3]]
     # wide nodes = the inner nodes of the binary tree (a single-leaf scene gets one node with an absent child)
     inner = [i for i, t in enumerate(tree) if t[2] >= 0]
