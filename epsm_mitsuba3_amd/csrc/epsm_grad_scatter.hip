@@ -256,28 +256,87 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
     if (threadIdx.x < K) { s_ptrs.v[threadIdx.x] = F.g.v[threadIdx.x]; s_ptrs.s[threadIdx.x] = F.s[threadIdx.x]; }
     const LdsArgs A{F.g.N, F.g.cam, F.g.dlduv, F.g.dldp, F.g.dlduv_stride, &s_ptrs};
     T.clear();                                   // ends with a barrier: the table of pointers is visible too
-    // Chunk order: groups of 4 consecutive chunks (16 pixels at 64 spp share triangles),
-    // groups dealt round-robin over the workgroups so that the chip streams one contiguous
-    // window of every record array at a time (measured: same speed as one contiguous range
-    // per workgroup, but independent of how the driver places workgroups).
-    const int64_t n_chunks = (F.g.N + 255) / 256;
-    constexpr int group = 4;
+    // A workgroup takes WINDOWS of 1024 consecutive paths (16 pixels at 64 spp share triangles), dealt round-robin
+    // over the workgroups.  Inside a window the paths are counting-sorted (stable) by the number of vertices
+    // they are live in, and the sorted list is dealt in slots of 64 to the four waves round-robin: a wave then
+    // holds paths of ONE length -- a step nobody needs is skipped by the whole wave (the flags are independent
+    // per path in the worst case, 41 % lane utilisation unsorted) -- and every wave gets short and long slots,
+    // so the four SIMDs stay balanced without a barrier between slots.
+    constexpr int kWindow = 1024, kSlots = kWindow / 64, kKeys = K + 1, kSub = kWindow / 256;
+    __shared__ uint16_t s_perm[kWindow];
+    __shared__ int s_cnt[kKeys * kSub * 4];            // [key][sub-chunk j][wave w]: histogram, then offsets
+    const int64_t n_windows = (F.g.N + kWindow - 1) / kWindow;
+    const int64_t windows_per_block = (chunks_per_block + kSub - 1) / kSub;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll 1
-    for (int64_t it = 0; it < chunks_per_block; ++it) {
-        const int64_t c = ((it / group) * gridDim.x + blockIdx.x) * group + (it % group);
-        if (c >= n_chunks) continue;
-        const int64_t i0 = c * 256 + threadIdx.x;
-        const bool ok = i0 < F.g.N;
-        const int64_t i = ok ? i0 : F.g.N - 1;    // lanes past the end recompute the last path and add nothing
-        const ScatterOut<kBits> out{F, s_ptrs, T, Q, i, ok};
-        if (VARIANT == EPSM_VARIANT_MANIFOLD)
-            manifold_path<float, K, FULL_D>(A, i, dcols, out);
-        else
-            caustic_path<float, K, FULL_D>(A, i, dcols, out);
-        Q.drain(T);
-        // workgroup-uniform census (three barriers) once per group of chunks; a table that fills up in
-        // between sends the overflow straight to HBM (LdsTable::add)
-        if ((it % group) == group - 1 && T.crowded()) T.flush();
+    for (int64_t wi = 0; wi < windows_per_block; ++wi) {
+        const int64_t win = wi * gridDim.x + blockIdx.x;
+        if (win >= n_windows) break;                   // workgroup-uniform
+        const int64_t base = win * kWindow;
+        // -- histogram of the path lengths: thread t holds paths base + j*256 + t
+        int key[kSub], rank[kSub];
+        {
+            // all flag loads of the window first (clamped index, no branch: a branch per sub-chunk would put its
+            // consumer behind it and serialise four HBM round trips), then the keys
+            Flags<K> fl[kSub];
+#pragma unroll
+            for (int j = 0; j < kSub; ++j) {
+                const int64_t p = base + j * 256 + threadIdx.x;
+                fl[j] = load_flags<float, K>(A, p < F.g.N ? p : F.g.N - 1);
+            }
+#pragma unroll
+            for (int j = 0; j < kSub; ++j) {
+                const int64_t p = base + j * 256 + threadIdx.x;
+                const int e = VARIANT == EPSM_VARIANT_MANIFOLD ? manifold_extent<K>(fl[j]) : caustic_extent<K>(fl[j]);
+                key[j] = p < F.g.N ? e : 0;
+            }
+        }
+        // (a separate loop: the LDS stores below must not sit between the flag loads of consecutive sub-chunks)
+#pragma unroll
+        for (int j = 0; j < kSub; ++j) {
+#pragma unroll
+            for (int q = 0; q < kKeys; ++q) {
+                const unsigned long long m = __ballot(key[j] == q);
+                if (key[j] == q) rank[j] = __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
+                if (lane == 0) s_cnt[(q * kSub + j) * 4 + wv] = __popcll(m);
+            }
+        }
+        __syncthreads();
+        if (wv == 0) {                                 // exclusive scan in (key, j, wave) order = stable sort order
+            constexpr int kEntries = kKeys * kSub * 4;
+            int carry = 0;
+#pragma unroll
+            for (int q0 = 0; q0 < kEntries; q0 += 64) {
+                const int q = q0 + lane;
+                const int c = q < kEntries ? s_cnt[q] : 0;
+                int inc = c;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+                if (q < kEntries) s_cnt[q] = carry + inc - c;
+                carry += __shfl(inc, 63);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kSub; ++j) s_perm[s_cnt[(key[j] * kSub + j) * 4 + wv] + rank[j]] = (uint16_t) (j * 256 + threadIdx.x);
+        __syncthreads();
+        // -- the wave's four slots
+#pragma unroll 1
+        for (int g = 0; g < kSlots / 4; ++g) {
+            const int slot = g * 4 + ((wv + g) & 3);   // rotate: no wave always gets the longest slot of a quarter
+            const int64_t i0 = base + s_perm[slot * 64 + lane];
+            const bool ok = i0 < F.g.N;
+            const int64_t i = ok ? i0 : F.g.N - 1;     // lanes past the end recompute the last path and add nothing
+            const ScatterOut<kBits> out{F, s_ptrs, T, Q, i, ok};
+            if (VARIANT == EPSM_VARIANT_MANIFOLD)
+                manifold_path<float, K, FULL_D>(A, i, dcols, out);
+            else
+                caustic_path<float, K, FULL_D>(A, i, dcols, out);
+            Q.drain(T);
+        }
+        // workgroup-uniform census (three barriers) once per window; a table that fills up in between sends
+        // the overflow straight to HBM (LdsTable::add)
+        if (T.crowded()) T.flush();
     }
     T.flush();
 }

@@ -369,6 +369,36 @@ template <typename R, int K, typename Args> EPSM_HD Flags<K> load_flags(const Ar
 // ============================================================================
 // "manifold"  (epsm.py:745-946)
 // ============================================================================
+// Number of vertices whose geometry a path needs (`nv` of manifold_path / caustic_path): the steps a lane is live
+// in.  Only used to GROUP paths of similar length into the same wave (epsm_grad_scatter.hip); the path functions
+// derive their own masks, so a mismatch here could only cost time, never change a result.
+template <int K> EPSM_HD int manifold_extent(const Flags<K> &fl) {
+    bool valid = true;
+    int hasdiffuse = 0, nv = 0;
+#pragma unroll
+    for (int id = 1; id <= K; ++id) {
+        valid = valid && fl.mesh[id];
+        hasdiffuse += fl.diffuse[id] ? 1 : 0;
+        valid = valid && (hasdiffuse < 2);
+        const bool spec = valid && (hasdiffuse == 0);
+        if (spec && fl.active[id] && fl.active_em[id]) nv = id;
+        if ((id < K) && spec && fl.active[id + 1] && fl.diffuse[id + 1]) nv = id + 1;
+    }
+    return nv;
+}
+template <int K> EPSM_HD int caustic_extent(const Flags<K> &fl) {
+    bool valid = true;
+    int hasdiffuse = 0, nv = 0;
+#pragma unroll
+    for (int id = 1; id <= K; ++id) {
+        valid = valid && fl.mesh[id];
+        hasdiffuse += fl.diffuse[id] ? 1 : 0;
+        valid = valid && (hasdiffuse < 2);
+        if ((id < K) && fl.diffuse[1] && valid && fl.active[id + 1] && (fl.diffuse[id + 1] || fl.null_[id + 1])) nv = id + 1;
+    }
+    return nv;
+}
+
 template <typename R, int K, bool FULL_D, typename Out, typename Args>
 EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) {
     const Flags<K> fl = load_flags<R, K>(A, i);
