@@ -135,6 +135,7 @@ template <typename R> struct VertexPtrs {
     const uint8_t *active, *active_em, *ismesh;
 };
 
+template <int K> struct Flags;
 template <typename R> struct GradArgs {
     int64_t N;
     const R *cam;
@@ -147,6 +148,7 @@ template <typename R> struct GradArgs {
     R *out_light;            // (K,N,3)
     R *out_diffuse;          // (K,N,3)
     EPSM_HD const VertexPtrs<R> &vtx(int k) const { return v[k]; }
+    template <int K> EPSM_HD Flags<K> flags(int64_t i) const;      // from the record arrays (defined below load_flags)
 };
 
 template <typename R> EPSM_HD V3<R> load3(const R *base, int64_t i) {
@@ -350,6 +352,15 @@ template <typename R, bool FULL_D, typename Args> EPSM_HD V2<R> load_d(const Arg
 template <int K> struct Flags {
     bool diffuse[K + 2], null_[K + 2], active[K + 2], active_em[K + 2], mesh[K + 2];
 };
+// five bits per vertex in one word (the fused kernel parks a window's flags in LDS)
+template <int K> EPSM_HD uint32_t pack_flags(const Flags<K> &f) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 1; k <= K; ++k)
+        w |= ((f.diffuse[k] ? 1u : 0u) | (f.null_[k] ? 2u : 0u) | (f.active[k] ? 4u : 0u) | (f.active_em[k] ? 8u : 0u) |
+              (f.mesh[k] ? 16u : 0u)) << (5 * (k - 1));
+    return w;
+}
 template <typename R, int K, typename Args> EPSM_HD Flags<K> load_flags(const Args &A, int64_t i) {
     Flags<K> f;
 #pragma unroll
@@ -365,6 +376,19 @@ template <typename R, int K, typename Args> EPSM_HD Flags<K> load_flags(const Ar
     f.diffuse[K + 1] = f.null_[K + 1] = f.active[K + 1] = f.active_em[K + 1] = f.mesh[K + 1] = false;
     return f;
 }
+template <int K> EPSM_HD Flags<K> unpack_flags(uint32_t w) {
+    Flags<K> f;
+    f.diffuse[0] = f.null_[0] = f.active[0] = f.active_em[0] = f.mesh[0] = false;
+    f.diffuse[K + 1] = f.null_[K + 1] = f.active[K + 1] = f.active_em[K + 1] = f.mesh[K + 1] = false;
+#pragma unroll
+    for (int k = 1; k <= K; ++k) {
+        const uint32_t b = w >> (5 * (k - 1));
+        f.diffuse[k] = (b & 1u) != 0; f.null_[k] = (b & 2u) != 0; f.active[k] = (b & 4u) != 0;
+        f.active_em[k] = (b & 8u) != 0; f.mesh[k] = (b & 16u) != 0;
+    }
+    return f;
+}
+template <typename R> template <int K> EPSM_HD Flags<K> GradArgs<R>::flags(int64_t i) const { return load_flags<R, K>(*this, i); }
 
 // ============================================================================
 // "manifold"  (epsm.py:745-946)
@@ -401,7 +425,7 @@ template <int K> EPSM_HD int caustic_extent(const Flags<K> &fl) {
 
 template <typename R, int K, bool FULL_D, typename Out, typename Args>
 EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) {
-    const Flags<K> fl = load_flags<R, K>(A, i);
+    const Flags<K> fl = A.template flags<K>(i);
 
     // term masks (epsm.py:793-802, 852-855, 916-920).  wN[id]: light-sampling
     // sub-path at depth id; wC[id]: continuing sub-path x_{id-1},x_id,x_{id+1}.
@@ -567,7 +591,7 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
 // recursion that does not depend on the depth, y_1 closes it per depth.
 template <typename R, int K, bool FULL_D, typename Out, typename Args>
 EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
-    const Flags<K> fl = load_flags<R, K>(A, i);
+    const Flags<K> fl = A.template flags<K>(i);
     constexpr int P = 5 * K - 2;
 
     bool wP[K + 1], wD[K + 1];
