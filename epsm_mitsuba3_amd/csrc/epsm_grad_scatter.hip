@@ -23,7 +23,7 @@ namespace {
 
 constexpr int kBits = 11;                  // 2048-row table = 32 KB of LDS
 constexpr int kQueueCap = 512;             // items per wave queue: 4 x 8 KB; 64 KB per workgroup in all, 2 workgroups per CU
-constexpr int kFusedBlocks = 2048;
+constexpr int kFusedBlocks = 2048;             // 512 / 1024 / 8192 measured within 2 %
 
 struct FusedArgs {
     GradArgs<float> g;
@@ -266,11 +266,13 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
     LdsArgs<VARIANT == EPSM_VARIANT_MANIFOLD> A{F.g.N, F.g.cam, F.g.dlduv, F.g.dldp, F.g.dlduv_stride, &s_ptrs, s_flags, 0};
     T.clear();                                   // ends with a barrier: the table of pointers is visible too
     // A workgroup takes WINDOWS of 1024 consecutive paths (16 pixels at 64 spp share triangles), dealt round-robin
-    // over the workgroups.  Inside a window the paths are counting-sorted (stable) by the number of vertices
-    // they are live in, and the sorted list is dealt in slots of 64 to the four waves round-robin: a wave then
-    // holds paths of ONE length -- a step nobody needs is skipped by the whole wave (the flags are independent
-    // per path in the worst case, 41 % lane utilisation unsorted) -- and every wave gets short and long slots,
-    // so the four SIMDs stay balanced without a barrier between slots.
+    // over the workgroups.  Each 256-path sub-chunk of a window is counting-sorted (stable) by the number of
+    // vertices its paths are live in and cut into four 64-path slots; in step g the four waves take the four
+    // slots of sub-chunk g, rotated so that every wave meets each length class once per window.  A wave then
+    // holds paths of (nearly) ONE length -- a step nobody needs is skipped by the whole wave (the flags are
+    // independent per path in the worst case: 41 % lane utilisation unsorted) -- the four SIMDs stay balanced
+    // without a barrier between steps, and the cache lines of a sub-chunk are touched by the four waves at about
+    // the same time (sorting the whole window at once re-fetched every line ~2x: 19 GB instead of 10.8 GB).
     constexpr int kWindow = 1024, kSlots = kWindow / 64, kKeys = K + 1, kSub = kWindow / 256;
     __shared__ uint16_t s_perm[kWindow];
     __shared__ int s_cnt[kKeys * kSub * 4];            // [key][sub-chunk j][wave w]: histogram, then offsets
@@ -312,11 +314,11 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
             for (int q = 0; q < kKeys; ++q) {
                 const unsigned long long m = __ballot(key[j] == q);
                 if (key[j] == q) rank[j] = __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
-                if (lane == 0) s_cnt[(q * kSub + j) * 4 + wv] = __popcll(m);
+                if (lane == 0) s_cnt[(j * kKeys + q) * 4 + wv] = __popcll(m);
             }
         }
         __syncthreads();
-        if (wv == 0) {                                 // exclusive scan in (key, j, wave) order = stable sort order
+        if (wv == 0) {                                 // exclusive scan in (j, key, wave) order: each sub-chunk sorted on its own
             constexpr int kEntries = kKeys * kSub * 4;
             int carry = 0;
 #pragma unroll
@@ -332,12 +334,12 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < kSub; ++j) s_perm[s_cnt[(key[j] * kSub + j) * 4 + wv] + rank[j]] = (uint16_t) (j * 256 + threadIdx.x);
+        for (int j = 0; j < kSub; ++j) s_perm[s_cnt[(j * kKeys + key[j]) * 4 + wv] + rank[j]] = (uint16_t) (j * 256 + threadIdx.x);
         __syncthreads();
         // -- the wave's four slots
 #pragma unroll 1
         for (int g = 0; g < kSlots / 4; ++g) {
-            const int slot = g * 4 + ((wv + g) & 3);   // rotate: no wave always gets the longest slot of a quarter
+            const int slot = g * 4 + ((wv + g) & 3);   // sub-chunk g, quartile rotated: every wave gets each length class once
             const int64_t i0 = base + s_perm[slot * 64 + lane];
             const bool ok = i0 < F.g.N;
             const int64_t i = ok ? i0 : F.g.N - 1;     // lanes past the end recompute the last path and add nothing
