@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
     // the same time (sorting the whole window at once re-fetched every line ~2x: 19 GB instead of 10.8 GB).
     constexpr int kWindow = 1024, kSlots = kWindow / 64, kKeys = K + 1, kSub = kWindow / 256;
     __shared__ uint16_t s_perm[kWindow];
+    __shared__ int s_sort;
     __shared__ int s_cnt[kKeys * kSub * 4];            // [key][sub-chunk j][wave w]: histogram, then offsets
     const int64_t n_windows = (F.g.N + kWindow - 1) / kWindow;
     const int64_t windows_per_block = (chunks_per_block + kSub - 1) / kSub;
@@ -318,8 +319,24 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
             }
         }
         __syncthreads();
-        if (wv == 0) {                                 // exclusive scan in (j, key, wave) order: each sub-chunk sorted on its own
+        if (wv == 0) {
             constexpr int kEntries = kKeys * kSub * 4;
+            // Is sorting worth its gathers?  Steps the 16 natural 64-path groups would run (max length each) against
+            // the steps the paths need (sum of lengths / 64): coherent records (real traces) keep their order.
+            int gmax = 0, gsum = 0;
+            if (lane < kSub * 4) {
+                const int j = lane >> 2, w = lane & 3;
+#pragma unroll
+                for (int q = 0; q < kKeys; ++q) {
+                    const int c = s_cnt[(j * kKeys + q) * 4 + w];
+                    if (c > 0) gmax = q;
+                    gsum += q * c;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { gmax += __shfl_xor(gmax, off); gsum += __shfl_xor(gsum, off); }
+            if (lane == 0) s_sort = 64 * gmax * 4 > 5 * gsum;      // natural order costs > 1.25x the sorted one
+            // exclusive scan in (j, key, wave) order: each sub-chunk sorted on its own
             int carry = 0;
 #pragma unroll
             for (int q0 = 0; q0 < kEntries; q0 += 64) {
@@ -333,8 +350,10 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
             }
         }
         __syncthreads();
+        const bool sorted = s_sort != 0;
 #pragma unroll
-        for (int j = 0; j < kSub; ++j) s_perm[s_cnt[(j * kKeys + key[j]) * 4 + wv] + rank[j]] = (uint16_t) (j * 256 + threadIdx.x);
+        for (int j = 0; j < kSub; ++j)
+            s_perm[sorted ? s_cnt[(j * kKeys + key[j]) * 4 + wv] + rank[j] : j * 256 + threadIdx.x] = (uint16_t) (j * 256 + threadIdx.x);
         __syncthreads();
         // -- the wave's four slots
 #pragma unroll 1
