@@ -21,7 +21,7 @@ using epsm_host::fail;
 
 namespace {
 
-constexpr int kBits = 11;                  // 2048-row table = 32 KB of LDS
+constexpr int kBits = 11;                  // 2048-row table = 32 KB of LDS (1024 rows: +5 %)
 constexpr int kQueueCap = 512;             // items per wave queue: 4 x 8 KB; 64 KB per workgroup in all, 2 workgroups per CU
 constexpr int kFusedBlocks = 2048;             // 512 / 1024 / 8192 measured within 2 %
 
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
     const LdsTable<kBits> T{s_keys, s_vals, &s_used, F.gpos, F.gnrm, F.galpha, (uint32_t) F.V};
     WaveQueue<kQueueCap> Q{s_queue[threadIdx.x >> 6], 0};
     if (threadIdx.x < K) { s_ptrs.v[threadIdx.x] = F.g.v[threadIdx.x]; s_ptrs.s[threadIdx.x] = F.s[threadIdx.x]; }
-    __shared__ uint32_t s_flags[1024];
+    __shared__ uint32_t s_flags[VARIANT == EPSM_VARIANT_MANIFOLD ? 1024 : 1];
     LdsArgs<VARIANT == EPSM_VARIANT_MANIFOLD> A{F.g.N, F.g.cam, F.g.dlduv, F.g.dldp, F.g.dlduv_stride, &s_ptrs, s_flags, 0};
     T.clear();                                   // ends with a barrier: the table of pointers is visible too
     // A workgroup takes WINDOWS of 1024 consecutive paths (16 pixels at 64 spp share triangles), dealt round-robin
