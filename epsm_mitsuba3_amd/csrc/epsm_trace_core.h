@@ -143,22 +143,13 @@ struct BvhStack { uint32_t *base; int stride; };
 
 // Ordered traversal of the two-wide BVH: one 64-byte node holds both children's boxes, leaf children are
 // intersected on the spot, of two inner children the nearer is followed and the farther pushed.
-#ifdef EPSM_BVH_STATS
-static long g_bvh_nodes = 0, g_bvh_tris = 0, g_bvh_rays = 0;
-#endif
 template <bool ANY_HIT>
 EPSM_HD TriHit intersect(const EpsmScene &S, Ray r, const BvhStack &st) {
-#ifdef EPSM_BVH_STATS
-    __atomic_fetch_add(&g_bvh_rays, 1, __ATOMIC_RELAXED);
-#endif
     TriHit best; best.hit = false; best.tri = 0; best.t = r.maxt; best.u = best.v = 0.f;
     if (S.n_nodes <= 0) return best;
     const F3 inv_d = f3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
     int32_t best_e = -1;
     auto leaf = [&](int32_t first, int32_t count) {
-#ifdef EPSM_BVH_STATS
-        __atomic_fetch_add(&g_bvh_tris, count, __ATOMIC_RELAXED);
-#endif
         for (int32_t e = first; e < first + count; ++e) {
             const float *q = S.tri_verts + 9 * (int64_t) e;
             float t, u, v;
@@ -177,9 +168,6 @@ EPSM_HD TriHit intersect(const EpsmScene &S, Ray r, const BvhStack &st) {
     int sp = 0;
     for (;;) {
         while (cur >= 0 && cur != kBvhNone) {
-#ifdef EPSM_BVH_STATS
-            __atomic_fetch_add(&g_bvh_nodes, 1, __ATOMIC_RELAXED);
-#endif
             const EpsmBvhNode n = S.bvh[cur];
             float t0, t1;
             const bool h0 = n.c0 != kBvhNone && hit_box(n.lo0, n.hi0, r.o, inv_d, r.maxt, t0);
