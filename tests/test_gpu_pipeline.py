@@ -115,3 +115,48 @@ def test_fused_equals_two_stage_at_scale(kind, profile, res, spp, V):
     m = float(bufs[1].abs().max())
     assert m > 0
     assert float((bufs[0] - bufs[1]).abs().max()) <= 2e-4 * m
+
+
+def _permute_info(info, perm):
+    out = []
+    for rec in info:
+        r = {}
+        for k, v in rec.items():
+            if isinstance(v, (list, tuple)):
+                r[k] = [x[perm] for x in v]
+            elif isinstance(v, torch.Tensor):
+                r[k] = v[perm]
+            else:
+                r[k] = v
+        out.append(r)
+    return out
+
+
+@pytest.mark.parametrize("kind,profile,n", [("manifold", "bathroom", 1 << 22), ("manifold_caustic", "pool", 1 << 20),
+                                            ("manifold", "mixed", (1 << 20) + 777)])
+def test_fused_sums_do_not_depend_on_the_order_of_the_paths(kind, profile, n):
+    """Size-independent property at 2^20 .. 2^22 paths: the parameter gradients are sums over paths, so any
+    permutation of the wavefront gives the same buffers (up to the order of float additions).  The fused kernel
+    regroups the paths of every 1024-path window by chain length and merges rows over waves: a shuffled
+    wavefront runs through completely different windows, slots and merges."""
+    from epsm_mitsuba3_amd.records import PackedRecords, PackedScatter
+    from epsm_mitsuba3_amd.synth import synth_path_info, synth_scatter_info
+    from epsm_mitsuba3_amd.tangent_scatter import manifold_grad_scatter
+    dev = torch.device("cuda", 0)
+    K, V, B = 5, 20000, 4
+    pi, dlduv, dldp = synth_path_info(n, K, seed=21, device=dev, profile=profile)
+    si = synth_scatter_info(n, K, V, seed=21, device=dev, n_bsdfs=B, res=256, spp=64, shadow=True)
+    g = torch.Generator(device=dev).manual_seed(4)
+    perm = torch.randperm(n, generator=g, device=dev)
+    bufs = []
+    for p in (None, perm):
+        a, b = (pi, si) if p is None else (_permute_info(pi, p), _permute_info(si, p))
+        d, q = (dlduv, dldp) if p is None else (dlduv[p], dldp[p])
+        gp, gn, ga = torch.zeros((V, 3), device=dev), torch.zeros((V, 3), device=dev), torch.zeros(B, device=dev)
+        manifold_grad_scatter(kind, PackedRecords(a, device=dev), PackedScatter(b, device=dev), d, q, gp, gn, ga)
+        torch.cuda.synchronize()
+        bufs.append([t.double().cpu() for t in (gp, gn, ga)])
+    for x, y, name in zip(bufs[0], bufs[1], ("pos", "nrm", "alpha")):
+        m = float(x.abs().max())
+        assert m > 0, name
+        assert float((x - y).abs().max()) <= 3e-4 * m, name
