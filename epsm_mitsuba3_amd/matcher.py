@@ -70,10 +70,36 @@ class Matcher:
         # matcher.py:14-17: pos[..., 0] = x (column), pos[..., 1] = y (row)
         self.pos = torch.stack([gx, gy], dim=2).reshape(-1, 2).to(self.device)
         self.blur, self.scaling = 0.01, 0.9
+        self.num_vectors, self.num_principle_vectors, self.rgb_weight = 50, 3, 1.0       # matcher.py:22-25
 
     def match_Sinkhorn(self, render_point: torch.Tensor, gt_rgb: torch.Tensor) -> torch.Tensor:
         target = torch.cat([gt_rgb.clamp(0, 1).to(self.device, torch.float32), self.pos], dim=1)      # matcher.py:52-54
         render = torch.cat([render_point.clamp(0, 1).to(self.device, torch.float32), self.pos], dim=1).requires_grad_(True)
         loss = sinkhorn_divergence(render, target, self.blur, self.scaling)
         (g,) = torch.autograd.grad(loss * self.resolution * self.resolution, [render])                 # matcher.py:60
+        return g
+
+    def match_sliced_wasserstein(self, render_point: torch.Tensor, gt_rgb: torch.Tensor, generator=None) -> torch.Tensor:
+        """matcher.py:76-116 (the reference's geomloss-free alternative): both point clouds (r,g,b,x,y) are
+        projected onto ``num_vectors`` random unit directions of the (principal colour axes + position) space,
+        each projection is matched by sorting, and the gradient of the summed squared differences w.r.t. the
+        rendered points is returned, (res^2, 5)."""
+        w = self.rgb_weight
+        target = torch.cat([gt_rgb.clamp(0, 1).to(self.device, torch.float32) * w, self.pos], dim=1)
+        render = torch.cat([render_point.clamp(0, 1).to(self.device, torch.float32).detach() * w, self.pos], dim=1).requires_grad_(True)
+        q = self.num_principle_vectors
+        if q > 0:
+            assert q <= 3
+            _, _, Vp = torch.pca_lowrank(target[:, :3], q=3)                       # colour axes of the TARGET
+            t_pts = torch.cat([target[:, :3] @ Vp[:, :q], target[:, 3:]], dim=1)
+            r_pts = torch.cat([render[:, :3] @ Vp[:, :q], render[:, 3:]], dim=1)
+        else:
+            t_pts, r_pts = target, render
+        dim = 2 + (q if q > 0 else 3)
+        dirs = torch.rand((dim, self.num_vectors), device=self.device, generator=generator) * 2.0 - 1.0
+        dirs = torch.nn.functional.normalize(dirs, p=2, dim=0)
+        pr, _ = torch.sort(r_pts @ dirs, dim=0, stable=True)
+        pt, _ = torch.sort(t_pts @ dirs, dim=0, stable=True)
+        (g,) = torch.autograd.grad(((pr - pt) ** 2).sum(), [render])
+        g[:, :3] /= w
         return g

@@ -37,3 +37,21 @@ def test_descent_on_the_matcher_gradient_moves_a_blob_onto_the_target():
     # bright pixels of the rendered blob are asked to move in +x (negative gradient = descent direction)
     bright = blob(0.3, 0.5)[:, 0] > 0.5
     assert float(grad[bright, 3].mean()) < -0.05 and abs(float(grad[bright, 4].mean())) < 0.05
+
+
+def test_sliced_wasserstein_moves_a_blob_towards_its_target():
+    """match_sliced_wasserstein (matcher.py:76-116): zero for identical images; for a shifted blob the position
+    gradient of the bright pixels points from where the blob is to where it should be (descent direction = -g)."""
+    from epsm_mitsuba3_amd.matcher import Matcher
+    res = 24
+    m = Matcher(res, "cpu")
+    yy, xx = torch.meshgrid(torch.arange(res), torch.arange(res), indexing="ij")
+    blob = lambda cx, cy: torch.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / 8.0)[..., None].repeat(1, 1, 3).reshape(-1, 3).float()
+    a, b = blob(7, 12), blob(15, 12)                                   # target is 8 pixels to the right
+    gen = torch.Generator().manual_seed(0)
+    g_same = m.match_sliced_wasserstein(a, a, generator=gen)
+    assert g_same.shape == (res * res, 5) and float(g_same.abs().max()) < 1e-6
+    g = m.match_sliced_wasserstein(a, b, generator=torch.Generator().manual_seed(0))
+    bright = a[:, 0] > 0.5
+    assert float(g[bright, 3].mean()) < 0                               # -g points to +x
+    assert abs(float(g[bright, 4].mean())) < 0.3 * abs(float(g[bright, 3].mean()))
