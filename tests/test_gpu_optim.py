@@ -40,3 +40,13 @@ def test_human_pose_is_recovered_through_per_vertex_gradients():
     hist, opt = run("manifold", "human", iterations=80, lr=0.03, log=lambda s: None)
     assert hist[0] > 0.6
     assert min(hist[-15:]) < 0.35 * hist[0], hist
+
+
+def test_objects_seen_in_a_mirror_are_moved_onto_their_targets():
+    """The reference's headline configuration (exp/bathroom.py): three tiles whose coloured side is visible only in
+    a mirror are translated until the mirror image matches -- camera -> mirror (delta) -> diffuse object; the
+    gradient arrives through diffuse_grad[1] of the continuing sub-path."""
+    from epsm_mitsuba3_amd.optim import run
+    hist, opt = run("manifold", "bathroom", iterations=60, lr=0.02, log=lambda s: None)
+    assert hist[0] > 0.65
+    assert min(hist[-10:]) < 0.25 * hist[0], hist
