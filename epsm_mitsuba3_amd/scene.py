@@ -528,8 +528,21 @@ class Scene:
         return self.alpha_slots[i]
 
     def set_alpha(self, bsdf_name: str, alpha: float):
+        """``params['<bsdf>.alpha.value'] = alpha; params.update()``: only the BSDF table is rewritten (in place)."""
         self.bsdf_desc[self.bsdf_names.index(bsdf_name)]["alpha"] = float(alpha)
-        self._upload()
+        self._bsdf_buf.copy_(torch.frombuffer(bytearray(bytes(self._bsdf_structs())), dtype=torch.uint8))
+
+    def _bsdf_structs(self):
+        bs = (EpsmBsdf * max(1, len(self.bsdf_desc)))()
+        for i, b in enumerate(self.bsdf_desc):
+            c = bs[i]
+            c.type, c.twosided, c.distr, c.sample_visible = b["type"], b["twosided"], b["distr"], b["sample_visible"]
+            c.reflectance[:] = [float(x) for x in b["reflectance"]]
+            c.alpha = float(b["alpha"])
+            c.eta[:] = [float(x) for x in b["eta"]]; c.k[:] = [float(x) for x in b["k"]]
+            c.int_ior, c.ext_ior = float(b["int_ior"]), float(b["ext_ior"])
+            c.alpha_slot = self.alpha_slots.get(i, -1)
+        return bs
 
     def set_vertex_positions(self, mesh_name: str, v):
         """``params['<mesh>.vertex_positions'] = v; params.update()``: everything stays on the device -- the
@@ -605,15 +618,7 @@ class Scene:
         if self.T > 0:
             self.bvh = DeviceBvh(build_bvh(P, TRI), dev)
             self.bvh.refit(self.positions, self.tri)
-        bs = (EpsmBsdf * max(1, len(self.bsdf_desc)))()
-        for i, b in enumerate(self.bsdf_desc):
-            c = bs[i]
-            c.type, c.twosided, c.distr, c.sample_visible = b["type"], b["twosided"], b["distr"], b["sample_visible"]
-            c.reflectance[:] = [float(x) for x in b["reflectance"]]
-            c.alpha = float(b["alpha"])
-            c.eta[:] = [float(x) for x in b["eta"]]; c.k[:] = [float(x) for x in b["k"]]
-            c.int_ior, c.ext_ior = float(b["int_ior"]), float(b["ext_ior"])
-            c.alpha_slot = self.alpha_slots.get(i, -1)
+        bs = self._bsdf_structs()
         em = (EpsmEmitter * max(1, len(self.emitter_desc)))()
         for i, e in enumerate(self.emitter_desc):
             c = em[i]
