@@ -184,6 +184,8 @@ typedef struct EpsmScatterRecord {
  *     normals:  d/dn_j of  sh_frame.n . out_param[5it+3]        (:645; mesh.cpp:784-790 or flat :729,811-816)
  *     grad_alpha[bsdf_id] += dhf_dalpha . out_param[5it+4]      (bsdf_sample.hf * path_grad[5it+4], :645)
  *     grad_pos[evidx_j] += eb_j * out_light[it] * eweight       (si_direct.p * light_grad[it] * sum Lr_dir, :626-627)
+ *     it = 0 only, with sc[0].shadow = [s0,s1,s2, sb0,sb1, dis, mode]:
+ *     grad_pos[s_j]     += sb_j * dis * out_diffuse[0]          (si_direct.p * diffuse_grad[0] * dis, :616-618)
  *   (for "manifold_caustic" the last vertex has no n,m entries.)
  *   grad_pos / grad_nrm: (V,3) f32, grad_alpha: (B) f32; accumulated, not cleared.
  * ------------------------------------------------------------------------- */
@@ -198,7 +200,9 @@ int epsm_scatter(int variant, int64_t N, int K,
  *     calc_grad (epsm.py:275) followed by the Backward-mode replay (epsm.py:283-297)
  *     without materialising final_param_grad / light_grad / diffuse_grad in HBM.
  *     Arguments as in the two calls above; results are ACCUMULATED into
- *     grad_pos / grad_nrm (V,3) and grad_alpha (B).  This is what
+ *     grad_pos / grad_nrm (V,3) and grad_alpha (B) with float atomics (the sums are
+ *     those of the two-call form up to the order of the additions; the kernel regroups
+ *     paths inside 1024-path windows, so the order also differs from run to run).  This is what
  *     EPSMIntegrator.render_backward uses; the two-call form exists for callers that
  *     want calc_grad's lists (the drop-in of INTEGRATION.md section 1).
  * ------------------------------------------------------------------------- */
