@@ -5,10 +5,11 @@
 
 A "step" is one backward pass of the hot path over one wavefront of synthetic path
 records that are already resident in HBM: zero the parameter-gradient buffer ->
-first-vertex tangent -> per-path constraint Jacobian + block solve + adjoint
-gradients + scatter into the parameter-gradient buffer (one fused launch,
-``epsm_manifold_grad_scatter``; ``--two-stage``: ``epsm_manifold_grad`` then
-``epsm_scatter``, the reference's shape) -> one RCCL all-reduce of that buffer
+first-vertex tangent + per-path constraint Jacobian + block solve + adjoint
+gradients + scatter into the parameter-gradient buffer in ONE launch
+(``epsm_backward_pass``; ``--separate-tangent``: ``epsm_first_vertex_tangent`` then
+``epsm_manifold_grad_scatter``; ``--two-stage``: tangent, ``epsm_manifold_grad``,
+``epsm_scatter`` -- the reference's shape) -> one RCCL all-reduce of that buffer
 when N > 1.  At N=1 the workload is BASELINE.json ``configs[1]``: bathroom,
 ``manifold``, 512x512 @ 64 spp -> 16 777 216 paths, 5 logged vertices each
 (SURVEY.md 8d).  With N>1 every rank processes its own wavefront of that size
@@ -17,7 +18,8 @@ when N > 1.  At N=1 the workload is BASELINE.json ``configs[1]``: bathroom,
 Prints ONE JSON line (rank 0).  ``value`` = paths/s over all ranks for the whole
 step; ``grad_image_ms`` = wall-clock of the step; ``roofline`` prices the dominant
 kernel (the fused gradient+scatter kernel) against the 8 TB/s HBM peak using the
-ALGORITHMIC bytes (32 + 116*K per path fused, 32 + 200*K stand-alone)
+ALGORITHMIC bytes (56 + 116*K per path in one launch, 32 + 116*K fused, 32 + 200*K
+stand-alone)
 and its own launch time measured with HIP events on the launch stream; ``cpu_baseline`` times oracle/ (the C restatement of
 the reference's calc_grad) on this box's host cores on a bounded sample of the same
 records.
@@ -56,6 +58,8 @@ def parse():
     ap.add_argument("--variant", default="manifold", choices=["manifold", "manifold_caustic"])
     ap.add_argument("--profile", default="bathroom")
     ap.add_argument("--scene-vertices", type=int, default=100000, help="size V of the scatter target")
+    ap.add_argument("--separate-tangent", action="store_true",
+                    help="tangent kernel + fused gradient/scatter kernel instead of the single epsm_backward_pass launch")
     ap.add_argument("--two-stage", action="store_true",
                     help="calc_grad lists + separate scatter (the reference's shape) instead of the fused kernel")
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
@@ -140,7 +144,8 @@ def main():
     N = args.res * args.res * args.spp              # paths of one gradient image, per rank
     scene = epsm.SyntheticScene(res=args.res, n_vertices=K, n_scene_vertices=V, n_bsdfs=B,
                                 profile=args.profile, device=dev, tile_paths=N)
-    integ = epsm.load_dict({"type": args.variant, "max_depth": 8, "fused": not args.two_stage})
+    integ = epsm.load_dict({"type": args.variant, "max_depth": 8, "fused": not args.two_stage,
+                            "fuse_tangent": not args.separate_tangent})
     # this rank's wavefront: one resident tile (seeded by rank so shards differ)
     trace = scene.tile(0, 0, N, seed=rank, spp=args.spp, K=K)
     packed = (PackedRecords(trace.path_info, device=dev), PackedScatter(trace.scatter_info, device=dev))
@@ -215,14 +220,17 @@ def main():
         fused = not args.two_stage
         # 32+116K B/path when the per-path gradients are never written (fused),
         # 32+200K B/path for the stand-alone gradient kernel
-        alg = (32 + 116 * K if fused else algorithmic_bytes_per_path(K)) * N
+        one_launch = fused and not args.separate_tangent
+        # one launch (epsm_backward_pass): rays 48 B + image-gradient 8 B per path instead of cam 12 + dlduv 8 + dldp 12
+        alg = ((56 if one_launch else 32) + 116 * K if fused else algorithmic_bytes_per_path(K)) * N
         kernel_ms = stage_ms["grad"]
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tfile):
             for rec in json.load(open(tfile)):
-                if (rec["kernel"] == ("epsm_grad_scatter_kernel" if fused else "epsm_grad_kernel") and rec["paths"] == N
+                want = "epsm_backward_pass" if one_launch else ("epsm_grad_scatter_kernel" if fused else "epsm_grad_kernel")
+                if (rec["kernel"] == want and rec["paths"] == N
                         and rec["K"] == K and rec["variant"] == args.variant and rec["profile"] == args.profile):
                     traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
         result = {
@@ -239,10 +247,11 @@ def main():
                        "sharding": f"{world} x pixel/sample-tile shard, one all-reduce of the {params.flat.numel() * 4} B "
                                    f"parameter-gradient buffer per step"},
             "stages_ms": stage_ms,
-            "pipeline": "fused" if fused else "two-stage",
+            "pipeline": ("one launch (epsm_backward_pass)" if one_launch else "tangent + fused") if fused else "two-stage",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "epsm_grad_scatter_kernel (fused calc_grad + scatter)" if fused else "epsm_grad_kernel",
+                         "kernel": ("epsm_grad_scatter_kernel<tangents in kernel> (epsm_backward_pass: tangent + calc_grad + scatter)"
+                                    if one_launch else "epsm_grad_scatter_kernel (fused calc_grad + scatter)") if fused else "epsm_grad_kernel",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg,
                          "algorithmic_bytes_per_path": alg // N},
         }

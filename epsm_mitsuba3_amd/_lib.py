@@ -59,6 +59,12 @@ def _declare(lib):
         C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_float,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    if not os.environ.get("EPSM_AB_OLD"):      # (set for A/B runs against a library built before this entry point existed)
+        lib.epsm_backward_pass.restype = C.c_int
+        lib.epsm_backward_pass.argtypes = [
+            C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.epsm_trace_paths.restype = C.c_int
     lib.epsm_film_splat.restype = C.c_int
     lib.epsm_film_develop.restype = C.c_int

@@ -9,11 +9,13 @@
 // same triangles return -> they stay in the table) and flush to HBM with float
 // atomics when the table fills and once at the end.
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "epsm_common.h"
 #include "epsm_path_core.h"
 #include "epsm_scatter_core.h"
+#include "epsm_tangent_core.h"
 #include "epsm_wave_scatter.h"
 
 using namespace epsm;
@@ -31,7 +33,11 @@ struct FusedArgs {
     float *gpos, *gnrm, *galpha;
     int64_t V, B;
     int P, K;
+    TangentIn tin;                   // epsm_backward_pass: the first-vertex tangent is computed in the kernel
+    float *grad_o_sum;
 };
+// where the tangents of a path come from
+enum { kTangentsTwoColumns = 0, kTangentsFullRows = 1, kTangentsInKernel = 2 };
 
 // The 85 array pointers of a K = 5 launch are 170 SGPRs: kept as kernel arguments the compiler hoists them
 // out of the persistent loop and spills ~240 of them into VGPR lanes (a v_readlane per use: ~10 % of the
@@ -41,10 +47,12 @@ struct PtrTable {
     VertexPtrs<float> v[kMaxVertices];
     ScatterPtrs<float> s[kMaxVertices];
 };
-template <bool FLAGS_IN_LDS> struct LdsArgs {
+template <bool FLAGS_IN_LDS, int DMODE> struct LdsArgs {
     int64_t N;
     const float *cam, *dlduv, *dldp;
     int64_t dlduv_stride;
+    V2<float> lane_d;                // kTangentsInKernel: this lane's (d b0, d b1) and d si.p of the current slot
+    V3<float> lane_dp;
     const PtrTable *tab;             // LDS
     const uint32_t *win_flags;       // LDS: packed flags of the current window's paths, indexed by path - win_base
     int64_t win_base;
@@ -54,6 +62,14 @@ template <bool FLAGS_IN_LDS> struct LdsArgs {
     template <int K> __device__ __forceinline__ Flags<K> flags(int64_t i) const {
         if (FLAGS_IN_LDS) return unpack_flags<K>(win_flags[i - win_base]);
         return load_flags<float, K>(*this, i);
+    }
+    __device__ __forceinline__ V3<float> dldp_at(int64_t i) const {
+        if (DMODE == kTangentsInKernel) return lane_dp;
+        return load3(dldp, i);
+    }
+    template <bool FULL_D> __device__ __forceinline__ V2<float> d_at(int64_t i, int k, int dcols) const {
+        if (DMODE == kTangentsInKernel) return k == 1 ? lane_d : mk2<float>(0.f, 0.f);
+        return load_d<float, FULL_D>(*this, i, k, dcols);
     }
 };
 
@@ -250,7 +266,7 @@ template <int BITS> struct ScatterOut {
 
 namespace {
 
-template <int K, int VARIANT, bool FULL_D>
+template <int K, int VARIANT, int DMODE>
 // waves-per-SIMD 2: without it hipcc budgets 128 VGPRs from the LDS-derived occupancy and spills 720 B/lane
 __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, int dcols, int64_t chunks_per_block) {
     constexpr int kTableSize = 1 << kBits;
@@ -263,7 +279,10 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
     WaveQueue<kQueueCap> Q{s_queue[threadIdx.x >> 6], 0};
     if (threadIdx.x < K) { s_ptrs.v[threadIdx.x] = F.g.v[threadIdx.x]; s_ptrs.s[threadIdx.x] = F.s[threadIdx.x]; }
     __shared__ uint32_t s_flags[VARIANT == EPSM_VARIANT_MANIFOLD ? 1024 : 1];
-    LdsArgs<VARIANT == EPSM_VARIANT_MANIFOLD> A{F.g.N, F.g.cam, F.g.dlduv, F.g.dldp, F.g.dlduv_stride, &s_ptrs, s_flags, 0};
+    constexpr bool FULL_D = DMODE == kTangentsFullRows;
+    LdsArgs<VARIANT == EPSM_VARIANT_MANIFOLD, DMODE> A{F.g.N, F.g.cam, F.g.dlduv, F.g.dldp, F.g.dlduv_stride,
+                                                       mk2<float>(0.f, 0.f), zero3<float>(), &s_ptrs, s_flags, 0};
+    V3<float> gd_acc = zero3<float>();           // kTangentsInKernel: sum of grad_d over this lane's paths
     T.clear();                                   // ends with a barrier: the table of pointers is visible too
     // A workgroup takes WINDOWS of 1024 consecutive paths (16 pixels at 64 spp share triangles), dealt round-robin
     // over the workgroups.  Each 256-path sub-chunk of a window is counting-sorted (stable) by the number of
@@ -363,6 +382,13 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
             const bool ok = i0 < F.g.N;
             const int64_t i = ok ? i0 : F.g.N - 1;     // lanes past the end recompute the last path and add nothing
             const ScatterOut<kBits> out{F, s_ptrs, T, Q, i, ok};
+            if (DMODE == kTangentsInKernel) {              // epsm.py:250-272 for this path, in registers
+                const Tangent t = first_vertex_tangent(F.tin, i, s_ptrs.v[0].p0, s_ptrs.v[0].p1, s_ptrs.v[0].p2,
+                                                       s_ptrs.v[0].active[i] != 0);
+                A.lane_d = mk2<float>(t.db0, t.db1);
+                A.lane_dp = t.dp;
+                if (ok) gd_acc = gd_acc + t.gd;
+            }
             if (VARIANT == EPSM_VARIANT_MANIFOLD)
                 manifold_path<float, K, FULL_D>(A, i, dcols, out);
             else
@@ -374,51 +400,52 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
         if (T.crowded()) T.flush();
     }
     T.flush();
+    if (DMODE == kTangentsInKernel && F.grad_o_sum) {      // epsm.py:260-261: d/d ray.o = -sum grad_d, one atomic triple per workgroup
+        __shared__ float s_part[4][3];
+        float sx = -gd_acc.x, sy = -gd_acc.y, sz = -gd_acc.z;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off, 64); sy += __shfl_down(sy, off, 64); sz += __shfl_down(sz, off, 64); }
+        if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6][0] = sx; s_part[threadIdx.x >> 6][1] = sy; s_part[threadIdx.x >> 6][2] = sz; }
+        __syncthreads();
+        if (threadIdx.x < 3)
+            atomicAdd(F.grad_o_sum + threadIdx.x, s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+    }
 }
 
-template <int K, int VARIANT, bool FULL_D>
+template <int K, int VARIANT, int DMODE>
 hipError_t launch(const FusedArgs &F, int dcols, hipStream_t s) {
     const int64_t chunks = (F.g.N + 255) / 256;
     const int64_t blocks = chunks < kFusedBlocks ? chunks : kFusedBlocks;
     int64_t per = (chunks + blocks - 1) / blocks;
     per = (per + 15) / 16 * 16;              // whole groups
-    hipLaunchKernelGGL((epsm_grad_scatter_kernel<K, VARIANT, FULL_D>), dim3((unsigned) blocks), dim3(256), 0, s,
+    hipLaunchKernelGGL((epsm_grad_scatter_kernel<K, VARIANT, DMODE>), dim3((unsigned) blocks), dim3(256), 0, s,
                        F, dcols, per);
     return hipGetLastError();
 }
-template <int VARIANT, bool FULL_D>
+template <int VARIANT, int DMODE>
 hipError_t launch_k(int K, const FusedArgs &F, int dcols, hipStream_t s) {
     switch (K) {
-        case 1: return launch<1, VARIANT, FULL_D>(F, dcols, s);
-        case 2: return launch<2, VARIANT, FULL_D>(F, dcols, s);
-        case 3: return launch<3, VARIANT, FULL_D>(F, dcols, s);
-        case 4: return launch<4, VARIANT, FULL_D>(F, dcols, s);
-        default: return launch<5, VARIANT, FULL_D>(F, dcols, s);
+        case 1: return launch<1, VARIANT, DMODE>(F, dcols, s);
+        case 2: return launch<2, VARIANT, DMODE>(F, dcols, s);
+        case 3: return launch<3, VARIANT, DMODE>(F, dcols, s);
+        case 4: return launch<4, VARIANT, DMODE>(F, dcols, s);
+        default: return launch<5, VARIANT, DMODE>(F, dcols, s);
     }
 }
 
 }  // namespace
 
-extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
-                                          const float *cam, const EpsmVertexRecord *verts,
-                                          const EpsmScatterRecord *sc,
-                                          const float *dlduv, int64_t dlduv_stride, int dlduv_cols,
-                                          const float *dldp, float clip,
-                                          float *grad_pos, float *grad_nrm, float *grad_alpha,
-                                          int64_t V, int64_t B, void *stream) {
-    epsm_host::err_buf()[0] = 0;
-    if (variant != EPSM_VARIANT_MANIFOLD && variant != EPSM_VARIANT_MANIFOLD_CAUSTIC)
-        return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: unknown variant");
-    if (K < 1 || K > EPSM_MAX_VERTICES) return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: K must be in 1..5");
-    if (N == 0) return EPSM_OK;
-    if (N < 0) return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: bad N");
-    if (!cam || !verts || !sc || !dlduv || !dldp || !grad_pos || !grad_nrm)
-        return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: NULL argument");
-    if (dlduv_cols < 0 || dlduv_stride < (dlduv_cols < 2 * K ? dlduv_cols : 2 * K))
-        return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: dlduv_stride smaller than the columns to read");
-    if (V < 0 || B < 0 || 2 * V + B >= 0xFFFFFFFFLL)
-        return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: bad buffer sizes (need 2V+B < 2^32-1)");
-    FusedArgs F;
+// Shared by the two entry points: validates the records, fills FusedArgs.  Returns EPSM_OK or fails with `who` in the text.
+static int fill_args(FusedArgs &F, const char *who, int variant, int64_t N, int K, const float *cam,
+                     const EpsmVertexRecord *verts, const EpsmScatterRecord *sc, float clip,
+                     float *grad_pos, float *grad_nrm, float *grad_alpha, int64_t V, int64_t B) {
+    char msg[160];
+    auto bad = [&](const char *what) { snprintf(msg, sizeof(msg), "%s: %s", who, what); return fail(EPSM_EINVAL, msg); };
+    if (variant != EPSM_VARIANT_MANIFOLD && variant != EPSM_VARIANT_MANIFOLD_CAUSTIC) return bad("unknown variant");
+    if (K < 1 || K > EPSM_MAX_VERTICES) return bad("K must be in 1..5");
+    if (N < 0) return bad("bad N");
+    if (!cam || !verts || !sc || !grad_pos || !grad_nrm) return bad("NULL argument");
+    if (V < 0 || B < 0 || 2 * V + B >= 0xFFFFFFFFLL) return bad("bad buffer sizes (need 2V+B < 2^32-1)");
     memset(&F, 0, sizeof(F));
     F.g.N = N;
     F.g.cam = cam;
@@ -427,9 +454,9 @@ extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
         const EpsmScatterRecord &s = sc[k];
         if (!v.p0 || !v.p1 || !v.p2 || !v.n0 || !v.n1 || !v.n2 || !v.b0 || !v.b1 || !v.eta || !v.light ||
             !v.bsdf || !v.active || !v.active_em || !v.ismesh || !s.tri)
-            return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: NULL pointer in a vertex / scatter record");
+            return bad("NULL pointer in a vertex / scatter record");
         if ((((uintptr_t) s.tri) | ((uintptr_t) s.aux) | ((uintptr_t) s.emit) | ((uintptr_t) s.shadow)) & 15)
-            return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: tri/aux/emit/shadow must be 16-byte aligned");
+            return bad("tri/aux/emit/shadow must be 16-byte aligned");
         VertexPtrs<float> &o = F.g.v[k];
         o.p0 = (const float *) v.p0; o.p1 = (const float *) v.p1; o.p2 = (const float *) v.p2;
         o.n0 = (const float *) v.n0; o.n1 = (const float *) v.n1; o.n2 = (const float *) v.n2;
@@ -440,24 +467,69 @@ extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
         t.tri = s.tri; t.aux = s.aux; t.emit = s.emit;
         t.shadow = k == 0 ? s.shadow : nullptr;       // epsm.py:610: `iteration == 0`
     }
-    F.g.dlduv = dlduv;
-    F.g.dlduv_stride = dlduv_stride;
-    F.g.dldp = dldp;
     F.g.clip = (clip > 0.0f && clip <= 3.402823466e+38f) ? clip : 3.402823466e+38f;
     F.gpos = grad_pos; F.gnrm = grad_nrm; F.galpha = grad_alpha;
     F.V = V; F.B = grad_alpha ? B : 0;
     F.P = epsm_num_param_grads(variant, K);
     F.K = K;
+    return EPSM_OK;
+}
+
+extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
+                                          const float *cam, const EpsmVertexRecord *verts,
+                                          const EpsmScatterRecord *sc,
+                                          const float *dlduv, int64_t dlduv_stride, int dlduv_cols,
+                                          const float *dldp, float clip,
+                                          float *grad_pos, float *grad_nrm, float *grad_alpha,
+                                          int64_t V, int64_t B, void *stream) {
+    epsm_host::err_buf()[0] = 0;
+    if (N == 0 && K >= 1 && K <= EPSM_MAX_VERTICES &&
+        (variant == EPSM_VARIANT_MANIFOLD || variant == EPSM_VARIANT_MANIFOLD_CAUSTIC)) return EPSM_OK;
+    FusedArgs F;
+    const int rc = fill_args(F, "epsm_manifold_grad_scatter", variant, N, K, cam, verts, sc, clip, grad_pos, grad_nrm, grad_alpha, V, B);
+    if (rc != EPSM_OK) return rc;
+    if (!dlduv || !dldp) return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: NULL argument");
+    if (dlduv_cols < 0 || dlduv_stride < (dlduv_cols < 2 * K ? dlduv_cols : 2 * K))
+        return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: dlduv_stride smaller than the columns to read");
+    F.g.dlduv = dlduv;
+    F.g.dlduv_stride = dlduv_stride;
+    F.g.dldp = dldp;
     int dcols = dlduv_cols > 2 * K ? 2 * K : dlduv_cols;
     const bool full_d = dcols > 2;
     hipStream_t s = (hipStream_t) stream;
     hipError_t e;
     if (variant == EPSM_VARIANT_MANIFOLD)
-        e = full_d ? launch_k<EPSM_VARIANT_MANIFOLD, true>(K, F, dcols, s)
-                   : launch_k<EPSM_VARIANT_MANIFOLD, false>(K, F, dcols, s);
+        e = full_d ? launch_k<EPSM_VARIANT_MANIFOLD, kTangentsFullRows>(K, F, dcols, s)
+                   : launch_k<EPSM_VARIANT_MANIFOLD, kTangentsTwoColumns>(K, F, dcols, s);
     else
-        e = full_d ? launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, true>(K, F, dcols, s)
-                   : launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, false>(K, F, dcols, s);
+        e = full_d ? launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, kTangentsFullRows>(K, F, dcols, s)
+                   : launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, kTangentsTwoColumns>(K, F, dcols, s);
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_manifold_grad_scatter", e);
+    return EPSM_OK;
+}
+
+extern "C" int epsm_backward_pass(int variant, int64_t N, int K, int64_t path_offset, int spp, int res,
+                                  const float *ray_o, const float *ray_d, const float *ray_dx, const float *ray_dy,
+                                  const float *grad_img, int img_width, int img_channels,
+                                  const EpsmVertexRecord *verts, const EpsmScatterRecord *sc, float clip,
+                                  float *grad_pos, float *grad_nrm, float *grad_alpha, float *grad_o_sum,
+                                  int64_t V, int64_t B, void *stream) {
+    epsm_host::err_buf()[0] = 0;
+    if (N == 0 && K >= 1 && K <= EPSM_MAX_VERTICES &&
+        (variant == EPSM_VARIANT_MANIFOLD || variant == EPSM_VARIANT_MANIFOLD_CAUSTIC)) return EPSM_OK;
+    FusedArgs F;
+    const int rc = fill_args(F, "epsm_backward_pass", variant, N, K, ray_o, verts, sc, clip, grad_pos, grad_nrm, grad_alpha, V, B);
+    if (rc != EPSM_OK) return rc;
+    if (!ray_d || !ray_dx || !ray_dy || !grad_img) return fail(EPSM_EINVAL, "epsm_backward_pass: NULL argument");
+    if (spp < 1 || res < 1 || img_width < res || img_channels < 5)
+        return fail(EPSM_EINVAL, "epsm_backward_pass: need spp>=1, res>=1, img_width>=res, img_channels>=5");
+    if (path_offset < 0 || (int64_t) res * res * spp < path_offset + N)
+        return fail(EPSM_EINVAL, "epsm_backward_pass: path_offset + N exceeds res*res*spp");
+    F.tin = TangentIn{path_offset, spp, res, img_width, img_channels, ray_o, ray_d, ray_dx, ray_dy, grad_img};
+    F.grad_o_sum = grad_o_sum;
+    hipStream_t s = (hipStream_t) stream;
+    const hipError_t e = variant == EPSM_VARIANT_MANIFOLD ? launch_k<EPSM_VARIANT_MANIFOLD, kTangentsInKernel>(K, F, 2, s)
+                                                          : launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, kTangentsInKernel>(K, F, 2, s);
+    if (e != hipSuccess) return epsm_host::hip_fail("epsm_backward_pass", e);
     return EPSM_OK;
 }

@@ -149,6 +149,9 @@ template <typename R> struct GradArgs {
     R *out_diffuse;          // (K,N,3)
     EPSM_HD const VertexPtrs<R> &vtx(int k) const { return v[k]; }
     template <int K> EPSM_HD Flags<K> flags(int64_t i) const;      // from the record arrays (defined below load_flags)
+    // the tangents of the first vertex (dldp) and of vertex k (columns 2(k-1), 2(k-1)+1 of dlduv)
+    EPSM_HD V3<R> dldp_at(int64_t i) const { const R *p = dldp + 3 * i; return mk3<R>(p[0], p[1], p[2]); }
+    template <bool FULL_D> EPSM_HD V2<R> d_at(int64_t i, int k, int dcols) const;      // defined below load_d
 };
 
 template <typename R> EPSM_HD V3<R> load3(const R *base, int64_t i) {
@@ -345,6 +348,9 @@ template <typename R, bool FULL_D, typename Args> EPSM_HD V2<R> load_d(const Arg
     R y = c + 1 < dcols ? row[c + 1] : R(0);
     return mk2<R>(x, y);
 }
+template <typename R> template <bool FULL_D> EPSM_HD V2<R> GradArgs<R>::d_at(int64_t i, int k, int dcols) const {
+    return load_d<R, FULL_D>(*this, i, k, dcols);
+}
 
 // ----------------------------------------------------------------------------
 // per-depth masks from the flag words (no geometry needed)
@@ -448,7 +454,7 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
     }
 
     // diffuse_grad[0] = dldp where the first hit is diffuse (epsm.py:791-792)
-    out.diffuse_first(fl.diffuse[1] ? load3(A.dldp, i) : zero3<R>());
+    out.diffuse_first(fl.diffuse[1] ? A.dldp_at(i) : zero3<R>());
 
     // ---- pass 1: forward recursion (pivots of the continuing rows, z vectors)
     struct Keep { V3<R> x, e1, e2, n, light; R eta, b0, b1; };
@@ -489,7 +495,7 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
             kp[k].light = r.light;
             const Frame<R> fr = make_frame(nr.n);
             const V3<R> xp = (k == 1) ? cam : kp[k - 1].x;
-            const V2<R> dk = load_d<R, FULL_D>(A, i, k, dcols);
+            const V2<R> dk = A.template d_at<FULL_D>(i, k, dcols);
 
             V2<R> rhs = dk;
             M2<R> T;                  // Sinv_{k-1} A^C_{k-1,k}
@@ -612,7 +618,7 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
         }
     }
 
-    out.diffuse_first(fl.diffuse[1] ? load3(A.dldp, i) : zero3<R>());   // epsm.py:998-1000
+    out.diffuse_first(fl.diffuse[1] ? A.dldp_at(i) : zero3<R>());   // epsm.py:998-1000
 
     const V3<R> cam = load3(A.cam, i);
     Geo<R> gcur, gnext;
@@ -645,7 +651,7 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
             const R eta = A.vtx(k - 1).eta[i];
             const Frame<R> fr = make_frame(nr.n);
             const HalfVec<R> h = halfvec_fwd(xprev, gcur.x, gnext.x, fr, eta);
-            const V2<R> dk = load_d<R, FULL_D>(A, i, k, dcols);
+            const V2<R> dk = A.template d_at<FULL_D>(i, k, dcols);
             // pseudo-constraint rows (always needed: they close the system at depth k)
             const Sweep<R> w0 = wo2_rev(fr, h, R(1), R(0));
             const Sweep<R> w1 = wo2_rev(fr, h, R(0), R(1));

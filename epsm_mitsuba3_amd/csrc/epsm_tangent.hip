@@ -9,6 +9,7 @@
 // 4*12 (rays) + 3*12 (triangle) + 1 (mask) in, 12 + 4*stride out per path.
 #include "epsm_common.h"
 #include "epsm_path_core.h"
+#include "epsm_tangent_core.h"
 
 using namespace epsm;
 using epsm_host::fail;
@@ -33,40 +34,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __device__ __forceinline__ void tangent_one(const TangentArgs &A, int64_t i, V3<float> &gd_acc) {
-    const int64_t pix = (A.path_offset + i) / A.spp;
-    const int64_t y = pix / A.res, x = pix % A.res;
-    const float *g = A.grad_img + (y * A.img_width + x) * A.img_channels;
-    const float gx = g[3], gy = g[4];
-    const V3<float> d = load3(A.d, i), dx = load3(A.dx, i), dy = load3(A.dy, i);
-    const V3<float> gd = (dx - d) * gx + (dy - d) * gy;            // epsm.py:255
-    gd_acc = gd_acc + gd;
-    float db0 = 0.f, db1 = 0.f;
-    V3<float> dp = zero3<float>();
-    if (A.active[i]) {
-        const V3<float> o = load3(A.o, i);
-        const V3<float> p0 = load3(A.p0, i), p1 = load3(A.p1, i), p2 = load3(A.p2, i);
-        const V3<float> e1 = p1 - p0, e2 = p2 - p0;               // mesh.h:349
-        const V3<float> pvec = cross(d, e2);
-        const float inv_det = rcp_(dot(e1, pvec));
-        const V3<float> tvec = o - p0;
-        const float u = dot(tvec, pvec) * inv_det;
-        const V3<float> qvec = cross(tvec, e1);
-        const float v = dot(d, qvec) * inv_det;
-        // forward derivative along gd (ray origin fixed)
-        const V3<float> dpvec = cross(gd, e2);
-        const float ddet = dot(e1, dpvec);
-        const float du = (dot(tvec, dpvec) - u * ddet) * inv_det;
-        const float dv = (dot(gd, qvec) - v * ddet) * inv_det;
-        db1 = du;                                                  // b1 = prim_uv.x  (mesh.cpp:698)
-        db0 = -du - dv;                                            // b0 = 1 - b1 - b2
-        dp = e1 * du + e2 * dv;                                    // d (p0 b0 + p1 b1 + p2 b2)
-    }
+    const TangentIn in{A.path_offset, A.spp, A.res, A.img_width, A.img_channels, A.o, A.d, A.dx, A.dy, A.grad_img};
+    const Tangent t = first_vertex_tangent(in, i, A.p0, A.p1, A.p2, A.active[i] != 0);
+    gd_acc = gd_acc + t.gd;
     float *row = A.dlduv + i * A.dlduv_stride;
-    row[0] = db0;
-    row[1] = db1;
+    row[0] = t.db0;
+    row[1] = t.db1;
     for (int64_t c = 2; c < A.dlduv_stride; ++c) row[c] = 0.f;
     float *q = A.dldp + 3 * i;
-    q[0] = dp.x; q[1] = dp.y; q[2] = dp.z;
+    q[0] = t.dp.x; q[1] = t.dp.y; q[2] = t.dp.z;
 }
 
 // Grid-stride over the paths (at most kMaxBlocks workgroups): the camera-origin

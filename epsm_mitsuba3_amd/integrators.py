@@ -26,7 +26,7 @@ from . import dist as _dist
 from .manifold_grad import OUTLIER_CLIP, calc_grad as _calc_grad, manifold_grad_packed
 from .params import ParamGrads
 from .records import PackedRecords, PackedScatter
-from .tangent_scatter import first_vertex_tangent, manifold_grad_scatter, scatter
+from .tangent_scatter import backward_pass, first_vertex_tangent, manifold_grad_scatter, scatter
 
 
 @dataclass
@@ -61,6 +61,7 @@ class EPSMIntegrator:
         # hard-coded in the reference (epsm.py:142,145,549,648,932-944); explicit options here
         self.backward_sensor = props.get("backward_sensor", 2)
         self.backward_spp = props.get("backward_spp", 8)
+        self.fuse_tangent = bool(props.get("fuse_tangent", True))   # with `fused`: epsm_backward_pass (one launch per tile)
         self.max_log_depth = min(props.get("max_log_depth", 5), 5)
         self.outlier_clip = props.get("outlier_clip", OUTLIER_CLIP)
         # True: calc_grad and the scatter run as ONE kernel (no dense per-path gradient lists);
@@ -118,14 +119,23 @@ class EPSMIntegrator:
         rec, sc = packed if packed is not None else (PackedRecords(trace.path_info, device=dev),
                                                      PackedScatter(trace.scatter_info, device=dev))
         mark = mark or (lambda name: None)
+        fused = self.fused if fused is None else fused
+        if fused and self.fuse_tangent:
+            # one launch for the whole tile: tangents live in registers, gradients go into the parameter buffers
+            mark("tangent")
+            backward_pass(self.variant, rec, sc, trace.ray_o, trace.ray_d, trace.ray_dx, trace.ray_dy, grad_in,
+                          trace.spp, trace.res, params.pos, params.nrm, params.alpha if params.B else None,
+                          params.cam_origin, clip=self.outlier_clip, path_offset=trace.path_offset)
+            mark("grad"); mark("scatter")
+            return None
         first = trace.path_info[1]
         dlduv, dldp, grad_o = first_vertex_tangent(
             trace.ray_o, trace.ray_d, trace.ray_dx, trace.ray_dy, grad_in, trace.spp, trace.res,
             first["points"][0], first["points"][1], first["points"][2], first["active"],
             dlduv_width=2, want_origin_grad=True, path_offset=trace.path_offset)
         mark("tangent")
-        if self.fused if fused is None else fused:
-            # one launch: gradients go from registers into the parameter buffers
+        if fused:
+            # gradients go from registers into the parameter buffers
             manifold_grad_scatter(self.variant, rec, sc, dlduv, dldp, params.pos, params.nrm,
                                   params.alpha if params.B else None, clip=self.outlier_clip)
             params.cam_origin += grad_o

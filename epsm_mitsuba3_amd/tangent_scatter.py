@@ -109,3 +109,39 @@ def manifold_grad_scatter(variant: str, rec: PackedRecords, sc: PackedScatter, d
             grad_pos.data_ptr(), grad_nrm.data_ptr(), grad_alpha.data_ptr() if grad_alpha is not None else None,
             V, B, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "epsm_manifold_grad_scatter")
+
+
+def backward_pass(variant: str, rec: PackedRecords, sc: PackedScatter, ray_o, ray_d, ray_dx, ray_dy,
+                  grad_in: torch.Tensor, spp: int, res: int, grad_pos: torch.Tensor, grad_nrm: torch.Tensor,
+                  grad_alpha: Optional[torch.Tensor] = None, grad_origin: Optional[torch.Tensor] = None,
+                  clip: float = 0.1, path_offset: int = 0) -> None:
+    """Tangent + calc_grad + scatter in ONE launch (``epsm_backward_pass``): everything ``render_backward`` does
+    between the trace and the parameter gradients (epsm.py:238-297).  ``grad_origin`` (3,) accumulates the
+    camera-origin gradient; all results accumulate in place."""
+    dev = rec.device
+    if dev.type != "cuda":
+        raise _lib.EpsmError("backward_pass: records must live on the GPU (no CPU fallback)")
+    N, K = rec.N, rec.K
+    o, d, dx, dy = (_f32(t, dev, (N, 3)) for t in (ray_o, ray_d, ray_dx, ray_dy))
+    g = _f32(grad_in, dev)
+    if g.dim() != 3 or g.shape[2] < 5 or g.shape[0] < res or g.shape[1] < res:
+        raise ValueError(f"grad_in must be (H>=res, W>=res, >=5), got {tuple(g.shape)}")
+    for t in (grad_pos, grad_nrm):
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.device == dev
+    V = grad_pos.shape[0]
+    assert tuple(grad_pos.shape) == (V, 3) and tuple(grad_nrm.shape) == (V, 3)
+    B = 0
+    if grad_alpha is not None:
+        assert grad_alpha.is_contiguous() and grad_alpha.dtype == torch.float32 and grad_alpha.device == dev
+        B = grad_alpha.numel()
+    if grad_origin is not None:
+        assert grad_origin.is_contiguous() and grad_origin.dtype == torch.float32 and grad_origin.numel() == 3
+    with torch.cuda.device(dev):
+        rc = _lib.lib().epsm_backward_pass(
+            VARIANTS[variant], N, K, int(path_offset), int(spp), int(res), o.data_ptr(), d.data_ptr(), dx.data_ptr(),
+            dy.data_ptr(), g.data_ptr(), int(g.shape[1]), int(g.shape[2]), C.addressof(rec.records), C.addressof(sc.records),
+            float(clip), grad_pos.data_ptr(), grad_nrm.data_ptr(),
+            grad_alpha.data_ptr() if grad_alpha is not None else None,
+            grad_origin.data_ptr() if grad_origin is not None else None, V, B,
+            torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "epsm_backward_pass")

@@ -2,7 +2,8 @@
 // no Python, no torch.  It is the shape of what a C++ integrator plugin of the reference would do in
 // render_backward (epsm.py:84-306) once the path records are on the device:
 //
-//     epsm_first_vertex_tangent  ->  epsm_manifold_grad_scatter            (one fused launch)
+//     epsm_backward_pass                                                   (the whole pass in one launch)
+//     epsm_first_vertex_tangent  ->  epsm_manifold_grad_scatter            (tangent, then one fused launch)
 //                                ->  epsm_manifold_grad -> epsm_scatter    (the reference's two stages)
 //
 // and it checks that both routes accumulate the same parameter gradients, that the error convention of
@@ -209,6 +210,7 @@ int main(int argc, char **argv) {
     const int P = epsm_num_param_grads(variant, K);
     DeviceArray<float> out_p((size_t) P * N * 3), out_l((size_t) K * N * 3), out_d((size_t) K * N * 3);
     DeviceArray<float> pos_a(3 * V), nrm_a(3 * V), alpha_a(B), pos_b(3 * V), nrm_b(3 * V), alpha_b(B);
+    DeviceArray<float> pos_c(3 * V), nrm_c(3 * V), alpha_c(B), grad_o_c(3);
 
     Timer t;
     // ---- first-vertex tangent (epsm.py:250-272)
@@ -222,9 +224,10 @@ int main(int argc, char **argv) {
     const float ms_tangent = t.stop_ms();
 
     // ---- the reference's two stages: calc_grad (epsm.py:745 / 952), then the scatter (epsm.py:559-562, 622-627, 644-645)
-    float ms_grad = 0, ms_scatter = 0, ms_fused = 0;
+    float ms_grad = 0, ms_scatter = 0, ms_fused = 0, ms_pass = 0;
     for (int rep = 0; rep < 2; ++rep) {            // first round warms up (code objects, clocks)
         pos_a.zero(); nrm_a.zero(); alpha_a.zero(); pos_b.zero(); nrm_b.zero(); alpha_b.zero();
+        pos_c.zero(); nrm_c.zero(); alpha_c.zero(); grad_o_c.zero();
         t.start();
         EPSM_CALL(epsm_manifold_grad(variant, N, K, d_cam.ptr, vrec.data(), dlduv.ptr, 2, 2, dldp.ptr, 0.1f,
                                      out_p.ptr, out_l.ptr, out_d.ptr, nullptr));
@@ -238,21 +241,33 @@ int main(int argc, char **argv) {
         EPSM_CALL(epsm_manifold_grad_scatter(variant, N, K, d_cam.ptr, vrec.data(), srec.data(), dlduv.ptr, 2, 2, dldp.ptr, 0.1f,
                                              pos_b.ptr, nrm_b.ptr, alpha_b.ptr, V, B, nullptr));
         ms_fused = t.stop_ms();
+        // ---- and the whole backward pass (tangent included) in one launch
+        t.start();
+        EPSM_CALL(epsm_backward_pass(variant, N, K, 0, spp, res, d_o.ptr, d_d.ptr, d_dx.ptr, d_dy.ptr, d_img.ptr, res, 5,
+                                     vrec.data(), srec.data(), 0.1f, pos_c.ptr, nrm_c.ptr, alpha_c.ptr, grad_o_c.ptr, V, B, nullptr));
+        ms_pass = t.stop_ms();
     }
     HIP_OK(hipDeviceSynchronize());
 
     const std::vector<float> pa = pos_a.download(), pb = pos_b.download(), na = nrm_a.download(), nb = nrm_b.download(),
-                             aa = alpha_a.download(), ab = alpha_b.download(), uv = dlduv.download();
+                             aa = alpha_a.download(), ab = alpha_b.download(), uv = dlduv.download(),
+                             pc = pos_c.download(), nc = nrm_c.download(), ac = alpha_c.download(),
+                             go = grad_o.download(), goc = grad_o_c.download();
     const double mp = max_abs(pa), mn = max_abs(na), ma = max_abs(aa);
-    const double ep = max_diff(pa, pb), en = max_diff(na, nb), ea = max_diff(aa, ab);
+    const double ep = std::fmax(max_diff(pa, pb), max_diff(pa, pc)), en = std::fmax(max_diff(na, nb), max_diff(na, nc)),
+                 ea = std::fmax(max_diff(aa, ab), max_diff(aa, ac));
+    // the stand-alone tangent call ran twice into grad_o (it accumulates), the one-launch pass once per round
+    const double eo = max_diff(std::vector<float>{go[0] * 0.5f, go[1] * 0.5f, go[2] * 0.5f}, goc), mo = max_abs(goc);
     std::printf("epsm_host_driver: N=%lld K=%d variant=%d V=%lld (res %d @ %d spp)\n", (long long) N, K, variant, (long long) V, res, spp);
     std::printf("  tangent        %8.3f ms  %7.2f Gpaths/s   max|dlduv| %.3g\n", ms_tangent, N / ms_tangent * 1e-6, max_abs(uv));
     std::printf("  calc_grad      %8.3f ms  %7.2f Gpaths/s\n", ms_grad, N / ms_grad * 1e-6);
     std::printf("  scatter        %8.3f ms\n", ms_scatter);
     std::printf("  fused          %8.3f ms  %7.2f Gpaths/s   (two stages: %.3f ms)\n", ms_fused, N / ms_fused * 1e-6, ms_grad + ms_scatter);
-    std::printf("  fused vs two-stage: pos %.3g / %.3g  nrm %.3g / %.3g  alpha %.3g / %.3g  (max |diff| / max |value|)\n", ep, mp, en, mn, ea, ma);
+    std::printf("  one launch     %8.3f ms  %7.2f Gpaths/s   (tangent + fused: %.3f ms)\n", ms_pass, N / ms_pass * 1e-6, ms_tangent + ms_fused);
+    std::printf("  fused / one launch vs two-stage: pos %.3g / %.3g  nrm %.3g / %.3g  alpha %.3g / %.3g  (max |diff| / max |value|)\n", ep, mp, en, mn, ea, ma);
     // (K = 1 has no continuing rows, hence no alpha gradient: only the position buffer must be non-zero)
-    const bool ok = mp > 0 && max_abs(uv) > 0 && ep <= 2e-4 * mp && en <= 2e-4 * mn + 1e-30 && ea <= 2e-4 * ma + 1e-30;
+    const bool ok = mp > 0 && max_abs(uv) > 0 && ep <= 2e-4 * mp && en <= 2e-4 * mn + 1e-30 && ea <= 2e-4 * ma + 1e-30 &&
+                    mo > 0 && eo <= 1e-3 * mo;
     std::printf("%s\n", ok ? "OK" : "MISMATCH");
     return ok ? 0 : 1;
 }

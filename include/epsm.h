@@ -215,6 +215,21 @@ int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
                                int64_t V, int64_t B, void *stream);
 
 /* Human-readable text of the last failure on the calling thread ("" if none). */
+/* ---------------------------------------------------------------------------
+ * epsm_backward_pass  --  epsm_first_vertex_tangent + epsm_manifold_grad_scatter in ONE launch:
+ *     everything render_backward does between the trace and the parameter gradients
+ *     (epsm.py:238-297).  The tangents dlduv / dldp1 are computed per path in registers
+ *     instead of being written and read back; cam of epsm_manifold_grad is ray_o
+ *     (epsm.py:547); grad_o_sum (3 floats, may be NULL) receives -sum grad_d (epsm.py:260-261).
+ *     Arguments as in the two calls it replaces.
+ * ------------------------------------------------------------------------- */
+int epsm_backward_pass(int variant, int64_t N, int K, int64_t path_offset, int spp, int res,
+                       const float *ray_o, const float *ray_d, const float *ray_dx, const float *ray_dy,
+                       const float *grad_img, int img_width, int img_channels,
+                       const EpsmVertexRecord *verts, const EpsmScatterRecord *sc, float clip,
+                       float *grad_pos, float *grad_nrm, float *grad_alpha, float *grad_o_sum,
+                       int64_t V, int64_t B, void *stream);
+
 const char *epsm_last_error(void);
 
 /* ABI version of the loaded library (EPSM_ABI_VERSION at build time). */

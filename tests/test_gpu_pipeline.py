@@ -6,7 +6,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("fused", [True, False])
+# "pass": one launch per tile (epsm_backward_pass); "kernel": tangent kernel + fused gradient/scatter kernel;
+# False: the reference's three stages (tangent, calc_grad lists, scatter)
+@pytest.mark.parametrize("fused", ["pass", "kernel", False])
 @pytest.mark.parametrize("kind,profile", [("manifold", "bathroom"), ("manifold_caustic", "caustic"),
                                           ("manifold", "mixed"), ("manifold_caustic", "mixed")])
 def test_render_backward_matches_oracle_pipeline(kind, profile, fused):
