@@ -66,6 +66,9 @@ def _declare(lib):
             C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.epsm_trace_paths.restype = C.c_int
+    lib.epsm_trace_paths_wavefront.restype = C.c_int
+    lib.epsm_trace_workspace_bytes.restype = C.c_size_t
+    lib.epsm_trace_workspace_bytes.argtypes = [C.c_int64]
     lib.epsm_film_splat.restype = C.c_int
     lib.epsm_film_develop.restype = C.c_int
     return lib

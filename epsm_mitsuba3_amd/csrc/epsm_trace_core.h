@@ -139,59 +139,82 @@ struct TriHit { bool hit; uint32_t tri; float t, u, v; };
 // conflict-free; a local array on the host).  Depth of the tree <= kBvhStack.
 constexpr int kBvhStack = 32;
 constexpr int32_t kBvhNone = 0x7fffffff;
-struct BvhStack { uint32_t *base; int stride; };
+// The first `cap` entries live at base (LDS); a stack that grows beyond them continues at ovf[(k - cap) * ovf_stride]
+// (global memory, rarely reached: the wavefront kernels keep only 16 entries per path in LDS to run 8 waves per SIMD).
+struct BvhStack {
+    uint32_t *base; int stride;
+    int cap = kBvhStack; uint32_t *ovf = nullptr; int64_t ovf_stride = 0;
+    EPSM_HD void put(int k, uint32_t v) const { if (k < cap) base[k * stride] = v; else ovf[(int64_t) (k - cap) * ovf_stride] = v; }
+    EPSM_HD uint32_t get(int k) const { return k < cap ? base[k * stride] : ovf[(int64_t) (k - cap) * ovf_stride]; }
+};
 
-// Ordered traversal of the two-wide BVH: one 64-byte node holds both children's boxes, leaf children are
-// intersected on the spot, of two inner children the nearer is followed and the farther pushed.
+// Ordered traversal of the two-wide BVH: one 64-byte node holds both children's boxes, of two inner children the
+// nearer is followed and the farther pushed.  While-while: a ROUND descends through inner nodes until the current
+// reference is a leaf, then intersects that leaf's triangles -- the lanes of a wave run the (long) triangle code
+// together instead of each one in the middle of its own descent.  A reference is a node index (>= 0), a leaf
+// ~((first << 3) | count) (< 0) or kBvhNone.  The traversal is a resumable object so that the wavefront kernels can
+// give a lane whose ray is finished a new ray between two rounds.
+struct Traversal {
+    Ray r;
+    F3 inv_d;
+    int32_t cur, best_e;
+    int sp;
+    TriHit best;
+};
+EPSM_HD void trav_begin(Traversal &T, const EpsmScene &S, const Ray &r) {
+    T.r = r;
+    T.best.hit = false; T.best.tri = 0; T.best.t = r.maxt; T.best.u = T.best.v = 0.f;
+    T.inv_d = f3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+    T.best_e = -1;
+    T.cur = S.n_nodes > 0 ? 0 : kBvhNone;
+    T.sp = 0;
+}
+EPSM_HD bool trav_done(const Traversal &T) { return T.cur == kBvhNone; }
+template <bool ANY_HIT>
+EPSM_HD void trav_round(Traversal &T, const EpsmScene &S, const BvhStack &st) {
+    while (T.cur >= 0 && T.cur != kBvhNone) {
+        const EpsmBvhNode n = S.bvh[T.cur];
+        float t0, t1;
+        const bool h0 = n.c0 != kBvhNone && hit_box(n.lo0, n.hi0, T.r.o, T.inv_d, T.r.maxt, t0);
+        const bool h1 = n.c1 != kBvhNone && hit_box(n.lo1, n.hi1, T.r.o, T.inv_d, T.r.maxt, t1);
+        if (h0 && h1) {
+            const bool first0 = t0 <= t1;
+            if (T.sp < kBvhStack) st.put(T.sp++, (uint32_t) (first0 ? n.c1 : n.c0));
+            T.cur = first0 ? n.c0 : n.c1;
+        } else if (h0) {
+            T.cur = n.c0;
+        } else if (h1) {
+            T.cur = n.c1;
+        } else {
+            T.cur = T.sp > 0 ? (int32_t) st.get(--T.sp) : kBvhNone;
+        }
+    }
+    if (T.cur == kBvhNone) return;
+    const uint32_t ref = ~(uint32_t) T.cur;
+    const int32_t first = (int32_t) (ref >> 3), count = (int32_t) (ref & 7u);
+    for (int32_t e = first; e < first + count; ++e) {
+        const float *q = S.tri_verts + 9 * (int64_t) e;
+        float t, u, v;
+        if (moeller_trumbore(T.r, ld3(q), ld3(q + 3), ld3(q + 6), t, u, v)) {
+            T.best.hit = true; T.best_e = e; T.best.t = t; T.best.u = u; T.best.v = v;
+            T.r.maxt = t;
+            if (ANY_HIT) break;
+        }
+    }
+    if (ANY_HIT && T.best.hit) { T.cur = kBvhNone; return; }
+    T.cur = T.sp > 0 ? (int32_t) st.get(--T.sp) : kBvhNone;
+}
+EPSM_HD TriHit trav_result(const Traversal &T, const EpsmScene &S) {
+    TriHit best = T.best;
+    if (best.hit) best.tri = S.prim_index[T.best_e];
+    return best;
+}
 template <bool ANY_HIT>
 EPSM_HD TriHit intersect(const EpsmScene &S, Ray r, const BvhStack &st) {
-    TriHit best; best.hit = false; best.tri = 0; best.t = r.maxt; best.u = best.v = 0.f;
-    if (S.n_nodes <= 0) return best;
-    const F3 inv_d = f3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
-    int32_t best_e = -1;
-    auto leaf = [&](int32_t first, int32_t count) {
-        for (int32_t e = first; e < first + count; ++e) {
-            const float *q = S.tri_verts + 9 * (int64_t) e;
-            float t, u, v;
-            if (moeller_trumbore(r, ld3(q), ld3(q + 3), ld3(q + 6), t, u, v)) {
-                best.hit = true; best_e = e; best.t = t; best.u = u; best.v = v;
-                r.maxt = t;
-                if (ANY_HIT) return;
-            }
-        }
-    };
-    // while-while traversal: descend through inner nodes until the current reference is a leaf, then intersect
-    // that leaf's triangles -- the lanes of a wave run the (long) triangle code together instead of each one
-    // in the middle of its own descent.  A reference is a node index (>= 0), a leaf ~((first << 3) | count)
-    // (< 0) or kBvhNone.
-    int32_t cur = 0;
-    int sp = 0;
-    for (;;) {
-        while (cur >= 0 && cur != kBvhNone) {
-            const EpsmBvhNode n = S.bvh[cur];
-            float t0, t1;
-            const bool h0 = n.c0 != kBvhNone && hit_box(n.lo0, n.hi0, r.o, inv_d, r.maxt, t0);
-            const bool h1 = n.c1 != kBvhNone && hit_box(n.lo1, n.hi1, r.o, inv_d, r.maxt, t1);
-            if (h0 && h1) {
-                const bool first0 = t0 <= t1;
-                if (sp < kBvhStack) st.base[(sp++) * st.stride] = (uint32_t) (first0 ? n.c1 : n.c0);
-                cur = first0 ? n.c0 : n.c1;
-            } else if (h0) {
-                cur = n.c0;
-            } else if (h1) {
-                cur = n.c1;
-            } else {
-                cur = sp > 0 ? (int32_t) st.base[(--sp) * st.stride] : kBvhNone;
-            }
-        }
-        if (cur == kBvhNone) break;
-        const uint32_t ref = ~(uint32_t) cur;
-        leaf((int32_t) (ref >> 3), (int32_t) (ref & 7u));
-        if (ANY_HIT && best.hit) break;
-        cur = sp > 0 ? (int32_t) st.base[(--sp) * st.stride] : kBvhNone;
-    }
-    if (best.hit) best.tri = S.prim_index[best_e];
-    return best;
+    Traversal T;
+    trav_begin(T, S, r);
+    while (!trav_done(T)) trav_round<ANY_HIT>(T, S, st);
+    return trav_result(T, S);
 }
 
 // ---------------------------------------------------------------------------
@@ -467,8 +490,9 @@ EPSM_HD F3 emitter_normal(const EpsmScene &S, const EpsmMesh &m, const uint32_t 
     if (m.flags & EPSM_MESH_FLIP_NORMALS) n = -n;
     return n;
 }
+template <class Vis>
 EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit &ref, float u, float v, bool active,
-                                               const BvhStack &st) {
+                                               Vis &vis) {
     EmitterSample e;
     e.p = e.n = e.d = e.weight = zero3<float>(); e.pdf = 0.f; e.dist = 0.f; e.delta = false; e.valid = false;
     e.vi[0] = e.vi[1] = e.vi[2] = kNoIndex; e.b0 = e.b1 = 0.f;
@@ -524,7 +548,7 @@ EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit
     if (e.valid) {                                                        // scene.cpp:270-275 test_visibility
         float dist;
         const Ray sr = spawn_ray_to(ref, e.p, dist);
-        if (intersect<true>(S, sr, st).hit) e.weight = zero3<float>();
+        if (vis.occluded(S, sr)) e.weight = zero3<float>();
     }
     return e;
 }
@@ -618,108 +642,156 @@ EPSM_HD void write_record(const EpsmRecordOut &R, int64_t i, bool active, const 
     e[0] = es.vi[0]; e[1] = es.vi[1]; e[2] = es.vi[2]; e[3] = f2u(es.b0); e[4] = f2u(es.b1); e[5] = f2u(eweight); e[6] = 0; e[7] = 0;
 }
 
-EPSM_HD void trace_one_path(const TraceArgs &A, int64_t i, const BvhStack &st) {
-    const EpsmScene &S = A.S;
+// Default record of the occluder term: "no occluder" (epsm.py:609-620 not taken)
+EPSM_HD void write_no_occluder(uint32_t *o) {
+    o[0] = o[1] = o[2] = kNoIndex; o[3] = o[4] = o[5] = o[6] = o[7] = 0u;
+}
+// Occluder of the first vertex's emitter sample (epsm.py:609-620; integrators with max_depth <= 3): closest hit of the
+// ray towards the sample, NO maximum distance, as scene.ray_intersect(si.spawn_ray(ds.d)).  `sr` = spawn_ray(si, ds.d),
+// `oh` its closest hit, sip = si.p, esp = ds.p.
+EPSM_HD void write_occluder(const EpsmScene &S, uint32_t *o, const Ray &sr, const TriHit &oh, F3 sip, F3 esp) {
+    uint32_t w[8] = {kNoIndex, kNoIndex, kNoIndex, 0u, 0u, 0u, 0u, 0u};
+    if (oh.hit) {
+        const SurfHit occ = surface_interaction(S, sr, oh);
+        if (occ.mesh_flags & EPSM_MESH_IS_MESH) {
+            const F3 a = esp - occ.p, b = esp - sip;
+            float dis = sqrtf(dot(a, a)) / sqrtf(dot(b, b));                     // :614
+            if (!(dis >= 0.01f)) dis = 0.f;                                      // :615
+            w[0] = occ.vi[0]; w[1] = occ.vi[1]; w[2] = occ.vi[2];
+            w[3] = f2u(occ.b0); w[4] = f2u(occ.b1); w[5] = f2u(dis); w[6] = occ.mesh_flags & 0xFu;
+        }
+    }
+    for (int j = 0; j < 8; ++j) o[j] = w[j];
+}
+
+// What a path carries from one bounce to the next (the loop state of epsm.py:527-545)
+struct PathState {
+    Ray ray;
+    F3 L, beta, prev_p;
+    float eta, prev_bsdf_pdf;
+    int depth;
+    bool active, prev_bsdf_delta;
+    Pcg32 rng;
+};
+
+// sample_rays (common.py:291-422) + the initial loop state
+EPSM_HD PathState path_begin(const TraceArgs &A, int64_t i) {
     const int64_t widx = A.path_offset + i;
-    Pcg32 rng = seed_sampler(A.seed, (uint32_t) widx);                    // common.py:475 sampler.seed(seed, wavefront_size)
-    const PrimaryRay pr = sample_primary_ray(A.C, widx, A.spp, rng);
+    PathState s;
+    s.rng = seed_sampler(A.seed, (uint32_t) widx);                        // common.py:475 sampler.seed(seed, wavefront_size)
+    const PrimaryRay pr = sample_primary_ray(A.C, widx, A.spp, s.rng);
     st3(A.ray_o, i, pr.ray.o); st3(A.ray_d, i, pr.ray.d); st3(A.ray_dx, i, pr.dx); st3(A.ray_dy, i, pr.dy);
     if (A.film_pos) { A.film_pos[2 * i] = pr.px; A.film_pos[2 * i + 1] = pr.py; }
+    s.ray = pr.ray;
+    s.L = zero3<float>(); s.beta = f3(1.f, 1.f, 1.f); s.prev_p = zero3<float>();
+    s.eta = 1.f; s.prev_bsdf_pdf = 1.f;
+    s.depth = 0;
+    s.active = true; s.prev_bsdf_delta = true;
+    return s;
+}
+EPSM_HD int path_max_depth(const TraceArgs &A) { return A.max_depth < 6 ? A.max_depth : 6; }   // epsm.py:549
 
-    Ray ray = pr.ray;
-    F3 L = zero3<float>(), beta = f3(1.f, 1.f, 1.f);
-    float eta = 1.f;
-    int depth = 0;
-    bool active = true;
-    F3 prev_p = zero3<float>();
-    float prev_bsdf_pdf = 1.f;
-    bool prev_bsdf_delta = true;
-    const int max_depth = A.max_depth < 6 ? A.max_depth : 6;              // epsm.py:549
+// One iteration of the loop of epsm.py:551-735 AFTER the closest hit `th` of s.ray is known.  The two places
+// where the reference traces further rays from inside the iteration go through the policy `vis`:
+//   vis.occluded(S, ray)                      visibility of the emitter sample (scene.cpp:270-275)
+//   vis.direct(L, Le, Lr_dir)                 L += Le + Lr_dir (epsm.py:658); a deferred policy adds Lr_dir once it knows
+//   vis.occluder(A, i, si, es, active_em)     the occluder record of the first vertex (epsm.py:609-620)
+// so that the one-launch tracer answers them on the spot (InlineVis) and the wavefront tracer
+// (epsm_trace_wavefront.h) queues them for its shadow-ray stage.
+template <class Vis>
+EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState &s, const TriHit &th, Vis &vis) {
+    const EpsmScene &S = A.S;
+    const SurfHit si = surface_interaction(S, s.ray, th);                 // epsm.py:556-558
+    EpsmBsdf bsdf;
+    bsdf.type = EPSM_BSDF_DIFFUSE_T; bsdf.twosided = 0; bsdf.distr = 0; bsdf.sample_visible = 1; bsdf.alpha = 0.1f;
+    bsdf.reflectance[0] = bsdf.reflectance[1] = bsdf.reflectance[2] = 0.f;
+    bsdf.eta[0] = bsdf.eta[1] = bsdf.eta[2] = 0.f; bsdf.k[0] = bsdf.k[1] = bsdf.k[2] = 1.f;
+    bsdf.int_ior = 1.5046f; bsdf.ext_ior = 1.000277f; bsdf.alpha_slot = -1; bsdf.pad = 0;
+    uint32_t flags = 0;
+    if (si.valid && si.bsdf >= 0) { bsdf = S.bsdfs[si.bsdf]; flags = bsdf_flags(bsdf); }
 
-    for (int iteration = 0; iteration < max_depth; ++iteration) {         // epsm.py:551 (lanes stay in the loop, masked)
-        TriHit th; th.hit = false; th.tri = 0; th.t = kInf; th.u = th.v = 0.f;
-        if (active) th = intersect<false>(S, ray, st);
-        const SurfHit si = surface_interaction(S, ray, th);               // epsm.py:556-558
-        EpsmBsdf bsdf;
-        bsdf.type = EPSM_BSDF_DIFFUSE_T; bsdf.twosided = 0; bsdf.distr = 0; bsdf.sample_visible = 1; bsdf.alpha = 0.1f;
-        bsdf.reflectance[0] = bsdf.reflectance[1] = bsdf.reflectance[2] = 0.f;
-        bsdf.eta[0] = bsdf.eta[1] = bsdf.eta[2] = 0.f; bsdf.k[0] = bsdf.k[1] = bsdf.k[2] = 1.f;
-        bsdf.int_ior = 1.5046f; bsdf.ext_ior = 1.000277f; bsdf.alpha_slot = -1; bsdf.pad = 0;
-        uint32_t flags = 0;
-        if (si.valid && si.bsdf >= 0) { bsdf = S.bsdfs[si.bsdf]; flags = bsdf_flags(bsdf); }
-
-        // ---- direct emission, MIS against the emitter sample of the previous bounce (epsm.py:569-577)
-        F3 Le = zero3<float>();
-        if (si.valid && si.emitter >= 0 && si.wi.z > 0.f) {                // area.cpp eval: front side only
-            const float em_pdf = prev_bsdf_delta ? 0.f : pdf_emitter_direction(S, prev_p, si);
-            const float mis = mis_weight(prev_bsdf_pdf, em_pdf);
-            Le = mul3(beta, ld3(S.emitters[si.emitter].radiance)) * mis;
-        }
-        // ---- emitter sampling (epsm.py:582-605)
-        bool active_next = (depth + 1 < A.max_depth) && si.valid;
-        bool active_em = active_next && (flags & kFlSmooth);
-        const float e1 = rng.next_1d(), e2 = rng.next_1d();              // sampler.next_2d()
-        const EmitterSample es = sample_emitter_direction(S, si, e1, e2, active_em, st);
-        active_em = active_em && es.pdf != 0.f;                           // :590
-        F3 Lr_dir = zero3<float>();
-        if (active_em) {
-            const F3 wo = to_local(si, es.d);
-            F3 bval; float bpdf;
-            bsdf_eval_pdf(bsdf, si.wi, wo, bval, bpdf);
-            const float mis_em = es.delta ? 1.f : mis_weight(es.pdf, bpdf);
-            Lr_dir = mul3(mul3(beta, bval), es.weight) * mis_em;          // :605
-        }
-        // ---- occluder of the first vertex's emitter sample (epsm.py:609-620; integrators with max_depth <= 3):
-        //      closest hit of the ray towards the sample, NO maximum distance, as scene.ray_intersect(si.spawn_ray(ds.d))
-        if (iteration == 0 && A.K_log > 0 && A.rec[0].shadow) {
-            uint32_t w[8] = {kNoIndex, kNoIndex, kNoIndex, 0u, 0u, 0u, 0u, 0u};
-            if (A.max_depth <= 3 && active_em) {
-                const Ray sr = spawn_ray(si, es.d);
-                const TriHit oh = intersect<false>(S, sr, st);
-                if (oh.hit) {
-                    const SurfHit occ = surface_interaction(S, sr, oh);
-                    if (occ.mesh_flags & EPSM_MESH_IS_MESH) {
-                        const F3 a = es.p - occ.p, b = es.p - si.p;
-                        float dis = sqrtf(dot(a, a)) / sqrtf(dot(b, b));             // :614
-                        if (!(dis >= 0.01f)) dis = 0.f;                              // :615
-                        w[0] = occ.vi[0]; w[1] = occ.vi[1]; w[2] = occ.vi[2];
-                        w[3] = f2u(occ.b0); w[4] = f2u(occ.b1); w[5] = f2u(dis); w[6] = occ.mesh_flags & 0xFu;
-                    }
-                }
-            }
-            uint32_t *o = A.rec[0].shadow + 8 * i;
-            for (int j = 0; j < 8; ++j) o[j] = w[j];
-        }
-        // ---- BSDF sampling: once detached, once attached with fresh numbers (epsm.py:633-643)
-        rng.next_1d(); rng.next_1d(); rng.next_1d();
-        const float s1 = rng.next_1d(), s2x = rng.next_1d(), s2y = rng.next_1d();
-        const BsdfSample bs = bsdf_sample(bsdf, si.wi, s1, s2x, s2y, active_next);
-        // ---- log (epsm.py:648-654)
-        if (iteration < A.K_log)
-            write_record(A.rec[iteration], i, active && si.valid, si, flags, es, active_em, bs,
-                         Lr_dir.x + Lr_dir.y + Lr_dir.z, bsdf.alpha_slot);
-        // ---- update (epsm.py:658-683)
-        if (active) L = L + Le + Lr_dir;
-        const F3 wo_world = to_world(si, bs.wo);
-        ray = spawn_ray(si, wo_world);
-        eta *= bs.valid ? bs.eta : 1.f;
-        beta = bs.valid ? mul3(beta, bs.weight) : zero3<float>();
-        prev_p = si.p;
-        prev_bsdf_pdf = bs.pdf;
-        prev_bsdf_delta = (bs.sampled_type & kFlDelta) != 0;
-        const float beta_max = max3(beta);
-        active_next = active_next && beta_max != 0.f;
-        const float rr_prob = fminf(beta_max * eta * eta, 0.95f);
-        const bool rr_active = depth >= A.rr_depth;
-        if (rr_active) beta = beta * (1.f / rr_prob);
-        const bool rr_continue = rng.next_1d() < rr_prob;
-        active_next = active_next && (!rr_active || rr_continue);
-        if (si.valid && active) depth += 1;                               // :734
-        active = active && active_next;                                   // :735
+    // ---- direct emission, MIS against the emitter sample of the previous bounce (epsm.py:569-577)
+    F3 Le = zero3<float>();
+    if (si.valid && si.emitter >= 0 && si.wi.z > 0.f) {                    // area.cpp eval: front side only
+        const float em_pdf = s.prev_bsdf_delta ? 0.f : pdf_emitter_direction(S, s.prev_p, si);
+        const float mis = mis_weight(s.prev_bsdf_pdf, em_pdf);
+        Le = mul3(s.beta, ld3(S.emitters[si.emitter].radiance)) * mis;
     }
-    // bounces never reached are logged as inactive zeros
-    st3(A.radiance, i, L);
-    if (A.valid) A.valid[i] = depth != 0;
+    // ---- emitter sampling (epsm.py:582-605)
+    bool active_next = (s.depth + 1 < A.max_depth) && si.valid;
+    bool active_em = active_next && (flags & kFlSmooth);
+    const float e1 = s.rng.next_1d(), e2 = s.rng.next_1d();              // sampler.next_2d()
+    const EmitterSample es = sample_emitter_direction(S, si, e1, e2, active_em, vis);
+    active_em = active_em && es.pdf != 0.f;                               // :590
+    F3 Lr_dir = zero3<float>();
+    if (active_em) {
+        const F3 wo = to_local(si, es.d);
+        F3 bval; float bpdf;
+        bsdf_eval_pdf(bsdf, si.wi, wo, bval, bpdf);
+        const float mis_em = es.delta ? 1.f : mis_weight(es.pdf, bpdf);
+        Lr_dir = mul3(mul3(s.beta, bval), es.weight) * mis_em;            // :605
+    }
+    // ---- occluder of the first vertex's emitter sample (epsm.py:609-620)
+    if (iteration == 0 && A.K_log > 0 && A.rec[0].shadow) vis.occluder(A, i, si, es, active_em);
+    // ---- BSDF sampling: once detached, once attached with fresh numbers (epsm.py:633-643)
+    s.rng.next_1d(); s.rng.next_1d(); s.rng.next_1d();
+    const float s1 = s.rng.next_1d(), s2x = s.rng.next_1d(), s2y = s.rng.next_1d();
+    const BsdfSample bs = bsdf_sample(bsdf, si.wi, s1, s2x, s2y, active_next);
+    // ---- log (epsm.py:648-654)
+    if (iteration < A.K_log)
+        write_record(A.rec[iteration], i, s.active && si.valid, si, flags, es, active_em, bs,
+                     Lr_dir.x + Lr_dir.y + Lr_dir.z, bsdf.alpha_slot);
+    // ---- update (epsm.py:658-683)
+    if (s.active) vis.direct(s.L, Le, Lr_dir);
+    const F3 wo_world = to_world(si, bs.wo);
+    s.ray = spawn_ray(si, wo_world);
+    s.eta *= bs.valid ? bs.eta : 1.f;
+    s.beta = bs.valid ? mul3(s.beta, bs.weight) : zero3<float>();
+    s.prev_p = si.p;
+    s.prev_bsdf_pdf = bs.pdf;
+    s.prev_bsdf_delta = (bs.sampled_type & kFlDelta) != 0;
+    const float beta_max = max3(s.beta);
+    active_next = active_next && beta_max != 0.f;
+    const float rr_prob = fminf(beta_max * s.eta * s.eta, 0.95f);
+    const bool rr_active = s.depth >= A.rr_depth;
+    if (rr_active) s.beta = s.beta * (1.f / rr_prob);
+    const bool rr_continue = s.rng.next_1d() < rr_prob;
+    active_next = active_next && (!rr_active || rr_continue);
+    if (si.valid && s.active) s.depth += 1;                               // :734
+    s.active = s.active && active_next;                                   // :735
+}
+EPSM_HD void path_end(const TraceArgs &A, int64_t i, const PathState &s) {
+    st3(A.radiance, i, s.L);
+    if (A.valid) A.valid[i] = s.depth != 0;
+}
+
+// Every further ray answered on the spot, with the path's own traversal stack.
+struct InlineVis {
+    const BvhStack &st;
+    EPSM_HD bool occluded(const EpsmScene &S, const Ray &sr) { return intersect<true>(S, sr, st).hit; }
+    EPSM_HD void direct(F3 &L, F3 Le, F3 Lr_dir) { L = L + Le + Lr_dir; }
+    EPSM_HD void occluder(const TraceArgs &A, int64_t i, const SurfHit &si, const EmitterSample &es, bool active_em) {
+        uint32_t *o = A.rec[0].shadow + 8 * i;
+        if (A.max_depth <= 3 && active_em) {
+            const Ray sr = spawn_ray(si, es.d);
+            write_occluder(A.S, o, sr, intersect<false>(A.S, sr, st), si.p, es.p);
+        } else {
+            write_no_occluder(o);
+        }
+    }
+};
+
+// The whole path in one go (one lane carries it through all bounces; lanes stay in the loop, masked: epsm.py:551).
+EPSM_HD void trace_one_path(const TraceArgs &A, int64_t i, const BvhStack &st) {
+    PathState s = path_begin(A, i);
+    InlineVis vis{st};
+    const int max_depth = path_max_depth(A);
+    for (int iteration = 0; iteration < max_depth; ++iteration) {
+        TriHit th; th.hit = false; th.tri = 0; th.t = kInf; th.u = th.v = 0.f;
+        if (s.active) th = intersect<false>(A.S, s.ray, st);
+        path_bounce(A, i, iteration, s, th, vis);                         // bounces never reached are logged as inactive zeros
+    }
+    path_end(A, i, s);
 }
 
 }  // namespace epsm

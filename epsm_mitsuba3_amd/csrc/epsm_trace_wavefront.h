@@ -1,0 +1,240 @@
+// epsm_trace_wavefront.h -- the tracer as a wavefront of stages with compaction between bounces
+// (include/epsm_trace.h: epsm_trace_paths_wavefront).
+//
+// The reference runs sample_path as a Python-unrolled wavefront (one Dr.Jit kernel per bounce over ALL lanes,
+// masked, epsm.py:551).  epsm_trace_paths keeps a lane on its path through every bounce of one launch; on a scene
+// with many triangles that kernel is bound by divergence: dead paths stay in their wave, lanes without an emitter
+// sample idle through the shadow-ray traversal of their neighbours, and the 148 registers of the whole path cap
+// the occupancy of what is a pointer-chasing loop.  Here a bounce is three small kernels over QUEUES of live paths:
+//
+//   extend   closest hit of the path's ray            (traversal only: few registers, many waves per SIMD)
+//   shade    path_bounce() of epsm_trace_core.h: surface interaction, emission + MIS, emitter sample, BSDF sample,
+//            vertex log, Russian roulette; appends the path to the next bounce's queue if it lives on and to the
+//            shadow queue if its emitter sample needs a visibility ray (wave-level ballot + prefix count, one
+//            atomic per wave)
+//   shadow   any-hit of the queued visibility rays; adds the direct light or zeroes the logged emitter weight;
+//            the occluder record of the first vertex (epsm.py:609-620) when the integrator asks for it
+//
+// and a last pass (`finish`) writes radiance / valid and the inactive-zero records of the bounces a path never
+// reached (the reference logs masked lanes as zeros).  Per-path results are identical to epsm_trace_paths: the
+// arithmetic is the same code (path_begin / path_bounce / path_end), only the order in which paths are visited
+// differs.  State between the stages lives in a caller-provided workspace, ten 16-byte words per path (+ 3 queue
+// entries and the 64-byte overflow area of its traversal stack).
+#pragma once
+
+#include "epsm_trace_core.h"
+
+namespace epsm {
+
+struct alignas(16) W4 { uint32_t x, y, z, w; };
+EPSM_HD float u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+EPSM_HD W4 pack4(F3 v, float w) { W4 o; o.x = f2u(v.x); o.y = f2u(v.y); o.z = f2u(v.z); o.w = f2u(w); return o; }
+EPSM_HD W4 pack4u(F3 v, uint32_t w) { W4 o; o.x = f2u(v.x); o.y = f2u(v.y); o.z = f2u(v.z); o.w = w; return o; }
+EPSM_HD F3 xyz(const W4 &q) { return f3(u2f(q.x), u2f(q.y), u2f(q.z)); }
+
+constexpr int kWfArrays = 10;                 // 16-byte words per path in the workspace
+constexpr int kWfMaxDepth = 6;                // epsm.py:549
+constexpr int kWfCounters = 64;               // uint32 header: [b] = paths alive into bounce b, [8 + b] = shadow rays of bounce b
+constexpr uint32_t kWfOccluder = 1u;          // sh_d.w: the shadow stage also owes the occluder record
+
+struct WfState {                              // device pointers into the workspace
+    uint32_t *counters;
+    W4 *ray_o;        // ray.o, ray.maxt
+    W4 *ray_d;        // ray.d, eta
+    W4 *hit;          // tri (kNoIndex: miss), t, u, v
+    W4 *beta;         // beta, prev_bsdf_pdf
+    W4 *L;            // L, depth | prev_bsdf_delta << 8 | bounces done << 16
+    W4 *prev_p;       // prev_p, -
+    W4 *rng;          // state lo, hi, inc lo, hi
+    W4 *sh_o;         // visibility ray o, maxt
+    W4 *sh_d;         // visibility ray d, kWfOccluder
+    W4 *sh_L;         // Lr_dir of the pending emitter sample, -
+    uint32_t *queue[2];   // path ids alive into bounce b: queue[b & 1]
+    uint32_t *shadow_queue;
+    uint32_t *stack_ovf;  // (kWfStackOvf, N): traversal-stack entries beyond the kWfStackLds a path keeps in LDS
+    int64_t N;
+};
+constexpr int kWfStackLds = 16, kWfStackOvf = kBvhStack - kWfStackLds;
+// path i's traversal stack: `lds` = its LDS column (entry k at lds[k * stride])
+EPSM_HD BvhStack wf_stack(const WfState &W, int64_t i, uint32_t *lds, int stride) {
+    BvhStack st{lds, stride};
+    st.cap = kWfStackLds; st.ovf = W.stack_ovf + i; st.ovf_stride = W.N;
+    return st;
+}
+EPSM_HD size_t wf_align(size_t x) { return (x + 255) & ~(size_t) 255; }
+EPSM_HD size_t wf_workspace_bytes(int64_t N) {
+    return wf_align(kWfCounters * 4) + (size_t) kWfArrays * wf_align((size_t) N * 16) + 3 * wf_align((size_t) N * 4) +
+           wf_align((size_t) N * 4 * kWfStackOvf);
+}
+EPSM_HD WfState wf_carve(void *workspace, int64_t N) {
+    char *p = (char *) workspace;
+    WfState W;
+    W.counters = (uint32_t *) p; p += wf_align(kWfCounters * 4);
+    W4 **arr[kWfArrays] = {&W.ray_o, &W.ray_d, &W.hit, &W.beta, &W.L, &W.prev_p, &W.rng, &W.sh_o, &W.sh_d, &W.sh_L};
+    for (int a = 0; a < kWfArrays; ++a) { *arr[a] = (W4 *) p; p += wf_align((size_t) N * 16); }
+    W.queue[0] = (uint32_t *) p; p += wf_align((size_t) N * 4);
+    W.queue[1] = (uint32_t *) p; p += wf_align((size_t) N * 4);
+    W.shadow_queue = (uint32_t *) p; p += wf_align((size_t) N * 4);
+    W.stack_ovf = (uint32_t *) p;
+    W.N = N;
+    return W;
+}
+
+EPSM_HD void wf_store(const WfState &W, int64_t i, const PathState &s, int done) {
+    W.ray_o[i] = pack4(s.ray.o, s.ray.maxt);
+    W.ray_d[i] = pack4(s.ray.d, s.eta);
+    W.beta[i] = pack4(s.beta, s.prev_bsdf_pdf);
+    W.L[i] = pack4u(s.L, (uint32_t) s.depth | (s.prev_bsdf_delta ? 0x100u : 0u) | ((uint32_t) done << 16));
+    W.prev_p[i] = pack4(s.prev_p, 0.f);
+    W4 r; r.x = (uint32_t) s.rng.state; r.y = (uint32_t) (s.rng.state >> 32); r.z = (uint32_t) s.rng.inc; r.w = (uint32_t) (s.rng.inc >> 32);
+    W.rng[i] = r;
+}
+EPSM_HD PathState wf_load(const WfState &W, int64_t i) {
+    PathState s;
+    const W4 o = W.ray_o[i], d = W.ray_d[i], b = W.beta[i], l = W.L[i], r = W.rng[i];
+    s.ray.o = xyz(o); s.ray.maxt = u2f(o.w);
+    s.ray.d = xyz(d); s.eta = u2f(d.w);
+    s.beta = xyz(b); s.prev_bsdf_pdf = u2f(b.w);
+    s.L = xyz(l); s.depth = (int) (l.w & 0xFFu); s.prev_bsdf_delta = (l.w & 0x100u) != 0;
+    s.prev_p = xyz(W.prev_p[i]);
+    s.rng.state = (uint64_t) r.x | ((uint64_t) r.y << 32); s.rng.inc = (uint64_t) r.z | ((uint64_t) r.w << 32);
+    s.active = true;                                                     // only live paths are queued
+    return s;
+}
+
+// ---- stage: generate (sample_rays).  Every path is alive into bounce 0, the queue of bounce 0 is the identity.
+EPSM_HD void wf_generate(const TraceArgs &A, const WfState &W, int64_t i) {
+    const PathState s = path_begin(A, i);
+    wf_store(W, i, s, 0);
+}
+
+// ---- stage: extend.  Closest hit of path i's ray, as a resumable job (begin, traversal rounds until done).
+struct WfJob {
+    int64_t i;
+    int phase;                     // shadow stage: 0 = visibility (any hit), 1 = occluder record (closest hit)
+    Traversal T;
+};
+EPSM_HD void wf_extend_begin(const TraceArgs &A, const WfState &W, int64_t i, WfJob &J) {
+    const W4 o = W.ray_o[i], d = W.ray_d[i];
+    Ray r; r.o = xyz(o); r.maxt = u2f(o.w); r.d = xyz(d);
+    J.i = i; J.phase = 0;
+    trav_begin(J.T, A.S, r);
+}
+// one round; true when the job is finished (its result is written)
+EPSM_HD bool wf_extend_round(const TraceArgs &A, const WfState &W, WfJob &J, uint32_t *lds, int stride) {
+    if (!trav_done(J.T)) trav_round<false>(J.T, A.S, wf_stack(W, J.i, lds, stride));
+    if (!trav_done(J.T)) return false;
+    const TriHit th = trav_result(J.T, A.S);
+    W4 h; h.x = th.hit ? th.tri : kNoIndex; h.y = f2u(th.t); h.z = f2u(th.u); h.w = f2u(th.v);
+    W.hit[J.i] = h;
+    return true;
+}
+EPSM_HD void wf_extend(const TraceArgs &A, const WfState &W, int64_t i, uint32_t *lds, int stride) {
+    WfJob J;
+    wf_extend_begin(A, W, i, J);
+    while (!wf_extend_round(A, W, J, lds, stride)) {}
+}
+
+// Visibility policy of the shade stage: nothing is traced, the questions are written down for the shadow stage.
+struct DeferredVis {
+    bool pending, want_occluder;
+    Ray sr;
+    F3 Lr;
+    EPSM_HD bool occluded(const EpsmScene &, const Ray &r) { pending = true; sr = r; return false; }   // optimistic
+    EPSM_HD void direct(F3 &L, F3 Le, F3 Lr_dir) { L = L + Le; Lr = Lr_dir; }                           // + Lr_dir if visible
+    EPSM_HD void occluder(const TraceArgs &A, int64_t i, const SurfHit &, const EmitterSample &, bool active_em) {
+        if (A.max_depth <= 3 && active_em) want_occluder = true;         // active_em => the visibility ray is pending too
+        else write_no_occluder(A.rec[0].shadow + 8 * i);
+    }
+};
+
+// ---- stage: shade.  Returns through `alive` / `shadow` whether path i goes on to bounce `iteration + 1` / has a
+//      visibility ray pending; the caller compacts.
+EPSM_HD void wf_shade(const TraceArgs &A, const WfState &W, int64_t i, int iteration, bool &alive, bool &shadow) {
+    PathState s = wf_load(W, i);
+    const W4 h = W.hit[i];
+    TriHit th; th.hit = h.x != kNoIndex; th.tri = th.hit ? h.x : 0u; th.t = u2f(h.y); th.u = u2f(h.z); th.v = u2f(h.w);
+    DeferredVis vis; vis.pending = false; vis.want_occluder = false; vis.Lr = zero3<float>();
+    vis.sr.o = vis.sr.d = zero3<float>(); vis.sr.maxt = 0.f;
+    path_bounce(A, i, iteration, s, th, vis);
+    wf_store(W, i, s, iteration + 1);
+    if (vis.pending) {
+        W.sh_o[i] = pack4(vis.sr.o, vis.sr.maxt);
+        W.sh_d[i] = pack4u(vis.sr.d, vis.want_occluder ? kWfOccluder : 0u);
+        W.sh_L[i] = pack4(vis.Lr, 0.f);
+    }
+    alive = s.active && iteration + 1 < path_max_depth(A);
+    shadow = vis.pending;
+}
+
+// ---- stage: shadow.  The visibility ray of path i's emitter sample at bounce `iteration` (any hit), then -- when the
+//      shade stage asked for it -- the occluder record of the first vertex (closest hit); a resumable job like extend.
+EPSM_HD void wf_shadow_begin(const TraceArgs &A, const WfState &W, int64_t i, WfJob &J) {
+    const W4 o = W.sh_o[i], d = W.sh_d[i];
+    Ray sr; sr.o = xyz(o); sr.maxt = u2f(o.w); sr.d = xyz(d);
+    J.i = i; J.phase = 0;
+    trav_begin(J.T, A.S, sr);
+}
+EPSM_HD bool wf_shadow_round(const TraceArgs &A, const WfState &W, int iteration, WfJob &J, uint32_t *lds, int stride) {
+    const BvhStack st = wf_stack(W, J.i, lds, stride);
+    const int64_t i = J.i;
+    if (J.phase == 0) {
+        if (!trav_done(J.T)) trav_round<true>(J.T, A.S, st);
+        if (!trav_done(J.T)) return false;
+        if (J.T.best.hit) {                                              // occluded
+            if (iteration < A.K_log) A.rec[iteration].emit[8 * i + 5] = 0u;   // Lr_dir = 0: the logged weight with it
+        } else {
+            const W4 l = W.L[i];
+            const F3 L = xyz(l) + xyz(W.sh_L[i]);                        // (L + Le) + Lr_dir, epsm.py:658
+            W.L[i] = pack4u(L, l.w);
+        }
+        if (!(W.sh_d[i].w & kWfOccluder)) return true;
+        // iteration 0, max_depth <= 3, K_log > 0: si.p is the path's prev_p by now, ds.p was logged as the vertex's
+        // light point; ds.d as in sample_emitter_direction, the origin of spawn_ray(si, ds.d) is that of the visibility ray
+        const F3 sip = xyz(W.prev_p[i]), esp = ld3(A.rec[0].light + 3 * i);
+        const F3 dd = esp - sip;
+        const float dist = sqrtf(dot(dd, dd));
+        Ray r2; r2.o = xyz(W.sh_o[i]); r2.d = dd * (1.f / dist); r2.maxt = kInf;
+        J.phase = 1;
+        trav_begin(J.T, A.S, r2);
+        return false;
+    }
+    if (!trav_done(J.T)) trav_round<false>(J.T, A.S, st);
+    if (!trav_done(J.T)) return false;
+    const F3 sip = xyz(W.prev_p[i]), esp = ld3(A.rec[0].light + 3 * i);
+    const F3 dd = esp - sip;
+    const float dist = sqrtf(dot(dd, dd));
+    Ray r2; r2.o = xyz(W.sh_o[i]); r2.d = dd * (1.f / dist); r2.maxt = kInf;
+    write_occluder(A.S, A.rec[0].shadow + 8 * i, r2, trav_result(J.T, A.S), sip, esp);
+    return true;
+}
+EPSM_HD void wf_shadow(const TraceArgs &A, const WfState &W, int64_t i, int iteration, uint32_t *lds, int stride) {
+    WfJob J;
+    wf_shadow_begin(A, W, i, J);
+    while (!wf_shadow_round(A, W, iteration, J, lds, stride)) {}
+}
+
+// A bounce the path never reached: what path_bounce logs for a masked lane (epsm.py:551: inactive zeros).
+EPSM_HD void write_dead_record(const EpsmRecordOut &R, int64_t i) {
+    const F3 z = zero3<float>();
+    st3(R.p0, i, z); st3(R.p1, i, z); st3(R.p2, i, z); st3(R.p, i, z);
+    st3(R.n0, i, z); st3(R.n1, i, z); st3(R.n2, i, z); st3(R.normal, i, z);
+    R.b0[i] = 0.f; R.b1[i] = 0.f; R.eta[i] = 0.f;
+    st3(R.hf, i, z); st3(R.light, i, z);
+    R.bsdf[i] = 0u;
+    R.active[i] = 0; R.active_em[i] = 0; R.ismesh[i] = 0;
+    uint32_t *t = R.tri + 4 * i; t[0] = t[1] = t[2] = kNoIndex; t[3] = 0u;
+    uint32_t *a = R.aux + 4 * i; a[0] = kNoIndex; a[1] = a[2] = a[3] = 0u;
+    uint32_t *e = R.emit + 8 * i; e[0] = e[1] = e[2] = kNoIndex; e[3] = e[4] = e[5] = e[6] = e[7] = 0u;
+}
+
+// ---- stage: finish.  radiance / valid of path i and the records of the bounces it did not reach.
+EPSM_HD void wf_finish(const TraceArgs &A, const WfState &W, int64_t i) {
+    const W4 l = W.L[i];
+    st3(A.radiance, i, xyz(l));
+    if (A.valid) A.valid[i] = (l.w & 0xFFu) != 0;
+    const int done = (int) (l.w >> 16);
+    for (int k = done; k < A.K_log; ++k) write_dead_record(A.rec[k], i);
+}
+
+}  // namespace epsm

@@ -420,6 +420,11 @@ class Scene:
         # test hook: tests/host_harness compiles the tracer's per-path code for the CPU and plugs
         # its entry points in here; the product path (None) is the HIP library and needs a GPU
         self._backend = None
+        # "mega": one launch, a lane carries its path through all bounces; "wavefront": queues of live paths,
+        # three kernels per bounce; "auto": wavefront from WAVEFRONT_MIN_TRIANGLES triangles on (where the
+        # one-launch form is bound by divergence; below, the wavefront's state traffic costs more than it saves)
+        self.tracer = "auto"
+        self._wf_workspace = None
         self._upload()
 
     # -- construction from the reference's dict shape ---------------------------------------
@@ -640,6 +645,13 @@ class Scene:
         self.c_scene = s
 
     # -- tracing ---------------------------------------------------------------------------------
+    WAVEFRONT_MIN_TRIANGLES = 20000
+
+    def use_wavefront(self) -> bool:
+        if self.tracer not in ("auto", "mega", "wavefront"):
+            raise ValueError("Scene.tracer must be 'auto', 'mega' or 'wavefront'")
+        return self.tracer == "wavefront" or (self.tracer == "auto" and self.T >= self.WAVEFRONT_MIN_TRIANGLES)
+
     def _trace(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int,
                want_radiance: bool = True):
         from .integrators import PathTrace
@@ -683,12 +695,20 @@ class Scene:
                          "eta": t["eta"], "hf": t["hf"]})
             sinfo.append({"tri": t["tri"], "aux": t["aux"] if self.alpha_slots else None, "emit": t["emit"], "shadow": shadow})
         cs = sensor.c_struct()
-        rc = lib.epsm_trace_paths(
-            C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
-            C.c_int64(lo), C.c_int64(n), K, C.c_void_p(ray[0].data_ptr()), C.c_void_p(ray[1].data_ptr()),
-            C.c_void_p(ray[2].data_ptr()), C.c_void_p(ray[3].data_ptr()),
-            C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()), C.c_void_p(valid.data_ptr()),
-            C.c_void_p(C.addressof(recs)), C.c_void_p(stream))
+        args = [C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
+                C.c_int64(lo), C.c_int64(n), K, C.c_void_p(ray[0].data_ptr()), C.c_void_p(ray[1].data_ptr()),
+                C.c_void_p(ray[2].data_ptr()), C.c_void_p(ray[3].data_ptr()),
+                C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()), C.c_void_p(valid.data_ptr()),
+                C.c_void_p(C.addressof(recs))]
+        if self.use_wavefront() and n > 0:
+            # queues of live paths, three small kernels per bounce (include/epsm_trace.h); the workspace is scratch
+            # and is kept between calls
+            need = int(lib.epsm_trace_workspace_bytes(C.c_int64(n)))
+            if self._wf_workspace is None or self._wf_workspace.numel() < need:
+                self._wf_workspace = torch.empty(need, device=dev, dtype=torch.uint8)
+            rc = lib.epsm_trace_paths_wavefront(*args, C.c_void_p(self._wf_workspace.data_ptr()), C.c_size_t(need), C.c_void_p(stream))
+        else:
+            rc = lib.epsm_trace_paths(*args, C.c_void_p(stream))
         if rc != 0:
             _lib.check(rc, "epsm_trace_paths") if self._backend is None else (_ for _ in ()).throw(RuntimeError(f"host tracer rc={rc}"))
         tr = PathTrace(res=sensor.width, spp=spp, ray_o=ray[0], ray_d=ray[1], ray_dx=ray[2], ray_dy=ray[3],

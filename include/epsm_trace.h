@@ -136,6 +136,26 @@ int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor,
                      float *film_pos, float *radiance, uint8_t *valid,
                      const EpsmRecordOut *recs, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * epsm_trace_paths_wavefront -- the same function (same arguments, same per-path results) run as a
+ *   wavefront of stages with compaction between the bounces: per bounce one closest-hit kernel, one
+ *   shading kernel (the loop body of epsm.py:551-735) and one shadow-ray kernel over QUEUES of the
+ *   paths that are still alive, then one pass that writes radiance / valid and the inactive-zero
+ *   records of the bounces a path never reached.  Pays on scenes with many triangles, where the
+ *   one-launch form is bound by divergence (dead lanes, mixed closest-hit / shadow traversals) and by
+ *   the occupancy its register count allows; costs 172 B/path/bounce of state traffic, so small scenes
+ *   are faster in one launch.
+ *   workspace        device memory, 16-byte aligned, >= epsm_trace_workspace_bytes(N); contents are
+ *                    scratch (no state is kept between calls)
+ * ------------------------------------------------------------------------- */
+size_t epsm_trace_workspace_bytes(int64_t N);
+int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSensor *sensor,
+                               uint32_t seed, int spp, int max_depth, int rr_depth,
+                               int64_t path_offset, int64_t N, int K_log,
+                               float *ray_o, float *ray_d, float *ray_dx, float *ray_dy,
+                               float *film_pos, float *radiance, uint8_t *valid,
+                               const EpsmRecordOut *recs, void *workspace, size_t workspace_bytes, void *stream);
+
 /* epsm_film_splat -- ImageBlock::put + weight division (film.develop): accumulates
  * radiance with the reconstruction filter into accum (height,width,4) [r,g,b,w] (atomics);
  * epsm_film_develop divides into image (height,width,3). */

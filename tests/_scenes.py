@@ -17,13 +17,16 @@ def host_tracer():
     global _lib
     if _lib is None:
         src = os.path.join(_DIR, "trace_host.cpp")
-        hdr = os.path.join(_DIR, "..", "..", "epsm_mitsuba3_amd", "csrc", "epsm_trace_core.h")
-        if (not os.path.isfile(_SO)) or any(os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr)):
+        csrc = os.path.join(_DIR, "..", "..", "epsm_mitsuba3_amd", "csrc")
+        hdrs = [os.path.join(csrc, h) for h in ("epsm_trace_core.h", "epsm_trace_wavefront.h")]
+        if (not os.path.isfile(_SO)) or any(os.path.getmtime(p) > os.path.getmtime(_SO) for p in [src] + hdrs):
             subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wno-unknown-pragmas",
                             "-ffp-contract=off", "-o", _SO, src], check=True)
         _lib = C.CDLL(_SO)
-        for n in ("epsm_trace_paths", "epsm_film_splat", "epsm_film_develop"):
+        for n in ("epsm_trace_paths", "epsm_trace_paths_wavefront", "epsm_film_splat", "epsm_film_develop"):
             getattr(_lib, n).restype = C.c_int
+        _lib.epsm_trace_workspace_bytes.restype = C.c_size_t
+        _lib.epsm_trace_workspace_bytes.argtypes = [C.c_int64]
     return _lib
 
 

@@ -4,6 +4,7 @@
 #include <math.h>
 #include <string.h>
 #include "../../epsm_mitsuba3_amd/csrc/epsm_trace_core.h"
+#include "../../epsm_mitsuba3_amd/csrc/epsm_trace_wavefront.h"
 
 using namespace epsm;
 
@@ -24,6 +25,42 @@ extern "C" int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor
         uint32_t stack[kBvhStack];
         trace_one_path(A, i, BvhStack{stack, 1});
     }
+    return 0;
+}
+
+// The wavefront form, stage by stage as the device launches them (serial loops in place of the kernels; the queues
+// are appended in path order here, on the device in the order the waves arrive -- per-path results do not depend on it).
+extern "C" size_t epsm_trace_workspace_bytes(int64_t N) { return N > 0 ? wf_workspace_bytes(N) : 0; }
+extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSensor *sensor, uint32_t seed, int spp, int max_depth,
+                                          int rr_depth, int64_t path_offset, int64_t N, int K_log, float *ray_o, float *ray_d,
+                                          float *ray_dx, float *ray_dy, float *film_pos, float *radiance, uint8_t *valid,
+                                          const EpsmRecordOut *recs, void *workspace, size_t workspace_bytes, void *) {
+    if (!workspace || workspace_bytes < wf_workspace_bytes(N)) return -22;
+    TraceArgs A;
+    memset(&A, 0, sizeof(A));
+    A.S = *scene; A.C = *sensor;
+    A.seed = seed; A.spp = spp; A.max_depth = max_depth; A.rr_depth = rr_depth; A.K_log = K_log;
+    A.path_offset = path_offset; A.N = N;
+    A.ray_o = ray_o; A.ray_d = ray_d; A.ray_dx = ray_dx; A.ray_dy = ray_dy;
+    A.film_pos = film_pos; A.radiance = radiance; A.valid = valid;
+    for (int k = 0; k < K_log; ++k) A.rec[k] = recs[k];
+    const WfState W = wf_carve(workspace, N);
+    memset(W.counters, 0, kWfCounters * sizeof(uint32_t));
+    uint32_t stack[kWfStackLds];
+    for (int64_t i = 0; i < N; ++i) wf_generate(A, W, i);
+    for (int b = 0; b < path_max_depth(A); ++b) {
+        const int64_t count = b == 0 ? N : (int64_t) W.counters[b];
+        for (int64_t q = 0; q < count; ++q) wf_extend(A, W, b == 0 ? q : (int64_t) W.queue[b & 1][q], stack, 1);
+        for (int64_t q = 0; q < count; ++q) {
+            const int64_t i = b == 0 ? q : (int64_t) W.queue[b & 1][q];
+            bool alive, shadow;
+            wf_shade(A, W, i, b, alive, shadow);
+            if (alive) W.queue[(b + 1) & 1][W.counters[b + 1]++] = (uint32_t) i;
+            if (shadow) W.shadow_queue[W.counters[8 + b]++] = (uint32_t) i;
+        }
+        for (int64_t q = 0; q < (int64_t) W.counters[8 + b]; ++q) wf_shadow(A, W, (int64_t) W.shadow_queue[q], b, stack, 1);
+    }
+    for (int64_t i = 0; i < N; ++i) wf_finish(A, W, i);
     return 0;
 }
 

@@ -1,0 +1,116 @@
+"""The wavefront form of the tracer (epsm_trace_wavefront.h: queues of live paths, extend / shade / shadow stages,
+finish pass) against the one-launch form, both on the host build of tests/host_harness: every output array must be
+IDENTICAL, bit for bit -- the per-path arithmetic is the same code, only the order of visiting paths differs."""
+import numpy as np
+import pytest
+import torch
+
+from _scenes import floor_and_light, on_host, quad, sensor
+from epsm_mitsuba3_amd import scene as S
+
+
+def _rich_scene(res=12, spp=8, point_light=False, occluder=False, device="cpu"):
+    """Rough-conductor sphere-ish blob + glass slab + diffuse floor under an area light (and a point light): every
+    BSDF branch, emitter hits after delta / smooth bounces, shadow rays that are blocked and that are not."""
+    fv, ff = quad(0.0, 3.0, up=True)
+    lv, lf = quad(3.0, 0.4, up=False)
+    gv, gf = quad(0.8, 0.7, up=True)
+    g2v, g2f = quad(0.6, 0.7, up=False)
+    pv, pf = quad(0.3, 0.5, up=True)
+    pv = (S.rotate([1, 0, 0], 12.0)[:3, :3] @ pv.T).T + np.array([0.9, 0.2, 0.0])
+    glass = {"type": "dielectric", "int_ior": 1.5, "ext_ior": 1.0}
+    d = {"type": "scene", "cam": sensor([0.3, -3.0, 2.2], [0, 0, 0.3], up=(0, 0, 1), res=res, spp=spp, rfilter="gaussian"),
+         "floor": {"type": "mesh", "vertices": fv, "faces": ff, "face_normals": True,
+                   "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.7, 0.5, 0.3]}}},
+         "top": {"type": "mesh", "vertices": gv - np.array([0.8, 0, 0]), "faces": gf, "face_normals": True, "bsdf": glass},
+         "bottom": {"type": "mesh", "vertices": g2v - np.array([0.8, 0, 0]), "faces": g2f, "face_normals": True, "bsdf": glass},
+         "plate": {"type": "mesh", "vertices": pv, "faces": pf,
+                   "bsdf": {"type": "roughconductor", "material": "Al", "distribution": "ggx", "alpha": 0.15}},
+         "light": {"type": "mesh", "vertices": lv, "faces": lf, "face_normals": True,
+                   "emitter": {"type": "area", "radiance": {"type": "rgb", "value": 25.0}}}}
+    if point_light:
+        d["pl"] = {"type": "point", "position": [1.5, -1.0, 2.5], "intensity": {"type": "rgb", "value": 8.0}}
+    if occluder:
+        ov, of = quad(1.5, 0.5, up=True)
+        d["occ"] = {"type": "mesh", "vertices": ov, "faces": of, "face_normals": True,
+                    "bsdf": {"type": "twosided", "bsdf": {"type": "diffuse"}}}
+    sc = S.Scene.from_dict(d, device=device)
+    if str(device) == "cpu":
+        on_host(sc)
+    sc.attach("plate", positions=True, normals=True)
+    sc.attach_alpha("plate.bsdf")
+    return sc
+
+
+def _all_arrays(tr):
+    out = {"ray_o": tr.ray_o, "ray_d": tr.ray_d, "ray_dx": tr.ray_dx, "ray_dy": tr.ray_dy, "film_pos": tr.film_pos,
+           "radiance": tr.radiance, "valid": tr.valid}
+    for k, rec in enumerate(tr.path_info[1:]):
+        for name, v in rec.items():
+            if isinstance(v, torch.Tensor):
+                out[f"v{k}.{name}"] = v
+            elif isinstance(v, (list, tuple)):
+                for j, x in enumerate(v):
+                    out[f"v{k}.{name}{j}"] = x
+    for k, rec in enumerate(tr.scatter_info):
+        for name, v in rec.items():
+            if v is not None:
+                out[f"s{k}.{name}"] = v
+    return out
+
+
+def _same(a, b):
+    x, y = _all_arrays(a), _all_arrays(b)
+    assert x.keys() == y.keys()
+    for name in x:
+        xa, ya = x[name].contiguous().view(torch.uint8), y[name].contiguous().view(torch.uint8)
+        assert torch.equal(xa, ya), name                        # bit for bit (NaN-safe)
+
+
+@pytest.mark.parametrize("max_depth,K,point_light,occluder", [
+    (6, 5, False, False), (4, 3, True, False), (3, 2, False, True), (2, 2, True, True), (1, 1, False, False), (5, 0, True, False)])
+def test_wavefront_equals_one_launch(max_depth, K, point_light, occluder):
+    res, spp = 12, 8
+    sc = _rich_scene(res, spp, point_light, occluder)
+    n = res * res * spp
+    sc.tracer = "mega"
+    a = sc._trace(0, seed=5, spp=spp, max_depth=max_depth, K=K, lo=0, hi=n)
+    sc.tracer = "wavefront"
+    b = sc._trace(0, seed=5, spp=spp, max_depth=max_depth, K=K, lo=0, hi=n)
+    _same(a, b)
+    if K >= 2 and max_depth >= 3:
+        v1, v2 = a.path_info[1], a.path_info[2]
+        assert 0 < int((v2["active"] > 0).sum()) < int((v1["active"] > 0).sum()) <= n      # paths die on the way: compaction is exercised
+    if K > 0 and 2 <= max_depth <= 3:                              # (max_depth 1: no emitter sampling at all)
+        sh = a.scatter_info[0]["shadow"]
+        assert sh is not None and int((sh[:, 0] != -1).sum()) > 0                           # occluder records exist
+
+
+def test_wavefront_on_a_sub_range_and_ragged_tile():
+    """path_offset > 0 and a path count that is no multiple of anything."""
+    sc = _rich_scene(10, 4)
+    lo, hi = 37, 10 * 10 * 4 - 13
+    sc.tracer = "mega"
+    a = sc._trace(0, seed=9, spp=4, max_depth=4, K=4, lo=lo, hi=hi)
+    sc.tracer = "wavefront"
+    b = sc._trace(0, seed=9, spp=4, max_depth=4, K=4, lo=lo, hi=hi)
+    _same(a, b)
+
+
+def test_primal_image_is_the_same():
+    sc = _rich_scene(16, 8, point_light=True)
+    sc.tracer = "mega"
+    a = sc.render_primal(sensor=0, seed=1, spp=8, max_depth=5)
+    sc.tracer = "wavefront"
+    b = sc.render_primal(sensor=0, seed=1, spp=8, max_depth=5)
+    assert torch.equal(a, b) and float(a.max()) > 0
+
+
+def test_auto_picks_the_wavefront_for_large_scenes():
+    sc = floor_and_light()
+    assert sc.tracer == "auto" and not sc.use_wavefront()
+    sc.WAVEFRONT_MIN_TRIANGLES = 2
+    assert sc.use_wavefront()
+    sc.tracer = "nope"
+    with pytest.raises(ValueError):
+        sc.use_wavefront()

@@ -41,7 +41,10 @@ if dev == "cuda":
             torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize(); out.append((time.perf_counter() - t) * 1e3)
         return sorted(out)[n // 2]
     N = 512 * 512 * 16
-    ms = timed(lambda: sc.render_primal(sensor=0, seed=0, spp=16, max_depth=4))
-    print(f"primal 512x512@16 ({N} paths): {ms:.2f} ms = {N/ms/1e3:.1f} Mpaths/s")
-    ms = timed(lambda: sc.trace_paths(sensor=0, seed=0, spp=16, max_depth=4))
-    print(f"trace+log: {ms:.2f} ms = {N/ms/1e3:.1f} Mpaths/s")
+    sc.tile_paths = int(sys.argv[2]) if len(sys.argv) > 2 else sc.tile_paths
+    for mode in ("mega", "wavefront"):
+        sc.tracer = mode
+        ms = timed(lambda: sc.render_primal(sensor=0, seed=0, spp=16, max_depth=4))
+        print(f"[{mode}] primal 512x512@16 ({N} paths, tiles of {sc.tile_paths}): {ms:.2f} ms = {N/ms/1e3:.1f} Mpaths/s")
+        ms = timed(lambda: sc.trace_paths(sensor=0, seed=0, spp=16, max_depth=4))
+        print(f"[{mode}] trace+log: {ms:.2f} ms = {N/ms/1e3:.1f} Mpaths/s")
