@@ -22,17 +22,6 @@ __global__ __launch_bounds__(128) void epsm_trace_kernel(TraceArgs A) {
 constexpr int kWfThreads = 128;                         // traversal kernels
 constexpr int kWfMaxBlocks = 16384;
 
-// Appends the lanes with `pred` to a queue: ballot + prefix count over the wave, ONE atomic per wave.
-__device__ __forceinline__ void wf_enqueue(bool pred, uint32_t *queue, uint32_t *counter, uint32_t i) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0ull) return;
-    const int lane = (int) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int leader = __ffsll((long long) m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t) __popcll(m));
-    base = (uint32_t) __shfl((int) base, leader);
-    if (pred) queue[base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = i;
-}
 __device__ __forceinline__ int64_t wf_count(const TraceArgs &A, const WfState &W, int b) {
     return b == 0 ? A.N : (int64_t) W.counters[b];
 }
@@ -49,15 +38,71 @@ __global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_kernel(TraceArgs A,
     for (int64_t q = (int64_t) blockIdx.x * kWfThreads + threadIdx.x; q < count; q += (int64_t) gridDim.x * kWfThreads)
         wf_extend(A, W, b == 0 ? q : (int64_t) W.queue[b & 1][q], s_stack + threadIdx.x, kWfThreads);
 }
-// (160 registers, 3 waves per SIMD; capped at 128 for 4 waves it spills 96 B/lane and is no faster)
-__global__ __launch_bounds__(256) void epsm_wf_shade_kernel(TraceArgs A, WfState W, int b) {
-    const int64_t count = wf_count(A, W, b);
-    for (int64_t q = (int64_t) blockIdx.x * 256 + threadIdx.x; q < count; q += (int64_t) gridDim.x * 256) {
-        const int64_t i = b == 0 ? q : (int64_t) W.queue[b & 1][q];
-        bool alive, shadow;
-        wf_shade(A, W, i, b, alive, shadow);
-        wf_enqueue(alive, W.queue[(b + 1) & 1], W.counters + b + 1, (uint32_t) i);
-        wf_enqueue(shadow, W.shadow_queue, W.counters + 8 + b, (uint32_t) i);
+// (160 registers, 3 waves per SIMD; capped at 128 for 4 waves it spills 96 B/lane and is no faster.)
+// One 256-slot chunk of the queue per workgroup.  Appending the survivors to the next queue with one atomic per
+// wave on the queue's counter made this kernel 1.23 ms at 4.2 M paths whatever it computed (knock-outs: the log
+// writes cost nothing, each of the two queues 0.6 ms: 65 536 same-address atomics, ~9 ns apiece at the memory
+// side); it leaves a flag per slot and two counts per chunk instead.
+__global__ __launch_bounds__(kWfChunk) void epsm_wf_shade_kernel(TraceArgs A, WfState W, int b) {
+    const int64_t count = wf_count(A, W, b), q = (int64_t) blockIdx.x * kWfChunk + threadIdx.x;
+    if ((int64_t) blockIdx.x * kWfChunk >= count) return;           // workgroup-uniform
+    bool alive = false, shadow = false;
+    if (q < count) {
+        wf_shade(A, W, b == 0 ? q : (int64_t) W.queue[b & 1][q], b, alive, shadow);
+        W.flags[q] = (uint8_t) ((alive ? kWfAlive : 0) | (shadow ? kWfShadow : 0));
+    }
+    __shared__ uint32_t s_n[2][kWfChunk / 64];
+    const unsigned long long ma = __ballot(alive), ms = __ballot(shadow);
+    if ((threadIdx.x & 63) == 0) { s_n[0][threadIdx.x >> 6] = (uint32_t) __popcll(ma); s_n[1][threadIdx.x >> 6] = (uint32_t) __popcll(ms); }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        W.chunk_counts[threadIdx.x * W.chunks + blockIdx.x] = s_n[threadIdx.x][0] + s_n[threadIdx.x][1] + s_n[threadIdx.x][2] + s_n[threadIdx.x][3];
+}
+// Exclusive scan of the chunk counts of both queues (<= 65 536 chunks each at 2^24 paths), ONE workgroup: thread t
+// sums a strip, the strips' sums are scanned over the workgroup, the strip is rewritten as offsets.  Also
+// publishes the two queue lengths of the next stages.
+__global__ __launch_bounds__(1024) void epsm_wf_scan_kernel(TraceArgs A, WfState W, int b) {
+    const int64_t count = wf_count(A, W, b), n = (count + kWfChunk - 1) / kWfChunk;
+    const int64_t strip = (n + 1023) / 1024, lo = (int64_t) threadIdx.x * strip, hi = lo + strip < n ? lo + strip : n;
+    __shared__ uint32_t s_w[2][16];
+    uint32_t total[2];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        uint32_t *c = W.chunk_counts + which * W.chunks;
+        uint32_t sum = 0;
+        for (int64_t k = lo; k < hi; ++k) sum += c[k];
+        uint32_t inc = sum;                                       // inclusive scan over the wave, then over the 16 waves
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t) __shfl_up((int) inc, off); if ((int) (threadIdx.x & 63) >= off) inc += t; }
+        if ((threadIdx.x & 63) == 63) s_w[which][threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const uint32_t v = s_w[which][w]; if (w < (int) (threadIdx.x >> 6)) before += v; all += v; }
+        uint32_t run = before + inc - sum;
+        for (int64_t k = lo; k < hi; ++k) { const uint32_t v = c[k]; c[k] = run; run += v; }
+        total[which] = all;
+    }
+    if (threadIdx.x == 0) { W.counters[b + 1] = total[0]; W.counters[8 + b] = total[1]; }
+}
+// Writes the queue of bounce b + 1 and the shadow queue of bounce b, in path order (stable).
+__global__ __launch_bounds__(kWfChunk) void epsm_wf_compact_kernel(TraceArgs A, WfState W, int b) {
+    const int64_t count = wf_count(A, W, b), q = (int64_t) blockIdx.x * kWfChunk + threadIdx.x;
+    if ((int64_t) blockIdx.x * kWfChunk >= count) return;           // workgroup-uniform
+    const uint8_t f = q < count ? W.flags[q] : (uint8_t) 0;
+    const uint32_t i = q < count ? (b == 0 ? (uint32_t) q : W.queue[b & 1][q]) : 0u;
+    __shared__ uint32_t s_n[2][kWfChunk / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m[2] = {__ballot((f & kWfAlive) != 0), __ballot((f & kWfShadow) != 0)};
+    if (lane == 0) { s_n[0][wv] = (uint32_t) __popcll(m[0]); s_n[1][wv] = (uint32_t) __popcll(m[1]); }
+    __syncthreads();
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (!((f >> which) & 1)) continue;
+        uint32_t off = W.chunk_counts[which * W.chunks + blockIdx.x];
+        for (int w = 0; w < wv; ++w) off += s_n[which][w];
+        off += (uint32_t) __popcll(m[which] & ((1ull << lane) - 1ull));
+        (which == 0 ? W.queue[(b + 1) & 1] : W.shadow_queue)[off] = i;
     }
 }
 __global__ __launch_bounds__(kWfThreads) void epsm_wf_shadow_kernel(TraceArgs A, WfState W, int b) {
@@ -184,7 +229,7 @@ __global__ __launch_bounds__(256) void epsm_film_develop_kernel(int64_t n, const
 static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene, const EpsmSensor *sensor,
                            uint32_t seed, int spp, int max_depth, int rr_depth, int64_t path_offset, int64_t N, int K_log,
                            float *ray_o, float *ray_d, float *ray_dx, float *ray_dy, float *film_pos, float *radiance,
-                           uint8_t *valid, const EpsmRecordOut *recs) {
+                           uint8_t *valid, const EpsmRecordOut *recs, uint32_t flags) {
     char msg[200];
     auto bad = [&](const char *what) { snprintf(msg, sizeof(msg), "%s: %s", who, what); return fail(EPSM_EINVAL, msg); };
     if (!scene || !sensor) return bad("NULL scene / sensor");
@@ -199,7 +244,9 @@ static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene
                                    !scene->meshes || !scene->bsdfs || !scene->bvh || !scene->prim_index || !scene->tri_verts))
         return bad("NULL scene array");
     if (scene->n_emitters > 0 && !scene->emitters) return bad("NULL emitters");
+    if (flags & ~(uint32_t) EPSM_TRACE_SPARSE_LOG) return bad("unknown flag");
     memset(&A, 0, sizeof(A));
+    A.flags = flags;
     A.S = *scene; A.C = *sensor;
     A.seed = seed; A.spp = spp; A.max_depth = max_depth; A.rr_depth = rr_depth; A.K_log = K_log;
     A.path_offset = path_offset; A.N = N;
@@ -220,12 +267,12 @@ extern "C" int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor
                                 int64_t path_offset, int64_t N, int K_log,
                                 float *ray_o, float *ray_d, float *ray_dx, float *ray_dy,
                                 float *film_pos, float *radiance, uint8_t *valid,
-                                const EpsmRecordOut *recs, void *stream) {
+                                const EpsmRecordOut *recs, uint32_t flags, void *stream) {
     epsm_host::err_buf()[0] = 0;
     if (scene && sensor && N == 0) return EPSM_OK;
     TraceArgs A;
     const int rc = fill_trace_args(A, "epsm_trace_paths", scene, sensor, seed, spp, max_depth, rr_depth, path_offset, N, K_log,
-                                   ray_o, ray_d, ray_dx, ray_dy, film_pos, radiance, valid, recs);
+                                   ray_o, ray_d, ray_dx, ray_dy, film_pos, radiance, valid, recs, flags);
     if (rc != EPSM_OK) return rc;
     hipLaunchKernelGGL(epsm_trace_kernel, dim3((unsigned) ((N + 127) / 128)), dim3(128), 0, (hipStream_t) stream, A);
     hipError_t e = hipGetLastError();
@@ -240,12 +287,12 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
                                           int64_t path_offset, int64_t N, int K_log,
                                           float *ray_o, float *ray_d, float *ray_dx, float *ray_dy,
                                           float *film_pos, float *radiance, uint8_t *valid,
-                                          const EpsmRecordOut *recs, void *workspace, size_t workspace_bytes, void *stream) {
+                                          const EpsmRecordOut *recs, uint32_t flags, void *workspace, size_t workspace_bytes, void *stream) {
     epsm_host::err_buf()[0] = 0;
     if (scene && sensor && N == 0) return EPSM_OK;
     TraceArgs A;
     const int rc = fill_trace_args(A, "epsm_trace_paths_wavefront", scene, sensor, seed, spp, max_depth, rr_depth, path_offset,
-                                   N, K_log, ray_o, ray_d, ray_dx, ray_dy, film_pos, radiance, valid, recs);
+                                   N, K_log, ray_o, ray_d, ray_dx, ray_dy, film_pos, radiance, valid, recs, flags);
     if (rc != EPSM_OK) return rc;
     if (!workspace || (((uintptr_t) workspace) & 15) || workspace_bytes < wf_workspace_bytes(N))
         return fail(EPSM_EINVAL, "epsm_trace_paths_wavefront: workspace NULL, not 16-byte aligned or smaller than epsm_trace_workspace_bytes(N)");
@@ -257,11 +304,14 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
     auto blocks = [&](int threads) { const int64_t b = (N + threads - 1) / threads; return dim3((unsigned) (b < kWfMaxBlocks ? b : kWfMaxBlocks)); };
     hipLaunchKernelGGL(epsm_wf_generate_kernel, blocks(256), dim3(256), 0, s, A, W);
     const int depth = path_max_depth(A);
+    const dim3 chunks((unsigned) W.chunks);
     for (int b = 0; b < depth; ++b) {
         // the queue lengths of bounce b live on the device: every stage is launched for the worst case and its
         // surplus workgroups leave at once (no host round trip between the bounces)
         hipLaunchKernelGGL(epsm_wf_extend_kernel, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
-        hipLaunchKernelGGL(epsm_wf_shade_kernel, blocks(256), dim3(256), 0, s, A, W, b);
+        hipLaunchKernelGGL(epsm_wf_shade_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
+        hipLaunchKernelGGL(epsm_wf_scan_kernel, dim3(1), dim3(1024), 0, s, A, W, b);
+        hipLaunchKernelGGL(epsm_wf_compact_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_shadow_kernel, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
     }
     hipLaunchKernelGGL(epsm_wf_finish_kernel, blocks(256), dim3(256), 0, s, A, W);

@@ -607,7 +607,13 @@ EPSM_HD PrimaryRay sample_primary_ray(const EpsmSensor &C, int64_t wavefront_ind
 // ---------------------------------------------------------------------------
 // the path (epsm.py:503-742)
 // ---------------------------------------------------------------------------
-EPSM_HD void st3(float *base, int64_t i, F3 v) { if (base) { base[3 * i] = v.x; base[3 * i + 1] = v.y; base[3 * i + 2] = v.z; } }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(EPSM_TRACE_NT_STORES)
+// the log is written once and read by a later kernel: streaming stores
+template <class T> EPSM_HD void st1(T *p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T> EPSM_HD void st1(T *p, T v) { *p = v; }
+#endif
+EPSM_HD void st3(float *base, int64_t i, F3 v) { if (base) { st1(base + 3 * i, v.x); st1(base + 3 * i + 1, v.y); st1(base + 3 * i + 2, v.z); } }
 EPSM_HD uint32_t f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
 
 struct TraceArgs {
@@ -615,6 +621,7 @@ struct TraceArgs {
     EpsmSensor C;
     uint32_t seed;
     int spp, max_depth, rr_depth, K_log;
+    uint32_t flags;                  // EPSM_TRACE_*
     int64_t path_offset, N;
     float *ray_o, *ray_d, *ray_dx, *ray_dy, *film_pos, *radiance;
     uint8_t *valid;
@@ -628,20 +635,25 @@ EPSM_HD void write_record(const EpsmRecordOut &R, int64_t i, bool active, const 
     // analytic shapes leave the EPSM fields zero and ismesh = 0 (interaction.h:221-224 zero-initialised)
     st3(R.p0, i, mesh ? h.p0 : z); st3(R.p1, i, mesh ? h.p1 : z); st3(R.p2, i, mesh ? h.p2 : z); st3(R.p, i, h.p);
     st3(R.n0, i, mesh ? h.n0 : z); st3(R.n1, i, mesh ? h.n1 : z); st3(R.n2, i, mesh ? h.n2 : z); st3(R.normal, i, h.shn);
-    R.b0[i] = mesh ? h.b0 : 0.f; R.b1[i] = mesh ? h.b1 : 0.f;
-    R.eta[i] = bs.eta;
+    st1(R.b0 + i, mesh ? h.b0 : 0.f); st1(R.b1 + i, mesh ? h.b1 : 0.f);
+    st1(R.eta + i, bs.eta);
     st3(R.hf, i, bs.hf); st3(R.light, i, es.p);
-    R.bsdf[i] = flags;
-    R.active[i] = active ? 1 : 0; R.active_em[i] = active_em ? 1 : 0; R.ismesh[i] = mesh ? 1 : 0;
+    st1(R.bsdf + i, flags);
+    st1(R.active + i, (uint8_t) (active ? 1 : 0)); st1(R.active_em + i, (uint8_t) (active_em ? 1 : 0)); st1(R.ismesh + i, (uint8_t) (mesh ? 1 : 0));
     uint32_t *t = R.tri + 4 * i;
-    t[0] = mesh ? h.vi[0] : kNoIndex; t[1] = mesh ? h.vi[1] : kNoIndex; t[2] = mesh ? h.vi[2] : kNoIndex;
-    t[3] = h.mesh_flags & 0xFu;
+    st1(t, mesh ? h.vi[0] : kNoIndex); st1(t + 1, mesh ? h.vi[1] : kNoIndex); st1(t + 2, mesh ? h.vi[2] : kNoIndex);
+    st1(t + 3, h.mesh_flags & 0xFu);
     uint32_t *a = R.aux + 4 * i;
-    a[0] = alpha_slot >= 0 ? (uint32_t) alpha_slot : kNoIndex; a[1] = f2u(bs.dhf.x); a[2] = f2u(bs.dhf.y); a[3] = f2u(bs.dhf.z);
+    st1(a, alpha_slot >= 0 ? (uint32_t) alpha_slot : kNoIndex); st1(a + 1, f2u(bs.dhf.x)); st1(a + 2, f2u(bs.dhf.y)); st1(a + 3, f2u(bs.dhf.z));
     uint32_t *e = R.emit + 8 * i;
-    e[0] = es.vi[0]; e[1] = es.vi[1]; e[2] = es.vi[2]; e[3] = f2u(es.b0); e[4] = f2u(es.b1); e[5] = f2u(eweight); e[6] = 0; e[7] = 0;
+    st1(e, es.vi[0]); st1(e + 1, es.vi[1]); st1(e + 2, es.vi[2]); st1(e + 3, f2u(es.b0)); st1(e + 4, f2u(es.b1)); st1(e + 5, f2u(eweight)); st1(e + 6, 0u); st1(e + 7, 0u);
 }
 
+// EPSM_TRACE_SPARSE_LOG: a bounce the path did not reach leaves only the fields the gradient kernels' masks read
+EPSM_HD void write_dead_masks(const EpsmRecordOut &R, int64_t i) {
+    st1(R.bsdf + i, 0u);
+    st1(R.active + i, (uint8_t) 0); st1(R.active_em + i, (uint8_t) 0); st1(R.ismesh + i, (uint8_t) 0);
+}
 // Default record of the occluder term: "no occluder" (epsm.py:609-620 not taken)
 EPSM_HD void write_no_occluder(uint32_t *o) {
     o[0] = o[1] = o[2] = kNoIndex; o[3] = o[4] = o[5] = o[6] = o[7] = 0u;
@@ -738,9 +750,13 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
     const float s1 = s.rng.next_1d(), s2x = s.rng.next_1d(), s2y = s.rng.next_1d();
     const BsdfSample bs = bsdf_sample(bsdf, si.wi, s1, s2x, s2y, active_next);
     // ---- log (epsm.py:648-654)
-    if (iteration < A.K_log)
-        write_record(A.rec[iteration], i, s.active && si.valid, si, flags, es, active_em, bs,
-                     Lr_dir.x + Lr_dir.y + Lr_dir.z, bsdf.alpha_slot);
+    if (iteration < A.K_log) {
+        if (s.active || !(A.flags & EPSM_TRACE_SPARSE_LOG))
+            write_record(A.rec[iteration], i, s.active && si.valid, si, flags, es, active_em, bs,
+                         Lr_dir.x + Lr_dir.y + Lr_dir.z, bsdf.alpha_slot);
+        else
+            write_dead_masks(A.rec[iteration], i);
+    }
     // ---- update (epsm.py:658-683)
     if (s.active) vis.direct(s.L, Le, Lr_dir);
     const F3 wo_world = to_world(si, bs.wo);

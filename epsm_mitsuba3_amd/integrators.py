@@ -102,7 +102,8 @@ class EPSMIntegrator:
         rank, world = _dist.world()
         traces = scene.trace_paths(sensor=self.backward_sensor, seed=seed, spp=self.backward_spp,
                                    max_depth=min(self.max_depth, 6), max_log_depth=self.max_log_depth,
-                                   rank=rank, world_size=world)
+                                   rank=rank, world_size=world,
+                                   sparse_log=True)   # the log is consumed here and nowhere else: skip the zeros of dead bounces
         if isinstance(traces, PathTrace):
             traces = [traces]
         for trace in traces:                       # this rank's pixel/sample tiles

@@ -42,6 +42,9 @@ IOR = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "bk7": 1.5046, "glass": 
 
 
 # ---------------------------------------------------------------------------- ctypes mirrors
+EPSM_TRACE_SPARSE_LOG = 0x1          # include/epsm_trace.h
+
+
 class EpsmMesh(C.Structure):
     _fields_ = [("tri_begin", C.c_uint32), ("tri_count", C.c_uint32), ("flags", C.c_uint32), ("bsdf", C.c_int32),
                 ("emitter", C.c_int32), ("area", C.c_float), ("cdf_begin", C.c_uint32), ("pad", C.c_uint32)]
@@ -645,7 +648,8 @@ class Scene:
         self.c_scene = s
 
     # -- tracing ---------------------------------------------------------------------------------
-    WAVEFRONT_MIN_TRIANGLES = 20000
+    WAVEFRONT_MIN_TRIANGLES = 40000      # measured break-even on MI355X (38 k triangles: 3.9 ms either way per 4.2 M paths)
+    WAVEFRONT_TILE_PATHS = 1 << 22       # the wavefront form is 26 launches per tile: larger tiles when nothing is sharded
 
     def use_wavefront(self) -> bool:
         if self.tracer not in ("auto", "mega", "wavefront"):
@@ -653,7 +657,7 @@ class Scene:
         return self.tracer == "wavefront" or (self.tracer == "auto" and self.T >= self.WAVEFRONT_MIN_TRIANGLES)
 
     def _trace(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int,
-               want_radiance: bool = True):
+               want_radiance: bool = True, sparse_log: bool = False):
         from .integrators import PathTrace
         dev = self.device
         if dev.type != "cuda" and self._backend is None:
@@ -699,7 +703,7 @@ class Scene:
                 C.c_int64(lo), C.c_int64(n), K, C.c_void_p(ray[0].data_ptr()), C.c_void_p(ray[1].data_ptr()),
                 C.c_void_p(ray[2].data_ptr()), C.c_void_p(ray[3].data_ptr()),
                 C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()), C.c_void_p(valid.data_ptr()),
-                C.c_void_p(C.addressof(recs))]
+                C.c_void_p(C.addressof(recs)), C.c_uint32(EPSM_TRACE_SPARSE_LOG if sparse_log else 0)]
         if self.use_wavefront() and n > 0:
             # queues of live paths, three small kernels per bounce (include/epsm_trace.h); the workspace is scratch
             # and is kept between calls
@@ -717,16 +721,20 @@ class Scene:
         tr.film_pos, tr.radiance, tr.valid = film_pos, radiance, valid
         return tr
 
-    def trace_paths(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1):
-        """This rank's tiles of the backward wavefront of ``sensors[sensor]`` (epsm.py:142-181)."""
+    def trace_paths(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1, sparse_log=False):
+        """This rank's tiles of the backward wavefront of ``sensors[sensor]`` (epsm.py:142-181).  ``sparse_log``:
+        EPSM_TRACE_SPARSE_LOG -- bounces a path did not reach carry only their (zero) mask fields, which is all the
+        gradient kernels read of them; the other arrays are uninitialised there."""
         s = self.sensors[min(sensor, len(self.sensors) - 1)]
         if s.width != s.height:
             raise ValueError("the EPSM backward pass assumes a square film (epsm.py:239)")
         K = min(max_log_depth, max_depth, 5)
         n_total = s.width * s.height * spp
-        tiles = _dist.tile_ranges(n_total, self.tile_paths)
+        tile = max(self.tile_paths, self.WAVEFRONT_TILE_PATHS) if (world_size == 1 and self.use_wavefront()) else self.tile_paths
+        tiles = _dist.tile_ranges(n_total, tile)
         si = min(sensor, len(self.sensors) - 1)
-        return [self._trace(si, seed, spp, max_depth, K, *tiles[t]) for t in _dist.my_tiles(len(tiles), rank, world_size)]
+        return [self._trace(si, seed, spp, max_depth, K, *tiles[t], sparse_log=sparse_log)
+                for t in _dist.my_tiles(len(tiles), rank, world_size)]
 
     def render_primal(self, sensor=0, seed=0, spp=0, max_depth=6, rank=None, world_size=None) -> torch.Tensor:
         """(H,W,3) image: sample_rays + path tracing + film splat / develop (epsm.py:13-76).  With more than

@@ -38,8 +38,8 @@ class SyntheticScene:
         return PathTrace(res=self.res, spp=spp, ray_o=o, ray_d=d, ray_dx=dx, ray_dy=dy, path_info=pi,
                          scatter_info=si, path_offset=lo, n_paths_total=self.res * self.res * spp)
 
-    def trace_paths(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1
-                    ) -> List[PathTrace]:
+    def trace_paths(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1,
+                    sparse_log=False) -> List[PathTrace]:
         """This rank's tiles (round-robin over ranks) of the backward wavefront."""
         K = min(self.K, max_log_depth, max_depth)
         n_total = self.res * self.res * spp

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EPSM_ABI_VERSION 2
+#define EPSM_ABI_VERSION 3
 
 /* BSDF flag bits tested by the hot path (include/mitsuba/render/bsdf.h:40-46,101). */
 #define EPSM_BSDF_NULL     0x1u

@@ -44,6 +44,13 @@ enum { EPSM_DISTR_BECKMANN = 0, EPSM_DISTR_GGX = 1 };
 enum { EPSM_EMITTER_AREA = 0, EPSM_EMITTER_POINT = 1 };
 enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
 
+/* Tracer flags.
+ * EPSM_TRACE_SPARSE_LOG: for a bounce a path did NOT reach, only the four fields the gradient kernels' masks read
+ *   (bsdf = 0, active = active_em = ismesh = 0) are written; every other array keeps its previous contents at that
+ *   (path, bounce).  The reference logs masked lanes as zeros (epsm.py:551, 648-654) and so does the default; the
+ *   zeros are 203 B per dead (path, bounce) that epsm_manifold_grad / _scatter / epsm_backward_pass never read. */
+#define EPSM_TRACE_SPARSE_LOG 0x1u
+
 typedef struct EpsmMesh {
     uint32_t tri_begin, tri_count;   /* this mesh's range in the triangle arrays */
     uint32_t flags;                  /* EPSM_MESH_* */
@@ -128,13 +135,14 @@ typedef struct EpsmRecordOut {
  *   ray_o/d/dx/dy (N,3), film_pos (N,2), radiance (N,3), valid (N) u8: outputs (any may be NULL
  *                                    except ray_*); radiance = L of epsm.py:658, valid = depth != 0
  *   recs                             K_log records to fill (all fields written for every path)
+ *   flags                            0 or EPSM_TRACE_SPARSE_LOG
  * ------------------------------------------------------------------------- */
 int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor,
                      uint32_t seed, int spp, int max_depth, int rr_depth,
                      int64_t path_offset, int64_t N, int K_log,
                      float *ray_o, float *ray_d, float *ray_dx, float *ray_dy,
                      float *film_pos, float *radiance, uint8_t *valid,
-                     const EpsmRecordOut *recs, void *stream);
+                     const EpsmRecordOut *recs, uint32_t flags, void *stream);
 
 /* ---------------------------------------------------------------------------
  * epsm_trace_paths_wavefront -- the same function (same arguments, same per-path results) run as a
@@ -154,7 +162,7 @@ int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSensor *sensor,
                                int64_t path_offset, int64_t N, int K_log,
                                float *ray_o, float *ray_d, float *ray_dx, float *ray_dy,
                                float *film_pos, float *radiance, uint8_t *valid,
-                               const EpsmRecordOut *recs, void *workspace, size_t workspace_bytes, void *stream);
+                               const EpsmRecordOut *recs, uint32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 
 /* epsm_film_splat -- ImageBlock::put + weight division (film.develop): accumulates
  * radiance with the reconstruction filter into accum (height,width,4) [r,g,b,w] (atomics);

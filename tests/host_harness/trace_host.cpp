@@ -11,9 +11,10 @@ using namespace epsm;
 extern "C" int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor, uint32_t seed, int spp, int max_depth,
                                 int rr_depth, int64_t path_offset, int64_t N, int K_log, float *ray_o, float *ray_d,
                                 float *ray_dx, float *ray_dy, float *film_pos, float *radiance, uint8_t *valid,
-                                const EpsmRecordOut *recs, void *) {
+                                const EpsmRecordOut *recs, uint32_t flags, void *) {
     TraceArgs A;
     memset(&A, 0, sizeof(A));
+    A.flags = flags;
     A.S = *scene; A.C = *sensor;
     A.seed = seed; A.spp = spp; A.max_depth = max_depth; A.rr_depth = rr_depth; A.K_log = K_log;
     A.path_offset = path_offset; A.N = N;
@@ -34,10 +35,11 @@ extern "C" size_t epsm_trace_workspace_bytes(int64_t N) { return N > 0 ? wf_work
 extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSensor *sensor, uint32_t seed, int spp, int max_depth,
                                           int rr_depth, int64_t path_offset, int64_t N, int K_log, float *ray_o, float *ray_d,
                                           float *ray_dx, float *ray_dy, float *film_pos, float *radiance, uint8_t *valid,
-                                          const EpsmRecordOut *recs, void *workspace, size_t workspace_bytes, void *) {
+                                          const EpsmRecordOut *recs, uint32_t flags, void *workspace, size_t workspace_bytes, void *) {
     if (!workspace || workspace_bytes < wf_workspace_bytes(N)) return -22;
     TraceArgs A;
     memset(&A, 0, sizeof(A));
+    A.flags = flags;
     A.S = *scene; A.C = *sensor;
     A.seed = seed; A.spp = spp; A.max_depth = max_depth; A.rr_depth = rr_depth; A.K_log = K_log;
     A.path_offset = path_offset; A.N = N;

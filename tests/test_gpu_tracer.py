@@ -142,6 +142,43 @@ def test_wavefront_workspace_is_checked():
     assert sc._wf_workspace.numel() >= lib.epsm_trace_workspace_bytes(C.c_int64(500)) and bool(torch.isfinite(tr.radiance).all())
 
 
+@pytest.mark.parametrize("tracer", ["mega", "wavefront"])
+def test_sparse_log_gives_the_same_gradients(tracer):
+    """The backward pass on a sparse log (dead bounces carry only their mask fields, the rest of those rows is
+    whatever the allocator handed out -- here NaNs on purpose) equals the backward pass on the dense log."""
+    import epsm_mitsuba3_amd as epsm
+    from test_tracer_wavefront_host import _rich_scene
+    dev = torch.device("cuda", 0)
+    res, spp = 32, 16
+    sc = _rich_scene(res, spp, point_light=True, device=dev)
+    sc.attach("floor", positions=True)
+    sc.tracer = tracer
+    n = res * res * spp
+    g = torch.Generator().manual_seed(0)
+    grad_in = torch.zeros((res, res, 5)); grad_in[..., 3:] = torch.randn((res, res, 2), generator=g) * 1e-2
+    grad_in = grad_in.to(dev)
+    for variant in ("manifold", "manifold_caustic"):
+        integ = epsm.load_dict({"type": variant, "max_depth": 5})
+        dense = sc._trace(0, seed=2, spp=spp, max_depth=5, K=5, lo=0, hi=n)
+        pd = sc.param_grads()
+        integ.backward_from_trace(dense, pd, grad_in)
+        torch.cuda.synchronize()
+        poison = [torch.full((n * 64,), float("nan"), device=dev) for _ in range(8)]   # what torch.empty will hand out next
+        del poison
+        sparse = sc._trace(0, seed=2, spp=spp, max_depth=5, K=5, lo=0, hi=n, sparse_log=True)
+        ps = sc.param_grads()
+        integ.backward_from_trace(sparse, ps, grad_in)
+        torch.cuda.synchronize()
+        m = float(pd.flat.abs().max())
+        assert m > 0 and bool(torch.isfinite(ps.flat).all())
+        assert float((pd.flat - ps.flat).abs().max()) <= 1e-4 * m, variant
+        # two-stage route (calc_grad lists + scatter) on the sparse log as well
+        p2 = sc.param_grads()
+        epsm.load_dict({"type": variant, "max_depth": 5, "fused": False}).backward_from_trace(sparse, p2, grad_in)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(p2.flat).all()) and float((pd.flat - p2.flat).abs().max()) <= 1e-3 * m, variant
+
+
 @pytest.mark.parametrize("rfilter", [1, 0])                      # EPSM_RFILTER_GAUSSIAN, EPSM_RFILTER_BOX
 @pytest.mark.parametrize("res,spp,n_cut", [(24, 64, 0), (24, 128, 0), (32, 16, 0), (40, 8, 0), (33, 5, 0), (24, 64, 37), (16, 0, 0)])
 def test_film_splat_matches_host(res, spp, n_cut, rfilter):

@@ -114,3 +114,29 @@ def test_auto_picks_the_wavefront_for_large_scenes():
     sc.tracer = "nope"
     with pytest.raises(ValueError):
         sc.use_wavefront()
+
+
+@pytest.mark.parametrize("tracer", ["mega", "wavefront"])
+def test_sparse_log_keeps_everything_a_live_vertex_has(tracer):
+    """EPSM_TRACE_SPARSE_LOG: the mask fields are written for every (path, bounce) and equal the dense log's; every
+    other array equals the dense log wherever the vertex is live (what the gradient kernels read)."""
+    sc = _rich_scene(12, 8, point_light=True)
+    sc.tracer = tracer
+    n = 12 * 12 * 8
+    a = sc._trace(0, seed=5, spp=8, max_depth=5, K=4, lo=0, hi=n)
+    b = sc._trace(0, seed=5, spp=8, max_depth=5, K=4, lo=0, hi=n, sparse_log=True)
+    for name in ("ray_o", "ray_d", "ray_dx", "ray_dy", "film_pos", "radiance", "valid"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    dead_total = 0
+    for k in range(1, 5):
+        ra, rb = a.path_info[k], b.path_info[k]
+        for name in ("active", "active_em", "ismesh", "bsdf"):
+            assert torch.equal(ra[name], rb[name]), (k, name)
+        live = ra["active"] > 0
+        dead_total += int((~live).sum())
+        xa, xb = _all_arrays(a), _all_arrays(b)
+        for name in xa:
+            if name.startswith(f"v{k - 1}.") or name.startswith(f"s{k - 1}."):
+                u, v = xa[name][live], xb[name][live]
+                assert torch.equal(u.contiguous().view(torch.uint8), v.contiguous().view(torch.uint8)), (k, name)
+    assert dead_total > n                                           # there were dead bounces to skip

@@ -48,3 +48,5 @@ if dev == "cuda":
         print(f"[{mode}] primal 512x512@16 ({N} paths, tiles of {sc.tile_paths}): {ms:.2f} ms = {N/ms/1e3:.1f} Mpaths/s")
         ms = timed(lambda: sc.trace_paths(sensor=0, seed=0, spp=16, max_depth=4))
         print(f"[{mode}] trace+log: {ms:.2f} ms = {N/ms/1e3:.1f} Mpaths/s")
+        ms = timed(lambda: sc.trace_paths(sensor=0, seed=0, spp=16, max_depth=4, sparse_log=True))
+        print(f"[{mode}] trace+sparse log: {ms:.2f} ms = {N/ms/1e3:.1f} Mpaths/s")

@@ -1,6 +1,6 @@
 """Wall-clock of the real pipeline on the analytic 'plate' scene: primal render and one backward pass
 (trace with vertex log -> tangent -> fused gradient/scatter), per stage, via HIP events."""
-import importlib, sys, time
+import importlib, sys, time; sys.path.insert(0, ".")
 import torch
 import epsm_mitsuba3_amd as epsm
 
