@@ -69,6 +69,8 @@ def parse():
                          "times per step (configs 3, 4: 1024x1024 @ 256 spp = 16 slabs of 2^24 paths)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-real-scene", action="store_true",
+                    help="skip the secondary leg that traces a real scene (128 k triangles) and runs the backward pass on its records")
     return ap.parse_args()
 
 
@@ -105,6 +107,37 @@ def cpu_baseline(path_info, variant, target_s):
     return {"value": n1 / dt1, "unit": "paths/s", "cores": int(cores), "kind": "port",
             "sample": f"calc_grad only (the dominant stage), first {n1} paths of the same wavefront, "
                       f"oracle/epsm_oracle.c fp32 + OpenMP, {dt1:.2f} s"}
+
+
+def real_scene_leg(variant, res, spp, dev):
+    """Secondary figure, outside the timed region: gradient image of a TRACED scene (epsm_mitsuba3_amd/exp/clutter.py,
+    the stand-in for the bathroom asset the reference does not ship): render_backward = native tracer with vertex log
+    -> tangent + calc_grad + scatter, wall-clock, median of 3."""
+    import epsm_mitsuba3_amd as epsm
+    from epsm_mitsuba3_amd.exp import clutter
+    scene = clutter.load_scene(dev, n_spheres=100, res=res, spp=spp)
+    for i in range(0, 100, 3):
+        scene.attach(f"s{i}", positions=True, normals=True)
+    integ = epsm.load_dict({"type": variant, "max_depth": clutter.max_depth})
+    integ.backward_spp = spp
+    params = scene.param_grads()
+    g = torch.Generator(device=dev).manual_seed(2)
+    grad_in = torch.randn((res, res, 5), generator=g, device=dev) * 1e-3
+
+    def timed(fn, n=3):
+        fn(); out = []
+        for _ in range(n):
+            torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize()
+            out.append((time.perf_counter() - t) * 1e3)
+        return sorted(out)[n // 2]
+    total = timed(lambda: integ.render_backward(scene, params, grad_in, seed=1))
+    trace = timed(lambda: scene.trace_paths(sensor=2, seed=1, spp=spp, max_depth=clutter.max_depth, sparse_log=True))
+    n = res * res * spp
+    return {"scene": f"exp/clutter.py: floor + 100 tessellated spheres + area light = {scene.T} triangles", "variant": variant,
+            "paths": n, "max_depth": clutter.max_depth, "tracer": "wavefront" if scene.use_wavefront() else "one launch",
+            "grad_image_ms": total, "trace_and_log_ms": trace, "backward_ms": total - trace, "paths_per_s": n / (total * 1e-3),
+            "note": "render_backward on traced records (trace + vertex log -> tangent + calc_grad + scatter), wall-clock, "
+                    "median of 3; outside the timed region"}
 
 
 CONFIGS = {
@@ -265,6 +298,10 @@ def main():
                                                 "note": "outside the timed region; first stage of --two-stage"}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(trace.path_info, args.variant, args.cpu_seconds)
+        if not args.no_real_scene and world == 1 and args.config in (0, 2):
+            del packed, out, trace
+            torch.cuda.empty_cache()
+            result["real_scene"] = real_scene_leg(args.variant, args.res, args.spp, dev)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -144,8 +144,16 @@ constexpr int32_t kBvhNone = 0x7fffffff;
 struct BvhStack {
     uint32_t *base; int stride;
     int cap = kBvhStack; uint32_t *ovf = nullptr; int64_t ovf_stride = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // `base` is LDS on the device: say so, or the two-way choice below becomes ONE flat load / store whose address is
+    // selected (flat accesses to LDS take the long way through the texture path and wait on both counters)
+    typedef __attribute__((address_space(3))) uint32_t LdsWord;
+    EPSM_HD void put(int k, uint32_t v) const { if (k < cap) ((LdsWord *) base)[k * stride] = v; else ovf[(int64_t) (k - cap) * ovf_stride] = v; }
+    EPSM_HD uint32_t get(int k) const { if (k < cap) return ((LdsWord *) base)[k * stride]; return ovf[(int64_t) (k - cap) * ovf_stride]; }
+#else
     EPSM_HD void put(int k, uint32_t v) const { if (k < cap) base[k * stride] = v; else ovf[(int64_t) (k - cap) * ovf_stride] = v; }
     EPSM_HD uint32_t get(int k) const { return k < cap ? base[k * stride] : ovf[(int64_t) (k - cap) * ovf_stride]; }
+#endif
 };
 
 // Ordered traversal of the two-wide BVH: one 64-byte node holds both children's boxes, of two inner children the

@@ -4,8 +4,8 @@ T=gpurun_out/r1z
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > ${T}_pytest.log
 python __graft_entry__.py smoke > ${T}_smoke.log 2>&1
 python bench.py > ${T}_bench.json 2> ${T}_bench.err
-python bench.py --two-stage --no-cpu-baseline > ${T}_bench_two_stage.json 2>> ${T}_bench.err
-B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+python bench.py --two-stage --no-cpu-baseline --no-real-scene > ${T}_bench_two_stage.json 2>> ${T}_bench.err
+B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-real-scene"
 rocprofv3 --kernel-trace --stats --output-format csv -d ${T}_trace -- $B > ${T}_trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d ${T}_trace_two_stage -- $B --two-stage > ${T}_trace2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "epsm" --output-format csv -d ${T}_pmc_fetch -- $B > ${T}_pmc1.log 2>&1
