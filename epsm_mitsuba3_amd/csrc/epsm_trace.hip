@@ -31,7 +31,11 @@ __global__ __launch_bounds__(256) void epsm_wf_generate_kernel(TraceArgs A, WfSt
 // Traversal kernels: 8 KB of LDS stacks per workgroup, 47-50 registers: 8 waves per SIMD.
 // (Tried and dropped: persistent waves whose idle lanes fetch new rays between two traversal rounds -- from a shared
 // queue head the ~10^5 same-address atomics serialise, from a static share per wave the primary rays lose their
-// coherence: 667 -> 1226 us for bounce 0, -5..10 % for the later bounces, +1.1 ms per 4.2 M paths in all.)
+// coherence: 667 -> 1226 us for bounce 0, -5..10 % for the later bounces, +1.1 ms per 4.2 M paths in all.
+// And: ONE loop whose every turn runs one kind of step -- a node step or a triangle test -- chosen by majority among
+// the unfinished lanes (the while-while loops run for the slowest lane: 27 % of the VALU lanes busy).  Same hits;
+// 5.6-5.7 ms against 5.3-5.4 ms at 128 k triangles, 8.7 against 8.9 ms at 512 k: the step-wise traversal state
+// (leaf cursor kept across turns) costs the while-while form 5-7 % where both share it, so it was not kept.)
 __global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_kernel(TraceArgs A, WfState W, int b) {
     __shared__ uint32_t s_stack[kWfStackLds * kWfThreads];
     const int64_t count = wf_count(A, W, b);

@@ -211,7 +211,11 @@ class Mesh:
 
 
 # ---------------------------------------------------------------------------- BVH
-LEAF_SIZE = 4
+# Leaves of <= 6 triangles with the SAH split used all the way down: -12 % trace time on the 128 k-triangle scene
+# against leaves of 4 under a median split below 24 triangles (both tracer forms; 2x the build time, paid once:
+# vertex updates refit).  Measured 3..7 for both numbers: tools/gpu_bvh_ab.sh.
+LEAF_SIZE = 6
+SAH_MIN = 6
 
 
 def _sah_split(cen: np.ndarray, lo: np.ndarray, hi: np.ndarray, bins: int = 16):
@@ -249,7 +253,7 @@ def _sah_split(cen: np.ndarray, lo: np.ndarray, hi: np.ndarray, bins: int = 16):
     return best[1]
 
 
-def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE, sah_min: int = 24):
+def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE, sah_min: int = SAH_MIN):
     """Binned-SAH BVH (16 bins per axis; nodes of <= ``sah_min`` triangles: median split), emitted as two-wide nodes (``EpsmBvhNode``: the boxes of both
     children in one 64-byte record, leaf children embedded).  Returns a dict:
 
