@@ -246,7 +246,7 @@ template <int BITS> struct ScatterOut {
         g = fin(g);
         Tri t = pre_tri(1, nz3(g));
         float b0 = 0.f, b1 = 0.f;
-        if (ok && nz3(g)) { b0 = P.v[0].b0[i]; b1 = P.v[0].b1[i]; }
+        if (ok && nz3(g)) { b0 = gl(P.v[0].b0)[i]; b1 = gl(P.v[0].b1)[i]; }
         diffuse(0, g, b0, b1, t);
         // occluder of the first vertex's emitter sample: si_direct.p * diffuse_grad[0] * dis (epsm.py:609-620)
         if (P.s[0].shadow) {
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
             const ScatterOut<kBits> out{F, s_ptrs, T, Q, i, ok};
             if (DMODE == kTangentsInKernel) {              // epsm.py:250-272 for this path, in registers
                 const Tangent t = first_vertex_tangent(F.tin, i, s_ptrs.v[0].p0, s_ptrs.v[0].p1, s_ptrs.v[0].p2,
-                                                       s_ptrs.v[0].active[i] != 0);
+                                                       gl(s_ptrs.v[0].active)[i] != 0);
                 A.lane_d = mk2<float>(t.db0, t.db1);
                 A.lane_dp = t.dp;
                 if (ok) gd_acc = gd_acc + t.gd;

@@ -154,8 +154,17 @@ template <typename R> struct GradArgs {
     template <bool FULL_D> EPSM_HD V2<R> d_at(int64_t i, int k, int dcols) const;      // defined below load_d
 };
 
+// Record arrays are GLOBAL memory: gl() says so.  A pointer that reaches the code through memory (the fused kernel
+// keeps its 85 array pointers in an LDS table) is a generic pointer to the compiler, and a load through it is a FLAT
+// load: it counts on vmcnt AND lgkmcnt, so every wait for an LDS operation also waits for the record loads in flight
+// and the other way round -- the prefetch of the next vertex and the LDS queue / table traffic serialise each other.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T> EPSM_HD const __attribute__((address_space(1))) T *gl(const T *p) { return (const __attribute__((address_space(1))) T *) p; }
+#else
+template <typename T> EPSM_HD const T *gl(const T *p) { return p; }
+#endif
 template <typename R> EPSM_HD V3<R> load3(const R *base, int64_t i) {
-    const R *p = base + 3 * i;
+    const auto *p = gl(base) + 3 * i;
     return mk3<R>(p[0], p[1], p[2]);
 }
 
@@ -234,8 +243,8 @@ template <typename R> struct Geo {      // from "points" + "uv": x = p0 b0 + p1 
 template <typename R> EPSM_HD Geo<R> load_geo(const VertexPtrs<R> &v, int64_t i) {
     Geo<R> g;
     V3<R> p0 = load3(v.p0, i), p1 = load3(v.p1, i), p2 = load3(v.p2, i);
-    g.b0 = v.b0[i];
-    g.b1 = v.b1[i];
+    g.b0 = gl(v.b0)[i];
+    g.b1 = gl(v.b1)[i];
     R b2 = R(1) - g.b0 - g.b1;
     g.x = p0 * g.b0 + p1 * g.b1 + p2 * b2;
     g.e1 = p0 - p2;
@@ -342,7 +351,7 @@ template <typename R> EPSM_HD M2<R> madd2(M2<R> p, M2<R> q) { M2<R> r; r.a = p.a
 
 template <typename R, bool FULL_D, typename Args> EPSM_HD V2<R> load_d(const Args &A, int64_t i, int k /*1-based*/, int dcols) {
     if (!FULL_D && k > 1) return mk2<R>(R(0), R(0));
-    const R *row = A.dlduv + i * A.dlduv_stride;
+    const auto *row = gl(A.dlduv) + i * A.dlduv_stride;
     int c = 2 * (k - 1);
     R x = c < dcols ? row[c] : R(0);
     R y = c + 1 < dcols ? row[c + 1] : R(0);
@@ -371,12 +380,12 @@ template <typename R, int K, typename Args> EPSM_HD Flags<K> load_flags(const Ar
     Flags<K> f;
 #pragma unroll
     for (int k = 1; k <= K; ++k) {
-        uint32_t b = A.vtx(k - 1).bsdf[i];
+        uint32_t b = gl(A.vtx(k - 1).bsdf)[i];
         f.diffuse[k] = (b & kBsdfDiffuse) != 0;
         f.null_[k] = (b & kBsdfNull) != 0;
-        f.active[k] = A.vtx(k - 1).active[i] != 0;
-        f.active_em[k] = A.vtx(k - 1).active_em[i] != 0;
-        f.mesh[k] = A.vtx(k - 1).ismesh[i] != 0;
+        f.active[k] = gl(A.vtx(k - 1).active)[i] != 0;
+        f.active_em[k] = gl(A.vtx(k - 1).active_em)[i] != 0;
+        f.mesh[k] = gl(A.vtx(k - 1).ismesh)[i] != 0;
     }
     f.diffuse[0] = f.null_[0] = f.active[0] = f.active_em[0] = f.mesh[0] = false;
     f.diffuse[K + 1] = f.null_[K + 1] = f.active[K + 1] = f.active_em[K + 1] = f.mesh[K + 1] = false;
@@ -471,7 +480,7 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
         Raw r;
         r.g = load_geo(A.vtx(kk - 1), i);
         r.nr = load_nrm(A.vtx(kk - 1), i, r.g.b0, r.g.b1);
-        r.eta = A.vtx(kk - 1).eta[i];
+        r.eta = gl(A.vtx(kk - 1).eta)[i];
         r.light = load3(A.vtx(kk - 1).light, i);
         return r;
     };
@@ -648,7 +657,7 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
             b0 = gcur.b0; b1 = gcur.b1;
             const Nrm<R> nr = load_nrm(A.vtx(k - 1), i, gcur.b0, gcur.b1);
             ncur = nr.n;
-            const R eta = A.vtx(k - 1).eta[i];
+            const R eta = gl(A.vtx(k - 1).eta)[i];
             const Frame<R> fr = make_frame(nr.n);
             const HalfVec<R> h = halfvec_fwd(xprev, gcur.x, gnext.x, fr, eta);
             const V2<R> dk = A.template d_at<FULL_D>(i, k, dcols);

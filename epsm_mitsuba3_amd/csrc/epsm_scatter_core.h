@@ -31,7 +31,10 @@ EPSM_HD float bits_to_float(uint32_t u) { union { uint32_t u; float f; } c; c.u 
 struct U4 { uint32_t x, y, z, w; };
 EPSM_HD U4 load_u4(const uint32_t *base, int64_t i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint4 v = *reinterpret_cast<const uint4 *>(base + 4 * i);
+    // one 16-byte GLOBAL load (gl(), epsm_path_core.h; a built-in vector type: copying a HIP uint4 out of an
+    // address-space pointer goes through a generic reference and becomes a flat load again)
+    typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+    const U32x4 v = *(const __attribute__((address_space(1))) U32x4 *) (base + 4 * i);
     U4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
 #else
     const uint32_t *p = base + 4 * i;
@@ -109,7 +112,7 @@ EPSM_HD VertexItems<R> vertex_items(const VertexPtrs<R> &v, const ScatterPtrs<R>
     const bool idx_ok = o.vi[0] < (uint64_t) V && o.vi[1] < (uint64_t) V && o.vi[2] < (uint64_t) V;
     o.pos_ok = idx_ok && (mode & kModePos);
     o.nrm_ok = idx_ok && (mode & kModeNrm) && (mode & kModeVertexNormals);
-    const R b0 = v.b0[i], b1 = v.b1[i], b2 = R(1) - b0 - b1;
+    const R b0 = gl(v.b0)[i], b1 = gl(v.b1)[i], b2 = R(1) - b0 - b1;
     // (1) si.p_j * path_grad[5it+j] (epsm.py:559-560)  +  (2) si_follow.p * diffuse_grad[it] with
     //     detached barycentrics (epsm.py:561-562)
     o.pos[0] = g.gp[0] + g.gdiff * b0;

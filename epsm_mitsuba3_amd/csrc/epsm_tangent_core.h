@@ -22,7 +22,7 @@ EPSM_HD Tangent first_vertex_tangent(const TangentIn &A, int64_t i, const float 
                                      bool active) {
     const int64_t pix = (A.path_offset + i) / A.spp;
     const int64_t y = pix / A.res, x = pix % A.res;
-    const float *g = A.grad_img + (y * A.img_width + x) * A.img_channels;
+    const auto *g = gl(A.grad_img) + (y * A.img_width + x) * A.img_channels;
     const float gx = g[3], gy = g[4];
     const V3<float> d = load3(A.d, i), dx = load3(A.dx, i), dy = load3(A.dy, i);
     Tangent t;

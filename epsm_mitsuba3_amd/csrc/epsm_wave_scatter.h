@@ -87,6 +87,11 @@ struct LdsTable {
         if (y != 0.f) atomicAdd(p + 1, y);
         if (z != 0.f) atomicAdd(p + 2, z);
     }
+    // LDS atomic rates on MI355X (tools/micro/lds_atomics.hip; lane-ops per clock and CU, scattered rows / 16 hot rows):
+    // ds_add_f32 0.33 / 0.42, read + ds_cmpst float-add loop 3.3 / 0.47, ds_add_u64 6.1 / 3.4, ds_add_u32 11.4 / 4.3,
+    // ds_cmpst_rtn 5.6.  Both alternatives to ds_add_f32 were tried here and lost: the cmpst loop (5.4 against 5.0 ms;
+    // a drain iteration carries several items of the same row) and 64-bit fixed-point sums with ds_add_u64 (rows of
+    // 28 B: 1024 rows fit, 5.2 ms -- what a 1024-row float table costs as well; the specular profile 49 against 18 ms).
     __device__ __forceinline__ void add(uint32_t key, float x, float y, float z) const {
         if (x == 0.f && y == 0.f && z == 0.f) return;
         uint32_t slot = (key * 2654435761u) >> (32 - kTableBits);
@@ -233,9 +238,15 @@ struct QItem { uint32_t key; float x, y, z; };
 // copies pushed the fused kernel past the instruction cache (70 KB of code).
 template <typename Table>
 __device__ __attribute__((noinline)) void drain_queue(const QItem *q, int n, Table T) {
+    // q is LDS: say so.  Through the generic pointer of this out-of-line function the read was a FLAT load, whose
+    // s_waitcnt vmcnt(0) also waits for every global load in flight -- the vertex records the path code had
+    // prefetched -- at each drain.
+    typedef __attribute__((address_space(3))) const uint32_t LdsWord;
+    LdsWord *ql = (LdsWord *) q;
 #pragma unroll 1
     for (int idx = lane_id(); idx < n; idx += 64) {
-        const QItem it = q[idx];
+        QItem it;
+        it.key = ql[4 * idx]; it.x = __uint_as_float(ql[4 * idx + 1]); it.y = __uint_as_float(ql[4 * idx + 2]); it.z = __uint_as_float(ql[4 * idx + 3]);
         T.add(it.key, it.x, it.y, it.z);
     }
 }
