@@ -1,6 +1,6 @@
 # Round-1 evidence run: tests, smoke, bench (with cpu baseline), kernel-trace stats, PMC traffic
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-T=gpurun_out/r1z
+T=gpurun_out/${1:-r1z}
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > ${T}_pytest.log
 python __graft_entry__.py smoke > ${T}_smoke.log 2>&1
 python bench.py > ${T}_bench.json 2> ${T}_bench.err
