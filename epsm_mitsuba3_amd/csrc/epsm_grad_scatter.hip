@@ -23,8 +23,16 @@ using epsm_host::fail;
 
 namespace {
 
-constexpr int kBits = 11;                  // 2048-row table = 32 KB of LDS (1024 rows: +5 %)
-constexpr int kQueueCap = 512;             // items per wave queue: 4 x 8 KB; 64 KB per workgroup in all, 2 workgroups per CU
+// LDS of a workgroup (two per CU: <= 80 KB each): the accumulator table, four wave queues, and 7.5 KB of window
+// flags / permutation / counters / pointer table.  Both sizes matter and neither has to be a power of two (the
+// table hashes by multiply-shift).  Measured on config 2 / specular / V = 10^6 (ms; pool and V = 7 829 do not move):
+//   2048 rows, 512 items: 4.94 / 18.5 / 5.69      2304, 576: 4.65 / 15.5 / 5.55      2432, 544: 4.71 / 14.4 / 5.38
+//   2560, 512: 4.79 / 13.2 / 5.36      3072, 384: 5.00      2048, 384: 5.58      2048, 640: 5.39      1536, 768: 5.51
+// (a queue must hold the largest push, 6 rows from 64 lanes = 384 items; the less room beyond that, the more often a
+// wave drains a few items with most lanes idle; the table is flushed when a census finds it half full, and a window
+// of 1024 paths leaves ~1250 distinct rows on config 2).
+constexpr int kBits = 2304;                // table rows, 16 B each = 36 KB
+constexpr int kQueueCap = 576;             // items per wave queue: 4 x 9 KB
 constexpr int kFusedBlocks = 2048;             // 512 / 1024 / 8192 measured within 2 %
 
 struct FusedArgs {
@@ -269,7 +277,7 @@ namespace {
 template <int K, int VARIANT, int DMODE>
 // waves-per-SIMD 2: without it hipcc budgets 128 VGPRs from the LDS-derived occupancy and spills 720 B/lane
 __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, int dcols, int64_t chunks_per_block) {
-    constexpr int kTableSize = 1 << kBits;
+    constexpr int kTableSize = kBits;
     __shared__ uint32_t s_keys[kTableSize];
     __shared__ float s_vals[kTableSize * 3];
     __shared__ int s_used;

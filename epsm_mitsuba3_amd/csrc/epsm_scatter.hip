@@ -24,7 +24,7 @@ constexpr int kScatterBlocks = 2048;            // persistent workgroups (8 per 
 // chunks (neighbouring pixels -> the same triangles come back -> they stay in its table).
 template <int BITS>
 __global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A, Targets tg, int64_t chunks_per_block) {
-    constexpr int kTableSize = 1 << BITS;
+    constexpr int kTableSize = BITS;      // rows
     __shared__ uint32_t s_keys[kTableSize];
     __shared__ float s_vals[kTableSize * 3];
     __shared__ int s_used;
@@ -113,7 +113,7 @@ extern "C" int epsm_scatter(int variant, int64_t N, int K,
     const int64_t chunks_per_block = (chunks + blocks - 1) / blocks;
     // Adaptive run merge (<= 16 runs per wave), 2048-row table (4 workgroups per CU): the winner of the A/B on
     // config 2 over {runs + hot-key rounds, direct LDS atomics, adaptive 8 / 16} x {1024, 2048, 4096 rows}.
-    hipLaunchKernelGGL((epsm_scatter_kernel<11>), dim3((unsigned) blocks), dim3(256), 0, (hipStream_t) stream, A, T, chunks_per_block);
+    hipLaunchKernelGGL((epsm_scatter_kernel<2048>), dim3((unsigned) blocks), dim3(256), 0, (hipStream_t) stream, A, T, chunks_per_block);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_scatter", e);
     return EPSM_OK;
