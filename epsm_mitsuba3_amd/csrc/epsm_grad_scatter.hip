@@ -30,7 +30,8 @@ namespace {
 //   2560, 512: 4.79 / 13.2 / 5.36      3072, 384: 5.00      2048, 384: 5.58      2048, 640: 5.39      1536, 768: 5.51
 // (a queue must hold the largest push, 6 rows from 64 lanes = 384 items; the less room beyond that, the more often a
 // wave drains a few items with most lanes idle; the table is flushed when a census finds it half full, and a window
-// of 1024 paths leaves ~1250 distinct rows on config 2).
+// of 1024 paths leaves ~1250 distinct rows on config 2).  Re-measured with the drain inlined: 2304/576 4.5-4.6,
+// 2432/544, 2560/512, 2816/448 4.7 (specular 14.5 / 13.3 / 11.7 against 15.9), 2048/640 5.25.
 constexpr int kBits = 2304;                // table rows, 16 B each = 36 KB
 constexpr int kQueueCap = 576;             // items per wave queue: 4 x 9 KB
 constexpr int kFusedBlocks = 2048;             // 512 / 1024 / 8192 measured within 2 %
