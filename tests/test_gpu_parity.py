@@ -102,7 +102,7 @@ def test_general_dlduv_columns(dev):
 
 @pytest.mark.parametrize("variant,profile", [("manifold", "bathroom"), ("manifold_caustic", "pool")])
 def test_full_size_properties(variant, profile, dev):
-    """Size-independent properties on a 2^22-path wavefront (oracle too slow there):
+    """Size-independent properties on a 2^24-path wavefront -- BASELINE.json configs[1] at full size (oracle too slow there):
     determinism, exact linearity in the tangents (scaling by 2 is exact in binary
     floating point when the clamp is off), permutation equivariance, and a spot
     check of 4096 random paths against the oracle."""
@@ -110,7 +110,7 @@ def test_full_size_properties(variant, profile, dev):
     from epsm_mitsuba3_amd.records import PackedRecords
     from epsm_mitsuba3_amd.manifold_grad import manifold_grad_packed
     from oracle.binding import oracle_calc_grad
-    N, K = 1 << 22, 5
+    N, K = 1 << 24, 5
     pi, dlduv, dldp = synth_path_info(N, K, seed=2, device=dev, profile=profile, tangent_scale=1e-5)
     rec = PackedRecords(pi, device=dev)
     a = manifold_grad_packed(variant, rec, dlduv, dldp, clip=0.0, dlduv_cols=2)
