@@ -183,19 +183,15 @@ EPSM_HD void trav_round(Traversal &T, const EpsmScene &S, const BvhStack &st) {
     while (T.cur >= 0 && T.cur != kBvhNone) {
         const EpsmBvhNode n = S.bvh[T.cur];
         float t0, t1;
-        const bool h0 = n.c0 != kBvhNone && hit_box(n.lo0, n.hi0, T.r.o, T.inv_d, T.r.maxt, t0);
-        const bool h1 = n.c1 != kBvhNone && hit_box(n.lo1, n.hi1, T.r.o, T.inv_d, T.r.maxt, t1);
-        if (h0 && h1) {
-            const bool first0 = t0 <= t1;
-            if (T.sp < kBvhStack) st.put(T.sp++, (uint32_t) (first0 ? n.c1 : n.c0));
-            T.cur = first0 ? n.c0 : n.c1;
-        } else if (h0) {
-            T.cur = n.c0;
-        } else if (h1) {
-            T.cur = n.c1;
-        } else {
-            T.cur = T.sp > 0 ? (int32_t) st.get(--T.sp) : kBvhNone;
-        }
+        // both boxes always, the four outcomes by selects: the lanes of a wave take all of them anyway, and as
+        // branches each costs its mask bookkeeping and a jump (only the stack accesses stay conditional)
+        const bool b0 = hit_box(n.lo0, n.hi0, T.r.o, T.inv_d, T.r.maxt, t0), b1 = hit_box(n.lo1, n.hi1, T.r.o, T.inv_d, T.r.maxt, t1);
+        const bool h0 = b0 & (n.c0 != kBvhNone), h1 = b1 & (n.c1 != kBvhNone);
+        const bool first0 = t0 <= t1, both = h0 & h1;
+        const int32_t near = (h0 & (first0 | !h1)) ? n.c0 : n.c1, far = first0 ? n.c1 : n.c0;
+        if (both & (T.sp < kBvhStack)) st.put(T.sp++, (uint32_t) far);
+        if (h0 | h1) T.cur = near;
+        else T.cur = T.sp > 0 ? (int32_t) st.get(--T.sp) : kBvhNone;
     }
     if (T.cur == kBvhNone) return;
     const uint32_t ref = ~(uint32_t) T.cur;
