@@ -652,7 +652,7 @@ class Scene:
         self.c_scene = s
 
     # -- tracing ---------------------------------------------------------------------------------
-    WAVEFRONT_MIN_TRIANGLES = 25000      # measured break-even on MI355X with the sparse log (25.6 k triangles: 2.8 / 2.9 ms per 4.2 M paths)
+    WAVEFRONT_MIN_TRIANGLES = 40000      # measured break-even on MI355X with the sparse log (38 k triangles: 3.03 / 3.05 ms per 4.2 M paths)
     WAVEFRONT_TILE_PATHS = 1 << 22       # the wavefront form is 26 launches per tile: larger tiles when nothing is sharded
 
     def use_wavefront(self) -> bool:
