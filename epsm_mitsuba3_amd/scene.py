@@ -431,7 +431,7 @@ class Scene:
         # three kernels per bounce; "auto": wavefront from WAVEFRONT_MIN_TRIANGLES triangles on (where the
         # one-launch form is bound by divergence; below, the wavefront's state traffic costs more than it saves)
         self.tracer = "auto"
-        self._wf_workspace = None
+        self._wf_workspace = {}        # scratch of the wavefront tracer, one per stream it was used on
         self._upload()
 
     # -- construction from the reference's dict shape ---------------------------------------
@@ -712,9 +712,10 @@ class Scene:
             # queues of live paths, three small kernels per bounce (include/epsm_trace.h); the workspace is scratch
             # and is kept between calls
             need = int(lib.epsm_trace_workspace_bytes(C.c_int64(n)))
-            if self._wf_workspace is None or self._wf_workspace.numel() < need:
-                self._wf_workspace = torch.empty(need, device=dev, dtype=torch.uint8)
-            rc = lib.epsm_trace_paths_wavefront(*args, C.c_void_p(self._wf_workspace.data_ptr()), C.c_size_t(need), C.c_void_p(stream))
+            ws = self._wf_workspace.get(stream)               # per stream: launches on one stream are ordered, two streams are not
+            if ws is None or ws.numel() < need:
+                ws = self._wf_workspace[stream] = torch.empty(need, device=dev, dtype=torch.uint8)
+            rc = lib.epsm_trace_paths_wavefront(*args, C.c_void_p(ws.data_ptr()), C.c_size_t(need), C.c_void_p(stream))
         else:
             rc = lib.epsm_trace_paths(*args, C.c_void_p(stream))
         if rc != 0:

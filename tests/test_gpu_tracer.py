@@ -136,10 +136,17 @@ def test_wavefront_workspace_is_checked():
     assert need >= 1000 * 172
     sc = _scene(torch.device("cuda", 0))
     sc.tracer = "wavefront"
-    sc._wf_workspace = torch.empty(16, device="cuda", dtype=torch.uint8)       # too small: replaced by _trace
+    stream = torch.cuda.current_stream(torch.device("cuda", 0)).cuda_stream
+    sc._wf_workspace[stream] = torch.empty(16, device="cuda", dtype=torch.uint8)       # too small: replaced by _trace
     tr = sc._trace(0, seed=1, spp=8, max_depth=3, K=2, lo=0, hi=500)
     torch.cuda.synchronize()
-    assert sc._wf_workspace.numel() >= lib.epsm_trace_workspace_bytes(C.c_int64(500)) and bool(torch.isfinite(tr.radiance).all())
+    assert sc._wf_workspace[stream].numel() >= lib.epsm_trace_workspace_bytes(C.c_int64(500)) and bool(torch.isfinite(tr.radiance).all())
+    # a second stream gets its own scratch (two traces in flight must not share queues and path state)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        tr2 = sc._trace(0, seed=1, spp=8, max_depth=3, K=2, lo=0, hi=500)
+    side.synchronize(); torch.cuda.synchronize()
+    assert len(sc._wf_workspace) == 2 and torch.equal(tr.radiance, tr2.radiance)
 
 
 @pytest.mark.parametrize("tracer", ["mega", "wavefront"])
