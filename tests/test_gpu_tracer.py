@@ -127,6 +127,29 @@ def test_gpu_wavefront_tracer_equals_one_launch(max_depth, K):
     assert torch.allclose(a.radiance.mean(0), b.radiance.mean(0), rtol=1e-3)
 
 
+def test_gpu_wavefront_edge_sizes_and_empty_scene():
+    """One path, a ragged handful, and a scene without a single triangle: the queues, chunk counts and the scan of
+    the wavefront form at their smallest."""
+    from test_tracer_wavefront_host import _rich_scene
+    from _scenes import sensor
+    from epsm_mitsuba3_amd import scene as S
+    dev = torch.device("cuda", 0)
+    sc = _rich_scene(8, 8, device=dev)
+    for n in (1, 65, 257):
+        sc.tracer = "mega"
+        a = sc._trace(0, seed=3, spp=8, max_depth=4, K=3, lo=5, hi=5 + n)
+        sc.tracer = "wavefront"
+        b = sc._trace(0, seed=3, spp=8, max_depth=4, K=3, lo=5, hi=5 + n)
+        torch.cuda.synchronize()
+        assert torch.equal(a.path_info[1]["active"], b.path_info[1]["active"]) and torch.equal(a.valid, b.valid), n
+        assert torch.allclose(a.radiance, b.radiance, rtol=1e-4, atol=1e-6), n
+    empty = S.Scene.from_dict({"type": "scene", "cam": sensor([1.0, 2.0, 3.0], [1.0, 2.0, -5.0], up=(0, 1, 0), res=8, spp=2)}, device=dev)
+    empty.tracer = "wavefront"
+    t = empty._trace(0, seed=1, spp=2, max_depth=3, K=2, lo=0, hi=128)
+    torch.cuda.synchronize()
+    assert not bool(t.valid.any()) and float(t.radiance.abs().max()) == 0 and not bool(t.path_info[1]["active"].any())
+
+
 def test_wavefront_workspace_is_checked():
     import ctypes as C
     from epsm_mitsuba3_amd import _lib

@@ -140,3 +140,25 @@ def test_sparse_log_keeps_everything_a_live_vertex_has(tracer):
                 u, v = xa[name][live], xb[name][live]
                 assert torch.equal(u.contiguous().view(torch.uint8), v.contiguous().view(torch.uint8)), (k, name)
     assert dead_total > n                                           # there were dead bounces to skip
+
+
+@pytest.mark.parametrize("n", [1, 65, 257])
+def test_wavefront_tiny_wavefronts(n):
+    sc = _rich_scene(8, 8)
+    sc.tracer = "mega"
+    a = sc._trace(0, seed=3, spp=8, max_depth=4, K=3, lo=5, hi=5 + n)
+    sc.tracer = "wavefront"
+    b = sc._trace(0, seed=3, spp=8, max_depth=4, K=3, lo=5, hi=5 + n)
+    _same(a, b)
+
+
+def test_wavefront_on_an_empty_scene():
+    """No triangles, no emitters: every path misses; both forms log the same zeros."""
+    d = {"type": "scene", "cam": sensor([1.0, 2.0, 3.0], [1.0, 2.0, -5.0], up=(0, 1, 0), res=8, spp=2)}
+    sc = on_host(S.Scene.from_dict(d, device="cpu"))
+    sc.tracer = "mega"
+    a = sc._trace(0, seed=1, spp=2, max_depth=3, K=2, lo=0, hi=128)
+    sc.tracer = "wavefront"
+    b = sc._trace(0, seed=1, spp=2, max_depth=3, K=2, lo=0, hi=128)
+    _same(a, b)
+    assert not bool(a.valid.any()) and float(a.radiance.abs().max()) == 0
