@@ -90,6 +90,9 @@ __global__ __launch_bounds__(1024) void epsm_wf_scan_kernel(TraceArgs A, WfState
     if (threadIdx.x == 0) { W.counters[b + 1] = total[0]; W.counters[8 + b] = total[1]; }
 }
 // Writes the queue of bounce b + 1 and the shadow queue of bounce b, in path order (stable).
+// (Tried: grouping the survivors of a chunk by the octant of their new direction, 8-bucket counting sort in LDS --
+// 4.95 -> 5.85 ms at 128 k triangles, 8.1 -> 9.3 ms at 512 k: path order keeps the samples of a pixel, which start
+// from almost the same point, next to each other, and that is worth more than a shared direction octant.)
 __global__ __launch_bounds__(kWfChunk) void epsm_wf_compact_kernel(TraceArgs A, WfState W, int b) {
     const int64_t count = wf_count(A, W, b), q = (int64_t) blockIdx.x * kWfChunk + threadIdx.x;
     if ((int64_t) blockIdx.x * kWfChunk >= count) return;           // workgroup-uniform
