@@ -9,6 +9,7 @@
 // same triangles return -> they stay in the table) and flush to HBM with float
 // atomics when the table fills and once at the end.
 #include <stdlib.h>
+#include <type_traits>
 #include <stdio.h>
 #include <string.h>
 
@@ -32,7 +33,8 @@ namespace {
 // wave drains a few items with most lanes idle; the table is flushed when a census finds it half full, and a window
 // of 1024 paths leaves ~1250 distinct rows on config 2).  Re-measured with the drain inlined: 2304/576 4.5-4.6,
 // 2432/544, 2560/512, 2816/448 4.7 (specular 14.5 / 13.3 / 11.7 against 15.9), 2048/640 5.25.
-constexpr int kBits = 2304;                // table rows, 16 B each = 36 KB
+constexpr int kBits = 2304;                // manifold: table rows, 16 B each (float sums) = 36 KB
+constexpr int kRowsCaustic = 1280;         // manifold_caustic: rows of 28 B (64-bit fixed-point sums, epsm_wave_scatter.h) = 35 KB
 constexpr int kQueueCap = 576;             // items per wave queue: 4 x 9 KB
 constexpr int kFusedBlocks = 2048;             // 512 / 1024 / 8192 measured within 2 %
 
@@ -92,10 +94,10 @@ template <bool FLAGS_IN_LDS, int DMODE> struct LdsArgs {
 // (measured on the bathroom / specular / pool profiles: 4, 8, 16, 32 for the triangle rows)
 constexpr int kMinMergeLanes = 16, kMinMergeLanesAlpha = 4;
 
-template <int BITS> struct ScatterOut {
+template <typename Table> struct ScatterOut {
     const FusedArgs &F;
     const PtrTable &P;
-    const LdsTable<BITS> &T;
+    const Table &T;
     WaveQueue<kQueueCap> &Q;
     int64_t i;
     bool ok;
@@ -278,13 +280,15 @@ namespace {
 template <int K, int VARIANT, int DMODE>
 // waves-per-SIMD 2: without it hipcc budgets 128 VGPRs from the LDS-derived occupancy and spills 720 B/lane
 __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, int dcols, int64_t chunks_per_block) {
-    constexpr int kTableSize = kBits;
+    typedef LdsTable<VARIANT == EPSM_VARIANT_MANIFOLD ? kBits : kRowsCaustic,
+                     typename std::conditional<VARIANT == EPSM_VARIANT_MANIFOLD, AccFloat, AccFixed64>::type> Table;
+    constexpr int kTableSize = Table::kTableSize;
     __shared__ uint32_t s_keys[kTableSize];
-    __shared__ float s_vals[kTableSize * 3];
+    __shared__ typename Table::Val s_vals[kTableSize * 3];
     __shared__ int s_used;
     __shared__ QItem s_queue[4][kQueueCap];
     __shared__ PtrTable s_ptrs;
-    const LdsTable<kBits> T{s_keys, s_vals, &s_used, F.gpos, F.gnrm, F.galpha, (uint32_t) F.V};
+    const Table T{s_keys, s_vals, &s_used, F.gpos, F.gnrm, F.galpha, (uint32_t) F.V};
     WaveQueue<kQueueCap> Q{s_queue[threadIdx.x >> 6], 0};
     if (threadIdx.x < K) { s_ptrs.v[threadIdx.x] = F.g.v[threadIdx.x]; s_ptrs.s[threadIdx.x] = F.s[threadIdx.x]; }
     __shared__ uint32_t s_flags[VARIANT == EPSM_VARIANT_MANIFOLD ? 1024 : 1];
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
             const int64_t i0 = base + s_perm[slot * 64 + lane];
             const bool ok = i0 < F.g.N;
             const int64_t i = ok ? i0 : F.g.N - 1;     // lanes past the end recompute the last path and add nothing
-            const ScatterOut<kBits> out{F, s_ptrs, T, Q, i, ok};
+            const ScatterOut<Table> out{F, s_ptrs, T, Q, i, ok};
             if (DMODE == kTangentsInKernel) {              // epsm.py:250-272 for this path, in registers
                 const Tangent t = first_vertex_tangent(F.tin, i, s_ptrs.v[0].p0, s_ptrs.v[0].p1, s_ptrs.v[0].p2,
                                                        gl(s_ptrs.v[0].active)[i] != 0);

@@ -69,11 +69,34 @@ __device__ __forceinline__ V3<float> seg_sum3(V3<float> v, int head) {
 constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
 constexpr int kMaxProbe = 8;
 
-template <int kRows>
+// What a table row sums in.  float: 12 B of values per row, ds_add_f32.  Fixed64: 64-bit fixed point with 32 fractional
+// bits, 24 B per row, ds_add_u64 -- |sum| < 2^31 and a resolution of 2.3e-10 are ample for rows whose terms are clamped
+// to +-0.1 (epsm.py:932-944) and end up in float32 buffers, and the sum does not depend on the order of the additions.
+// The integer atomic is ~18x faster than the float one (rates below), but a row is 1.75x as large: the fixed-point
+// table pays where few rows suffice (manifold_caustic: -6 % on the pool profile with 1280 rows) and loses where the
+// window's distinct rows need the 2304 that only float rows fit (manifold: 4.9 against 4.5 ms on config 2).
+struct AccFloat {
+    typedef float T;
+    __device__ __forceinline__ static void add(T *p, float x) { atomicAdd(p, x); }
+    __device__ __forceinline__ static float get(T q) { return q; }
+};
+struct AccFixed64 {
+    typedef long long T;
+    __device__ __forceinline__ static T to_fixed(float x) {
+        const float fl = floorf(x), hi = fminf(fmaxf(fl, -2147483520.f), 2147483520.f);
+        const uint32_t lo = (uint32_t) ((x - fl) * 4294967296.f);                 // fraction in [0,1): exact in float
+        return (T) (((unsigned long long) (uint32_t) (int) hi << 32) | lo);
+    }
+    __device__ __forceinline__ static void add(T *p, float x) { atomicAdd((unsigned long long *) p, (unsigned long long) to_fixed(x)); }
+    __device__ __forceinline__ static float get(T q) { return (float) ((double) q * 2.3283064365386963e-10); }
+};
+
+template <int kRows, typename Acc = AccFloat>
 struct LdsTable {
-    static constexpr int kTableSize = kRows;             // rows: 4 B key + 12 B value each; any count (multiply-shift hash)
+    static constexpr int kTableSize = kRows;             // rows: 4 B key + 3 values each; any count (multiply-shift hash)
+    typedef typename Acc::T Val;
     uint32_t *keys;      // [kTableSize]
-    float *vals;         // [kTableSize][3]
+    Val *vals;           // [kTableSize][3]
     int *used;           // number of occupied rows
     float *gpos, *gnrm, *galpha;
     uint32_t V;
@@ -101,9 +124,9 @@ struct LdsTable {
         for (int probe = 0; probe < kMaxProbe; ++probe) {
             const uint32_t prev = atomicCAS(&keys[slot], kEmptyKey, key);
             if (prev == kEmptyKey || prev == key) {
-                if (x != 0.f) atomicAdd(&vals[3 * slot + 0], x);
-                if (y != 0.f) atomicAdd(&vals[3 * slot + 1], y);
-                if (z != 0.f) atomicAdd(&vals[3 * slot + 2], z);
+                if (x != 0.f) Acc::add(&vals[3 * slot + 0], x);
+                if (y != 0.f) Acc::add(&vals[3 * slot + 1], y);
+                if (z != 0.f) Acc::add(&vals[3 * slot + 2], z);
                 return;
             }
             slot = slot + 1 == (uint32_t) kTableSize ? 0u : slot + 1;
@@ -113,7 +136,7 @@ struct LdsTable {
     // all threads of the workgroup; barriers inside
     __device__ __forceinline__ void clear() const {
         for (int e = threadIdx.x; e < kTableSize; e += blockDim.x) {
-            keys[e] = kEmptyKey; vals[3 * e] = 0.f; vals[3 * e + 1] = 0.f; vals[3 * e + 2] = 0.f;
+            keys[e] = kEmptyKey; vals[3 * e] = Val(0); vals[3 * e + 1] = Val(0); vals[3 * e + 2] = Val(0);
         }
         if (threadIdx.x == 0) *used = 0;
         __syncthreads();
@@ -127,8 +150,9 @@ struct LdsTable {
             const int e = q >> 2, c = q & 3;
             const uint32_t key = keys[e];
             if (key != kEmptyKey && c < 3) {
-                const float v = vals[3 * e + c];
-                if (v != 0.f) {
+                const Val qv = vals[3 * e + c];
+                if (qv != Val(0)) {
+                    const float v = Acc::get(qv);
                     if (key < V) atomicAdd(gpos + 3 * (int64_t) key + c, v);
                     else if (key < 2u * V) atomicAdd(gnrm + 3 * (int64_t) (key - V) + c, v);
                     else if (c == 0) atomicAdd(galpha + (key - 2u * V), v);
@@ -137,7 +161,7 @@ struct LdsTable {
         }
         __syncthreads();
         for (int e = threadIdx.x; e < kTableSize; e += blockDim.x) {
-            keys[e] = kEmptyKey; vals[3 * e] = 0.f; vals[3 * e + 1] = 0.f; vals[3 * e + 2] = 0.f;
+            keys[e] = kEmptyKey; vals[3 * e] = Val(0); vals[3 * e + 1] = Val(0); vals[3 * e + 2] = Val(0);
         }
         if (threadIdx.x == 0) *used = 0;
         __syncthreads();
