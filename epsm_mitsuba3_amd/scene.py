@@ -653,7 +653,7 @@ class Scene:
 
     # -- tracing ---------------------------------------------------------------------------------
     WAVEFRONT_MIN_TRIANGLES = 40000      # measured break-even on MI355X with the sparse log (38 k triangles: 3.03 / 3.05 ms per 4.2 M paths)
-    WAVEFRONT_TILE_PATHS = 1 << 22       # the wavefront form is 26 launches per tile: larger tiles when nothing is sharded
+    WAVEFRONT_TILE_PATHS = 1 << 22       # the wavefront form is 26 launches per tile: tiles as large as the sharding over the ranks allows
 
     def use_wavefront(self) -> bool:
         if self.tracer not in ("auto", "mega", "wavefront"):
@@ -735,7 +735,10 @@ class Scene:
             raise ValueError("the EPSM backward pass assumes a square film (epsm.py:239)")
         K = min(max_log_depth, max_depth, 5)
         n_total = s.width * s.height * spp
-        tile = max(self.tile_paths, self.WAVEFRONT_TILE_PATHS) if (world_size == 1 and self.use_wavefront()) else self.tile_paths
+        tile = self.tile_paths
+        if self.use_wavefront():       # as large as the sharding allows: every rank still gets a tile, none larger than 2^22 paths
+            per_rank = -(-n_total // max(1, world_size))
+            tile = max(self.tile_paths, min(self.WAVEFRONT_TILE_PATHS, per_rank))
         tiles = _dist.tile_ranges(n_total, tile)
         si = min(sensor, len(self.sensors) - 1)
         return [self._trace(si, seed, spp, max_depth, K, *tiles[t], sparse_log=sparse_log)

@@ -162,3 +162,22 @@ def test_wavefront_on_an_empty_scene():
     b = sc._trace(0, seed=1, spp=2, max_depth=3, K=2, lo=0, hi=128)
     _same(a, b)
     assert not bool(a.valid.any()) and float(a.radiance.abs().max()) == 0
+
+
+def test_wavefront_tiles_follow_the_sharding():
+    """The wavefront form runs in tiles as large as the sharding allows: one rank takes the whole wavefront (up to
+    2^22 paths), two ranks half each; the tiles of all ranks cover every path exactly once."""
+    sc = _rich_scene(8, 8)
+    sc.tile_paths = 64
+    sc.tracer = "wavefront"
+    n_total = 8 * 8 * 8
+    one = sc.trace_paths(sensor=0, seed=1, spp=8, max_depth=3, rank=0, world_size=1)
+    assert len(one) == 1 and one[0].ray_o.shape[0] == n_total
+    parts = [sc.trace_paths(sensor=0, seed=1, spp=8, max_depth=3, rank=r, world_size=2) for r in (0, 1)]
+    assert [len(p) for p in parts] == [1, 1]
+    spans = sorted((t.path_offset, t.path_offset + t.ray_o.shape[0]) for p in parts for t in p)
+    assert spans == [(0, n_total // 2), (n_total // 2, n_total)]
+    both = torch.cat([t.radiance for t in sorted((t for p in parts for t in p), key=lambda t: t.path_offset)])
+    assert torch.equal(both, one[0].radiance)
+    sc.tracer = "mega"                                   # the one-launch form keeps the sharding unit
+    assert len(sc.trace_paths(sensor=0, seed=1, spp=8, max_depth=3)) == n_total // 64
