@@ -652,7 +652,7 @@ class Scene:
         self.c_scene = s
 
     # -- tracing ---------------------------------------------------------------------------------
-    WAVEFRONT_MIN_TRIANGLES = 40000      # measured break-even on MI355X with the sparse log (38 k triangles: 3.03 / 3.05 ms per 4.2 M paths)
+    WAVEFRONT_MIN_TRIANGLES = 60000      # measured break-even on MI355X with the sparse log (64 k triangles: 4.02 / 3.93 ms per 4.2 M paths)
     WAVEFRONT_TILE_PATHS = 1 << 22       # the wavefront form is 26 launches per tile: tiles as large as the sharding over the ranks allows
 
     def use_wavefront(self) -> bool:
