@@ -19,8 +19,8 @@ namespace {
 struct Targets { float *gpos, *gnrm, *galpha; };
 
 constexpr int kScatterBlocks = 2048;            // persistent workgroups (8 per CU by count, 5 resident by LDS)
-// (table rows: 2048 = 32 KB.  3072 / 4096 / 4800 rows measured: 4.6 -> 5.6 / 6.8 / 6.8 ms on config 2 -- fewer resident
-// workgroups -- and only the specular profile gains, 17.8 -> 12 ms)
+// (table rows: 2048 = 32 KB.  1024 / 1536 / 3072 / 4096 / 4800 rows measured: 4.6 -> 8.5 / 5.6 / 5.6 / 6.8 / 6.8 ms on
+// config 2 -- too few rows, or too few resident workgroups -- and only the specular profile gains from more, 17.8 -> 12 ms)
 
 // One lane per path within a 256-path chunk; a workgroup walks a CONTIGUOUS range of
 // chunks (neighbouring pixels -> the same triangles come back -> they stay in its table).
