@@ -3,33 +3,43 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one backward pass of the hot path over one wavefront of synthetic path
-records that are already resident in HBM: zero the parameter-gradient buffer ->
-first-vertex tangent + per-path constraint Jacobian + block solve + adjoint
-gradients + scatter into the parameter-gradient buffer in ONE launch
-(``epsm_backward_pass``; ``--separate-tangent``: ``epsm_first_vertex_tangent`` then
-``epsm_manifold_grad_scatter``; ``--two-stage``: tangent, ``epsm_manifold_grad``,
-``epsm_scatter`` -- the reference's shape) -> one RCCL all-reduce of that buffer
-when N > 1.  At N=1 the workload is BASELINE.json ``configs[1]``: bathroom,
-``manifold``, 512x512 @ 64 spp -> 16 777 216 paths, 5 logged vertices each
-(SURVEY.md 8d).  With N>1 every rank processes its own wavefront of that size
-(weak scaling: pixel/sample tiles of a larger image sharded over the GPUs).
+Workload (default): the headline of BASELINE.json -- ONE gradient image of the bathroom
+configuration, ``manifold``, 1024 x 1024 @ 256 spp = 268 435 456 paths with 5 logged
+vertices each (``configs[3]`` without its 8-GPU suffix) -- as 16 DISTINCT
+slabs of 2^24 paths (64 image rows each), every slab seeded by its index and resident in
+HBM before the timed region.  A "step" is one backward pass over that image: zero the
+parameter-gradient buffer -> per slab ONE launch of ``epsm_backward_pass`` (first-vertex
+tangent + per-path constraint Jacobian + block solve + adjoint gradients + scatter into
+the parameter-gradient buffer) -> one RCCL all-reduce of the buffer when N > 1.
 
-Prints ONE JSON line (rank 0).  ``value`` = paths/s over all ranks for the whole
-step; ``grad_image_ms`` = wall-clock of the step; ``roofline`` prices the dominant
-kernel (the fused gradient+scatter kernel) against the 8 TB/s HBM peak using the
-ALGORITHMIC bytes (56 + 116*K per path in one launch, 32 + 116*K fused, 32 + 200*K
-stand-alone)
-and its own launch time measured with HIP events on the launch stream; ``cpu_baseline`` times oracle/ (the C restatement of
-the reference's calc_grad) on this box's host cores on a bounded sample of the same
-records.
+``--gpus N`` (N > 1): strong scaling of the same image -- slab s belongs to rank s % N,
+one process per GPU.  Started either by ``torch.distributed.run`` (RANK / WORLD_SIZE /
+LOCAL_RANK in the environment) or directly: then THIS process, before it touches the GPU,
+starts N children with those variables set, relays rank 0's JSON line and fails if any
+child fails.
+
+``--config n`` (1..5) runs BASELINE.json ``configs[n-1]`` instead (``--config 2`` is the
+512 x 512 @ 64 spp wavefront of round 1's line); ``--two-stage`` / ``--separate-tangent``
+time the reference-shaped pipelines.
+
+Prints ONE JSON line (rank 0).  ``value`` = paths/s over all ranks for the whole step;
+``grad_image_ms`` = wall-clock of the step = one gradient image; ``roofline`` prices the
+dominant kernel (one slab's ``epsm_grad_scatter_kernel`` launch) against the 8 TB/s HBM
+peak with the ALGORITHMIC bytes of SURVEY.md 8d (56 + 116 K per path in one launch,
+32 + 116 K fused, 32 + 200 K stand-alone) over its own average launch time, measured with
+HIP events on the launch stream around every launch of the timed region;
+``cpu_baseline`` times oracle/ (the C restatement: tangent + calc_grad + scatter) on this
+box's host cores on a bounded sample of the same records.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,6 +50,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+SLAB_PATHS = 1 << 24           # paths per resident slab (64 rows of a 1024-wide film at 256 spp)
 
 
 def algorithmic_bytes_per_path(K: int) -> int:
@@ -47,66 +58,157 @@ def algorithmic_bytes_per_path(K: int) -> int:
     return 32 + 200 * K
 
 
-def parse():
+CONFIGS = {
+    # n: (label, variant, profile, res, spp, K, V)
+    0: ("BASELINE.json metric: bathroom @ 256 spp, 1024x1024 (configs[3] on the given number of GPUs)", "manifold", "bathroom", 1024, 256, 5, 100000),
+    1: ("configs[0]: single glass-sphere caustic, manifold_caustic, 64x64 @ 4 spp", "manifold_caustic", "caustic", 64, 4, 4, 7829),
+    2: ("configs[1]: bathroom, manifold, 512x512 @ 64 spp", "manifold", "bathroom", 512, 64, 5, 100000),
+    3: ("configs[2]: pool caustic, manifold_caustic, 1024x1024 @ 256 spp", "manifold_caustic", "pool", 1024, 256, 5, 100000),
+    4: ("configs[3]: bathroom, manifold (hybrid phase 1), 1024x1024 @ 256 spp sharded over the ranks", "manifold", "bathroom", 1024, 256, 5, 100000),
+    5: ("configs[4]: human, manifold, 256x256 @ 8 spp, K=2, 7829-vertex mesh", "manifold", "bathroom", 256, 8, 2, 7829),
+}
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--res", type=int, default=512, help="image side (config 2: 512)")
-    ap.add_argument("--spp", type=int, default=64, help="samples per pixel (config 2: 64)")
-    ap.add_argument("--vertices", type=int, default=5, help="logged vertices per path (epsm.py:648)")
-    ap.add_argument("--variant", default="manifold", choices=["manifold", "manifold_caustic"])
-    ap.add_argument("--profile", default="bathroom")
-    ap.add_argument("--scene-vertices", type=int, default=100000, help="size V of the scatter target")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=0, choices=sorted(CONFIGS),
+                    help="0: the headline (default); n: BASELINE.json configs[n-1]")
+    ap.add_argument("--res", type=int, default=None, help="override the preset's film side")
+    ap.add_argument("--spp", type=int, default=None, help="override the preset's samples per pixel")
+    ap.add_argument("--vertices", type=int, default=None, help="override: logged vertices per path (epsm.py:648)")
+    ap.add_argument("--variant", default=None, choices=["manifold", "manifold_caustic"])
+    ap.add_argument("--profile", default=None)
+    ap.add_argument("--scene-vertices", type=int, default=None, help="override: size V of the scatter target")
     ap.add_argument("--separate-tangent", action="store_true",
                     help="tangent kernel + fused gradient/scatter kernel instead of the single epsm_backward_pass launch")
     ap.add_argument("--two-stage", action="store_true",
                     help="calc_grad lists + separate scatter (the reference's shape) instead of the fused kernel")
-    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
-                    help="preset of BASELINE.json configs[n-1] (0: the flags above; the default flags ARE config 2)")
-    ap.add_argument("--slabs", type=int, default=1,
-                    help="wavefronts larger than one resident slab: the resident records are processed this many "
-                         "times per step (configs 3, 4: 1024x1024 @ 256 spp = 16 slabs of 2^24 paths)")
+    ap.add_argument("--max-resident-gb", type=float, default=0.0,
+                    help="cap on the HBM used for resident slabs (0: 85 %% of what is free); when the rank's slabs do not "
+                         "fit, the resident ones are re-used round-robin and the JSON line says so")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-real-scene", action="store_true",
-                    help="skip the secondary leg that traces a real scene (128 k triangles) and runs the backward pass on its records")
-    return ap.parse_args()
+    ap.add_argument("--real-scene", action="store_true",
+                    help="add the secondary leg that traces a real scene (128 k triangles) and runs the backward pass on its records")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher + process group + one all-reduce of the parameter-gradient buffer only (gloo on a box "
+                         "without GPU): what tests/test_bench_launcher.py runs")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(path_info, variant, target_s):
-    """Oracle (kind 'port') on every host core, bounded sample of the same records."""
+# ---------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torch.distributed.run
+# ---------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Starts n fresh processes of this script (one per GPU) BEFORE anything here touched the GPU -- a process that
+    has initialised HIP must neither fork nor exec.  Rank 0's stdout is relayed; the first failing child ends the
+    others (by PID) and makes this process fail."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, rc = b"", 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            p = procs[r]
+            try:
+                if r == 0:
+                    o, _ = p.communicate(timeout=0.5)
+                    out0 += o or b""
+                else:
+                    p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.discard(r)
+            if p.returncode != 0:
+                rc = p.returncode or 1
+                print(f"bench.py: rank {r} exited with code {p.returncode}", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+        if rc:
+            for q in list(pending):
+                try:
+                    procs[q].wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    procs[q].kill()
+            break
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle's tangent + calc_grad + scatter on the host cores
+# ---------------------------------------------------------------------------------------------------------
+def cpu_baseline(trace, grad_in, variant, V, B, target_s):
+    """Oracle (kind 'port') on every host core, bounded sample: the first n paths of slab 0, all three stages of
+    the backward pass (epsm.py:238-297)."""
     from oracle import binding
-    from epsm_mitsuba3_amd.records import PackedRecords, VARIANTS, num_param_grads
+    from epsm_mitsuba3_amd.records import PackedRecords, PackedScatter, VARIANTS, num_param_grads
     binding.build()
-    N = path_info[0]["cam"].shape[0]
-    g = torch.Generator().manual_seed(0)
+    N = trace.ray_d.shape[0]
+    g_cpu = grad_in.detach().cpu().contiguous()
+
+    def host(v, n):
+        if isinstance(v, (list, tuple)):
+            return [host(x, n) for x in v]
+        return v[:n].cpu() if isinstance(v, torch.Tensor) else v
 
     def timed(n):
-        sl = slice(0, n)
-        pi = [{k: ([x[sl].cpu() for x in v] if isinstance(v, (list, tuple)) else
-                   (v[sl].cpu() if isinstance(v, torch.Tensor) else v)) for k, v in rec.items()} for rec in path_info]
+        pi = [{k: host(v, n) for k, v in rec.items()} for rec in trace.path_info]
+        si = [{k: host(v, n) for k, v in rec.items()} for rec in trace.scatter_info]
+        rays = [t[:n].cpu().contiguous() for t in (trace.ray_o, trace.ray_d, trace.ray_dx, trace.ray_dy)]
         rec = PackedRecords(pi, device="cpu")
+        sc = PackedScatter(si, device="cpu")
         K = rec.K
-        d2 = (torch.randn((n, 2), generator=g) * 1e-3).contiguous()
-        p = (torch.randn((n, 3), generator=g) * 1e-3).contiguous()
         P = num_param_grads(variant, K)
+        first = pi[1]
+        q = [first["points"][j].contiguous() for j in range(3)]
+        act = first["active"].to(torch.uint8).contiguous()
+        dlduv64 = torch.empty((n, 2), dtype=torch.float64); dldp64 = torch.empty((n, 3), dtype=torch.float64)
+        go = torch.zeros(3, dtype=torch.float64)
         op = torch.empty((P, n, 3)); ol = torch.empty((K, n, 3)); od = torch.empty((K, n, 3))
-        fn = binding.lib().epsm_oracle_calc_grad_f32
+        gp = torch.zeros((V, 3), dtype=torch.float64); gn = torch.zeros((V, 3), dtype=torch.float64)
+        ga = torch.zeros((max(B, 1),), dtype=torch.float64)
+        lib = binding._aux()
         t0 = time.perf_counter()
-        rc = fn(VARIANTS[variant], n, K, rec.cam.data_ptr(), C.addressof(rec.records), d2.data_ptr(),
-                2, 2, p.data_ptr(), 0.1, op.data_ptr(), ol.data_ptr(), od.data_ptr(), 0)
-        dt = time.perf_counter() - t0
-        assert rc > 0
-        return dt, rc
+        rc = lib.epsm_oracle_first_vertex_tangent(
+            n, int(trace.path_offset), int(trace.spp), int(trace.res), rays[0].data_ptr(), rays[1].data_ptr(),
+            rays[2].data_ptr(), rays[3].data_ptr(), g_cpu.data_ptr(), int(g_cpu.shape[1]), int(g_cpu.shape[2]),
+            q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), act.data_ptr(), dlduv64.data_ptr(), 2, dldp64.data_ptr(),
+            go.data_ptr())
+        assert rc == 0
+        d2, p3 = dlduv64.float(), dldp64.float()
+        cores = lib.epsm_oracle_calc_grad_f32(VARIANTS[variant], n, K, rec.cam.data_ptr(), C.addressof(rec.records),
+                                              d2.data_ptr(), 2, 2, p3.data_ptr(), 0.1, op.data_ptr(), ol.data_ptr(),
+                                              od.data_ptr(), 0)
+        assert cores > 0
+        op64, ol64, od64 = op.double(), ol.double(), od.double()
+        rc = lib.epsm_oracle_scatter(VARIANTS[variant], n, K, C.addressof(rec.records), C.addressof(sc.records),
+                                     sc.table_ptr(), sc.T, op64.data_ptr(), ol64.data_ptr(), od64.data_ptr(),
+                                     gp.data_ptr(), gn.data_ptr(), ga.data_ptr(), V, B)
+        assert rc == 0
+        return time.perf_counter() - t0, cores
 
     n0 = min(N, 1 << 16)
     dt0, cores = timed(n0)
-    n1 = int(min(N, max(n0, n0 / dt0 * target_s), 1 << 23))
+    n1 = int(min(N, max(n0, n0 / dt0 * target_s), 1 << 22))
     dt1, cores = timed(n1)
     return {"value": n1 / dt1, "unit": "paths/s", "cores": int(cores), "kind": "port",
-            "sample": f"calc_grad only (the dominant stage), first {n1} paths of the same wavefront, "
-                      f"oracle/epsm_oracle.c fp32 + OpenMP, {dt1:.2f} s"}
+            "sample": f"tangent + calc_grad + scatter (epsm.py:238-297) on the first {n1} paths of slab 0 of the same "
+                      f"workload, oracle/epsm_oracle.c (fp32) + oracle/epsm_oracle_aux.c (fp64), OpenMP on {int(cores)} "
+                      f"threads, {dt1:.2f} s"}
 
 
 def real_scene_leg(variant, res, spp, dev):
@@ -131,7 +233,11 @@ def real_scene_leg(variant, res, spp, dev):
             out.append((time.perf_counter() - t) * 1e3)
         return sorted(out)[n // 2]
     total = timed(lambda: integ.render_backward(scene, params, grad_in, seed=1))
-    trace = timed(lambda: scene.trace_paths(sensor=2, seed=1, spp=spp, max_depth=clutter.max_depth, sparse_log=True))
+
+    def trace_only():
+        for tr in scene.iter_traces(sensor=2, seed=1, spp=spp, max_depth=clutter.max_depth, sparse_log=True):
+            del tr
+    trace = timed(trace_only)
     n = res * res * spp
     return {"scene": f"exp/clutter.py: floor + 100 tessellated spheres + area light = {scene.T} triangles", "variant": variant,
             "paths": n, "max_depth": clutter.max_depth, "tracer": "wavefront" if scene.use_wavefront() else "one launch",
@@ -140,31 +246,77 @@ def real_scene_leg(variant, res, spp, dev):
                     "median of 3; outside the timed region"}
 
 
-CONFIGS = {
-    # n: (label, variant, profile, res, spp, K, V, slabs of the wavefront when it is run on ONE GPU)
-    1: ("configs[0]: single glass-sphere caustic, manifold_caustic, 64x64 @ 4 spp", "manifold_caustic", "caustic", 64, 4, 4, 7829, 1),
-    2: ("configs[1]: bathroom, manifold, 512x512 @ 64 spp", "manifold", "bathroom", 512, 64, 5, 100000, 1),
-    3: ("configs[2]: pool caustic, manifold_caustic, 1024x1024 @ 256 spp (16 slabs of 2^24 paths)", "manifold_caustic", "pool", 512, 64, 5, 100000, 16),
-    4: ("configs[3]: bathroom, manifold (hybrid phase 1), 1024x1024 @ 256 spp sharded over the ranks", "manifold", "bathroom", 512, 64, 5, 100000, 16),
-    5: ("configs[4]: human, manifold, 256x256 @ 8 spp, K=2, 7829-vertex mesh", "manifold", "bathroom", 256, 8, 2, 7829, 1),
-}
+def kernel_source_hash() -> str:
+    """Fingerprint of the kernel sources: profiles/traffic.json entries carry the one they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "epsm_mitsuba3_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) and not name.startswith("epsm_trace"):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def lookup_traffic(kernel, paths, K, variant, profile):
+    """HBM bytes per launch from the committed PMC run (profiles/traffic.json; tools/gpu_pmc_traffic.sh collects
+    FETCH_SIZE / WRITE_SIZE in their own rocprofv3 --pmc passes and applies the guide's corrections).  An entry counts
+    only for the kernel sources it was measured on."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.isfile(tfile):
+        return None, "no profiles/traffic.json"
+    src = kernel_source_hash()
+    stale = False
+    for rec in json.load(open(tfile)):
+        if (rec.get("kernel") == kernel and rec.get("paths") == paths and rec.get("K") == K
+                and rec.get("variant") == variant and rec.get("profile") == profile):
+            if rec.get("src_hash") == src:
+                return rec["hbm_bytes_per_launch"], rec.get("source")
+            stale = True
+    return None, ("stale: the kernel sources changed since the PMC run in profiles/traffic.json" if stale
+                  else "no PMC run for this kernel / workload in profiles/traffic.json")
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # nothing below has run yet: the GPU is untouched
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    label = "BASELINE.json configs[1]"
-    if args.config:
-        label, args.variant, args.profile, args.res, args.spp, args.vertices, args.scene_vertices, args.slabs = CONFIGS[args.config]
-        if args.config == 4:
-            args.slabs = max(1, args.slabs // world)          # strong scaling of ONE 1024x1024 @ 256 spp image
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
+
+    label, variant, profile, res, spp, K, V = CONFIGS[args.config]
+    variant = args.variant or variant
+    profile = args.profile or profile
+    res, spp = args.res or res, args.spp or spp
+    K, V = args.vertices or K, args.scene_vertices or V
+    B = 4
+    import torch.distributed as dist
+
+    if args.dry_run:
+        # the launcher path without a GPU: process group (gloo), one all-reduce of a parameter-gradient buffer
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from epsm_mitsuba3_amd.params import ParamGrads
+        from epsm_mitsuba3_amd import dist as edist
+        if world > 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        params = ParamGrads(V, B, device="cpu")
+        params.flat.fill_(float(rank + 1))
+        edist.allreduce_param_grads(params.flat)
+        ok = bool((params.flat == world * (world + 1) / 2).all())
+        ranks = dist.get_world_size() if world > 1 else 1
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "manifold_paths_per_s", "dry_run": True, "n_gpus": world, "rccl_ranks": ranks,
+                              "allreduce_ok": ok, "allreduce_bytes": params.flat.numel() * 4}))
+        sys.exit(0 if ok else 1)
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path to measure)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -173,39 +325,68 @@ def main():
     from epsm_mitsuba3_amd import dist as edist
     from epsm_mitsuba3_amd.records import PackedRecords, PackedScatter, num_param_grads
 
-    K, V, B = args.vertices, args.scene_vertices, 4
-    N = args.res * args.res * args.spp              # paths of one gradient image, per rank
-    scene = epsm.SyntheticScene(res=args.res, n_vertices=K, n_scene_vertices=V, n_bsdfs=B,
-                                profile=args.profile, device=dev, tile_paths=N)
-    integ = epsm.load_dict({"type": args.variant, "max_depth": 8, "fused": not args.two_stage,
-                            "fuse_tangent": not args.separate_tangent})
-    # this rank's wavefront: one resident tile (seeded by rank so shards differ)
-    trace = scene.tile(0, 0, N, seed=rank, spp=args.spp, K=K)
-    packed = (PackedRecords(trace.path_info, device=dev), PackedScatter(trace.scatter_info, device=dev))
-    P = num_param_grads(args.variant, K)
-    out = (torch.empty((P, N, 3), device=dev), torch.empty((K, N, 3), device=dev), torch.empty((K, N, 3), device=dev))
+    N_image = res * res * spp                                   # paths of ONE gradient image (all ranks together)
+    slab_paths = min(SLAB_PATHS, N_image)
+    n_slabs = -(-N_image // slab_paths)
+    my_slabs = list(range(rank, n_slabs, world))               # strong scaling: slab s -> rank s % world
+    fused = not args.two_stage
+    one_launch = fused and not args.separate_tangent
+    scene = epsm.SyntheticScene(res=res, n_vertices=K, n_scene_vertices=V, n_bsdfs=B,
+                                profile=profile, device=dev, tile_paths=slab_paths)
+    integ = epsm.load_dict({"type": variant, "max_depth": 8, "fused": fused, "fuse_tangent": not args.separate_tangent})
+
+    # -- this rank's slabs, resident in HBM (content depends only on the slab index) ------------------------
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    budget = min(free_b * 0.85, args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else float("inf"))
+    slabs, used0 = [], torch.cuda.memory_allocated(dev)
+    per_slab = None
+    for s in my_slabs:
+        if per_slab is not None and (len(slabs) + 1) * per_slab + 2 * per_slab * 0.25 > budget:
+            break                                               # the rest re-uses the resident ones (reported below)
+        lo, hi = s * slab_paths, min((s + 1) * slab_paths, N_image)
+        trace = scene.tile(s, lo, hi, seed=0, spp=spp, K=K, lean=True)
+        packed = (PackedRecords(trace.path_info, device=dev), PackedScatter(trace.scatter_info, device=dev, table=scene.triangle_table()))
+        slabs.append((trace, packed))
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if per_slab is None:
+            per_slab = torch.cuda.memory_allocated(dev) - used0
+    if not slabs:
+        raise SystemExit("bench.py: not even one slab fits into HBM")
+    resident_bytes = torch.cuda.memory_allocated(dev) - used0
+    n_my = len(my_slabs)
+    P = num_param_grads(variant, K)
+    out = None
+    if args.two_stage:
+        n0 = slabs[0][0].ray_d.shape[0]
+        out = (torch.empty((P, n0, 3), device=dev), torch.empty((K, n0, 3), device=dev), torch.empty((K, n0, 3), device=dev))
     g = torch.Generator(device=dev).manual_seed(1)
-    grad_in = torch.randn((args.res, args.res, 5), generator=g, device=dev) * 1e-3
+    grad_in = torch.randn((res, res, 5), generator=g, device=dev) * 1e-3
     params = epsm.ParamGrads(V, B, device=dev)
 
-    stage_events = []
+    launch_events = []          # (start, after-tangent, after-grad, after-scatter) of every launch of the timed region
+    step_events = []
 
     def step(record=False):
-        evs = [torch.cuda.Event(enable_timing=True)] if record else None
-
-        def mark(name):
-            if record:
-                e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
         params.flat.zero_()                      # every backward pass starts from dr.grad == 0 (optim.py: per iteration)
-        for _ in range(args.slabs - 1):          # earlier slabs of a wavefront that is larger than the resident one
-            integ.backward_from_trace(trace, params, grad_in, packed=packed, out=out)
+        for j in range(n_my):
+            trace, packed = slabs[j % len(slabs)]
+            if record:
+                evs = [torch.cuda.Event(enable_timing=True)]
+                evs[0].record()
+
+                def mark(name, evs=evs):
+                    e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+                integ.backward_from_trace(trace, params, grad_in, packed=packed, out=out, mark=mark)
+                launch_events.append(evs)
+            else:
+                integ.backward_from_trace(trace, params, grad_in, packed=packed, out=out)
         if record:
-            evs[0].record()                      # per-stage times are those of the step's last slab
-        integ.backward_from_trace(trace, params, grad_in, packed=packed, out=out, mark=mark)
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
         edist.allreduce_param_grads(params.flat)
-        mark("allreduce")
         if record:
-            stage_events.append(evs)
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            step_events.append((e0, e1))
 
     for _ in range(args.warmup):
         step()
@@ -221,87 +402,96 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rccl_ranks = 1
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                                   # the number of ranks RCCL actually summed over
+        rccl_ranks = int(round(float(probe.item())))
+        assert rccl_ranks == dist.get_world_size() == world
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * N * args.slabs * args.steps / elapsed
+    value = N_image * args.steps / elapsed
 
-    names = ["tangent", "grad", "scatter", "allreduce"]
-    stage_ms = {n: sum(evs[i].elapsed_time(evs[i + 1]) for evs in stage_events) / len(stage_events)
+    names = ["tangent", "grad", "scatter"]
+    stage_ms = {n: sum(evs[i].elapsed_time(evs[i + 1]) for evs in launch_events) / len(launch_events)
                 for i, n in enumerate(names)}
+    stage_ms["allreduce"] = sum(a.elapsed_time(b) for a, b in step_events) / len(step_events)
 
     # secondary figure, outside the timed region: the stand-alone gradient kernel (calc_grad's
     # dense lists, 32+200K B/path) -- the reference-shaped first stage of --two-stage
     dense_ms = None
-    if rank == 0 and not args.two_stage:
+    n_slab0 = slabs[0][0].ray_d.shape[0]
+    if rank == 0 and not args.two_stage and torch.cuda.mem_get_info(dev)[0] > 1.3 * (P + 2 * K) * n_slab0 * 12:
         from epsm_mitsuba3_amd.manifold_grad import manifold_grad_packed
-        d2 = torch.randn((N, 2), generator=g, device=dev) * 1e-3
-        p3 = torch.randn((N, 3), generator=g, device=dev) * 1e-3
+        d2 = torch.randn((n_slab0, 2), generator=g, device=dev) * 1e-3
+        p3 = torch.randn((n_slab0, 3), generator=g, device=dev) * 1e-3
+        dout = (torch.empty((P, n_slab0, 3), device=dev), torch.empty((K, n_slab0, 3), device=dev), torch.empty((K, n_slab0, 3), device=dev))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        manifold_grad_packed(args.variant, packed[0], d2, p3, dlduv_cols=2, out=out)
+        manifold_grad_packed(variant, slabs[0][1][0], d2, p3, dlduv_cols=2, out=dout)
         e0.record()
         for _ in range(5):
-            manifold_grad_packed(args.variant, packed[0], d2, p3, dlduv_cols=2, out=out)
+            manifold_grad_packed(variant, slabs[0][1][0], d2, p3, dlduv_cols=2, out=dout)
         e1.record()
         torch.cuda.synchronize()
         dense_ms = e0.elapsed_time(e1) / 5
+        del dout, d2, p3
 
     result = None
     if rank == 0:
-        fused = not args.two_stage
         # 32+116K B/path when the per-path gradients are never written (fused),
-        # 32+200K B/path for the stand-alone gradient kernel
-        one_launch = fused and not args.separate_tangent
+        # 32+200K B/path for the stand-alone gradient kernel;
         # one launch (epsm_backward_pass): rays 48 B + image-gradient 8 B per path instead of cam 12 + dlduv 8 + dldp 12
-        alg = ((56 if one_launch else 32) + 116 * K if fused else algorithmic_bytes_per_path(K)) * N
+        per_path = ((56 if one_launch else 32) + 116 * K) if fused else algorithmic_bytes_per_path(K)
+        alg = per_path * n_slab0
         kernel_ms = stage_ms["grad"]
         achieved = alg / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.isfile(tfile):
-            for rec in json.load(open(tfile)):
-                want = "epsm_backward_pass" if one_launch else ("epsm_grad_scatter_kernel" if fused else "epsm_grad_kernel")
-                if (rec["kernel"] == want and rec["paths"] == N
-                        and rec["K"] == K and rec["variant"] == args.variant and rec["profile"] == args.profile):
-                    traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
+        kname = "epsm_backward_pass" if one_launch else ("epsm_grad_scatter_kernel" if fused else "epsm_grad_kernel")
+        traffic, traffic_src = lookup_traffic(kname, n_slab0, K, variant, profile)
+        distinct = len(slabs) == n_my
         result = {
             "metric": "manifold_paths_per_s", "value": value, "unit": "paths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "grad_image_ms": ms_per_step,
-            "higher_is_better": True, "scaling": "strong" if args.config == 4 else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.profile}-like synthetic path records, {args.variant}, "
-                                   f"{args.res}x{args.res} @ {args.spp} spp = {N} resident paths/GPU x {args.slabs} slab(s) "
-                                   f"per step, K={K} logged vertices ({label}); scatter target V={V} vertices",
-                       "variant": args.variant, "profile": args.profile, "paths_per_gpu": N * args.slabs, "vertices": K,
-                       "scene_vertices": V,
-                       "sharding": f"{world} x pixel/sample-tile shard, one all-reduce of the {params.flat.numel() * 4} B "
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks,
+            "config": {"workload": f"{label}: {profile}-like synthetic path records, {variant}, {res}x{res} @ {spp} spp = "
+                                   f"{N_image} paths per gradient image, K={K} logged vertices, scatter target V={V} "
+                                   f"vertices; {n_slabs} slab(s) of {slab_paths} paths, slab s on rank s % {world}",
+                       "variant": variant, "profile": profile, "paths_per_image": N_image, "slabs": n_slabs,
+                       "slabs_per_gpu": n_my, "slabs_resident_per_gpu": len(slabs), "all_slabs_distinct": distinct,
+                       "resident_bytes_per_gpu": int(resident_bytes), "hbm_total_bytes": int(total_b),
+                       "vertices": K, "scene_vertices": V,
+                       "sharding": f"{world} rank(s), one all-reduce of the {params.flat.numel() * 4} B "
                                    f"parameter-gradient buffer per step"},
             "stages_ms": stage_ms,
-            "pipeline": ("one launch (epsm_backward_pass)" if one_launch else "tangent + fused") if fused else "two-stage",
+            "pipeline": ("one launch per slab (epsm_backward_pass)" if one_launch else "tangent + fused") if fused else "two-stage",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("epsm_grad_scatter_kernel<tangents in kernel> (epsm_backward_pass: tangent + calc_grad + scatter)"
                                     if one_launch else "epsm_grad_scatter_kernel (fused calc_grad + scatter)") if fused else "epsm_grad_kernel",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg,
-                         "algorithmic_bytes_per_path": alg // N},
+                         "kernel_ms": kernel_ms, "launches_timed": len(launch_events), "paths_per_launch": n_slab0,
+                         "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_path": per_path,
+                         "kernel_source_hash": kernel_source_hash()},
         }
+        if not distinct:
+            result["config"]["note"] = (f"only {len(slabs)} of this rank's {n_my} slabs fit into HBM next to each other; "
+                                        f"they are processed round-robin to make up the {n_my} launches of a step")
         if dense_ms is not None:
-            a2 = algorithmic_bytes_per_path(K) * N
+            a2 = algorithmic_bytes_per_path(K) * n_slab0
             result["standalone_grad_kernel"] = {"kernel": "epsm_grad_kernel", "kernel_ms": dense_ms,
-                                                "paths_per_s": N / (dense_ms * 1e-3),
+                                                "paths_per_s": n_slab0 / (dense_ms * 1e-3),
                                                 "achieved": a2 / (dense_ms * 1e-3) / 1e9, "unit": "GB/s",
                                                 "frac": a2 / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                "algorithmic_bytes_per_path": a2 // N,
+                                                "algorithmic_bytes_per_path": a2 // n_slab0,
                                                 "note": "outside the timed region; first stage of --two-stage"}
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(trace.path_info, args.variant, args.cpu_seconds)
-        if not args.no_real_scene and world == 1 and args.config in (0, 2):
-            del packed, out, trace
+            result["cpu_baseline"] = cpu_baseline(slabs[0][0], grad_in, variant, V, B, args.cpu_seconds)
+        if args.real_scene and world == 1:
+            del slabs, out
             torch.cuda.empty_cache()
-            result["real_scene"] = real_scene_leg(args.variant, args.res, args.spp, dev)
+            result["real_scene"] = real_scene_leg(variant, 512, 64, dev)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

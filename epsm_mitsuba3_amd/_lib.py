@@ -15,7 +15,7 @@ import subprocess
 import torch  # noqa: F401  (must be loaded before libepsm_hip.so, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 3          # EPSM_ABI_VERSION of include/epsm.h
+ABI_VERSION = 4          # EPSM_ABI_VERSION of include/epsm.h
 LIB_PATH = os.path.join(_HERE, os.environ.get("EPSM_LIB_NAME", "libepsm_hip.so"))   # EPSM_LIB_NAME: A/B builds
 _lib = None
 
@@ -52,25 +52,37 @@ def _declare(lib):
         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.epsm_scatter.restype = C.c_int
     lib.epsm_scatter.argtypes = [
-        C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.epsm_manifold_grad_scatter.restype = C.c_int
     lib.epsm_manifold_grad_scatter.argtypes = [
-        C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
         C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_float,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
-    if not os.environ.get("EPSM_AB_OLD"):      # (set for A/B runs against a library built before this entry point existed)
-        lib.epsm_backward_pass.restype = C.c_int
-        lib.epsm_backward_pass.argtypes = [
-            C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-            C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
-            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    lib.epsm_backward_pass.restype = C.c_int
+    lib.epsm_backward_pass.argtypes = [
+        C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    declare_tracer(lib)
+    return lib
+
+
+def declare_tracer(lib):
+    """Prototypes of include/epsm_trace.h (also applied to the host build of the tracer in tests/host_harness)."""
+    trace_args = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                  C.c_void_p, C.c_uint32]
     lib.epsm_trace_paths.restype = C.c_int
+    lib.epsm_trace_paths.argtypes = trace_args + [C.c_void_p]
     lib.epsm_trace_paths_wavefront.restype = C.c_int
+    lib.epsm_trace_paths_wavefront.argtypes = trace_args + [C.c_void_p, C.c_size_t, C.c_void_p]
     lib.epsm_trace_workspace_bytes.restype = C.c_size_t
     lib.epsm_trace_workspace_bytes.argtypes = [C.c_int64]
     lib.epsm_film_splat.restype = C.c_int
+    lib.epsm_film_splat.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.epsm_film_develop.restype = C.c_int
+    lib.epsm_film_develop.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
 

@@ -41,6 +41,7 @@ constexpr int kFusedBlocks = 2048;             // 512 / 1024 / 8192 measured wit
 struct FusedArgs {
     GradArgs<float> g;
     ScatterPtrs<float> s[kMaxVertices];
+    TriTable tab;                    // the scene's triangles: id -> [v0, v1, v2, mode]
     float *gpos, *gnrm, *galpha;
     int64_t V, B;
     int P, K;
@@ -147,24 +148,32 @@ template <typename Table> struct ScatterOut {
         }
     }
 
+    struct Id { uint32_t v; };
     struct Tri { uint32_t vi[3]; uint32_t mode; };
-    struct Aux { uint32_t bid; V3<float> dhf; uint32_t ei[3]; float eb0, eb1, ew; };
+    struct Aux { uint32_t bid; V3<float> dhf; uint32_t etri; float eb0, eb1, ew; };
 
     __device__ __forceinline__ V3<float> fin(V3<float> g) const {
         return mk3<float>(finalize(g.x, F.g.clip), finalize(g.y, F.g.clip), finalize(g.z, F.g.clip));
     }
     __device__ __forceinline__ bool any(bool p) const { return __ballot(p) != 0ull; }
-    // parameter addressing of vertex k, fetched ahead of the step that needs it
-    __device__ __forceinline__ Tri pre_tri(int k, bool live) const {
+    // triangle id of vertex k: 4 bytes from the path's log, loaded as soon as the path knows which vertices it needs
+    __device__ __forceinline__ Id pre_id(int k, bool live) const {
+        Id d; d.v = kNoIndex;
+        if (live && ok) d.v = gl(P.s[k - 1].tri)[i];
+        return d;
+    }
+    // parameter addressing of vertex k, fetched ahead of the step that needs it: the triangle's row of the scene
+    // table (16 B, L2 / MALL resident: 2V rows are a few MB)
+    __device__ __forceinline__ Tri pre_tri(int, bool live, Id id) const {
         Tri t; t.vi[0] = t.vi[1] = t.vi[2] = kNoIndex; t.mode = 0;
         if (live && ok) {
-            const U4 t4 = load_u4(P.s[k - 1].tri, i);
+            const U4 t4 = table_row(F.tab, id.v);
             t.vi[0] = t4.x; t.vi[1] = t4.y; t.vi[2] = t4.z; t.mode = t4.w;
         }
         return t;
     }
     __device__ __forceinline__ Aux pre_aux(int k, bool live) const {
-        Aux a; a.bid = kNoIndex; a.dhf = zero3<float>(); a.ei[0] = a.ei[1] = a.ei[2] = kNoIndex; a.eb0 = a.eb1 = a.ew = 0.f;
+        Aux a; a.bid = kNoIndex; a.dhf = zero3<float>(); a.etri = kNoIndex; a.eb0 = a.eb1 = a.ew = 0.f;
         if (live && ok) {
             const ScatterPtrs<float> &s = P.s[k - 1];
             if (s.aux && F.galpha) {
@@ -172,9 +181,8 @@ template <typename Table> struct ScatterOut {
                 a.bid = a4.x; a.dhf = mk3<float>(bits_to_float(a4.y), bits_to_float(a4.z), bits_to_float(a4.w));
             }
             if (s.emit) {
-                const U4 e4 = load_u4(s.emit, 2 * i), f4 = load_u4(s.emit, 2 * i + 1);
-                a.ei[0] = e4.x; a.ei[1] = e4.y; a.ei[2] = e4.z;
-                a.eb0 = bits_to_float(e4.w); a.eb1 = bits_to_float(f4.x); a.ew = bits_to_float(f4.y);
+                const U4 e4 = load_u4(s.emit, i);
+                a.etri = e4.x; a.eb0 = bits_to_float(e4.y); a.eb1 = bits_to_float(e4.z); a.ew = bits_to_float(e4.w);
             }
         }
         return a;
@@ -187,6 +195,9 @@ template <typename Table> struct ScatterOut {
         // epsm.py:559,644: `iteration*5+4 < len(path_grad)` -- the caustic variant never
         // scatters the (always zero) rows of its last vertex
         const float b0 = c.b0, b1 = c.b1, b2 = 1.f - b0 - b1;
+        // the emitter triangle's vertices: issued first, consumed after the hit triangle's rows are on their way
+        glight = fin(glight);
+        const U4 er = table_row(F.tab, ok && nz3(glight) ? a.etri : kNoIndex);
         V3<float> pos[3] = {fin(Gx * b0), fin(Gx * b1), fin(Gx * b2)};       // si.p_j * path_grad[5it+j]
         V3<float> nrm[3] = {zero3<float>(), zero3<float>(), zero3<float>()};
         gn = fin(gn);
@@ -230,11 +241,10 @@ template <typename Table> struct ScatterOut {
         // group B: bsdf_sample.hf * path_grad[5it+4]  and  si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627, 645)
         {
             gm = fin(gm);
-            glight = fin(glight);
             const bool a_ok = ok && has_nm && nz3(gm) && a.bid < (uint64_t) F.B;
-            const bool e_ok = ok && nz3(glight) && a.ei[0] < (uint64_t) F.V && a.ei[1] < (uint64_t) F.V && a.ei[2] < (uint64_t) F.V;
+            const bool e_ok = ok && nz3(glight) && er.x < (uint64_t) F.V && er.y < (uint64_t) F.V && er.z < (uint64_t) F.V && (er.w & kModePos);
             const V3<float> gl = e_ok ? glight * a.ew : zero3<float>();
-            const uint32_t keys[4] = {e_ok ? a.ei[0] : 0u, e_ok ? a.ei[1] : 0u, e_ok ? a.ei[2] : 0u,
+            const uint32_t keys[4] = {e_ok ? er.x : 0u, e_ok ? er.y : 0u, e_ok ? er.z : 0u,
                                       a_ok ? 2u * (uint32_t) F.V + a.bid : 0u};
             V3<float> vals[4] = {gl * a.eb0, gl * a.eb1, gl * (1.f - a.eb0 - a.eb1),
                                  mk3<float>(a_ok ? dot(gm, a.dhf) : 0.f, 0.f, 0.f)};
@@ -253,24 +263,23 @@ template <typename Table> struct ScatterOut {
         merge_equal<3, 2>(pos_v, t.vi, pos);
         push<3>(pos_v, t.vi, pos);
     }
-    __device__ __forceinline__ void diffuse_first(V3<float> g) const {
+    __device__ __forceinline__ void diffuse_first(V3<float> g, Id id) const {
         g = fin(g);
-        Tri t = pre_tri(1, nz3(g));
+        Tri t = pre_tri(1, nz3(g), id);
         float b0 = 0.f, b1 = 0.f;
         if (ok && nz3(g)) { b0 = gl(P.v[0].b0)[i]; b1 = gl(P.v[0].b1)[i]; }
         diffuse(0, g, b0, b1, t);
         // occluder of the first vertex's emitter sample: si_direct.p * diffuse_grad[0] * dis (epsm.py:609-620)
         if (P.s[0].shadow) {
-            ShadowItems<float> sh = shadow_items<float>(P.s[0].shadow, i, ok ? g : zero3<float>(), F.V);
+            ShadowItems<float> sh = shadow_items<float>(P.s[0].shadow, F.tab, i, ok ? g : zero3<float>(), F.V);
             merge_equal<3, 2>(sh.ok, sh.si, sh.val);
             push<3>(sh.ok, sh.si, sh.val);
         }
     }
-    __device__ __forceinline__ void poison(int) const {
-        // Rows of a term that later turned out non-finite are already in the accumulator.
-        // This only happens for inputs on which the reference itself raises "singular
-        // matrix" or zeroes the term; the dense path reproduces the zeroing.
-    }
+    // caustic_path: some lane's term at id* turned out non-finite after rows of its earlier vertices had gone into
+    // the accumulator -> the whole wave takes a second turn in which those lanes emit the same rows negated, so the
+    // sums end up where the dense route (which zeroes the path's rows, DenseOut::undo_needed) puts them.
+    __device__ __forceinline__ bool undo_needed(bool poisoned, int) const { return __ballot(poisoned && ok) != 0ull; }
 };
 
 }  // namespace
@@ -450,7 +459,7 @@ hipError_t launch_k(int K, const FusedArgs &F, int dcols, hipStream_t s) {
 
 // Shared by the two entry points: validates the records, fills FusedArgs.  Returns EPSM_OK or fails with `who` in the text.
 static int fill_args(FusedArgs &F, const char *who, int variant, int64_t N, int K, const float *cam,
-                     const EpsmVertexRecord *verts, const EpsmScatterRecord *sc, float clip,
+                     const EpsmVertexRecord *verts, const EpsmScatterRecord *sc, const uint32_t *tri_table, int64_t T, float clip,
                      float *grad_pos, float *grad_nrm, float *grad_alpha, int64_t V, int64_t B) {
     char msg[160];
     auto bad = [&](const char *what) { snprintf(msg, sizeof(msg), "%s: %s", who, what); return fail(EPSM_EINVAL, msg); };
@@ -459,7 +468,9 @@ static int fill_args(FusedArgs &F, const char *who, int variant, int64_t N, int 
     if (N < 0) return bad("bad N");
     if (!cam || !verts || !sc || !grad_pos || !grad_nrm) return bad("NULL argument");
     if (V < 0 || B < 0 || 2 * V + B >= 0xFFFFFFFFLL) return bad("bad buffer sizes (need 2V+B < 2^32-1)");
+    if (T < 0 || (T > 0 && !tri_table) || (((uintptr_t) tri_table) & 15)) return bad("bad triangle table (T rows of 16 B, 16-byte aligned)");
     memset(&F, 0, sizeof(F));
+    F.tab = TriTable{tri_table, T};
     F.g.N = N;
     F.g.cam = cam;
     for (int k = 0; k < K; ++k) {
@@ -468,8 +479,8 @@ static int fill_args(FusedArgs &F, const char *who, int variant, int64_t N, int 
         if (!v.p0 || !v.p1 || !v.p2 || !v.n0 || !v.n1 || !v.n2 || !v.b0 || !v.b1 || !v.eta || !v.light ||
             !v.bsdf || !v.active || !v.active_em || !v.ismesh || !s.tri)
             return bad("NULL pointer in a vertex / scatter record");
-        if ((((uintptr_t) s.tri) | ((uintptr_t) s.aux) | ((uintptr_t) s.emit) | ((uintptr_t) s.shadow)) & 15)
-            return bad("tri/aux/emit/shadow must be 16-byte aligned");
+        if (((((uintptr_t) s.aux) | ((uintptr_t) s.emit) | ((uintptr_t) s.shadow)) & 15) || (((uintptr_t) s.tri) & 3))
+            return bad("aux/emit/shadow must be 16-byte aligned (tri: 4)");
         VertexPtrs<float> &o = F.g.v[k];
         o.p0 = (const float *) v.p0; o.p1 = (const float *) v.p1; o.p2 = (const float *) v.p2;
         o.n0 = (const float *) v.n0; o.n1 = (const float *) v.n1; o.n2 = (const float *) v.n2;
@@ -490,7 +501,7 @@ static int fill_args(FusedArgs &F, const char *who, int variant, int64_t N, int 
 
 extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
                                           const float *cam, const EpsmVertexRecord *verts,
-                                          const EpsmScatterRecord *sc,
+                                          const EpsmScatterRecord *sc, const uint32_t *tri_table, int64_t T,
                                           const float *dlduv, int64_t dlduv_stride, int dlduv_cols,
                                           const float *dldp, float clip,
                                           float *grad_pos, float *grad_nrm, float *grad_alpha,
@@ -499,7 +510,7 @@ extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
     if (N == 0 && K >= 1 && K <= EPSM_MAX_VERTICES &&
         (variant == EPSM_VARIANT_MANIFOLD || variant == EPSM_VARIANT_MANIFOLD_CAUSTIC)) return EPSM_OK;
     FusedArgs F;
-    const int rc = fill_args(F, "epsm_manifold_grad_scatter", variant, N, K, cam, verts, sc, clip, grad_pos, grad_nrm, grad_alpha, V, B);
+    const int rc = fill_args(F, "epsm_manifold_grad_scatter", variant, N, K, cam, verts, sc, tri_table, T, clip, grad_pos, grad_nrm, grad_alpha, V, B);
     if (rc != EPSM_OK) return rc;
     if (!dlduv || !dldp) return fail(EPSM_EINVAL, "epsm_manifold_grad_scatter: NULL argument");
     if (dlduv_cols < 0 || dlduv_stride < (dlduv_cols < 2 * K ? dlduv_cols : 2 * K))
@@ -524,14 +535,15 @@ extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
 extern "C" int epsm_backward_pass(int variant, int64_t N, int K, int64_t path_offset, int spp, int res,
                                   const float *ray_o, const float *ray_d, const float *ray_dx, const float *ray_dy,
                                   const float *grad_img, int img_width, int img_channels,
-                                  const EpsmVertexRecord *verts, const EpsmScatterRecord *sc, float clip,
+                                  const EpsmVertexRecord *verts, const EpsmScatterRecord *sc,
+                                  const uint32_t *tri_table, int64_t T, float clip,
                                   float *grad_pos, float *grad_nrm, float *grad_alpha, float *grad_o_sum,
                                   int64_t V, int64_t B, void *stream) {
     epsm_host::err_buf()[0] = 0;
     if (N == 0 && K >= 1 && K <= EPSM_MAX_VERTICES &&
         (variant == EPSM_VARIANT_MANIFOLD || variant == EPSM_VARIANT_MANIFOLD_CAUSTIC)) return EPSM_OK;
     FusedArgs F;
-    const int rc = fill_args(F, "epsm_backward_pass", variant, N, K, ray_o, verts, sc, clip, grad_pos, grad_nrm, grad_alpha, V, B);
+    const int rc = fill_args(F, "epsm_backward_pass", variant, N, K, ray_o, verts, sc, tri_table, T, clip, grad_pos, grad_nrm, grad_alpha, V, B);
     if (rc != EPSM_OK) return rc;
     if (!ray_d || !ray_dx || !ray_dy || !grad_img) return fail(EPSM_EINVAL, "epsm_backward_pass: NULL argument");
     if (spp < 1 || res < 1 || img_width < res || img_channels < 5)

@@ -188,7 +188,10 @@ template <typename R> EPSM_HD void store3(R *base, int64_t slot, int64_t N, int6
 // result arrays (calc_grad's three lists, epsm.py:946); the fused kernel plugs in a
 // policy that accumulates straight into the parameter-gradient buffers instead
 // (epsm_grad_scatter.hip), so the 84 B/vertex of dense results never touch HBM.
-//   pre_tri(k, live) / pre_aux(k, live)
+//   pre_id(k, live)
+//        called once per vertex right after the flags are known: the 4-byte triangle id of
+//        the vertex's addressing, loaded well ahead of the table lookup that depends on it;
+//   pre_tri(k, live, id) / pre_aux(k, live)
 //        called at the TOP of the step that will emit vertex k, so that whatever the
 //        policy must fetch for it (parameter addressing) is in flight while the step's
 //        sweeps run -- a load issued where the gradient becomes known would be a
@@ -198,14 +201,18 @@ template <typename R> EPSM_HD void store3(R *base, int64_t slot, int64_t N, int6
 //        (slot +4; both only when has_nm), light_grad[k-1];
 //   diffuse(idx, g, b0, b1, tri)   diffuse_grad[idx] = position gradient of vertex idx+1,
 //        whose barycentrics / addressing are passed along;
-//   diffuse_first(g)  diffuse_grad[0] (known before anything else is computed);
-//   poison(P)         caustic only: a live term turned out non-finite after some of its
-//                     rows were already emitted -> all parameter rows are zero.
+//   diffuse_first(g, id)  diffuse_grad[0] (known before anything else is computed; id of vertex 1);
+//   undo_needed(poisoned, P)   caustic only: a live term turned out non-finite after some of its
+//                     rows were already emitted -> all parameter rows are zero.  Dense output
+//                     zeroes them and returns false; an accumulating policy returns true when
+//                     any lane of the wave is poisoned and the path function then emits the
+//                     negated rows in a second turn.
 // Every lane of a wave calls the policy at the same program points (lanes without a
 // gradient pass zeros), so a policy may use wave-wide operations.
 template <typename R> struct VCtx { R b0, b1; V3<R> n, e1, e2; };   // retained geometry of the vertex
 
 template <typename R> struct DenseOut {
+    struct Id {};
     struct Tri {};
     struct Aux {};
     const GradArgs<R> &A;
@@ -213,7 +220,8 @@ template <typename R> struct DenseOut {
     // any(p): may the step be skipped when p is false for this lane?  Dense output never
     // skips (zeros must be stored); the fused policy skips when p is false on the whole wave.
     EPSM_HD bool any(bool) const { return true; }
-    EPSM_HD Tri pre_tri(int, bool) const { return Tri{}; }
+    EPSM_HD Id pre_id(int, bool) const { return Id{}; }
+    EPSM_HD Tri pre_tri(int, bool, Id) const { return Tri{}; }
     EPSM_HD Aux pre_aux(int, bool) const { return Aux{}; }
     EPSM_HD void vertex(int k, bool has_nm, V3<R> Gx, V3<R> gn, V3<R> gm, V3<R> glight,
                         const VCtx<R> &c, const Tri &, const Aux &) const {
@@ -227,9 +235,11 @@ template <typename R> struct DenseOut {
         store3(A.out_light, k - 1, A.N, i, glight, A.clip);
     }
     EPSM_HD void diffuse(int idx, V3<R> g, R, R, const Tri &) const { store3(A.out_diffuse, idx, A.N, i, g, A.clip); }
-    EPSM_HD void diffuse_first(V3<R> g) const { store3(A.out_diffuse, 0, A.N, i, g, A.clip); }
-    EPSM_HD void poison(int P) const {
-        for (int q = 0; q < P; ++q) store3(A.out_param, q, A.N, i, zero3<R>(), A.clip);
+    EPSM_HD void diffuse_first(V3<R> g, Id) const { store3(A.out_diffuse, 0, A.N, i, g, A.clip); }
+    EPSM_HD bool undo_needed(bool poisoned, int P) const {
+        if (poisoned)
+            for (int q = 0; q < P; ++q) store3(A.out_param, q, A.N, i, zero3<R>(), A.clip);
+        return false;
     }
 };
 
@@ -462,8 +472,13 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
         }
     }
 
+    // triangle ids of the vertices that can receive rows (an accumulating policy looks their vertices up later)
+    typename Out::Id tid[K + 2];
+    static_for_up<1, K>([&](auto kc) EPSM_LAMBDA { constexpr int k = decltype(kc)::value; tid[k] = out.pre_id(k, k <= nv || k == 1); });
+    tid[0] = tid[K + 1] = out.pre_id(1, false);
+
     // diffuse_grad[0] = dldp where the first hit is diffuse (epsm.py:791-792)
-    out.diffuse_first(fl.diffuse[1] ? A.dldp_at(i) : zero3<R>());
+    out.diffuse_first(fl.diffuse[1] ? A.dldp_at(i) : zero3<R>(), tid[1]);
 
     // ---- pass 1: forward recursion (pivots of the continuing rows, z vectors)
     struct Keep { V3<R> x, e1, e2, n, light; R eta, b0, b1; };
@@ -545,11 +560,11 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
     V2<R> carry = mk2<R>(R(0), R(0));  // sum over deeper terms of their y_k
     int W = 0;                         // number of live terms with depth > k
     V3<R> GP = zero3<R>();             // d/dx_k through constraint k+1 (x_k as previous vertex)
-    typename Out::Tri tri_next = out.pre_tri(K, false);   // addressing of vertex k+1 (for diffuse_grad[k])
+    typename Out::Tri tri_next = out.pre_tri(K, false, tid[0]);   // addressing of vertex k+1 (for diffuse_grad[k])
     R nb0 = R(0), nb1 = R(0);
     static_for_down<K>([&](auto kc) EPSM_LAMBDA {
         constexpr int k = decltype(kc)::value;
-        const typename Out::Tri tri = out.pre_tri(k, k <= nv);
+        const typename Out::Tri tri = out.pre_tri(k, k <= nv, tid[k]);
         const typename Out::Aux aux = out.pre_aux(k, k <= nv);
         V3<R> Gxk = zero3<R>(), gnrm = Gxk, gm = Gxk, glight = Gxk, gdiff = Gxk;
         VCtx<R> ctx; ctx.b0 = ctx.b1 = R(0); ctx.n = ctx.e1 = ctx.e2 = zero3<R>();
@@ -627,12 +642,28 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
         }
     }
 
-    out.diffuse_first(fl.diffuse[1] ? A.dldp_at(i) : zero3<R>());   // epsm.py:998-1000
+    // A term whose solve turns out non-finite at depth id* contributes nothing to ANY parameter (the whole inverse is
+    // NaN -> nan_to_num, epsm.py:1076-1079), but the rows of vertices 1..id*-2 leave the lane before that is known.
+    // Dense output zeroes the path's rows afterwards (poison); an accumulating policy asks for a second turn of the
+    // loop in which the lanes concerned re-derive exactly those rows and emit them NEGATED.  Wave-uniform and rare
+    // (degenerate geometry only), so the common case runs the body once.
+    typename Out::Id tid[K + 2];
+    static_for_up<1, K>([&](auto kc) EPSM_LAMBDA { constexpr int k = decltype(kc)::value; tid[k] = out.pre_id(k, k <= nv || k == 1); });
+    tid[0] = tid[K + 1] = out.pre_id(1, false);
+    const int nv_all = nv, idstar_all = idstar;
+    bool poisoned = false;             // a live term turned out non-finite: zero every param gradient (nan_to_num)
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+    const bool undo = pass == 1;
+    if (undo) { nv = poisoned ? nv_all : 0; idstar = poisoned ? idstar_all : 0; }
+    const int undo_last = idstar - 2;  // undo turn: vertices 1..id*-2 were emitted before the term was known to be bad
+
+    if (!undo) out.diffuse_first(fl.diffuse[1] ? A.dldp_at(i) : zero3<R>(), tid[1]);   // epsm.py:998-1000
 
     const V3<R> cam = load3(A.cam, i);
     Geo<R> gcur, gnext;
     if (nv >= 1) gnext = load_geo(A.vtx(0), i);
-    typename Out::Tri tri_prev = out.pre_tri(1, false), tri_cur = out.pre_tri(1, nv >= 1);
+    typename Out::Tri tri_prev = out.pre_tri(1, false, tid[0]), tri_cur = out.pre_tri(1, nv >= 1, tid[1]);
     V3<R> n_prev = zero3<R>();
     V2<R> vprev = mk2<R>(R(0), R(0)), vcur = vprev;   // v_{k-1}, v_k   (v_1 = 0)
     V2<R> rprev = vprev;                               // r_{k-1}
@@ -641,7 +672,6 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
     R b0prev = R(0), b1prev = R(0);
     V3<R> Gx_prev = zero3<R>();        // -(d/dx_{k-1}) gathered so far for vertex k-1
     V3<R> gn_prev = zero3<R>(), gm_prev = zero3<R>();
-    bool poisoned = false;             // a live term turned out non-finite: zero every param gradient (nan_to_num)
 
     static_for_up<1, K>([&](auto kc) EPSM_LAMBDA {
         constexpr int k = decltype(kc)::value;
@@ -649,7 +679,7 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
         V3<R> Gx = zero3<R>(), ncur = zero3<R>();
         R b0 = R(0), b1 = R(0);
         const bool live = (k < K) && (k + 1 <= nv);    // depth k has a continuing sub-path we need
-        const typename Out::Tri tri_nxt = out.pre_tri(k < K ? k + 1 : K, live);   // vertex k+1: diffuse_grad[k] now, rows later
+        const typename Out::Tri tri_nxt = out.pre_tri(k < K ? k + 1 : K, live, tid[k < K ? k + 1 : K]);   // vertex k+1: diffuse_grad[k] now, rows later
         const typename Out::Aux aux_prev = out.pre_aux(k >= 2 ? k - 1 : 1, k >= 2 && (k - 1) <= idstar);
         if (live) {
             gcur = gnext;
@@ -708,12 +738,15 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
             rprev = rk;
             vprev = vcur;
         }
-        // vertex k-1 is complete once constraint k has been swept
-        if (k >= 2 && out.any((k - 1) <= idstar)) {
+        // vertex k-1 is complete once constraint k has been swept.  First turn: nothing more once the term is known
+        // to be bad; undo turn: minus what the first turn emitted before it knew.
+        const bool emit_prev = undo ? (k - 1) <= undo_last : ((k - 1) <= idstar && !poisoned);
+        if (k >= 2 && out.any(emit_prev)) {
+            const R m = emit_prev ? (undo ? R(-1) : R(1)) : R(0);
             VCtx<R> c; c.b0 = b0prev; c.b1 = b1prev; c.n = n_prev; c.e1 = e1prev; c.e2 = e2prev;
-            out.vertex(k - 1, true, Gx_prev, gn_prev, gm_prev, zero3<R>(), c, tri_prev, aux_prev);
+            out.vertex(k - 1, true, Gx_prev * m, gn_prev * m, gm_prev * m, zero3<R>(), c, tri_prev, aux_prev);
         }
-        if (k < K && out.any(live)) out.diffuse(k, gdiff, live ? gnext.b0 : R(0), live ? gnext.b1 : R(0), tri_nxt);
+        if (k < K && !undo && out.any(live)) out.diffuse(k, gdiff, live ? gnext.b0 : R(0), live ? gnext.b1 : R(0), tri_nxt);
         Gx_prev = Gx; gn_prev = gnrm; gm_prev = gm;
         tri_prev = tri_cur; tri_cur = tri_nxt;
         // geometry of vertex k, kept for its emission at step k+1 (flat-normal rows need e1,e2,n)
@@ -723,12 +756,13 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
         n_prev = ncur;
         b0prev = b0; b1prev = b1;
     });
-    // last vertex: only p0,p1,p2 are registered and no continuing row exists for it
-    {
+    // last vertex: only p0,p1,p2 are registered and no continuing row exists for it (id* <= K-1: never part of an undo)
+    if (!undo) {
         VCtx<R> c; c.b0 = b0prev; c.b1 = b1prev; c.n = n_prev; c.e1 = e1prev; c.e2 = e2prev;
-        out.vertex(K, false, Gx_prev, zero3<R>(), zero3<R>(), zero3<R>(), c, tri_prev, out.pre_aux(K, false));
+        out.vertex(K, false, poisoned ? zero3<R>() : Gx_prev, zero3<R>(), zero3<R>(), zero3<R>(), c, tri_prev, out.pre_aux(K, false));
     }
-    if (poisoned) out.poison(P);
+    if (undo || !out.undo_needed(poisoned, P)) break;
+    }
 }
 
 }  // namespace epsm

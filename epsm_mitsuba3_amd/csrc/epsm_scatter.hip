@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A,
             if (__ballot(live) == 0ull) continue;
             VertexItems<float> q;
             if (live) {
-                q = vertex_items(A.v[it], A.s[it], i, g, A.V, A.B);
+                q = vertex_items(A.v[it], A.s[it], A.tab, i, g, A.V, A.B);
             } else {
                 q.pos_ok = q.nrm_ok = q.alpha_ok = q.em_ok = q.sh_ok = false;
                 q.si[0] = q.si[1] = q.si[2] = kNoIndex;
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void epsm_scatter_kernel(ScatterArgs<float> A,
 
 extern "C" int epsm_scatter(int variant, int64_t N, int K,
                             const EpsmVertexRecord *verts, const EpsmScatterRecord *sc,
+                            const uint32_t *tri_table, int64_t T,
                             const float *out_param, const float *out_light, const float *out_diffuse,
                             float *grad_pos, float *grad_nrm, float *grad_alpha,
                             int64_t V, int64_t B, void *stream) {
@@ -86,6 +87,8 @@ extern "C" int epsm_scatter(int variant, int64_t N, int K,
     if (N < 0 || (N + 255) / 256 > 0x7fffffffLL) return fail(EPSM_EINVAL, "epsm_scatter: bad N");
     if (!verts || !sc || !out_param || !out_light || !out_diffuse || !grad_pos)
         return fail(EPSM_EINVAL, "epsm_scatter: NULL argument");
+    if (T < 0 || (T > 0 && !tri_table) || (((uintptr_t) tri_table) & 15))
+        return fail(EPSM_EINVAL, "epsm_scatter: bad triangle table (need T >= 0 rows of 16 B, 16-byte aligned)");
     if (!grad_nrm) return fail(EPSM_EINVAL, "epsm_scatter: grad_nrm is NULL (pass a (V,3) buffer; it stays zero "
                                             "when no mesh has EPSM_MODE_NRM_ATTACHED)");
     if (V < 0 || B < 0 || 2 * V + B >= 0xFFFFFFFFLL) return fail(EPSM_EINVAL, "epsm_scatter: bad buffer sizes (need 2V+B < 2^32-1)");
@@ -94,13 +97,14 @@ extern "C" int epsm_scatter(int variant, int64_t N, int K,
     A.N = N; A.K = K; A.P = epsm_num_param_grads(variant, K);
     A.out_param = out_param; A.out_light = out_light; A.out_diffuse = out_diffuse;
     A.V = V; A.B = grad_alpha ? B : 0;
+    A.tab = TriTable{tri_table, T};
     for (int k = 0; k < K; ++k) {
         const EpsmVertexRecord &v = verts[k];
         const EpsmScatterRecord &s = sc[k];
         if (!v.p0 || !v.p1 || !v.p2 || !v.n0 || !v.n1 || !v.n2 || !v.b0 || !v.b1 || !s.tri)
             return fail(EPSM_EINVAL, "epsm_scatter: NULL pointer in a vertex / scatter record");
-        if ((((uintptr_t) s.tri) | ((uintptr_t) s.aux) | ((uintptr_t) s.emit) | ((uintptr_t) s.shadow)) & 15)
-            return fail(EPSM_EINVAL, "epsm_scatter: tri/aux/emit/shadow must be 16-byte aligned");
+        if ((((uintptr_t) s.aux) | ((uintptr_t) s.emit) | ((uintptr_t) s.shadow)) & 15 || (((uintptr_t) s.tri) & 3))
+            return fail(EPSM_EINVAL, "epsm_scatter: aux/emit/shadow must be 16-byte aligned (tri: 4)");
         VertexPtrs<float> &o = A.v[k];
         o.p0 = (const float *) v.p0; o.p1 = (const float *) v.p1; o.p2 = (const float *) v.p2;
         o.n0 = (const float *) v.n0; o.n1 = (const float *) v.n1; o.n2 = (const float *) v.n2;
@@ -109,13 +113,13 @@ extern "C" int epsm_scatter(int variant, int64_t N, int K,
         t.tri = s.tri; t.aux = s.aux; t.emit = s.emit;
         t.shadow = k == 0 ? s.shadow : nullptr;       // epsm.py:610: `iteration == 0`
     }
-    Targets T{grad_pos, grad_nrm, grad_alpha};
+    Targets tg{grad_pos, grad_nrm, grad_alpha};
     const int64_t chunks = (N + 255) / 256;
     const int64_t blocks = chunks < kScatterBlocks ? chunks : kScatterBlocks;
     const int64_t chunks_per_block = (chunks + blocks - 1) / blocks;
     // Adaptive run merge (<= 16 runs per wave), 2048-row table (4 workgroups per CU): the winner of the A/B on
     // config 2 over {runs + hot-key rounds, direct LDS atomics, adaptive 8 / 16} x {1024, 2048, 4096 rows}.
-    hipLaunchKernelGGL((epsm_scatter_kernel<2048>), dim3((unsigned) blocks), dim3(256), 0, (hipStream_t) stream, A, T, chunks_per_block);
+    hipLaunchKernelGGL((epsm_scatter_kernel<2048>), dim3((unsigned) blocks), dim3(256), 0, (hipStream_t) stream, A, tg, chunks_per_block);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_scatter", e);
     return EPSM_OK;

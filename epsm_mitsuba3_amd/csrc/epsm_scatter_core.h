@@ -18,15 +18,17 @@ namespace epsm {
 constexpr uint32_t kNoIndex = 0xFFFFFFFFu;
 constexpr uint32_t kModeVertexNormals = 0x1u, kModeFlip = 0x2u, kModePos = 0x4u, kModeNrm = 0x8u;
 
-// EpsmScatterRecord (include/epsm.h): three packed arrays, one or two 16-byte loads each.
+// EpsmScatterRecord (include/epsm.h): a triangle id and up to three packed 16-byte records per vertex.
 // Float fields travel as raw bits; `R` only matters for the host harness / oracle where the
 // arrays still hold fp32.
 template <typename R> struct ScatterPtrs {
-    const uint32_t *tri;       // (N,4) v0,v1,v2,mode
+    const uint32_t *tri;       // (N)   id of the hit triangle (row of the triangle table)
     const uint32_t *aux;       // (N,4) bsdf_id, dhf xyz   or null
-    const uint32_t *emit;      // (N,8) e0,e1,e2, eb0,eb1,ew, 0,0   or null
-    const uint32_t *shadow;    // (N,8) s0,s1,s2, sb0,sb1,dis, mode,0   or null; first vertex only
+    const uint32_t *emit;      // (N,4) etri, eb0, eb1, ew   or null
+    const uint32_t *shadow;    // (N,4) stri, sb0, sb1, dis   or null; first vertex only
 };
+// The scene's triangle table (include/epsm.h): row t = [v0, v1, v2, mode]; ids >= T address nothing.
+struct TriTable { const uint32_t *rows; int64_t T; };
 EPSM_HD float bits_to_float(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
 struct U4 { uint32_t x, y, z, w; };
 EPSM_HD U4 load_u4(const uint32_t *base, int64_t i) {
@@ -42,11 +44,19 @@ EPSM_HD U4 load_u4(const uint32_t *base, int64_t i) {
 #endif
 }
 
+// one row of the triangle table; ids beyond the table give "no triangle"
+EPSM_HD U4 table_row(const TriTable &tab, uint32_t id) {
+    U4 r; r.x = r.y = r.z = 0xFFFFFFFFu; r.w = 0u;
+    if ((int64_t) id < tab.T) r = load_u4(tab.rows, (int64_t) id);
+    return r;
+}
+
 template <typename R> struct ScatterArgs {
     int64_t N;
     int K, P;                  // P = number of (N,3) arrays in out_param (5K or 5K-2)
     VertexPtrs<R> v[kMaxVertices];
     ScatterPtrs<R> s[kMaxVertices];
+    TriTable tab;
     const R *out_param, *out_light, *out_diffuse;
     int64_t V, B;
 };
@@ -86,14 +96,15 @@ template <typename R> struct VertexItems {
 // Occluder term: si_direct.p * diffuse_grad[0] * dis with detached barycentrics (epsm.py:609-620).
 template <typename R> struct ShadowItems { uint32_t si[3]; bool ok; V3<R> val[3]; };
 template <typename R>
-EPSM_HD ShadowItems<R> shadow_items(const uint32_t *shadow, int64_t i, V3<R> gdiff, int64_t V) {
+EPSM_HD ShadowItems<R> shadow_items(const uint32_t *shadow, const TriTable &tab, int64_t i, V3<R> gdiff, int64_t V) {
     ShadowItems<R> o;
     o.ok = false; o.si[0] = o.si[1] = o.si[2] = kNoIndex; o.val[0] = o.val[1] = o.val[2] = zero3<R>();
     if (!shadow || !nz3(gdiff)) return o;
-    const U4 a = load_u4(shadow, 2 * i), b = load_u4(shadow, 2 * i + 1);
-    o.si[0] = a.x; o.si[1] = a.y; o.si[2] = a.z;
-    const R c0 = R(bits_to_float(a.w)), c1 = R(bits_to_float(b.x)), dis = R(bits_to_float(b.y));
-    const uint32_t mode = b.z;
+    const U4 a = load_u4(shadow, i);
+    const U4 row = table_row(tab, a.x);
+    o.si[0] = row.x; o.si[1] = row.y; o.si[2] = row.z;
+    const R c0 = R(bits_to_float(a.y)), c1 = R(bits_to_float(a.z)), dis = R(bits_to_float(a.w));
+    const uint32_t mode = row.w;
     if (o.si[0] < (uint64_t) V && o.si[1] < (uint64_t) V && o.si[2] < (uint64_t) V && (mode & kModePos) && dis != R(0)) {
         o.ok = true;
         const V3<R> g = gdiff * dis;
@@ -103,10 +114,10 @@ EPSM_HD ShadowItems<R> shadow_items(const uint32_t *shadow, int64_t i, V3<R> gdi
 }
 
 template <typename R>
-EPSM_HD VertexItems<R> vertex_items(const VertexPtrs<R> &v, const ScatterPtrs<R> &s, int64_t i,
+EPSM_HD VertexItems<R> vertex_items(const VertexPtrs<R> &v, const ScatterPtrs<R> &s, const TriTable &tab, int64_t i,
                                     const VertexGrads<R> &g, int64_t V, int64_t B) {
     VertexItems<R> o;
-    const U4 t4 = load_u4(s.tri, i);
+    const U4 t4 = table_row(tab, gl(s.tri)[i]);
     const uint32_t mode = t4.w;
     o.vi[0] = t4.x; o.vi[1] = t4.y; o.vi[2] = t4.z;
     const bool idx_ok = o.vi[0] < (uint64_t) V && o.vi[1] < (uint64_t) V && o.vi[2] < (uint64_t) V;
@@ -156,18 +167,20 @@ EPSM_HD VertexItems<R> vertex_items(const VertexPtrs<R> &v, const ScatterPtrs<R>
     }
     // (4) si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627)
     o.em_ok = false; o.em[0] = o.em[1] = o.em[2] = zero3<R>(); o.ei[0] = o.ei[1] = o.ei[2] = kNoIndex;
-    if (s.emit) {
-        const U4 e4 = load_u4(s.emit, 2 * i), f4 = load_u4(s.emit, 2 * i + 1);
-        o.ei[0] = e4.x; o.ei[1] = e4.y; o.ei[2] = e4.z;
-        if (o.ei[0] < (uint64_t) V && o.ei[1] < (uint64_t) V && o.ei[2] < (uint64_t) V && nz3(g.glight)) {
-            const V3<R> gl = g.glight * R(bits_to_float(f4.y));
-            const R c0 = R(bits_to_float(e4.w)), c1 = R(bits_to_float(f4.x));
+    if (s.emit && nz3(g.glight)) {
+        const U4 e4 = load_u4(s.emit, i);
+        const U4 er = table_row(tab, e4.x);
+        o.ei[0] = er.x; o.ei[1] = er.y; o.ei[2] = er.z;
+        // (si_direct.p is AD-attached only when the emitter mesh's positions are)
+        if (o.ei[0] < (uint64_t) V && o.ei[1] < (uint64_t) V && o.ei[2] < (uint64_t) V && (er.w & kModePos)) {
+            const V3<R> gl = g.glight * R(bits_to_float(e4.w));
+            const R c0 = R(bits_to_float(e4.y)), c1 = R(bits_to_float(e4.z));
             o.em_ok = true;
             o.em[0] = gl * c0; o.em[1] = gl * c1; o.em[2] = gl * (R(1) - c0 - c1);
         }
     }
     // (5) occluder of the emitter sample of the first vertex (epsm.py:609-620)
-    const ShadowItems<R> sh = shadow_items<R>(s.shadow, i, g.gdiff, V);
+    const ShadowItems<R> sh = shadow_items<R>(s.shadow, tab, i, g.gdiff, V);
     o.sh_ok = sh.ok;
     for (int j = 0; j < 3; ++j) { o.si[j] = sh.si[j]; o.sh[j] = sh.val[j]; }
     return o;

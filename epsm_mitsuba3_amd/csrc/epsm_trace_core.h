@@ -484,7 +484,7 @@ struct EmitterSample {
     F3 p, n, d, weight;              // ds.p, ds.n, ds.d, radiance / pdf (already zero when occluded / facing away)
     float pdf, dist;
     bool delta, valid;
-    uint32_t vi[3]; float b0, b1;    // triangle + barycentrics of the sampled point (parameter addressing)
+    uint32_t tri; float b0, b1;      // triangle id + barycentrics of the sampled point (parameter addressing)
 };
 EPSM_HD F3 emitter_normal(const EpsmScene &S, const EpsmMesh &m, const uint32_t *iv, float w0, float w1, float w2, F3 q0, F3 q1, F3 q2) {
     F3 n = normalize3(cross(q1 - q0, q2 - q0));
@@ -499,7 +499,7 @@ EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit
                                                Vis &vis) {
     EmitterSample e;
     e.p = e.n = e.d = e.weight = zero3<float>(); e.pdf = 0.f; e.dist = 0.f; e.delta = false; e.valid = false;
-    e.vi[0] = e.vi[1] = e.vi[2] = kNoIndex; e.b0 = e.b1 = 0.f;
+    e.tri = kNoIndex; e.b0 = e.b1 = 0.f;
     if (!active || S.n_emitters <= 0) return e;
     // scene.cpp:233-246: uniform emitter choice, the sample is re-used
     const int count = S.n_emitters;
@@ -536,7 +536,7 @@ EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit
         const float w0 = 1.f - bx - by;
         e.p = q0 * w0 + q1 * bx + q2 * by;
         e.n = emitter_normal(S, m, iv, w0, bx, by, q0, q1, q2);
-        e.vi[0] = iv[0]; e.vi[1] = iv[1]; e.vi[2] = iv[2]; e.b0 = w0; e.b1 = bx;
+        e.tri = t; e.b0 = w0; e.b1 = bx;
         F3 d = e.p - ref.p;
         const float dist2 = dot(d, d);
         e.dist = sqrtf(dist2); e.d = d * (1.f / e.dist);
@@ -644,13 +644,11 @@ EPSM_HD void write_record(const EpsmRecordOut &R, int64_t i, bool active, const 
     st3(R.hf, i, bs.hf); st3(R.light, i, es.p);
     st1(R.bsdf + i, flags);
     st1(R.active + i, (uint8_t) (active ? 1 : 0)); st1(R.active_em + i, (uint8_t) (active_em ? 1 : 0)); st1(R.ismesh + i, (uint8_t) (mesh ? 1 : 0));
-    uint32_t *t = R.tri + 4 * i;
-    st1(t, mesh ? h.vi[0] : kNoIndex); st1(t + 1, mesh ? h.vi[1] : kNoIndex); st1(t + 2, mesh ? h.vi[2] : kNoIndex);
-    st1(t + 3, h.mesh_flags & 0xFu);
+    st1(R.tri + i, mesh ? h.tri : kNoIndex);                     // row of the scene's triangle table (include/epsm.h)
     uint32_t *a = R.aux + 4 * i;
     st1(a, alpha_slot >= 0 ? (uint32_t) alpha_slot : kNoIndex); st1(a + 1, f2u(bs.dhf.x)); st1(a + 2, f2u(bs.dhf.y)); st1(a + 3, f2u(bs.dhf.z));
-    uint32_t *e = R.emit + 8 * i;
-    st1(e, es.vi[0]); st1(e + 1, es.vi[1]); st1(e + 2, es.vi[2]); st1(e + 3, f2u(es.b0)); st1(e + 4, f2u(es.b1)); st1(e + 5, f2u(eweight)); st1(e + 6, 0u); st1(e + 7, 0u);
+    uint32_t *e = R.emit + 4 * i;
+    st1(e, es.tri); st1(e + 1, f2u(es.b0)); st1(e + 2, f2u(es.b1)); st1(e + 3, f2u(eweight));
 }
 
 // EPSM_TRACE_SPARSE_LOG: a bounce the path did not reach leaves only the fields the gradient kernels' masks read
@@ -660,24 +658,23 @@ EPSM_HD void write_dead_masks(const EpsmRecordOut &R, int64_t i) {
 }
 // Default record of the occluder term: "no occluder" (epsm.py:609-620 not taken)
 EPSM_HD void write_no_occluder(uint32_t *o) {
-    o[0] = o[1] = o[2] = kNoIndex; o[3] = o[4] = o[5] = o[6] = o[7] = 0u;
+    o[0] = kNoIndex; o[1] = o[2] = o[3] = 0u;
 }
 // Occluder of the first vertex's emitter sample (epsm.py:609-620; integrators with max_depth <= 3): closest hit of the
 // ray towards the sample, NO maximum distance, as scene.ray_intersect(si.spawn_ray(ds.d)).  `sr` = spawn_ray(si, ds.d),
 // `oh` its closest hit, sip = si.p, esp = ds.p.
 EPSM_HD void write_occluder(const EpsmScene &S, uint32_t *o, const Ray &sr, const TriHit &oh, F3 sip, F3 esp) {
-    uint32_t w[8] = {kNoIndex, kNoIndex, kNoIndex, 0u, 0u, 0u, 0u, 0u};
+    uint32_t w[4] = {kNoIndex, 0u, 0u, 0u};
     if (oh.hit) {
         const SurfHit occ = surface_interaction(S, sr, oh);
         if (occ.mesh_flags & EPSM_MESH_IS_MESH) {
             const F3 a = esp - occ.p, b = esp - sip;
             float dis = sqrtf(dot(a, a)) / sqrtf(dot(b, b));                     // :614
             if (!(dis >= 0.01f)) dis = 0.f;                                      // :615
-            w[0] = occ.vi[0]; w[1] = occ.vi[1]; w[2] = occ.vi[2];
-            w[3] = f2u(occ.b0); w[4] = f2u(occ.b1); w[5] = f2u(dis); w[6] = occ.mesh_flags & 0xFu;
+            w[0] = occ.tri; w[1] = f2u(occ.b0); w[2] = f2u(occ.b1); w[3] = f2u(dis);
         }
     }
-    for (int j = 0; j < 8; ++j) o[j] = w[j];
+    for (int j = 0; j < 4; ++j) o[j] = w[j];
 }
 
 // What a path carries from one bounce to the next (the loop state of epsm.py:527-545)
@@ -791,7 +788,7 @@ struct InlineVis {
     EPSM_HD bool occluded(const EpsmScene &S, const Ray &sr) { return intersect<true>(S, sr, st).hit; }
     EPSM_HD void direct(F3 &L, F3 Le, F3 Lr_dir) { L = L + Le + Lr_dir; }
     EPSM_HD void occluder(const TraceArgs &A, int64_t i, const SurfHit &si, const EmitterSample &es, bool active_em) {
-        uint32_t *o = A.rec[0].shadow + 8 * i;
+        uint32_t *o = A.rec[0].shadow + 4 * i;
         if (A.max_depth <= 3 && active_em) {
             const Ray sr = spawn_ray(si, es.d);
             write_occluder(A.S, o, sr, intersect<false>(A.S, sr, st), si.p, es.p);

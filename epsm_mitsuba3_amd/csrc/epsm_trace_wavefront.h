@@ -156,7 +156,7 @@ struct DeferredVis {
     EPSM_HD void direct(F3 &L, F3 Le, F3 Lr_dir) { L = L + Le; Lr = Lr_dir; }                           // + Lr_dir if visible
     EPSM_HD void occluder(const TraceArgs &A, int64_t i, const SurfHit &, const EmitterSample &, bool active_em) {
         if (A.max_depth <= 3 && active_em) want_occluder = true;         // active_em => the visibility ray is pending too
-        else write_no_occluder(A.rec[0].shadow + 8 * i);
+        else write_no_occluder(A.rec[0].shadow + 4 * i);
     }
 };
 
@@ -199,7 +199,7 @@ EPSM_HD bool wf_shadow_round(const TraceArgs &A, const WfState &W, int iteration
         if (!trav_done(J.T)) trav_round<true>(J.T, A.S, st);
         if (!trav_done(J.T)) return false;
         if (J.T.best.hit) {                                              // occluded
-            if (iteration < A.K_log) A.rec[iteration].emit[8 * i + 5] = 0u;   // Lr_dir = 0: the logged weight with it
+            if (iteration < A.K_log) A.rec[iteration].emit[4 * i + 3] = 0u;   // Lr_dir = 0: the logged weight with it
         } else {
             const W4 l = W.L[i];
             const F3 L = xyz(l) + xyz(W.sh_L[i]);                        // (L + Le) + Lr_dir, epsm.py:658
@@ -222,7 +222,7 @@ EPSM_HD bool wf_shadow_round(const TraceArgs &A, const WfState &W, int iteration
     const F3 dd = esp - sip;
     const float dist = sqrtf(dot(dd, dd));
     Ray r2; r2.o = xyz(W.sh_o[i]); r2.d = dd * (1.f / dist); r2.maxt = kInf;
-    write_occluder(A.S, A.rec[0].shadow + 8 * i, r2, trav_result(J.T, A.S), sip, esp);
+    write_occluder(A.S, A.rec[0].shadow + 4 * i, r2, trav_result(J.T, A.S), sip, esp);
     return true;
 }
 EPSM_HD void wf_shadow(const TraceArgs &A, const WfState &W, int64_t i, int iteration, uint32_t *lds, int stride) {
@@ -240,9 +240,9 @@ EPSM_HD void write_dead_record(const EpsmRecordOut &R, int64_t i) {
     st3(R.hf, i, z); st3(R.light, i, z);
     st1(R.bsdf + i, 0u);
     st1(R.active + i, (uint8_t) 0); st1(R.active_em + i, (uint8_t) 0); st1(R.ismesh + i, (uint8_t) 0);
-    uint32_t *t = R.tri + 4 * i; st1(t, kNoIndex); st1(t + 1, kNoIndex); st1(t + 2, kNoIndex); st1(t + 3, 0u);
+    st1(R.tri + i, kNoIndex);
     uint32_t *a = R.aux + 4 * i; st1(a, kNoIndex); st1(a + 1, 0u); st1(a + 2, 0u); st1(a + 3, 0u);
-    uint32_t *e = R.emit + 8 * i; st1(e, kNoIndex); st1(e + 1, kNoIndex); st1(e + 2, kNoIndex); for (int j = 3; j < 8; ++j) st1(e + j, 0u);
+    uint32_t *e = R.emit + 4 * i; st1(e, kNoIndex); st1(e + 1, 0u); st1(e + 2, 0u); st1(e + 3, 0u);
 }
 
 // ---- stage: finish.  radiance / valid of path i and the records of the bounces it did not reach.

@@ -83,9 +83,11 @@ struct AccFloat {
 struct AccFixed64 {
     typedef long long T;
     __device__ __forceinline__ static T to_fixed(float x) {
-        const float fl = floorf(x), hi = fminf(fmaxf(fl, -2147483520.f), 2147483520.f);
-        const uint32_t lo = (uint32_t) ((x - fl) * 4294967296.f);                 // fraction in [0,1): exact in float
-        return (T) (((unsigned long long) (uint32_t) (int) hi << 32) | lo);
+        // x * 2^32 is exact in float (a power-of-two scale); clamped to the int64 range first, so the conversion is
+        // defined for every finite input (|x| < 2^31 - 2^7), then rounded to nearest: resolution 2^-32.
+        // NaN (a degenerate normal row) counts as 0, as a float row that is never flushed would.
+        const float s = fminf(fmaxf(x == x ? x : 0.f, -2147483520.f), 2147483520.f) * 4294967296.f;
+        return (T) __float2ll_rn(s);
     }
     __device__ __forceinline__ static void add(T *p, float x) { atomicAdd((unsigned long long *) p, (unsigned long long) to_fixed(x)); }
     __device__ __forceinline__ static float get(T q) { return (float) ((double) q * 2.3283064365386963e-10); }

@@ -54,7 +54,7 @@ class EPSMIntegrator:
         max_depth = props.get("max_depth", 6)           # common.py:31-37
         if max_depth < 0 and max_depth != -1:
             raise Exception("\"max_depth\" must be set to -1 (infinite) or a value >= 0")
-        self.max_depth = max_depth if max_depth != -1 else 0xFFFFFFFF
+        self.max_depth = max_depth            # -1 = infinite (the reference stores 0xffffffff, common.py:37)
         self.rr_depth = props.get("rr_depth", 5)        # common.py:39-41
         if self.rr_depth <= 0:
             raise Exception("\"rr_depth\" must be set to a value greater than zero!")
@@ -69,7 +69,8 @@ class EPSMIntegrator:
         self.fused = props.get("fused", True)
 
     def to_string(self):
-        return f"{type(self).__name__}[max_depth = {self.max_depth}, rr_depth = {self.rr_depth}]"
+        md = 0xFFFFFFFF if self.max_depth < 0 else self.max_depth
+        return f"{type(self).__name__}[max_depth = {md}, rr_depth = {self.rr_depth}]"
 
     __repr__ = to_string
 
@@ -86,10 +87,14 @@ class EPSMIntegrator:
             raise Exception("develop=True must be specified when invoking AD integrators")
         if not hasattr(scene, "render_primal"):
             raise NotImplementedError("scene object has no render_primal(sensor, seed, spp, max_depth)")
-        img = scene.render_primal(sensor=sensor, seed=seed, spp=spp, max_depth=self.max_depth)
+        img = scene.render_primal(sensor=sensor, seed=seed, spp=spp, max_depth=self.primal_depth())
         pad = torch.zeros(img.shape[0], img.shape[1], 2, device=img.device, dtype=img.dtype)
         self.primal_image = torch.cat([img[..., :3], pad], dim=-1)
         return self.primal_image
+
+    def primal_depth(self) -> int:
+        """The primal pass has no 6-bounce cap (recorded loop, epsm.py:308-501); -1 = as deep as the tracer goes."""
+        return 1 << 20 if self.max_depth < 0 else int(self.max_depth)
 
     # -- backward -----------------------------------------------------------
     def render_backward(self, scene, params: ParamGrads, grad_in: torch.Tensor,
@@ -100,15 +105,27 @@ class EPSMIntegrator:
         if grad_in.shape[-1] == 3:
             raise NotImplementedError("colour-only adjoint (epsm.py:230-234) is the PRB path, not the EPSM hot path")
         rank, world = _dist.world()
-        traces = scene.trace_paths(sensor=self.backward_sensor, seed=seed, spp=self.backward_spp,
-                                   max_depth=min(self.max_depth, 6), max_log_depth=self.max_log_depth,
-                                   rank=rank, world_size=world,
-                                   sparse_log=True)   # the log is consumed here and nowhere else: skip the zeros of dead bounces
+        # dr.backward ACCUMULATES into the gradients that are already there.  With more than one rank only THIS
+        # call's contribution may be summed over the ranks: what `params` held on entry is already a sum over the
+        # ranks (or the caller's own data) and must not be multiplied by the world size.
+        target = params.scratch() if world > 1 else params
+        tracer = getattr(scene, "iter_traces", None) or scene.trace_paths      # a generator: one tile resident at a time
+        traces = tracer(sensor=self.backward_sensor, seed=seed, spp=self.backward_spp,
+                        max_depth=self.tracer_depth(), max_log_depth=self.max_log_depth, rank=rank, world_size=world,
+                        sparse_log=True)   # the log is consumed here and nowhere else: skip the zeros of dead bounces
         if isinstance(traces, PathTrace):
             traces = [traces]
         for trace in traces:                       # this rank's pixel/sample tiles
-            self.backward_from_trace(trace, params, grad_in)
-        _dist.allreduce_param_grads(params.flat)   # one RCCL all-reduce of the whole buffer
+            self.backward_from_trace(trace, target, grad_in)
+            del trace
+        if world > 1:
+            _dist.allreduce_param_grads(target.flat)   # one RCCL all-reduce of the whole buffer
+            params.flat += target.flat
+
+    def tracer_depth(self) -> int:
+        """``max_depth`` as the tracer takes it: the path loop stops after 6 bounces whatever the integrator says
+        (epsm.py:549) and -1 means "no limit" (common.py:31-37)."""
+        return 6 if self.max_depth < 0 else min(self.max_depth, 6)
 
     def backward_from_trace(self, trace: PathTrace, params: ParamGrads, grad_in: torch.Tensor,
                             packed=None, out=None, mark: Optional[Callable[[str], None]] = None,

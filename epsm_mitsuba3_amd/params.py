@@ -31,6 +31,14 @@ class ParamGrads:
         self.flat.zero_()
         return self
 
+    def scratch(self) -> "ParamGrads":
+        """A zeroed buffer of the same layout (allocated once, cleared on every call): what ONE backward pass
+        contributes before it is summed over the ranks and added to the accumulated gradients."""
+        s = getattr(self, "_scratch", None)
+        if s is None:
+            s = self._scratch = ParamGrads(self.V, self.B, device=self.flat.device, mesh_slices=self.mesh_slices)
+        return s.zero_()
+
     def mesh_pos(self, name: str) -> torch.Tensor:
         lo, hi = self.mesh_slices[name]
         return self.pos[lo:hi]

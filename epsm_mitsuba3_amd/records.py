@@ -8,7 +8,7 @@ row-major vectors, (N) fp32 scalars, (N) u8 masks, (N) u32 BSDF flags.
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -108,47 +108,122 @@ MODE_VERTEX_NORMALS, MODE_FLIP_NORMALS, MODE_POS_ATTACHED, MODE_NRM_ATTACHED = 1
 NO_INDEX = 0xFFFFFFFF
 
 
-def pack_scatter_vertex(rec: dict, device, float_dtype=torch.float32) -> dict:
-    """One logged vertex's parameter addressing -> the three packed int32 arrays of
-    ``EpsmScatterRecord``: ``tri (N,4) = [v0,v1,v2,mode]``, ``aux (N,4) = [bsdf_id, dhf xyz bits]``,
-    ``emit (N,8) = [e0,e1,e2, eb0,eb1,eweight bits, 0,0]``, and (first vertex, ``max_depth <= 3`` only)
-    ``shadow (N,8) = [s0,s1,s2, sb0,sb1,dis bits, mode, 0]``.  Accepts either the packed keys or the
-    loose ones (``vidx, mode, bsdf_id, dhf_dalpha, evidx, eb0, eb1, eweight, svidx, sb0, sb1, sdis, smode``)."""
-    dev = torch.device(device)
-    if "tri" in rec:
-        out = {"tri": rec["tri"], "aux": rec.get("aux"), "emit": rec.get("emit"), "shadow": rec.get("shadow")}
-    else:
-        i32 = lambda t: t.detach().to(dev).to(torch.int32)
-        bits = lambda t: t.detach().to(dev).to(torch.float32).contiguous().view(torch.int32)
-        tri = torch.cat([i32(rec["vidx"]).reshape(-1, 3), i32(rec["mode"]).reshape(-1, 1)], dim=1)
-        out = {"tri": tri, "aux": None, "emit": None, "shadow": None}
-        if rec.get("svidx") is not None:
-            n = tri.shape[0]
-            out["shadow"] = torch.cat([i32(rec["svidx"]).reshape(-1, 3), bits(rec["sb0"]).reshape(-1, 1),
-                                       bits(rec["sb1"]).reshape(-1, 1), bits(rec["sdis"]).reshape(-1, 1),
-                                       i32(rec["smode"]).reshape(-1, 1), torch.zeros((n, 1), dtype=torch.int32, device=dev)], dim=1)
-        if rec.get("bsdf_id") is not None and rec.get("dhf_dalpha") is not None:
-            out["aux"] = torch.cat([i32(rec["bsdf_id"]).reshape(-1, 1), bits(rec["dhf_dalpha"]).reshape(-1, 3)], dim=1)
+PACKED_KEYS = ("tri", "aux", "emit", "shadow")
+
+
+def _loose_to_packed(scatter_info: Sequence[dict], dev) -> tuple:
+    """Loose addressing (``vidx (N,3), mode (N), bsdf_id, dhf_dalpha (N,3), evidx (N,3), eb0, eb1, eweight, svidx (N,3),
+    sb0, sb1, sdis, smode``: vertex rows per path, the form small tests write by hand) -> packed records + a private
+    triangle table holding the distinct ``[v0, v1, v2, mode]`` rows.  A triple with a negative index means "none"."""
+    i32 = lambda t: t.detach().to(dev).to(torch.int64)
+    bits = lambda t: t.detach().to(dev).to(torch.float32).contiguous().view(torch.int32).to(torch.int64)
+    rows, spans = [], []
+
+    def add(vidx, mode):
+        v = i32(vidx).reshape(-1, 3)
+        m = i32(mode).reshape(-1, 1) if torch.is_tensor(mode) else torch.full((v.shape[0], 1), int(mode), dtype=torch.int64, device=dev)
+        spans.append((len(rows), v.shape[0]))
+        rows.append(torch.cat([v, m], dim=1))
+        return len(rows) - 1
+    slots = []
+    for rec in scatter_info:
+        n = i32(rec["vidx"]).reshape(-1, 3).shape[0]
+        slot = {"tri": add(rec["vidx"], rec.get("mode", MODE_POS_ATTACHED | MODE_NRM_ATTACHED | MODE_VERTEX_NORMALS))}
         if rec.get("evidx") is not None:
-            n = tri.shape[0]
-            out["emit"] = torch.cat([i32(rec["evidx"]).reshape(-1, 3), bits(rec["eb0"]).reshape(-1, 1),
-                                     bits(rec["eb1"]).reshape(-1, 1), bits(rec["eweight"]).reshape(-1, 1),
-                                     torch.zeros((n, 2), dtype=torch.int32, device=dev)], dim=1)
-    return {k: (None if v is None else v.detach().to(device=dev, dtype=torch.int32).contiguous()) for k, v in out.items()}
+            slot["emit"] = add(rec["evidx"], MODE_POS_ATTACHED)
+        if rec.get("svidx") is not None:
+            slot["shadow"] = add(rec["svidx"], rec.get("smode", MODE_POS_ATTACHED))
+        slots.append((slot, n))
+    allrows = torch.cat(rows, dim=0)
+    none = (allrows[:, :3] < 0).any(dim=1) | (allrows[:, :3] >= 0xFFFFFFFF).any(dim=1)
+    table, inv = torch.unique(allrows[~none], dim=0, return_inverse=True)
+    ids = torch.full((allrows.shape[0],), NO_INDEX, dtype=torch.int64, device=dev)
+    ids[~none] = inv
+    offs, o = [], 0
+    for r in rows:
+        offs.append(o); o += r.shape[0]
+    tid = lambda j: ids[offs[j]: offs[j] + rows[j].shape[0]]
+    out = []
+    for (slot, n), rec in zip(slots, scatter_info):
+        p = {"tri": tid(slot["tri"]), "aux": None, "emit": None, "shadow": None}
+        if rec.get("bsdf_id") is not None and rec.get("dhf_dalpha") is not None:
+            p["aux"] = torch.cat([i32(rec["bsdf_id"]).reshape(-1, 1), bits(rec["dhf_dalpha"]).reshape(-1, 3)], dim=1)
+        if "emit" in slot:
+            p["emit"] = torch.stack([tid(slot["emit"]), bits(rec["eb0"]), bits(rec["eb1"]), bits(rec["eweight"])], dim=1)
+        if "shadow" in slot:
+            p["shadow"] = torch.stack([tid(slot["shadow"]), bits(rec["sb0"]), bits(rec["sb1"]), bits(rec["sdis"])], dim=1)
+        out.append(p)
+    if table.shape[0] == 0:
+        table = torch.zeros((1, 4), dtype=torch.int64, device=dev)
+    return out, table
+
+
+def loose_from_packed(rec: dict, table: Optional[torch.Tensor] = None) -> dict:
+    """The inverse view of ``_loose_to_packed`` for ONE vertex: vertex rows and mode bits per path, looked up in the
+    triangle table (``vidx, mode, bsdf_id, dhf_dalpha, evidx, emode, eb0, eb1, eweight, svidx, smode, sb0, sb1, sdis``;
+    "no triangle" = rows of -1, mode 0).  What the kernels do with the records, spelled out in torch."""
+    table = (rec.get("table") if table is None else table).to(torch.int64)
+    T = table.shape[0]
+
+    def rows(ids):
+        ids = ids.to(torch.int64) & 0xFFFFFFFF
+        ok = ids < T
+        r = table[torch.where(ok, ids, torch.zeros_like(ids))]
+        return torch.where(ok[:, None], r[:, :3], torch.full_like(r[:, :3], -1)), torch.where(ok, r[:, 3], torch.zeros_like(ids))
+    f = lambda t: t.contiguous().view(torch.float32)
+    out = {}
+    out["vidx"], out["mode"] = rows(rec["tri"])
+    if rec.get("aux") is not None:
+        out["bsdf_id"], out["dhf_dalpha"] = rec["aux"][:, 0], f(rec["aux"][:, 1:4].to(torch.int32))
+    if rec.get("emit") is not None:
+        e = rec["emit"].to(torch.int32)
+        out["evidx"], out["emode"] = rows(e[:, 0])
+        out["eb0"], out["eb1"], out["eweight"] = f(e[:, 1]), f(e[:, 2]), f(e[:, 3])
+    if rec.get("shadow") is not None:
+        h = rec["shadow"].to(torch.int32)
+        out["svidx"], out["smode"] = rows(h[:, 0])
+        out["sb0"], out["sb1"], out["sdis"] = f(h[:, 1]), f(h[:, 2]), f(h[:, 3])
+    return out
 
 
 class PackedScatter:
-    """Per-vertex addressing of the parameter buffers next to ``PackedRecords``; keeps the packed
-    tensors alive next to the ctypes array.  ``scatter_info[k-1]``: see ``pack_scatter_vertex``."""
+    """Per-vertex addressing of the parameter buffers next to ``PackedRecords`` (``EpsmScatterRecord`` + the scene's
+    triangle table, include/epsm.h); keeps the tensors alive next to the ctypes array.
 
-    def __init__(self, scatter_info: Sequence[dict], device, float_dtype=torch.float32):
+    ``scatter_info[k-1]`` holds either the packed arrays -- ``tri (N) int32`` triangle ids, ``aux (N,4)``
+    ``[bsdf_id, d hf / d alpha bits]``, ``emit (N,4) [etri, eb0, eb1, eweight bits]``, ``shadow (N,4) [stri, sb0, sb1,
+    dis bits]`` (first vertex, ``max_depth <= 3`` only), any of the last three may be ``None`` -- with the table
+    ``(T,4) int32 [v0, v1, v2, mode]`` passed as ``table`` or stored under ``scatter_info[0]["table"]``; or the loose
+    per-path vertex triples of ``_loose_to_packed``."""
+
+    def __init__(self, scatter_info: Sequence[dict], device, float_dtype=torch.float32, table: Optional[torch.Tensor] = None):
         self.K = len(scatter_info)
-        self.device = torch.device(device)
-        self.packed = [pack_scatter_vertex(rec, self.device, float_dtype) for rec in scatter_info]
-        self.records = (EpsmScatterRecord * self.K)()
+        self.device = dev = torch.device(device)
+        if self.K and "tri" not in scatter_info[0]:
+            packed, table = _loose_to_packed(scatter_info, dev)
+        else:
+            packed = [{k: rec.get(k) for k in PACKED_KEYS} for rec in scatter_info]
+            if table is None and self.K:
+                table = scatter_info[0].get("table")
+            if table is None:
+                raise ValueError("PackedScatter: packed addressing needs the scene's triangle table")
+        conv = lambda v: None if v is None else v.detach().to(device=dev, dtype=torch.int32).contiguous()
+        self.packed = [{k: conv(v) for k, v in p.items()} for p in packed]
+        self.table = conv(table).reshape(-1, 4)
+        self.T = int(self.table.shape[0])
+        self.records = (EpsmScatterRecord * max(1, self.K))()
         for k, p in enumerate(self.packed):
             r = self.records[k]
+            n = p["tri"].shape[0]
+            for name, width in (("aux", 4), ("emit", 4), ("shadow", 4)):
+                if p[name] is not None and tuple(p[name].shape) != (n, width):
+                    raise ValueError(f"scatter record {name!r}: expected shape {(n, width)}, got {tuple(p[name].shape)}")
+            if p["tri"].dim() != 1:
+                raise ValueError(f"scatter record 'tri': expected {n} triangle ids, got shape {tuple(p['tri'].shape)}")
             r.tri = p["tri"].data_ptr()
             r.aux = p["aux"].data_ptr() if p["aux"] is not None else None
             r.emit = p["emit"].data_ptr() if p["emit"] is not None else None
             r.shadow = p["shadow"].data_ptr() if p.get("shadow") is not None else None
+
+    def table_ptr(self) -> int:
+        return self.table.data_ptr()

@@ -626,6 +626,14 @@ class Scene:
         self.tri = torch.from_numpy(np.ascontiguousarray(TRI, dtype=np.int32)).to(dev)
         self.tri_mesh = torch.from_numpy(np.ascontiguousarray(np.concatenate(tri_mesh) if tri_mesh else np.zeros(0), dtype=np.int32)).to(dev)
         self.emitter_cdf = f32(np.concatenate(cdf) if cdf else np.zeros(1))
+        # the triangle table of include/epsm.h: row t = [v0, v1, v2, EPSM_MODE_* of the owning mesh]; the tracer logs
+        # triangle ids, the gradient kernels look the vertex rows up here
+        mode = np.array([m.flags() & 0xF for m in self.meshes], dtype=np.int64)
+        tm = np.concatenate(tri_mesh).astype(np.int64) if tri_mesh else np.zeros(0, np.int64)
+        table = np.concatenate([TRI.reshape(-1, 3), mode[tm].reshape(-1, 1) if len(tm) else np.zeros((0, 1), np.int64)], axis=1)
+        if table.shape[0] == 0:
+            table = np.zeros((1, 4), np.int64)
+        self.tri_table = torch.from_numpy(np.ascontiguousarray(table, dtype=np.int32)).to(dev)
         self.bvh = None
         if self.T > 0:
             self.bvh = DeviceBvh(build_bvh(P, TRI), dev)
@@ -684,16 +692,16 @@ class Scene:
         if K > 0:
             f1 = torch.empty((3 * K, n), device=dev, dtype=torch.float32).unbind(0)
             bsdf = torch.empty((K, n), device=dev, dtype=torch.int32).unbind(0)
-            quad = torch.empty((2 * K, n, 4), device=dev, dtype=torch.int32).unbind(0)
-            # + the occluder record of the first vertex (integrators with max_depth <= 3, epsm.py:609-620)
+            tri_id = torch.empty((K, n), device=dev, dtype=torch.int32).unbind(0)
+            # aux, emit (+ the occluder record of the first vertex: integrators with max_depth <= 3, epsm.py:609-620)
             want_shadow = max_depth <= 3
-            emit = torch.empty((K + (1 if want_shadow else 0), n, 8), device=dev, dtype=torch.int32).unbind(0)
+            quad = torch.empty((2 * K + (1 if want_shadow else 0), n, 4), device=dev, dtype=torch.int32).unbind(0)
         for k in range(K):
             t = dict(zip(("p0", "p1", "p2", "p", "n0", "n1", "n2", "normal", "hf", "light"), v3[5 + 10 * k: 15 + 10 * k]))
             t.update(zip(("b0", "b1", "eta"), f1[3 * k: 3 * k + 3]))
             t.update(zip(("active", "active_em", "ismesh"), u8[1 + 3 * k: 4 + 3 * k]))
-            t["bsdf"], t["tri"], t["aux"], t["emit"] = bsdf[k], quad[2 * k], quad[2 * k + 1], emit[k]
-            shadow = emit[K] if (k == 0 and want_shadow) else None
+            t["bsdf"], t["tri"], t["aux"], t["emit"] = bsdf[k], tri_id[k], quad[2 * k], quad[2 * k + 1]
+            shadow = quad[2 * K] if (k == 0 and want_shadow) else None
             r = recs[k]
             for name, _ in EpsmRecordOut._fields_:
                 setattr(r, name, t[name].data_ptr() if name != "shadow" else (shadow.data_ptr() if shadow is not None else None))
@@ -701,7 +709,8 @@ class Scene:
                          "active_em": t["active_em"], "points": [t["p0"], t["p1"], t["p2"], t["p"]],
                          "uv": [t["b0"], t["b1"]], "normal": t["normal"], "normals": [t["n0"], t["n1"], t["n2"]],
                          "eta": t["eta"], "hf": t["hf"]})
-            sinfo.append({"tri": t["tri"], "aux": t["aux"] if self.alpha_slots else None, "emit": t["emit"], "shadow": shadow})
+            sinfo.append({"tri": t["tri"], "aux": t["aux"] if self.alpha_slots else None, "emit": t["emit"], "shadow": shadow,
+                          "table": self.tri_table})
         cs = sensor.c_struct()
         args = [C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
                 C.c_int64(lo), C.c_int64(n), K, C.c_void_p(ray[0].data_ptr()), C.c_void_p(ray[1].data_ptr()),
@@ -726,13 +735,17 @@ class Scene:
         tr.film_pos, tr.radiance, tr.valid = film_pos, radiance, valid
         return tr
 
-    def trace_paths(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1, sparse_log=False):
-        """This rank's tiles of the backward wavefront of ``sensors[sensor]`` (epsm.py:142-181).  ``sparse_log``:
-        EPSM_TRACE_SPARSE_LOG -- bounces a path did not reach carry only their (zero) mask fields, which is all the
-        gradient kernels read of them; the other arrays are uninitialised there."""
-        s = self.sensors[min(sensor, len(self.sensors) - 1)]
+    def iter_traces(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1, sparse_log=False):
+        """Generator over this rank's tiles of the backward wavefront of ``sensors[sensor]`` (epsm.py:142-181): a tile
+        is traced when the consumer asks for it, so ``render_backward`` holds ONE tile's records (~0.8 KB per path at
+        K = 5) at a time whatever the size of the wavefront.  ``sparse_log``: EPSM_TRACE_SPARSE_LOG -- bounces a path
+        did not reach carry only their (zero) mask fields, which is all the gradient kernels read of them; the other
+        arrays are uninitialised there."""
+        si = min(sensor, len(self.sensors) - 1)
+        s = self.sensors[si]
         if s.width != s.height:
             raise ValueError("the EPSM backward pass assumes a square film (epsm.py:239)")
+        max_depth = 6 if max_depth < 0 else min(int(max_depth), 6)       # -1 = no limit; the path loop stops at 6 (epsm.py:549)
         K = min(max_log_depth, max_depth, 5)
         n_total = s.width * s.height * spp
         tile = self.tile_paths
@@ -740,9 +753,12 @@ class Scene:
             per_rank = -(-n_total // max(1, world_size))
             tile = max(self.tile_paths, min(self.WAVEFRONT_TILE_PATHS, per_rank))
         tiles = _dist.tile_ranges(n_total, tile)
-        si = min(sensor, len(self.sensors) - 1)
-        return [self._trace(si, seed, spp, max_depth, K, *tiles[t], sparse_log=sparse_log)
-                for t in _dist.my_tiles(len(tiles), rank, world_size)]
+        for t in _dist.my_tiles(len(tiles), rank, world_size):
+            yield self._trace(si, seed, spp, max_depth, K, *tiles[t], sparse_log=sparse_log)
+
+    def trace_paths(self, *args, **kw):
+        """All of this rank's tiles at once (``list(iter_traces(...))``): for small wavefronts and the tests."""
+        return list(self.iter_traces(*args, **kw))
 
     def render_primal(self, sensor=0, seed=0, spp=0, max_depth=6, rank=None, world_size=None) -> torch.Tensor:
         """(H,W,3) image: sample_rays + path tracing + film splat / develop (epsm.py:13-76).  With more than

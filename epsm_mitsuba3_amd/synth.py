@@ -221,28 +221,53 @@ def synth_first_hit_triangles(o, d, seed: int = 0):
     return p0, p0 + e1, p0 + e2, (1 - u - v)[:, 0], u[:, 0]
 
 
+def synth_triangle_table(n_scene_vertices: int, device="cpu", n_emitter_tris: int = 32) -> torch.Tensor:
+    """The synthetic scene's triangle table ``(T,4) int32 [v0, v1, v2, mode]`` (include/epsm.h): V surface triangles
+    -- triangle t uses vertex rows (t, t+1, t+G) mod V, G = sqrt(2V) -- followed by ``n_emitter_tris`` emitter triangles
+    on the last 3 * n_emitter_tris vertex rows.  Modes per triangle (a fixed pseudo-random function of V): 60 % smooth
+    and attached, 25 % flat meshes, 10 % with flipped normals, 5 % detached.  Depends only on its arguments, so every
+    tile / rank / slab of a scene shares it."""
+    import math
+    V = int(n_scene_vertices)
+    dev = torch.device(device)
+    G = max(2, int(math.sqrt(2 * V)))
+    gen = torch.Generator(device="cpu").manual_seed(5150 + V)
+    r = torch.rand((V,), generator=gen)
+    mode = torch.full((V,), 4 | 8 | 1, dtype=torch.int64)                               # attached, vertex normals
+    mode = torch.where(r < 0.25, torch.tensor(4), mode)                                 # flat mesh
+    mode = torch.where((r >= 0.25) & (r < 0.35), torch.tensor(4 | 8 | 1 | 2), mode)     # flipped normals
+    mode = torch.where((r >= 0.35) & (r < 0.40), torch.tensor(1), mode)                 # detached
+    t = torch.arange(V)
+    rows = [torch.stack([t, (t + 1) % V, (t + G) % V, mode], dim=1)]
+    if n_emitter_tris > 0 and V >= 3 * n_emitter_tris:
+        e = V - 3 * n_emitter_tris + 3 * torch.arange(n_emitter_tris)
+        rows.append(torch.stack([e, e + 1, e + 2, torch.full_like(e, 4)], dim=1))
+    return torch.cat(rows, dim=0).to(torch.int32).to(dev).contiguous()
+
+
 def synth_scatter_info(n_paths: int, n_vertices: int, n_scene_vertices: int, seed: int = 0, device="cpu",
                        n_bsdfs: int = 4, coherent: bool = True, dtype=torch.float32, n_emitter_tris: int = 32,
-                       res: int = 0, spp: int = 1, path_offset: int = 0, shadow: bool = False):
-    """Per-vertex parameter addressing (``EpsmScatterRecord`` fields).
+                       res: int = 0, spp: int = 1, path_offset: int = 0, shadow: bool = False, table=None):
+    """Per-vertex parameter addressing (``EpsmScatterRecord`` fields, packed) of a synthetic trace over the scene of
+    ``synth_triangle_table``; every returned dict also carries that table under ``"table"``.
 
-    Coherence model (``coherent=True``; documented in DESIGN.md 7): the scene's triangles
-    (about 2V for V vertices) are laid out on a virtual G x G grid, G = sqrt(2V); the first
-    hit of a path is the triangle under its pixel (``res`` x ``res`` film mapped onto the
-    grid, so a triangle covers (res/G)^2 pixels and all ``spp`` samples of a pixel share
-    it); every further bounce jitters the grid cell by +-2^k cells, i.e. neighbouring
-    paths keep hitting nearby triangles but spread out with depth.  Triangle t uses
-    vertex rows (t, t+1, t+G) mod V.  With ``res = 0`` paths are grouped 16 at a time
-    instead of by pixel.  ``coherent=False`` draws every triangle uniformly.
-    Emitter samples land on a small emitter mesh (``n_emitter_tris`` triangles at the end
-    of the vertex buffer; 0 = anywhere), as area lights are a handful of triangles in
-    the reference's scenes -- every wave then adds to the same few rows.
-    ``shadow=True`` adds the occluder record of the first vertex (epsm.py:609-620, integrators with
-    max_depth <= 3): a triangle near the first hit's cell, dis in [0, 0.9) with 30 % zeros, 10 % detached."""
+    Coherence model (``coherent=True``; documented in DESIGN.md 7): the scene's surface triangles are laid out on a
+    virtual G x G grid, G = sqrt(2V); the first hit of a path is the triangle under its pixel (``res`` x ``res`` film
+    mapped onto the grid, so a triangle covers (res/G)^2 pixels and all ``spp`` samples of a pixel share it); every
+    further bounce jitters the grid cell by +-2^k cells, i.e. neighbouring paths keep hitting nearby triangles but
+    spread out with depth.  With ``res = 0`` paths are grouped 16 at a time instead of by pixel.  ``coherent=False``
+    draws every triangle uniformly.  3 % of the hits carry no triangle (EPSM_NO_INDEX).
+    Emitter samples land on the small emitter mesh at the end of the table (half of them nowhere), as area lights are
+    a handful of triangles in the reference's scenes -- every wave then adds to the same few rows.
+    ``shadow=True`` adds the occluder record of the first vertex (epsm.py:609-620, integrators with max_depth <= 3): a
+    triangle near the first hit's cell, dis in [0, 0.9) with 30 % zeros, 5 % without a triangle."""
     N, K, V = int(n_paths), int(n_vertices), int(n_scene_vertices)
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
     gen.manual_seed(99991 + int(seed))
+    if table is None:
+        table = synth_triangle_table(V, dev, n_emitter_tris)
+    has_emitters = table.shape[0] > V
     idx = torch.arange(N, device=dev) + int(path_offset)
     import math
     G = max(2, int(math.sqrt(2 * V)))
@@ -253,6 +278,9 @@ def synth_scatter_info(n_paths: int, n_vertices: int, n_scene_vertices: int, see
     else:
         grp = idx // 16
         cx, cy = grp % G, (grp // G) % G
+    del idx
+    none = torch.tensor(-1, device=dev, dtype=torch.int32)
+    bits = lambda t: t.to(torch.float32).contiguous().view(torch.int32)
     info = []
     for k in range(1, K + 1):
         if coherent:
@@ -263,36 +291,26 @@ def synth_scatter_info(n_paths: int, n_vertices: int, n_scene_vertices: int, see
             base = ((cy * G + cx) + k * 7) % V
         else:
             base = torch.randint(0, V, (N,), generator=gen, device=dev)
-        vidx = torch.stack([base, (base + 1) % V, (base + G) % V], dim=-1).to(torch.int32)
         r = torch.rand((N,), generator=gen, device=dev)
-        mode = torch.full((N,), 4 | 8 | 1, device=dev, dtype=torch.uint8)          # attached, vertex normals
-        mode = torch.where(r < 0.25, torch.tensor(4, device=dev, dtype=torch.uint8), mode)        # flat mesh
-        mode = torch.where((r >= 0.25) & (r < 0.35), torch.tensor(4 | 8 | 1 | 2, device=dev, dtype=torch.uint8), mode)
-        mode = torch.where((r >= 0.35) & (r < 0.40), torch.tensor(1, device=dev, dtype=torch.uint8), mode)  # detached
-        vidx = torch.where((r >= 0.40)[:, None] & (r < 0.43)[:, None], torch.full_like(vidx, -1), vidx)
-        if n_emitter_tris > 0 and V >= 3 * n_emitter_tris:
-            ebase = V - 3 * n_emitter_tris + 3 * torch.randint(0, n_emitter_tris, (N,), generator=gen, device=dev)
+        tri = torch.where((r >= 0.40) & (r < 0.43), none, base.to(torch.int32))
+        if has_emitters:
+            etri = (V + torch.randint(0, n_emitter_tris, (N,), generator=gen, device=dev)).to(torch.int32)
         else:
-            ebase = torch.randint(0, V, (N,), generator=gen, device=dev)
-        evidx = torch.stack([ebase, (ebase + 1) % V, (ebase + 2) % V], dim=-1).to(torch.int32)
-        evidx = torch.where((torch.rand((N,), generator=gen, device=dev) < 0.5)[:, None], evidx, torch.full_like(evidx, -1))
-        extra = {}
+            etri = torch.randint(0, V, (N,), generator=gen, device=dev).to(torch.int32)
+        etri = torch.where(torch.rand((N,), generator=gen, device=dev) < 0.5, etri, none)
+        rec = {"tri": tri, "table": table}
         if shadow and k == 1:
-            sbase = (base + 11 + torch.randint(0, 3, (N,), generator=gen, device=dev)) % V
-            svidx = torch.stack([sbase, (sbase + 1) % V, (sbase + G) % V], dim=-1).to(torch.int32)
-            svidx = torch.where((torch.rand((N,), generator=gen, device=dev) < 0.05)[:, None], torch.full_like(svidx, -1), svidx)
+            stri = ((base + 11 + torch.randint(0, 3, (N,), generator=gen, device=dev)) % V).to(torch.int32)
+            stri = torch.where(torch.rand((N,), generator=gen, device=dev) < 0.05, none, stri)
             sdis = _u(gen, (N,), 0.0, 0.9, dev, dtype)
             sdis = torch.where(torch.rand((N,), generator=gen, device=dev) < 0.3, torch.zeros_like(sdis), sdis)
-            smode = torch.where(torch.rand((N,), generator=gen, device=dev) < 0.1, 1, 4 | 8 | 1).to(torch.int32)
-            extra = {"svidx": svidx, "sb0": _u(gen, (N,), 0.0, 0.5, dev, dtype), "sb1": _u(gen, (N,), 0.0, 0.5, dev, dtype),
-                     "sdis": sdis, "smode": smode}
-        info.append({
-            **extra,
-            "vidx": vidx, "mode": mode,
-            "bsdf_id": torch.randint(-1, n_bsdfs, (N,), generator=gen, device=dev).to(torch.int32),
-            "dhf_dalpha": _u(gen, (N, 3), -1.0, 1.0, dev, dtype),
-            "evidx": evidx,
-            "eb0": _u(gen, (N,), 0.0, 0.5, dev, dtype), "eb1": _u(gen, (N,), 0.0, 0.5, dev, dtype),
-            "eweight": _u(gen, (N,), 0.0, 2.0, dev, dtype),
-        })
+            rec["shadow"] = torch.stack([stri, bits(_u(gen, (N,), 0.0, 0.5, dev, dtype)), bits(_u(gen, (N,), 0.0, 0.5, dev, dtype)),
+                                         bits(sdis)], dim=1)
+        bsdf_id = torch.randint(-1, n_bsdfs, (N,), generator=gen, device=dev).to(torch.int32)
+        rec["aux"] = torch.cat([bsdf_id[:, None], bits(_u(gen, (N, 3), -1.0, 1.0, dev, dtype))], dim=1)
+        del bsdf_id
+        rec["emit"] = torch.stack([etri, bits(_u(gen, (N,), 0.0, 0.5, dev, dtype)), bits(_u(gen, (N,), 0.0, 0.5, dev, dtype)),
+                                   bits(_u(gen, (N,), 0.0, 2.0, dev, dtype))], dim=1)
+        del etri, tri, r, base
+        info.append(rec)
     return info

@@ -75,7 +75,7 @@ def scatter(variant: str, rec: PackedRecords, sc: PackedScatter,
         B = grad_alpha.numel()
     with torch.cuda.device(dev):
         rc = _lib.lib().epsm_scatter(
-            VARIANTS[variant], N, K, C.addressof(rec.records), C.addressof(sc.records),
+            VARIANTS[variant], N, K, C.addressof(rec.records), C.addressof(sc.records), sc.table_ptr(), sc.T,
             out_param.data_ptr(), out_light.data_ptr(), out_diffuse.data_ptr(),
             grad_pos.data_ptr(), grad_nrm.data_ptr(), grad_alpha.data_ptr() if grad_alpha is not None else None,
             V, B, torch.cuda.current_stream(dev).cuda_stream)
@@ -105,7 +105,7 @@ def manifold_grad_scatter(variant: str, rec: PackedRecords, sc: PackedScatter, d
     with torch.cuda.device(dev):
         rc = _lib.lib().epsm_manifold_grad_scatter(
             VARIANTS[variant], N, K, rec.cam.data_ptr(), C.addressof(rec.records), C.addressof(sc.records),
-            d.data_ptr(), d.shape[1], int(dlduv_cols), p.data_ptr(), float(clip),
+            sc.table_ptr(), sc.T, d.data_ptr(), d.shape[1], int(dlduv_cols), p.data_ptr(), float(clip),
             grad_pos.data_ptr(), grad_nrm.data_ptr(), grad_alpha.data_ptr() if grad_alpha is not None else None,
             V, B, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "epsm_manifold_grad_scatter")
@@ -140,7 +140,7 @@ def backward_pass(variant: str, rec: PackedRecords, sc: PackedScatter, ray_o, ra
         rc = _lib.lib().epsm_backward_pass(
             VARIANTS[variant], N, K, int(path_offset), int(spp), int(res), o.data_ptr(), d.data_ptr(), dx.data_ptr(),
             dy.data_ptr(), g.data_ptr(), int(g.shape[1]), int(g.shape[2]), C.addressof(rec.records), C.addressof(sc.records),
-            float(clip), grad_pos.data_ptr(), grad_nrm.data_ptr(),
+            sc.table_ptr(), sc.T, float(clip), grad_pos.data_ptr(), grad_nrm.data_ptr(),
             grad_alpha.data_ptr() if grad_alpha is not None else None,
             grad_origin.data_ptr() if grad_origin is not None else None, V, B,
             torch.cuda.current_stream(dev).cuda_stream)

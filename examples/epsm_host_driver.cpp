@@ -84,7 +84,7 @@ void normalize3(float *v) { const float l = std::sqrt(v[0] * v[0] + v[1] * v[1] 
 VertexArrays make_vertex(int64_t N, int k, int64_t V, int res, int spp, std::vector<uint8_t> &alive, uint64_t seed) {
     Rng r(seed * 1000003ull + (uint64_t) k);
     std::vector<float> p[3], nn[3], b0(N), b1(N), eta(N), hf(3 * N), light(3 * N);
-    std::vector<uint32_t> bsdf(N), tri(4 * N), aux(4 * N), emit(8 * N);
+    std::vector<uint32_t> bsdf(N), tri(N), aux(4 * N), emit(4 * N);
     std::vector<uint8_t> act(N), act_em(N), ismesh(N);
     for (auto &a : p) a.resize(3 * N);
     for (auto &a : nn) a.resize(3 * N);
@@ -120,16 +120,12 @@ VertexArrays make_vertex(int64_t N, int k, int64_t V, int res, int spp, std::vec
             cx = ((cx + (int64_t) (r.next() % (2 * spread + 1)) - spread) % G + G) % G;
             cy = ((cy + (int64_t) (r.next() % (2 * spread + 1)) - spread) % G + G) % G;
         }
-        const uint32_t base = (uint32_t) (((cy * G + cx) + k * 7) % V);
-        tri[4 * i] = base; tri[4 * i + 1] = (uint32_t) ((base + 1) % V); tri[4 * i + 2] = (uint32_t) ((base + G) % V);
-        tri[4 * i + 3] = EPSM_MODE_POS_ATTACHED | EPSM_MODE_NRM_ATTACHED | EPSM_MODE_VERTEX_NORMALS;
+        tri[i] = (uint32_t) (((cy * G + cx) + k * 7) % V);          // id of the hit triangle (row of the table below)
         aux[4 * i] = (uint32_t) (r.next() % 4);
         for (int c = 0; c < 3; ++c) { const float d = r.uni(-1.f, 1.f); std::memcpy(&aux[4 * i + 1 + c], &d, 4); }
-        const uint32_t eb = (uint32_t) (V - 3 * n_emit_tris + 3 * (int64_t) (r.next() % n_emit_tris));
         const float e0 = r.uni(0.f, 0.5f), e1 = r.uni(0.f, 0.5f), ew = r.uni(0.f, 2.f);
-        emit[8 * i] = eb; emit[8 * i + 1] = eb + 1; emit[8 * i + 2] = eb + 2;
-        std::memcpy(&emit[8 * i + 3], &e0, 4); std::memcpy(&emit[8 * i + 4], &e1, 4); std::memcpy(&emit[8 * i + 5], &ew, 4);
-        emit[8 * i + 6] = emit[8 * i + 7] = 0;
+        emit[4 * i] = (uint32_t) (V + (int64_t) (r.next() % n_emit_tris));       // one of the emitter triangles
+        std::memcpy(&emit[4 * i + 1], &e0, 4); std::memcpy(&emit[4 * i + 2], &e1, 4); std::memcpy(&emit[4 * i + 3], &ew, 4);
     }
     VertexArrays v;
     for (int j = 0; j < 3; ++j) { v.p[j].upload(p[j]); v.n[j].upload(nn[j]); }
@@ -137,6 +133,23 @@ VertexArrays make_vertex(int64_t N, int k, int64_t V, int res, int spp, std::vec
     v.bsdf.upload(bsdf); v.tri.upload(tri); v.aux.upload(aux); v.emit.upload(emit);
     v.active.upload(act); v.active_em.upload(act_em); v.ismesh.upload(ismesh);
     return v;
+}
+
+// The scene's triangle table (include/epsm.h): V surface triangles on a G x G grid -- triangle t uses vertex rows
+// (t, t+1, t+G) mod V -- then 32 emitter triangles on the last 96 vertex rows; all meshes smooth and attached.
+std::vector<uint32_t> make_triangle_table(int64_t V) {
+    const int64_t G = (int64_t) std::fmax(2.0, std::floor(std::sqrt(2.0 * (double) V))), n_emit_tris = 32;
+    std::vector<uint32_t> t(4 * (size_t) (V + n_emit_tris));
+    for (int64_t i = 0; i < V; ++i) {
+        t[4 * i] = (uint32_t) i; t[4 * i + 1] = (uint32_t) ((i + 1) % V); t[4 * i + 2] = (uint32_t) ((i + G) % V);
+        t[4 * i + 3] = EPSM_MODE_POS_ATTACHED | EPSM_MODE_NRM_ATTACHED | EPSM_MODE_VERTEX_NORMALS;
+    }
+    for (int64_t j = 0; j < n_emit_tris; ++j) {
+        const uint32_t eb = (uint32_t) (V - 3 * n_emit_tris + 3 * j);
+        uint32_t *row = &t[4 * (size_t) (V + j)];
+        row[0] = eb; row[1] = eb + 1; row[2] = eb + 2; row[3] = EPSM_MODE_POS_ATTACHED;
+    }
+    return t;
 }
 
 double max_abs(const std::vector<float> &a) { double m = 0; for (float x : a) m = std::fmax(m, std::fabs((double) x)); return m; }
@@ -183,8 +196,10 @@ int main(int argc, char **argv) {
         const VertexArrays &v = verts[k];
         vrec[k] = EpsmVertexRecord{v.p[0].ptr, v.p[1].ptr, v.p[2].ptr, v.n[0].ptr, v.n[1].ptr, v.n[2].ptr, v.b0.ptr, v.b1.ptr,
                                    v.eta.ptr, v.hf.ptr, v.light.ptr, v.bsdf.ptr, v.active.ptr, v.active_em.ptr, v.ismesh.ptr};
-        srec[k] = EpsmScatterRecord{v.tri.ptr, v.aux.ptr, v.emit.ptr};
+        srec[k] = EpsmScatterRecord{v.tri.ptr, v.aux.ptr, v.emit.ptr, nullptr};
     }
+    DeviceArray<uint32_t> table(make_triangle_table(V));
+    const int64_t T = (int64_t) table.n / 4;
     Rng r(7);
     std::vector<float> cam(3 * N), ray_o(3 * N), ray_d(3 * N), ray_dx(3 * N), ray_dy(3 * N), grad_img((size_t) res * res * 5);
     for (auto &g : grad_img) g = 1e-3f * r.gauss();
@@ -233,18 +248,18 @@ int main(int argc, char **argv) {
                                      out_p.ptr, out_l.ptr, out_d.ptr, nullptr));
         ms_grad = t.stop_ms();
         t.start();
-        EPSM_CALL(epsm_scatter(variant, N, K, vrec.data(), srec.data(), out_p.ptr, out_l.ptr, out_d.ptr,
+        EPSM_CALL(epsm_scatter(variant, N, K, vrec.data(), srec.data(), table.ptr, T, out_p.ptr, out_l.ptr, out_d.ptr,
                                pos_a.ptr, nrm_a.ptr, alpha_a.ptr, V, B, nullptr));
         ms_scatter = t.stop_ms();
         // ---- the same in one launch; calc_grad's lists are never written
         t.start();
-        EPSM_CALL(epsm_manifold_grad_scatter(variant, N, K, d_cam.ptr, vrec.data(), srec.data(), dlduv.ptr, 2, 2, dldp.ptr, 0.1f,
+        EPSM_CALL(epsm_manifold_grad_scatter(variant, N, K, d_cam.ptr, vrec.data(), srec.data(), table.ptr, T, dlduv.ptr, 2, 2, dldp.ptr, 0.1f,
                                              pos_b.ptr, nrm_b.ptr, alpha_b.ptr, V, B, nullptr));
         ms_fused = t.stop_ms();
         // ---- and the whole backward pass (tangent included) in one launch
         t.start();
         EPSM_CALL(epsm_backward_pass(variant, N, K, 0, spp, res, d_o.ptr, d_d.ptr, d_dx.ptr, d_dy.ptr, d_img.ptr, res, 5,
-                                     vrec.data(), srec.data(), 0.1f, pos_c.ptr, nrm_c.ptr, alpha_c.ptr, grad_o_c.ptr, V, B, nullptr));
+                                     vrec.data(), srec.data(), table.ptr, T, 0.1f, pos_c.ptr, nrm_c.ptr, alpha_c.ptr, grad_o_c.ptr, V, B, nullptr));
         ms_pass = t.stop_ms();
     }
     HIP_OK(hipDeviceSynchronize());

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EPSM_ABI_VERSION 3
+#define EPSM_ABI_VERSION 4
 
 /* BSDF flag bits tested by the hot path (include/mitsuba/render/bsdf.h:40-46,101). */
 #define EPSM_BSDF_NULL     0x1u
@@ -152,23 +152,28 @@ int epsm_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, int res,
 #define EPSM_MODE_POS_ATTACHED   0x4u  /* vertex positions of this mesh receive gradients */
 #define EPSM_MODE_NRM_ATTACHED   0x8u  /* vertex normals of this mesh receive gradients */
 
+/* The scene's triangles: row t = [v0, v1, v2, mode] -- the rows of triangle t's vertices in the flat (V,3) position /
+ * normal buffers and the EPSM_MODE_* bits of its mesh.  One table per scene (16 B per triangle; it stays in L2 / MALL),
+ * rebuilt when a mesh is attached or detached.  A ray tracer reports a hit as a primitive index, so the per-path log
+ * below carries triangle IDS (4 B) instead of vertex triples.
+ * Passed to the scatter entry points as `tri_table` ((T,4) u32, 16-byte aligned) and `T`. */
+
 typedef struct EpsmScatterRecord {
-    const uint32_t *tri;    /* (N,4) u32  [v0, v1, v2, mode]: rows of the hit triangle's vertices in the flat (V,3)
-                                          position / normal buffers (EPSM_NO_INDEX = skip) and the EPSM_MODE_* bits
-                                          of the hit mesh; one 16-byte load per path */
+    const uint32_t *tri;    /* (N)   u32  id of the hit triangle = row of the triangle table (EPSM_NO_INDEX or any
+                                          id >= T = none: analytic shape, detached lane) */
     const uint32_t *aux;    /* (N,4)      [bsdf_id u32, d hf / d alpha as 3 x f32 bits]: slot in grad_alpha
                                           (EPSM_NO_INDEX = none) and the derivative of the sampled microfacet normal
-                                          w.r.t. the BSDF's alpha (roughconductor.cpp:249-255); may be NULL */
-    const uint32_t *emit;   /* (N,8)      [e0, e1, e2 u32, eb0, eb1, eweight f32, 0, 0]: triangle hit by the
-                                          emitter-sample shadow ray (epsm.py:622-625), its barycentrics and
-                                          sum_rgb(Lr_dir) (epsm.py:627); may be NULL */
-    const uint32_t *shadow; /* (N,8)      [s0, s1, s2 u32, sb0, sb1, dis f32, mode u32, 0]: read for the FIRST logged
-                                          vertex only (sc[0]).  The occluder term of epsm.py:609-620 (integrators with
-                                          max_depth <= 3): first surface hit by the ray from the first vertex towards
-                                          its emitter sample (closest hit, no maximum distance), its barycentrics,
-                                          dis = |ds.p - hit| / |ds.p - si.p| (0 when < 0.01, :614-615) and the
-                                          EPSM_MODE_* bits of the hit mesh; that triangle receives
-                                          diffuse_grad[0] * dis * barycentric (:616-618).  May be NULL */
+                                          w.r.t. the BSDF's alpha (roughconductor.cpp:249-255); may be NULL (no BSDF
+                                          parameter attached) */
+    const uint32_t *emit;   /* (N,4)      [etri u32, eb0, eb1, eweight f32]: triangle hit by the emitter-sample shadow
+                                          ray (epsm.py:622-625), its barycentrics and sum_rgb(Lr_dir) (epsm.py:627);
+                                          may be NULL */
+    const uint32_t *shadow; /* (N,4)      [stri u32, sb0, sb1, dis f32]: read for the FIRST logged vertex only (sc[0]).
+                                          The occluder term of epsm.py:609-620 (integrators with max_depth <= 3): first
+                                          surface hit by the ray from the first vertex towards its emitter sample
+                                          (closest hit, no maximum distance), its barycentrics and
+                                          dis = |ds.p - hit| / |ds.p - si.p| (0 when < 0.01, :614-615); that triangle
+                                          receives diffuse_grad[0] * dis * barycentric (:616-618).  May be NULL */
 } EpsmScatterRecord;
 
 /* ---------------------------------------------------------------------------
@@ -177,20 +182,22 @@ typedef struct EpsmScatterRecord {
  *     calc_grad are accumulated into the parameter-gradient buffers, i.e. the
  *     adjoint of the vertex gathers (mesh.h:94-106) as float atomics.
  *   per logged vertex k (iteration it = k-1):
- *     (vidx = tri[0..2], evidx = emit[0..2], eb = emit[3..4], eweight = emit[5], bsdf_id = aux[0],
- *      dhf_dalpha = aux[1..3])
+ *     (vidx = table[tri][0..2], mode = table[tri][3], evidx = table[emit[0]][0..2], eb = emit[1..2],
+ *      eweight = emit[3], bsdf_id = aux[0], dhf_dalpha = aux[1..3])
  *     grad_pos[vidx_j] += out_param[5it+j]                      (si.p_j * path_grad[5it+j],  :559-560)
  *     grad_pos[vidx_j] += b_j * out_diffuse[it]                 (si_follow.p * diffuse_grad[it], :561-562)
  *     normals:  d/dn_j of  sh_frame.n . out_param[5it+3]        (:645; mesh.cpp:784-790 or flat :729,811-816)
  *     grad_alpha[bsdf_id] += dhf_dalpha . out_param[5it+4]      (bsdf_sample.hf * path_grad[5it+4], :645)
- *     grad_pos[evidx_j] += eb_j * out_light[it] * eweight       (si_direct.p * light_grad[it] * sum Lr_dir, :626-627)
- *     it = 0 only, with sc[0].shadow = [s0,s1,s2, sb0,sb1, dis, mode]:
+ *     grad_pos[evidx_j] += eb_j * out_light[it] * eweight       (si_direct.p * light_grad[it] * sum Lr_dir, :626-627;
+ *                                                                only when the emitter triangle's mesh has
+ *                                                                EPSM_MODE_POS_ATTACHED, as for every position row)
+ *     it = 0 only, with sc[0].shadow = [stri, sb0, sb1, dis] and s_j = table[stri][j]:
  *     grad_pos[s_j]     += sb_j * dis * out_diffuse[0]          (si_direct.p * diffuse_grad[0] * dis, :616-618)
  *   (for "manifold_caustic" the last vertex has no n,m entries.)
  *   grad_pos / grad_nrm: (V,3) f32, grad_alpha: (B) f32; accumulated, not cleared.
  * ------------------------------------------------------------------------- */
 int epsm_scatter(int variant, int64_t N, int K,
-                 const EpsmVertexRecord *verts, const EpsmScatterRecord *sc,
+                 const EpsmVertexRecord *verts, const EpsmScatterRecord *sc, const uint32_t *tri_table, int64_t T,
                  const float *out_param, const float *out_light, const float *out_diffuse,
                  float *grad_pos, float *grad_nrm, float *grad_alpha,
                  int64_t V, int64_t B, void *stream);
@@ -208,13 +215,12 @@ int epsm_scatter(int variant, int64_t N, int K,
  * ------------------------------------------------------------------------- */
 int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
                                const float *cam, const EpsmVertexRecord *verts,
-                               const EpsmScatterRecord *sc,
+                               const EpsmScatterRecord *sc, const uint32_t *tri_table, int64_t T,
                                const float *dlduv, int64_t dlduv_stride, int dlduv_cols,
                                const float *dldp, float clip,
                                float *grad_pos, float *grad_nrm, float *grad_alpha,
                                int64_t V, int64_t B, void *stream);
 
-/* Human-readable text of the last failure on the calling thread ("" if none). */
 /* ---------------------------------------------------------------------------
  * epsm_backward_pass  --  epsm_first_vertex_tangent + epsm_manifold_grad_scatter in ONE launch:
  *     everything render_backward does between the trace and the parameter gradients
@@ -226,10 +232,11 @@ int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
 int epsm_backward_pass(int variant, int64_t N, int K, int64_t path_offset, int spp, int res,
                        const float *ray_o, const float *ray_d, const float *ray_dx, const float *ray_dy,
                        const float *grad_img, int img_width, int img_channels,
-                       const EpsmVertexRecord *verts, const EpsmScatterRecord *sc, float clip,
+                       const EpsmVertexRecord *verts, const EpsmScatterRecord *sc, const uint32_t *tri_table, int64_t T, float clip,
                        float *grad_pos, float *grad_nrm, float *grad_alpha, float *grad_o_sum,
                        int64_t V, int64_t B, void *stream);
 
+/* Human-readable text of the last failure on the calling thread ("" if none). */
 const char *epsm_last_error(void);
 
 /* ABI version of the loaded library (EPSM_ABI_VERSION at build time). */

@@ -121,8 +121,8 @@ typedef struct EpsmRecordOut {
     float *hf, *light;               /* (N,3) */
     uint32_t *bsdf;                  /* (N) */
     uint8_t *active, *active_em, *ismesh;  /* (N) */
-    uint32_t *tri, *aux, *emit;      /* (N,4) (N,4) (N,8): EpsmScatterRecord */
-    uint32_t *shadow;                /* (N,8): EpsmScatterRecord.shadow; written for the first logged vertex only and
+    uint32_t *tri, *aux, *emit;      /* (N) (N,4) (N,4): EpsmScatterRecord (tri = triangle id, emit = [etri, eb0, eb1, ew]) */
+    uint32_t *shadow;                /* (N,4): EpsmScatterRecord.shadow [stri, sb0, sb1, dis]; written for the first logged vertex only and
                                         only meaningful when max_depth <= 3 (epsm.py:610); may be NULL */
 } EpsmRecordOut;
 

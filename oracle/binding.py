@@ -18,8 +18,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    if force or not os.path.isfile(_LIB_PATH):
-        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)    # make decides what is stale
     return _LIB_PATH
 
 
@@ -77,7 +76,7 @@ def _aux():
             C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         l.epsm_oracle_scatter.restype = C.c_int
         l.epsm_oracle_scatter.argtypes = [
-            C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
         l._aux_ready = True
     return l
@@ -111,7 +110,7 @@ def oracle_scatter(variant, path_info, scatter_info, out_param, out_light, out_d
     gn = torch.zeros((V, 3), dtype=torch.float64)
     ga = torch.zeros((max(B, 1),), dtype=torch.float64)
     rc = _aux().epsm_oracle_scatter(VARIANTS[variant], rec.N, rec.K, C.addressof(rec.records), C.addressof(sc.records),
-                                    op.data_ptr(), ol.data_ptr(), od.data_ptr(),
+                                    sc.table_ptr(), sc.T, op.data_ptr(), ol.data_ptr(), od.data_ptr(),
                                     gp.data_ptr(), gn.data_ptr(), ga.data_ptr(), V, B)
     assert rc == 0
     return gp, gn, ga[:B]

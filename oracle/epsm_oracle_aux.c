@@ -1,7 +1,8 @@
 /*
  * epsm_oracle_aux.c -- TEST INFRASTRUCTURE, NOT PRODUCT.
  *
- * CPU restatements (float64, sequential, deterministic) of the two pieces of
+ * CPU restatements (float64; OpenMP over paths, so sums are deterministic up to the order of float64 additions --
+ * run with OMP_NUM_THREADS=1 for bit-reproducible results) of the two pieces of
  * EPSMIntegrator.render_backward that surround calc_grad:
  *
  *   epsm_oracle_first_vertex_tangent   epsm.py:238-272 with the Moeller-Trumbore
@@ -24,6 +25,9 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../include/epsm.h"
 
@@ -51,7 +55,8 @@ int epsm_oracle_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, in
                                      const uint8_t *active,
                                      double *dlduv, int64_t dlduv_stride, double *dldp,
                                      double *grad_o_sum) {
-    if (grad_o_sum) grad_o_sum[0] = grad_o_sum[1] = grad_o_sum[2] = 0.0;
+    double go0 = 0.0, go1 = 0.0, go2 = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : go0, go1, go2)
     for (int64_t i = 0; i < N; ++i) {
         int64_t pix = (path_offset + i) / spp, y = pix / res, x = pix % res;
         const float *g = grad_img + (y * img_width + x) * img_channels;
@@ -59,7 +64,7 @@ int epsm_oracle_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, in
         double gd[3];
         for (int c = 0; c < 3; ++c)   /* epsm.py:255 */
             gd[c] = ((double) ray_dx[3 * i + c] - ray_d[3 * i + c]) * gx + ((double) ray_dy[3 * i + c] - ray_d[3 * i + c]) * gy;
-        if (grad_o_sum) for (int c = 0; c < 3; ++c) grad_o_sum[c] += -gd[c];   /* epsm.py:260-261 */
+        go0 -= gd[0]; go1 -= gd[1]; go2 -= gd[2];   /* epsm.py:260-261 */
         double *row = dlduv + i * dlduv_stride;
         for (int64_t c = 0; c < dlduv_stride; ++c) row[c] = 0.0;
         dldp[3 * i] = dldp[3 * i + 1] = dldp[3 * i + 2] = 0.0;
@@ -82,13 +87,24 @@ int epsm_oracle_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, in
         for (int c = 0; c < 3; ++c)   /* si.p = p0 b0 + p1 b1 + p2 b2 ; epsm.py:270 */
             dldp[3 * i + c] = p0[3 * i + c] * b0.d + p1[3 * i + c] * b1.d + p2[3 * i + c] * b2.d;
     }
+    if (grad_o_sum) { grad_o_sum[0] = go0; grad_o_sum[1] = go1; grad_o_sum[2] = go2; }
     return 0;
 }
 
+static void add1(double *p, double x) {
+#pragma omp atomic
+    *p += x;
+}
 static void add3(double *buf, uint32_t v, const double *g, double w) {
-    buf[3 * (int64_t) v + 0] += g[0] * w;
-    buf[3 * (int64_t) v + 1] += g[1] * w;
-    buf[3 * (int64_t) v + 2] += g[2] * w;
+    add1(buf + 3 * (int64_t) v + 0, g[0] * w);
+    add1(buf + 3 * (int64_t) v + 1, g[1] * w);
+    add1(buf + 3 * (int64_t) v + 2, g[2] * w);
+}
+/* row `id` of the scene's triangle table (include/epsm.h): [v0, v1, v2, mode]; ids beyond the table address nothing */
+static int table_row(const uint32_t *table, int64_t T, uint32_t id, uint32_t row[4]) {
+    if ((int64_t) id >= T) { row[0] = row[1] = row[2] = 0xFFFFFFFFu; row[3] = 0u; return 0; }
+    memcpy(row, table + 4 * (int64_t) id, 16);
+    return 1;
 }
 static void cross(const double *a, const double *b, double *c) {
     c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
@@ -98,15 +114,18 @@ static void cross(const double *a, const double *b, double *c) {
  * fp32 (as logged), gradients in/out are fp64.  grad buffers are accumulated. */
 int epsm_oracle_scatter(int variant, int64_t N, int K,
                         const EpsmVertexRecord *verts, const EpsmScatterRecord *sc,
+                        const uint32_t *tri_table, int64_t T,
                         const double *out_param, const double *out_light, const double *out_diffuse,
                         double *grad_pos, double *grad_nrm, double *grad_alpha, int64_t V, int64_t B) {
     const int P = variant == EPSM_VARIANT_MANIFOLD_CAUSTIC ? 5 * K - 2 : 5 * K;
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) {
         for (int it = 0; it < K; ++it) {
             const EpsmVertexRecord *v = &verts[it];
             const EpsmScatterRecord *s = &sc[it];
-            const uint32_t mode = s->tri[4 * i + 3];
-            const uint32_t *vi = s->tri + 4 * i;
+            uint32_t vi[4];
+            table_row(tri_table, T, s->tri[i], vi);
+            const uint32_t mode = vi[3];
             const int idx_ok = vi[0] < (uint64_t) V && vi[1] < (uint64_t) V && vi[2] < (uint64_t) V;
             const double b0 = ((const float *) v->b0)[i], b1 = ((const float *) v->b1)[i], b2 = 1.0 - b0 - b1;
             const double bw[3] = {b0, b1, b2};
@@ -155,15 +174,16 @@ int epsm_oracle_scatter(int variant, int64_t N, int K,
                     if (bid < (uint64_t) B) {
                         const double *gm = out_param + ((int64_t) (5 * it + 4) * N + i) * 3;
                         const float *dh = (const float *) (s->aux + 4 * i + 1);
-                        grad_alpha[bid] += gm[0] * dh[0] + gm[1] * dh[1] + gm[2] * dh[2];
+                        add1(grad_alpha + bid, gm[0] * dh[0] + gm[1] * dh[1] + gm[2] * dh[2]);
                     }
                 }
             }
             /* epsm.py:609-620: occluder of the first vertex's emitter sample receives diffuse_grad[0] * dis */
             if (it == 0 && s->shadow) {
-                const uint32_t *h = s->shadow + 8 * i;
-                const float *hf = (const float *) (s->shadow + 8 * i + 3);
-                if (h[0] < (uint64_t) V && h[1] < (uint64_t) V && h[2] < (uint64_t) V && (h[6] & EPSM_MODE_POS_ATTACHED)) {
+                uint32_t h[4];
+                table_row(tri_table, T, s->shadow[4 * i], h);
+                const float *hf = (const float *) (s->shadow + 4 * i + 1);
+                if (h[0] < (uint64_t) V && h[1] < (uint64_t) V && h[2] < (uint64_t) V && (h[3] & EPSM_MODE_POS_ATTACHED)) {
                     double c0 = hf[0], c1 = hf[1], dis = hf[2];
                     const double *g = out_diffuse + ((int64_t) 0 * N + i) * 3;
                     add3(grad_pos, h[0], g, dis * c0); add3(grad_pos, h[1], g, dis * c1); add3(grad_pos, h[2], g, dis * (1.0 - c0 - c1));
@@ -171,9 +191,11 @@ int epsm_oracle_scatter(int variant, int64_t N, int K,
             }
             /* epsm.py:622-627 */
             if (s->emit) {
-                const uint32_t *e = s->emit + 8 * i;
-                const float *ef = (const float *) (s->emit + 8 * i + 3);
-                if (e[0] < (uint64_t) V && e[1] < (uint64_t) V && e[2] < (uint64_t) V) {
+                uint32_t e[4];
+                table_row(tri_table, T, s->emit[4 * i], e);
+                const float *ef = (const float *) (s->emit + 4 * i + 1);
+                /* si_direct.p is AD-attached only when the emitter mesh's positions are (dr.backward reaches nothing else) */
+                if (e[0] < (uint64_t) V && e[1] < (uint64_t) V && e[2] < (uint64_t) V && (e[3] & EPSM_MODE_POS_ATTACHED)) {
                     double c0 = ef[0], c1 = ef[1], w = ef[2];
                     const double *g = out_light + ((int64_t) it * N + i) * 3;
                     add3(grad_pos, e[0], g, w * c0); add3(grad_pos, e[1], g, w * c1); add3(grad_pos, e[2], g, w * (1.0 - c0 - c1));

@@ -18,7 +18,7 @@ def oracle_backward(variant, traces, grad_in, V, B, clip=0.1, straddle_band=0.0)
     go = torch.zeros(3, dtype=torch.float64)
     for tr in traces:
         pi = path_info_to(tr.path_info, device="cpu")
-        si = [{k: v.cpu() for k, v in r.items()} for r in tr.scatter_info]
+        si = [{k: (v.cpu() if v is not None else None) for k, v in r.items()} for r in tr.scatter_info]
         first = pi[1]
         dlduv, dldp, o = oracle_first_vertex_tangent(
             tr.ray_o, tr.ray_d, tr.ray_dx, tr.ray_dy, grad_in, tr.spp, tr.res,

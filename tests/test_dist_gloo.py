@@ -80,6 +80,61 @@ def test_two_rank_backward_matches_single_process():
     assert torch.allclose(got[0][2], single.flat, rtol=1e-5, atol=1e-7 * float(single.flat.abs().max()))
 
 
+class _OracleIntegrator:
+    """``ManifoldIntegrator`` whose per-tile arithmetic is the float64 oracle: what is under test is the
+    orchestration of ``render_backward`` (tiles of this rank, scratch buffer, ONE all-reduce, accumulation)."""
+
+    @staticmethod
+    def make():
+        import epsm_mitsuba3_amd as epsm
+        from _pipeline_oracle import oracle_backward
+
+        class Integ(epsm.ManifoldIntegrator):
+            def backward_from_trace(self, trace, params, grad_in, **kw):
+                gp, gn, ga, go = oracle_backward(self.variant, [trace], grad_in, params.V, params.B)
+                params.pos += gp.float(); params.nrm += gn.float(); params.alpha += ga.float(); params.cam_origin += go.float()
+        integ = Integ({"max_depth": 8})
+        integ.backward_spp = SPP
+        return integ
+
+
+def _accumulate_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    edist.init_from_env("gloo")
+    scene = SyntheticScene(res=RES, n_vertices=K, n_scene_vertices=V, n_bsdfs=B, profile="mixed", device="cpu", tile_paths=TILE)
+    integ = _OracleIntegrator.make()
+    params = ParamGrads(V, B, device="cpu")
+    integ.render_backward(scene, params, _grad_image(), seed=5)
+    once = params.flat.clone()
+    integ.render_backward(scene, params, _grad_image(), seed=5)      # dr.backward accumulates: NOT zeroed in between
+    q.put((rank, once, params.flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_render_backward_accumulates_without_rescaling():
+    """a second accumulating call must add ONE more copy of the gradients on every rank -- the values
+    already in ``params`` are a sum over the ranks and must not go through the all-reduce again."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_accumulate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    single, _ = _rank_work(0, 1)
+    m = float(single.flat.abs().max())
+    for rank, once, twice in got:
+        assert torch.allclose(once, single.flat, rtol=1e-5, atol=1e-7 * m)
+        assert torch.allclose(twice, 2 * single.flat, rtol=1e-5, atol=2e-7 * m)
+
+
 def _render_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))

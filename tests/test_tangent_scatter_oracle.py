@@ -12,6 +12,7 @@ import torch
 
 from epsm_mitsuba3_amd.synth import (synth_camera_rays, synth_first_hit_triangles, synth_path_info,
                                      synth_scatter_info)
+from epsm_mitsuba3_amd.records import loose_from_packed
 from oracle.binding import oracle_first_vertex_tangent, oracle_scatter, oracle_calc_grad
 
 
@@ -65,7 +66,7 @@ def _autograd_scatter(variant, pi, si, fp, lg, dg, V, B):
     alpha = torch.zeros(max(B, 1), dtype=torch.float64, requires_grad=True)
     loss = torch.zeros((), dtype=torch.float64)
     for it in range(K):
-        r, s = pi[it + 1], si[it]
+        r, s = pi[it + 1], loose_from_packed(si[it])
         mode = s["mode"].long()
         vidx = s["vidx"].long()
         ok = ((vidx >= 0) & (vidx < V)).all(-1)
@@ -103,7 +104,7 @@ def _autograd_scatter(variant, pi, si, fp, lg, dg, V, B):
                     hf = s["dhf_dalpha"][n].double() * alpha[bid]    # hf depends linearly on alpha with this slope
                     loss = loss + (hf * fp[5 * it + 4][n].double()).sum()
             ev = s["evidx"][n].long()
-            if ((ev >= 0) & (ev < V)).all():
+            if ((ev >= 0) & (ev < V)).all() and (int(s["emode"][n]) & 4):     # si_direct.p attached with the emitter mesh
                 c0, c1 = s["eb0"][n].double(), s["eb1"][n].double()
                 ep = [pos_attached[ev[j]] for j in range(3)]
                 direct_p = ep[0] * c0 + ep[1] * c1 + ep[2] * (1 - c0 - c1)

@@ -10,6 +10,7 @@ import torch
 
 from _scenes import floor_and_light, on_host, quad, sensor
 from epsm_mitsuba3_amd import scene as S
+from epsm_mitsuba3_amd.records import loose_from_packed
 
 
 def test_camera_rays_match_the_perspective_model():
@@ -155,14 +156,18 @@ def test_vertex_log_is_consistent():
     lp = v1["light"][em]
     assert torch.allclose(lp[:, 2], torch.full((int(em.sum()),), 2.0), atol=1e-5) and bool((lp[:, :2].abs() <= 0.0501).all())
     # parameter addressing: triangle rows inside the floor mesh's slice, mode bits = attached flat mesh
-    tri = tr.scatter_info[0]["tri"][act].long()
+    # (the log carries triangle ids; the scene's table turns them into vertex rows + mode bits, include/epsm.h)
+    tlo, thi = sc.mesh_tri_slices["floor"]
+    ids = tr.scatter_info[0]["tri"][act].long()
+    assert bool(((ids >= tlo) & (ids < thi)).all())
+    loose = loose_from_packed(tr.scatter_info[0])
     lo, hi = sc.mesh_slices["floor"]
-    assert bool(((tri[:, :3] >= lo) & (tri[:, :3] < hi)).all()) and bool((tri[:, 3] == 4).all())
-    aux = tr.scatter_info[0]["aux"][act]
-    assert bool((aux[:, 0] == 0).all())
-    emit = tr.scatter_info[0]["emit"][em].long()
+    vidx = loose["vidx"][act]
+    assert bool(((vidx >= lo) & (vidx < hi)).all()) and bool((loose["mode"][act] == 4).all())
+    assert bool((loose["bsdf_id"][act] == 0).all())
+    evidx = loose["evidx"][em]
     llo, lhi = sc.mesh_slices["light"]
-    assert bool(((emit[:, :3] >= llo) & (emit[:, :3] < lhi)).all())
+    assert bool(((evidx >= llo) & (evidx < lhi)).all())
     # second vertex of an inactive path is logged as zeros / inactive
     v2 = tr.path_info[2]
     dead = v2["active"] == 0
@@ -213,7 +218,9 @@ def test_occluder_record_of_the_first_vertex():
     v1 = tr.path_info[1]
     x = v1["points"][3]
     on_floor = (v1["active"] > 0) & (x[:, 2].abs() < 1e-5) & (v1["active_em"] > 0)
-    tri, fl = sh[:, :3].long(), sh[:, 3:6].contiguous().view(torch.float32)
+    assert tuple(sh.shape) == (n, 4)
+    loose = loose_from_packed(tr.scatter_info[0])
+    tri, fl = loose["svidx"], torch.stack([loose["sb0"], loose["sb1"], loose["sdis"]], dim=1)
     plo, phi = sc.mesh_slices["plate"]
     llo, lhi = sc.mesh_slices["light"]
     hit_plate = on_floor & ((tri >= plo) & (tri < phi)).all(1)
@@ -234,7 +241,7 @@ def test_occluder_record_of_the_first_vertex():
     assert torch.allclose(xp + (lp - xp) * s[:, None], p, atol=1e-4)
     assert torch.allclose(fl[hit_plate, 2].double(), (lp - p).norm(dim=1) / (lp - xp).norm(dim=1), atol=1e-5)
     assert torch.allclose(fl[hit_plate, 2], torch.full((int(hit_plate.sum()),), 2.0 / 3.0), atol=0.02)
-    assert bool((sh[hit_plate, 6] == 4).all())                         # the plate is a flat mesh with attached positions
+    assert bool((loose["smode"][hit_plate] == 4).all())                # the plate is a flat mesh with attached positions
     # paths without a usable emitter sample carry no occluder
     dead = ~((v1["active"] > 0) & (v1["active_em"] > 0))
     assert bool((sh[dead, 0] == -1).all()) and bool((fl[dead, 2] == 0).all())
@@ -271,7 +278,8 @@ def test_vertex_update_refits_the_bvh_and_recomputes_normals():
     n = 24 * 24 * 4
     a = moved._trace(0, seed=3, spp=4, max_depth=3, K=2, lo=0, hi=n)
     b = fresh._trace(0, seed=3, spp=4, max_depth=3, K=2, lo=0, hi=n)
-    on_tube = (a.path_info[1]["active"] > 0) & (a.scatter_info[0]["tri"][:, 0] >= lo) & (a.scatter_info[0]["tri"][:, 0] < hi)
+    v_first = loose_from_packed(a.scatter_info[0])["vidx"][:, 0]
+    on_tube = (a.path_info[1]["active"] > 0) & (v_first >= lo) & (v_first < hi)
     assert int(on_tube.sum()) > 100
     assert torch.equal(a.path_info[1]["active"], b.path_info[1]["active"])
     assert torch.allclose(a.path_info[1]["points"][3], b.path_info[1]["points"][3], atol=1e-5)

@@ -54,7 +54,7 @@ def _all_arrays(tr):
                     out[f"v{k}.{name}{j}"] = x
     for k, rec in enumerate(tr.scatter_info):
         for name, v in rec.items():
-            if v is not None:
+            if v is not None and name != "table":          # (the scene's triangle table is not a per-path array)
                 out[f"s{k}.{name}"] = v
     return out
 
