@@ -105,6 +105,9 @@ template <typename Table> struct ScatterOut {
 
     template <int ROWS>
     __device__ __forceinline__ void push(bool valid, const uint32_t key[ROWS], const V3<float> val[ROWS]) const {
+#ifdef EPSM_KO_NOPUSH
+        valid = valid && key[0] == 0x12345678u && val[0].x == 1.2345f;
+#endif
         Q.reserve(T, ROWS);
         Q.template push_rows<ROWS>(valid, key, val);
     }
@@ -117,6 +120,9 @@ template <typename Table> struct ScatterOut {
     template <int ROWS, int ROUNDS>
     __device__ __forceinline__ void merge_equal(bool &any, const uint32_t id[3], V3<float> vals[ROWS], int live_rows = ROWS) const {
         constexpr int kMin = ROWS == 1 ? kMinMergeLanesAlpha : kMinMergeLanes;
+#ifdef EPSM_KO_NOMERGE
+        return;
+#endif
         unsigned long long pending = __ballot(any);
 #pragma unroll 1
         for (int round = 0; round < ROUNDS; ++round) {
@@ -150,7 +156,8 @@ template <typename Table> struct ScatterOut {
 
     struct Id { uint32_t v; };
     struct Tri { uint32_t vi[3]; uint32_t mode; };
-    struct Aux { uint32_t bid; V3<float> dhf; uint32_t etri; float eb0, eb1, ew; };
+    struct Emit { uint32_t etri; float eb0, eb1, ew; };
+    struct Aux { uint32_t bid; V3<float> dhf; U4 er; float eb0, eb1, ew; };      // er: the emitter triangle's table row
 
     __device__ __forceinline__ V3<float> fin(V3<float> g) const {
         return mk3<float>(finalize(g.x, F.g.clip), finalize(g.y, F.g.clip), finalize(g.z, F.g.clip));
@@ -159,31 +166,64 @@ template <typename Table> struct ScatterOut {
     // triangle id of vertex k: 4 bytes from the path's log, loaded as soon as the path knows which vertices it needs
     __device__ __forceinline__ Id pre_id(int k, bool live) const {
         Id d; d.v = kNoIndex;
-        if (live && ok) d.v = gl(P.s[k - 1].tri)[i];
+#ifdef EPSM_KO_NOADDR
+        live = false;
+#endif
+        if (live && ok) d.v = lds_(P.s[k - 1].tri, i);
         return d;
     }
     // parameter addressing of vertex k, fetched ahead of the step that needs it: the triangle's row of the scene
     // table (16 B, L2 / MALL resident: 2V rows are a few MB)
     __device__ __forceinline__ Tri pre_tri(int, bool live, Id id) const {
         Tri t; t.vi[0] = t.vi[1] = t.vi[2] = kNoIndex; t.mode = 0;
+#ifdef EPSM_KO_NOADDR
+        live = false;
+#endif
+#ifdef EPSM_KO_NOTRI
+        live = live && i == -5;
+#endif
         if (live && ok) {
             const U4 t4 = table_row(F.tab, id.v);
             t.vi[0] = t4.x; t.vi[1] = t4.y; t.vi[2] = t4.z; t.mode = t4.w;
         }
         return t;
     }
-    __device__ __forceinline__ Aux pre_aux(int k, bool live) const {
-        Aux a; a.bid = kNoIndex; a.dhf = zero3<float>(); a.etri = kNoIndex; a.eb0 = a.eb1 = a.ew = 0.f;
+    // emitter-sample record of vertex k: [etri, eb0, eb1, eweight] (k may be a run-time value)
+    __device__ __forceinline__ Emit pre_emit(int k, bool live) const {
+        Emit e; e.etri = kNoIndex; e.eb0 = e.eb1 = e.ew = 0.f;
+#ifdef EPSM_KO_NOADDR
+        live = false;
+#endif
+#ifdef EPSM_KO_NOEMIT
+        live = live && i == -5;
+#endif
+        if (live && ok) {
+            const uint32_t *p = P.s[k - 1].emit;
+            if (p) {
+                const U4 e4 = load_u4(p, i);
+                e.etri = e4.x; e.eb0 = bits_to_float(e4.y); e.eb1 = bits_to_float(e4.z); e.ew = bits_to_float(e4.w);
+            }
+        }
+        return e;
+    }
+    // BSDF record of vertex k and the vertex rows of its emitter triangle (whose id arrived with `e`, a step ago)
+    __device__ __forceinline__ Aux pre_aux(int k, bool live, const Emit &e) const {
+        Aux a; a.bid = kNoIndex; a.dhf = zero3<float>(); a.eb0 = e.eb0; a.eb1 = e.eb1; a.ew = e.ew;
+        a.er.x = a.er.y = a.er.z = kNoIndex; a.er.w = 0u;
+#ifdef EPSM_KO_NOADDR
+        live = false;
+#endif
         if (live && ok) {
             const ScatterPtrs<float> &s = P.s[k - 1];
+#ifndef EPSM_KO_NOAUX
             if (s.aux && F.galpha) {
+#else
+            if (s.aux && F.galpha && i == -5) {
+#endif
                 const U4 a4 = load_u4(s.aux, i);
                 a.bid = a4.x; a.dhf = mk3<float>(bits_to_float(a4.y), bits_to_float(a4.z), bits_to_float(a4.w));
             }
-            if (s.emit) {
-                const U4 e4 = load_u4(s.emit, i);
-                a.etri = e4.x; a.eb0 = bits_to_float(e4.y); a.eb1 = bits_to_float(e4.z); a.ew = bits_to_float(e4.w);
-            }
+            a.er = table_row(F.tab, e.etri);
         }
         return a;
     }
@@ -195,9 +235,8 @@ template <typename Table> struct ScatterOut {
         // epsm.py:559,644: `iteration*5+4 < len(path_grad)` -- the caustic variant never
         // scatters the (always zero) rows of its last vertex
         const float b0 = c.b0, b1 = c.b1, b2 = 1.f - b0 - b1;
-        // the emitter triangle's vertices: issued first, consumed after the hit triangle's rows are on their way
         glight = fin(glight);
-        const U4 er = table_row(F.tab, ok && nz3(glight) ? a.etri : kNoIndex);
+        const U4 er = a.er;
         V3<float> pos[3] = {fin(Gx * b0), fin(Gx * b1), fin(Gx * b2)};       // si.p_j * path_grad[5it+j]
         V3<float> nrm[3] = {zero3<float>(), zero3<float>(), zero3<float>()};
         gn = fin(gn);
@@ -267,7 +306,7 @@ template <typename Table> struct ScatterOut {
         g = fin(g);
         Tri t = pre_tri(1, nz3(g), id);
         float b0 = 0.f, b1 = 0.f;
-        if (ok && nz3(g)) { b0 = gl(P.v[0].b0)[i]; b1 = gl(P.v[0].b1)[i]; }
+        if (ok && nz3(g)) { b0 = lds_(P.v[0].b0, i); b1 = lds_(P.v[0].b1, i); }
         diffuse(0, g, b0, b1, t);
         // occluder of the first vertex's emitter sample: si_direct.p * diffuse_grad[0] * dis (epsm.py:609-620)
         if (P.s[0].shadow) {
@@ -376,7 +415,11 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { gmax += __shfl_xor(gmax, off); gsum += __shfl_xor(gsum, off); }
+#ifdef EPSM_KO_NOSORT
+            if (lane == 0) s_sort = 0;
+#else
             if (lane == 0) s_sort = 64 * gmax * 4 > 5 * gsum;      // natural order costs > 1.25x the sorted one
+#endif
             // exclusive scan in (j, key, wave) order: each sub-chunk sorted on its own
             int carry = 0;
 #pragma unroll

@@ -163,9 +163,11 @@ template <typename T> EPSM_HD const __attribute__((address_space(1))) T *gl(cons
 #else
 template <typename T> EPSM_HD const T *gl(const T *p) { return p; }
 #endif
+// One element of a record array.  (Marking these streams non-temporal, so that the 10 GB of records of a launch do not
+// push the scene's triangle table and the parameter rows out of L2, measured 0 to +4 %: not kept.)
+template <typename T> EPSM_HD T lds_(const T *p, int64_t i) { return gl(p)[i]; }
 template <typename R> EPSM_HD V3<R> load3(const R *base, int64_t i) {
-    const auto *p = gl(base) + 3 * i;
-    return mk3<R>(p[0], p[1], p[2]);
+    return mk3<R>(lds_(base, 3 * i), lds_(base, 3 * i + 1), lds_(base, 3 * i + 2));
 }
 
 // torch.nan_to_num followed by the +-clip outlier removal (epsm.py:856, 932-944):
@@ -191,7 +193,10 @@ template <typename R> EPSM_HD void store3(R *base, int64_t slot, int64_t N, int6
 //   pre_id(k, live)
 //        called once per vertex right after the flags are known: the 4-byte triangle id of
 //        the vertex's addressing, loaded well ahead of the table lookup that depends on it;
-//   pre_tri(k, live, id) / pre_aux(k, live)
+//   pre_emit(k, live)
+//        the emitter-sample record of vertex k, requested ONE STEP before pre_aux(k, ...) so that the lookup
+//        that depends on it (emitter triangle -> vertex rows) can be issued at the top of step k;
+//   pre_tri(k, live, id) / pre_aux(k, live, emit)
 //        called at the TOP of the step that will emit vertex k, so that whatever the
 //        policy must fetch for it (parameter addressing) is in flight while the step's
 //        sweeps run -- a load issued where the gradient becomes known would be a
@@ -215,6 +220,7 @@ template <typename R> struct DenseOut {
     struct Id {};
     struct Tri {};
     struct Aux {};
+    struct Emit {};
     const GradArgs<R> &A;
     int64_t i;
     // any(p): may the step be skipped when p is false for this lane?  Dense output never
@@ -222,7 +228,8 @@ template <typename R> struct DenseOut {
     EPSM_HD bool any(bool) const { return true; }
     EPSM_HD Id pre_id(int, bool) const { return Id{}; }
     EPSM_HD Tri pre_tri(int, bool, Id) const { return Tri{}; }
-    EPSM_HD Aux pre_aux(int, bool) const { return Aux{}; }
+    EPSM_HD Emit pre_emit(int, bool) const { return Emit{}; }
+    EPSM_HD Aux pre_aux(int, bool, Emit) const { return Aux{}; }
     EPSM_HD void vertex(int k, bool has_nm, V3<R> Gx, V3<R> gn, V3<R> gm, V3<R> glight,
                         const VCtx<R> &c, const Tri &, const Aux &) const {
         store3(A.out_param, 5 * (k - 1) + 0, A.N, i, Gx * c.b0, A.clip);
@@ -253,8 +260,8 @@ template <typename R> struct Geo {      // from "points" + "uv": x = p0 b0 + p1 
 template <typename R> EPSM_HD Geo<R> load_geo(const VertexPtrs<R> &v, int64_t i) {
     Geo<R> g;
     V3<R> p0 = load3(v.p0, i), p1 = load3(v.p1, i), p2 = load3(v.p2, i);
-    g.b0 = gl(v.b0)[i];
-    g.b1 = gl(v.b1)[i];
+    g.b0 = lds_(v.b0, i);
+    g.b1 = lds_(v.b1, i);
     R b2 = R(1) - g.b0 - g.b1;
     g.x = p0 * g.b0 + p1 * g.b1 + p2 * b2;
     g.e1 = p0 - p2;
@@ -390,12 +397,12 @@ template <typename R, int K, typename Args> EPSM_HD Flags<K> load_flags(const Ar
     Flags<K> f;
 #pragma unroll
     for (int k = 1; k <= K; ++k) {
-        uint32_t b = gl(A.vtx(k - 1).bsdf)[i];
+        uint32_t b = lds_(A.vtx(k - 1).bsdf, i);
         f.diffuse[k] = (b & kBsdfDiffuse) != 0;
         f.null_[k] = (b & kBsdfNull) != 0;
-        f.active[k] = gl(A.vtx(k - 1).active)[i] != 0;
-        f.active_em[k] = gl(A.vtx(k - 1).active_em)[i] != 0;
-        f.mesh[k] = gl(A.vtx(k - 1).ismesh)[i] != 0;
+        f.active[k] = lds_(A.vtx(k - 1).active, i) != 0;
+        f.active_em[k] = lds_(A.vtx(k - 1).active_em, i) != 0;
+        f.mesh[k] = lds_(A.vtx(k - 1).ismesh, i) != 0;
     }
     f.diffuse[0] = f.null_[0] = f.active[0] = f.active_em[0] = f.mesh[0] = false;
     f.diffuse[K + 1] = f.null_[K + 1] = f.active[K + 1] = f.active_em[K + 1] = f.mesh[K + 1] = false;
@@ -456,6 +463,7 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
     // sub-path at depth id; wC[id]: continuing sub-path x_{id-1},x_id,x_{id+1}.
     bool wN[K + 1], wC[K + 1];
     int nv = 0;                       // last vertex whose geometry is needed
+    bool nvN = false;                 // ... and whether it has a light-sampling term (wN[nv])
     {
         bool valid = true;
         int hasdiffuse = 0;
@@ -467,8 +475,8 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
             const bool spec = valid && (hasdiffuse == 0);
             wN[id] = spec && fl.active[id] && fl.active_em[id];
             wC[id] = (id < K) && spec && fl.active[id + 1] && fl.diffuse[id + 1];
-            if (wN[id]) nv = id;
-            if (wC[id]) nv = id + 1;
+            if (wN[id]) { nv = id; nvN = true; }
+            if (wC[id]) { nv = id + 1; nvN = false; }
         }
     }
 
@@ -476,6 +484,8 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
     typename Out::Id tid[K + 2];
     static_for_up<1, K>([&](auto kc) EPSM_LAMBDA { constexpr int k = decltype(kc)::value; tid[k] = out.pre_id(k, k <= nv || k == 1); });
     tid[0] = tid[K + 1] = out.pre_id(1, false);
+    // the emitter-sample record of the vertex pass 2 starts with (the others are requested one step ahead there)
+    const typename Out::Emit em_first = out.pre_emit(nv >= 1 ? nv : 1, nvN);
 
     // diffuse_grad[0] = dldp where the first hit is diffuse (epsm.py:791-792)
     out.diffuse_first(fl.diffuse[1] ? A.dldp_at(i) : zero3<R>(), tid[1]);
@@ -495,7 +505,7 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
         Raw r;
         r.g = load_geo(A.vtx(kk - 1), i);
         r.nr = load_nrm(A.vtx(kk - 1), i, r.g.b0, r.g.b1);
-        r.eta = gl(A.vtx(kk - 1).eta)[i];
+        r.eta = lds_(A.vtx(kk - 1).eta, i);
         r.light = load3(A.vtx(kk - 1).light, i);
         return r;
     };
@@ -561,11 +571,13 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
     int W = 0;                         // number of live terms with depth > k
     V3<R> GP = zero3<R>();             // d/dx_k through constraint k+1 (x_k as previous vertex)
     typename Out::Tri tri_next = out.pre_tri(K, false, tid[0]);   // addressing of vertex k+1 (for diffuse_grad[k])
+    typename Out::Emit em_next = out.pre_emit(1, false);
     R nb0 = R(0), nb1 = R(0);
     static_for_down<K>([&](auto kc) EPSM_LAMBDA {
         constexpr int k = decltype(kc)::value;
         const typename Out::Tri tri = out.pre_tri(k, k <= nv, tid[k]);
-        const typename Out::Aux aux = out.pre_aux(k, k <= nv);
+        const typename Out::Aux aux = out.pre_aux(k, k <= nv, k == nv ? em_first : em_next);
+        if (k > 1) em_next = out.pre_emit(k - 1, k <= nv && wN[k - 1]);
         V3<R> Gxk = zero3<R>(), gnrm = Gxk, gm = Gxk, glight = Gxk, gdiff = Gxk;
         VCtx<R> ctx; ctx.b0 = ctx.b1 = R(0); ctx.n = ctx.e1 = ctx.e2 = zero3<R>();
         if (k <= nv) {
@@ -680,14 +692,14 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
         R b0 = R(0), b1 = R(0);
         const bool live = (k < K) && (k + 1 <= nv);    // depth k has a continuing sub-path we need
         const typename Out::Tri tri_nxt = out.pre_tri(k < K ? k + 1 : K, live, tid[k < K ? k + 1 : K]);   // vertex k+1: diffuse_grad[k] now, rows later
-        const typename Out::Aux aux_prev = out.pre_aux(k >= 2 ? k - 1 : 1, k >= 2 && (k - 1) <= idstar);
+        const typename Out::Aux aux_prev = out.pre_aux(k >= 2 ? k - 1 : 1, k >= 2 && (k - 1) <= idstar, out.pre_emit(1, false));   // (light_grad == 0)
         if (live) {
             gcur = gnext;
             gnext = load_geo(A.vtx(k < K ? k : K - 1), i);
             b0 = gcur.b0; b1 = gcur.b1;
             const Nrm<R> nr = load_nrm(A.vtx(k - 1), i, gcur.b0, gcur.b1);
             ncur = nr.n;
-            const R eta = gl(A.vtx(k - 1).eta)[i];
+            const R eta = lds_(A.vtx(k - 1).eta, i);
             const Frame<R> fr = make_frame(nr.n);
             const HalfVec<R> h = halfvec_fwd(xprev, gcur.x, gnext.x, fr, eta);
             const V2<R> dk = A.template d_at<FULL_D>(i, k, dcols);
@@ -759,7 +771,7 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
     // last vertex: only p0,p1,p2 are registered and no continuing row exists for it (id* <= K-1: never part of an undo)
     if (!undo) {
         VCtx<R> c; c.b0 = b0prev; c.b1 = b1prev; c.n = n_prev; c.e1 = e1prev; c.e2 = e2prev;
-        out.vertex(K, false, poisoned ? zero3<R>() : Gx_prev, zero3<R>(), zero3<R>(), zero3<R>(), c, tri_prev, out.pre_aux(K, false));
+        out.vertex(K, false, poisoned ? zero3<R>() : Gx_prev, zero3<R>(), zero3<R>(), zero3<R>(), c, tri_prev, out.pre_aux(K, false, out.pre_emit(1, false)));
     }
     if (undo || !out.undo_needed(poisoned, P)) break;
     }

@@ -184,6 +184,13 @@ struct LdsTable {
     }
 };
 
+// (Tried in round 2 and dropped: rows LOCKED with ds_cmpst_rtn -- top bit of the key -- and updated with plain loads,
+// VALU adds and one 16-byte store that also releases the lock, i.e. no float atomics at all.  Correct (all tests), but
+// 4.47 -> 5.02 ms on the headline slab and 4.92 -> 6.31 ms on config 2: the items of a drain iteration repeat their
+// keys (adjacent lanes push the same triangles), every repeat is another round of three dependent LDS round trips,
+// while the hardware float atomic resolves same-address lanes at ~2 clocks each.  The knock-out that drops the items
+// instead of inserting them saves 0.55 / 0.88 ms: that is all there is to gain from the insertion.)
+
 template <typename Table> __device__ __forceinline__ void atomic_add3(const Table &T, uint32_t key, V3<float> g) { T.add(key, g.x, g.y, g.z); }
 
 // Sum over the wave with DPP adds only (no LDS crossbar): quad swaps, half-row and row mirrors
@@ -276,7 +283,11 @@ __device__ __forceinline__ void drain_queue(const QItem *q, int n, Table T) {
     for (int idx = lane_id(); idx < n; idx += 64) {
         QItem it;
         it.key = ql[4 * idx]; it.x = __uint_as_float(ql[4 * idx + 1]); it.y = __uint_as_float(ql[4 * idx + 2]); it.z = __uint_as_float(ql[4 * idx + 3]);
+#ifndef EPSM_KO_NOINSERT                   // (knock-out build: what the insertion into the table costs)
         T.add(it.key, it.x, it.y, it.z);
+#else
+        if (it.key == 0x12345678u && it.x == 1.2345f) T.add(it.key, it.x, it.y, it.z);
+#endif
     }
 }
 

@@ -63,6 +63,33 @@ def oracle_calc_grad(variant: str, path_info, dlduv: torch.Tensor, dldp: torch.T
     return list(out_p.unbind(0)), list(out_l.unbind(0)), list(out_d.unbind(0)), rc
 
 
+def oracle_cond(variant: str, path_info, dlduv: torch.Tensor, dldp: torch.Tensor, dlduv_cols: int | None = None) -> torch.Tensor:
+    """(N,) float64: per path, the largest 2-norm condition number among the systems ``cur`` (epsm.py:844, 909) whose
+    solve the path's outputs use (1 where it uses none; inf where a system is not finite), from the float64 oracle.
+    SURVEY.md 8c states the fp32 tolerance for cond_2 < 1e4."""
+    rec = PackedRecords(path_info, device="cpu", float_dtype=torch.float64)
+    N, K = rec.N, rec.K
+    d = dlduv.detach().to("cpu", torch.float64).reshape(N, -1).contiguous()
+    p = dldp.detach().to("cpu", torch.float64).reshape(N, 3).contiguous()
+    cols = d.shape[1] if dlduv_cols is None else int(dlduv_cols)
+    P = num_param_grads(variant, K)
+    out = [torch.empty((P, N, 3), dtype=torch.float64), torch.empty((K, N, 3), dtype=torch.float64), torch.empty((K, N, 3), dtype=torch.float64)]
+    cond = torch.ones(N, dtype=torch.float64)
+    l = lib()
+    l.epsm_oracle_set_cond_out_f64.argtypes = [C.c_void_p]
+    l.epsm_oracle_set_cond_out_f64.restype = None
+    l.epsm_oracle_set_cond_out_f64(cond.data_ptr())
+    try:
+        rc = l.epsm_oracle_calc_grad_f64(VARIANTS[variant], N, K, rec.cam.data_ptr(), C.addressof(rec.records),
+                                         d.data_ptr(), d.shape[1], cols, p.data_ptr(), 0.1,
+                                         out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), 0)
+    finally:
+        l.epsm_oracle_set_cond_out_f64(None)
+    if rc < 0:
+        raise RuntimeError(f"oracle failed with code {rc}")
+    return cond
+
+
 # ---------------------------------------------------------------------------
 # tangent / scatter restatements (oracle/epsm_oracle_aux.c; "parity unpinned")
 # ---------------------------------------------------------------------------

@@ -239,6 +239,33 @@ static void dense_inverse(int n, real a[MAXM][MAXM], real inv[MAXM][MAXM]) {
     }
 }
 
+/* 2-norm condition number of the system a solve used, from the matrix and its computed inverse: largest singular
+ * values by power iteration on M^T M (n <= 10; an under-estimate if anything).  Test infrastructure of the test
+ * infrastructure: SURVEY.md 8c states the fp32 tolerance for paths with cond_2 < 1e4, so the parity tests need to know
+ * which paths those are.  Non-finite entries -> +inf. */
+static double norm2_est(int n, real m[MAXM][MAXM]) {
+    double x[MAXM], y[MAXM], z[MAXM], s = 0.0;
+    for (int r = 0; r < n; ++r) { x[r] = 1.0 + 0.37 * r; for (int c = 0; c < n; ++c) if (!isfinite((double) m[r][c])) return INFINITY; }
+    for (int it = 0; it < 80; ++it) {
+        for (int r = 0; r < n; ++r) { double a = 0; for (int c = 0; c < n; ++c) a += (double) m[r][c] * x[c]; y[r] = a; }
+        for (int c = 0; c < n; ++c) { double a = 0; for (int r = 0; r < n; ++r) a += (double) m[r][c] * y[r]; z[c] = a; }
+        double l = 0; for (int c = 0; c < n; ++c) l += z[c] * z[c];
+        l = sqrt(l);
+        if (!(l > 0)) return 0.0;
+        for (int c = 0; c < n; ++c) x[c] = z[c] / l;
+        s = sqrt(l);
+    }
+    return s;
+}
+static double cond2_est(int n, real a[MAXM][MAXM], real inv[MAXM][MAXM]) {
+    const double c = norm2_est(n, a) * norm2_est(n, inv);
+    return c == c ? c : INFINITY;
+}
+static double *FN(g_cond_out) = 0;
+/* buf: N doubles that the next calc_grad calls fill with max cond_2 over the solves whose results a path USES
+ * (1 for paths that use none); NULL switches it off again. */
+void FN(epsm_oracle_set_cond_out)(double *buf) { FN(g_cond_out) = buf; }
+
 typedef struct {
     const real *p[3], *n[3], *light;
     real b0, b1, eta;
@@ -297,6 +324,7 @@ static void one_path(int variant, int K, int64_t i, const real *cam_all, const E
     const int L = K + 1, M = 2 * L;
     work_t w;
     memset(&w, 0, sizeof(w));
+    double cond = 1.0;
     vtx_t v[ORACLE_MAX_K + 2];
     for (int k = 1; k <= K; ++k) load_vertex(&verts[k - 1], i, &v[k]);
     const real *cam = cam_all + 3 * i;
@@ -400,6 +428,7 @@ static void one_path(int variant, int K, int64_t i, const real *cam_all, const E
             real y[MAXM];   /* dlduv[:2id] . inv */
             for (int c = 0; c < n; ++c) { real s = 0; for (int r = 0; r < n; ++r) s += dlduv[r] * inv[r][c]; y[c] = s; }
             const int masked = (!valid) || (!v[id].active) || nolight || (hasdiffuse > 0);  /* :852-855 */
+            if (FN(g_cond_out) && !masked) { const double cc = cond2_est(n, cur, inv); if (!(cc <= cond)) cond = cc; }
             for (int q = 0; q < nparam; ++q)
                 for (int c = 0; c < 3; ++c) {
                     real s = 0;
@@ -489,6 +518,7 @@ static void one_path(int variant, int K, int64_t i, const real *cam_all, const E
                 masked_p = (!valid) || (!v[id + 1].active) || (!next_diffuse);
                 masked_d = (!valid) || (!v[id + 1].active) || ((!next_null) && (!next_diffuse));
             }
+            if (FN(g_cond_out) && !(masked_p && masked_d)) { const double cc = cond2_est(n, cur, inv); if (!(cc <= cond)) cond = cc; }
             for (int q = 0; q < nparam; ++q)
                 for (int c = 0; c < 3; ++c) {
                     real s = 0;
@@ -504,6 +534,8 @@ static void one_path(int variant, int K, int64_t i, const real *cam_all, const E
             }
         }
     }
+
+    if (FN(g_cond_out)) FN(g_cond_out)[i] = cond;
 
     /* remove outlier (epsm.py:932-944 / 1186-1198) */
     const int do_clip = (clip > 0) && !isinf(clip);
