@@ -422,6 +422,18 @@ template <int K> EPSM_HD Flags<K> unpack_flags(uint32_t w) {
 }
 template <typename R> template <int K> EPSM_HD Flags<K> GradArgs<R>::flags(int64_t i) const { return load_flags<R, K>(*this, i); }
 
+// Scalar type the 2x2 block recursion of `manifold` is COMPUTED in (pivots, forward vectors, adjoint seeds; they are
+// kept between the steps in the working precision R).  The reference inverts `cur` with a pivoted LU
+// (torch.linalg.inv, epsm.py:848,912); the block recursion cannot pivot -- the systems of the depths are the nested
+// leading blocks of ONE matrix, which is what makes a single O(K) recursion serve all of them -- and in float32 its
+// rounding errors grow like cond^2 where the pivoted LU's grow like cond: 0.7 % of the `specular` paths with
+// cond_2 < 1e4 were off by more than 4 eps cond, up to O(1).  Doing the ~60 flops per vertex of the recursion in
+// float64 (the 2x2 blocks themselves come out of float32 sweeps) removes that: 0.05 %, worst 4e-2 at cond 6e3
+// (tests/test_kernel_core_host.py, test_gpu_parity.py); +0.6 % kernel time fused, +4 % for the dense kernel.
+template <typename R> struct RecType { typedef double type; };
+template <typename Q, typename R> EPSM_HD M2<Q> cvm(M2<R> m) { M2<Q> o; o.a = Q(m.a); o.b = Q(m.b); o.c = Q(m.c); o.d = Q(m.d); return o; }
+template <typename Q, typename R> EPSM_HD V2<Q> cvv(V2<R> v) { return mk2<Q>(Q(v.x), Q(v.y)); }
+
 // ============================================================================
 // "manifold"  (epsm.py:745-946)
 // ============================================================================
@@ -493,9 +505,11 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
     // ---- pass 1: forward recursion (pivots of the continuing rows, z vectors)
     struct Keep { V3<R> x, e1, e2, n, light; R eta, b0, b1; };
     Keep kp[K + 2];
-    M2<R> Sinv[K + 1];
-    V2<R> z[K + 1], zN[K + 1];
-    z[0] = mk2<R>(R(0), R(0));
+    typedef typename RecType<R>::type Q;
+    typedef R St;                     // kept between the steps / passes in the working precision
+    M2<St> Sinv[K + 1];
+    V2<St> z[K + 1], zN[K + 1];
+    z[0] = mk2<St>(St(0), St(0));
 
     // Everything a vertex contributes to pass 1, fetched ONE STEP AHEAD of its use: with two
     // waves per SIMD a load consumed in the step that issued it is a fully exposed HBM
@@ -512,8 +526,8 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
     const V3<R> cam = load3(A.cam, i);
     Raw rnext;
     if (nv >= 1) rnext = load_raw(1);
-    M2<R> Aup;                        // A^C_{k-1,k}: continuing row k-1, column block k
-    Aup.a = Aup.b = Aup.c = Aup.d = R(0);
+    M2<Q> Aup;                        // A^C_{k-1,k}: continuing row k-1, column block k
+    Aup.a = Aup.b = Aup.c = Aup.d = Q(0);
 
     static_for_up<1, K>([&](auto kc) EPSM_LAMBDA {
         constexpr int k = decltype(kc)::value;
@@ -529,26 +543,26 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
             kp[k].light = r.light;
             const Frame<R> fr = make_frame(nr.n);
             const V3<R> xp = (k == 1) ? cam : kp[k - 1].x;
-            const V2<R> dk = A.template d_at<FULL_D>(i, k, dcols);
+            const V2<Q> dk = cvv<Q>(A.template d_at<FULL_D>(i, k, dcols));
 
-            V2<R> rhs = dk;
-            M2<R> T;                  // Sinv_{k-1} A^C_{k-1,k}
-            T.a = T.b = T.c = T.d = R(0);
+            V2<Q> rhs = dk;
+            M2<Q> T;                  // Sinv_{k-1} A^C_{k-1,k}
+            T.a = T.b = T.c = T.d = Q(0);
             if (k > 1) {
-                rhs = dk - vmul(z[k - 1], Aup);
-                T = mmul(Sinv[k - 1], Aup);
+                rhs = dk - vmul(cvv<Q>(z[k - 1]), Aup);
+                T = mmul(cvm<Q>(Sinv[k - 1]), Aup);
             }
             // light-sampling version (next point = emitter sample); its rows never serve
             // deeper terms (those see the continuing rows), so it is needed only when live
-            zN[k] = mk2<R>(R(0), R(0));
+            zN[k] = mk2<St>(St(0), St(0));
             if (wN[k]) {
                 const HalfVec<R> h = halfvec_fwd(xp, g.x, kp[k].light, fr, kp[k].eta);
                 const Sweep<R> s0 = halfvec_rev(fr, h, R(1), R(0));
                 const Sweep<R> s1 = halfvec_rev(fr, h, R(0), R(1));
-                M2<R> Akk = madd2(block2(s0.gxc, s1.gxc, g.e1, g.e2), block2(s0.gn, s1.gn, nr.dn1, nr.dn2));
-                M2<R> S = Akk;
-                if (k > 1) S = msub(Akk, mmul(block2(s0.gxp, s1.gxp, kp[k - 1].e1, kp[k - 1].e2), T));
-                zN[k] = vmul(rhs, minv(S));
+                M2<Q> Akk = cvm<Q>(madd2(block2(s0.gxc, s1.gxc, g.e1, g.e2), block2(s0.gn, s1.gn, nr.dn1, nr.dn2)));
+                M2<Q> S = Akk;
+                if (k > 1) S = msub(Akk, mmul(cvm<Q>(block2(s0.gxp, s1.gxp, kp[k - 1].e1, kp[k - 1].e2)), T));
+                zN[k] = cvv<St>(vmul(rhs, minv(S)));
             }
             // continuing version (next point = x_{k+1})
             if (has_next) {
@@ -556,18 +570,19 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
                 const HalfVec<R> h = halfvec_fwd(xp, g.x, gn_.x, fr, kp[k].eta);
                 const Sweep<R> s0 = halfvec_rev(fr, h, R(1), R(0));
                 const Sweep<R> s1 = halfvec_rev(fr, h, R(0), R(1));
-                M2<R> Akk = madd2(block2(s0.gxc, s1.gxc, g.e1, g.e2), block2(s0.gn, s1.gn, nr.dn1, nr.dn2));
-                M2<R> S = Akk;
-                if (k > 1) S = msub(Akk, mmul(block2(s0.gxp, s1.gxp, kp[k - 1].e1, kp[k - 1].e2), T));
-                Sinv[k] = minv(S);
-                z[k] = vmul(rhs, Sinv[k]);
-                Aup = block2(s0.gxn, s1.gxn, gn_.e1, gn_.e2);
+                M2<Q> Akk = cvm<Q>(madd2(block2(s0.gxc, s1.gxc, g.e1, g.e2), block2(s0.gn, s1.gn, nr.dn1, nr.dn2)));
+                M2<Q> S = Akk;
+                if (k > 1) S = msub(Akk, mmul(cvm<Q>(block2(s0.gxp, s1.gxp, kp[k - 1].e1, kp[k - 1].e2)), T));
+                const M2<Q> Si = minv(S);
+                Sinv[k] = cvm<St>(Si);
+                z[k] = cvv<St>(vmul(rhs, Si));
+                Aup = cvm<Q>(block2(s0.gxn, s1.gxn, gn_.e1, gn_.e2));
             }
         }
     });
 
     // ---- pass 2: backward recursion of the adjoint seeds + seeded sweeps
-    V2<R> carry = mk2<R>(R(0), R(0));  // sum over deeper terms of their y_k
+    V2<Q> carry = mk2<Q>(Q(0), Q(0));  // sum over deeper terms of their y_k
     int W = 0;                         // number of live terms with depth > k
     V3<R> GP = zero3<R>();             // d/dx_k through constraint k+1 (x_k as previous vertex)
     typename Out::Tri tri_next = out.pre_tri(K, false, tid[0]);   // addressing of vertex k+1 (for diffuse_grad[k])
@@ -583,9 +598,10 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
         if (k <= nv) {
             const bool fN = wN[k] && finite2(zN[k]);
             const bool fC = wC[k] && finite2(z[k]);
-            V2<R> sN = fN ? zN[k] : mk2<R>(R(0), R(0));
-            V2<R> sC = carry;
-            if (fC) sC = sC + z[k];
+            const V2<R> sN = fN ? cvv<R>(zN[k]) : mk2<R>(R(0), R(0));
+            V2<Q> sCq = carry;
+            if (fC) sCq = sCq + cvv<Q>(z[k]);
+            const V2<R> sC = cvv<R>(sCq);
             const bool has_next = (k < K) && (k + 1 <= nv);
             const Frame<R> fr = make_frame(kp[k].n);
             const V3<R> xp = (k == 1) ? cam : kp[k - 1].x;
@@ -608,10 +624,10 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
             W += (fN ? 1 : 0) + (fC ? 1 : 0);
             if (k > 1) {
                 if (W > 0) {
-                    V2<R> q = mk2<R>(dot(GP, kp[k - 1].e1), dot(GP, kp[k - 1].e2));
-                    carry = z[k - 1] * R(W) - vmul(q, Sinv[k - 1]);
+                    V2<Q> q = mk2<Q>(Q(dot(GP, kp[k - 1].e1)), Q(dot(GP, kp[k - 1].e2)));
+                    carry = cvv<Q>(z[k - 1]) * Q(W) - vmul(q, cvm<Q>(Sinv[k - 1]));
                 } else {
-                    carry = mk2<R>(R(0), R(0));
+                    carry = mk2<Q>(Q(0), Q(0));
                 }
             }
         }

@@ -84,3 +84,39 @@ def parity_report(mine: torch.Tensor, truth: torch.Tensor, yard: torch.Tensor | 
         "n_straddle": int(strad.sum()),
         "bad_idx": torch.nonzero(bad).flatten()[:8].tolist(),
     }
+
+
+COND_GATE = 1e4          # the fp32 tolerance is stated for paths whose system has cond_2 < 1e4
+EPS32 = 6e-8
+
+
+def gated_parity_report(mine: torch.Tensor, truth: torch.Tensor, cond: torch.Tensor, clip: float = 0.1,
+                        rel: float = 2e-4, k_eps: float = 4.0, gate: float = COND_GATE):
+    """Per-path parity of fp32 results against a float64 truth with the conditioning gate of SURVEY.md 8c.
+
+    ``cond`` (N,): largest cond_2 among the systems ``cur`` a path's outputs use (oracle.binding.oracle_cond).  A path
+    passes when its max-norm error is at most ``scale * max(rel, k_eps * eps32 * cond)`` -- the backward-stable bound
+    of an fp32 solve with a modest constant, no yardstick term -- with ``scale`` = max |truth| over the path (>= 1e-6).
+    Components within 2 % of the +-clip outlier threshold (epsm.py:932-944) are excluded as in ``parity_report``.
+    Returns the bad-path fractions INSIDE the gate (cond < gate: the number the tests bound) and OUTSIDE it (reported),
+    the share of paths inside, and the worst relative error inside."""
+    mine = mine.double(); truth = truth.double(); cond = cond.double()
+    strad = torch.zeros_like(truth, dtype=torch.bool)
+    if clip and clip > 0 and np.isfinite(clip):
+        strad = (truth.abs() > 0.98 * clip) | ((truth == 0) & (mine.abs() > 0.98 * clip))
+    err = torch.where(strad, torch.zeros_like(truth), (mine - truth).abs()).amax(dim=(0, 2))
+    scale = torch.where(strad, torch.zeros_like(truth), truth.abs()).amax(dim=(0, 2)).clamp_min(1e-6)
+    inside = cond < gate
+    tol = scale * torch.clamp(k_eps * EPS32 * cond, min=rel)
+    bad = err > tol
+    n_in, n_out = int(inside.sum()), int((~inside).sum())
+    relerr = err / scale
+    return {
+        "frac_bad_inside": float((bad & inside).sum()) / max(1, n_in),
+        "frac_bad_outside": float((bad & ~inside).sum()) / max(1, n_out),
+        "n_bad_inside": int((bad & inside).sum()),
+        "gate_share": n_in / max(1, n_in + n_out),
+        "worst_inside": float(relerr[inside].max()) if n_in else 0.0,
+        "median_rel": float(relerr.median()),
+        "bad_idx": torch.nonzero(bad & inside).flatten()[:8].tolist(),
+    }

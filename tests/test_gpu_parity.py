@@ -4,7 +4,7 @@ size-independent properties at the full benchmark size."""
 import pytest
 import torch
 
-from _util import golden_files, golden_id, load_golden, stack3, parity_report
+from _util import golden_files, golden_id, load_golden, stack3, parity_report, gated_parity_report
 
 pytestmark = pytest.mark.gpu
 
@@ -24,9 +24,11 @@ def _gpu(pi, dev):
 
 @pytest.mark.parametrize("path", FILES, ids=golden_id)
 def test_hip_matches_reference_golden(path, dev):
-    """Tolerance: per path, max-norm error <= 2e-4*scale + 16x the reference's own
-    fp32 distance to its float64 run; at most 2 % of paths may exceed it (they are
-    the ill-conditioned ones where the reference's fp32 LU is itself off)."""
+    """Tolerance, two ways.  (1) With the reference's own fp32 run as the yardstick: per path, max-norm error
+    <= 2e-4*scale + 16x the reference's fp32 distance to its float64 run; at most 1 % of the paths may exceed it.
+    (2) Without a yardstick, inside the conditioning gate of SURVEY.md 8c (cond_2 < 1e4 of the systems the path
+    uses, from the oracle): error <= scale * max(2e-4, 4 eps32 cond) on all but 0.5 % of the paths (one path on the
+    96..128-path files, five on the 1024-path ones)."""
     import epsm_mitsuba3_amd as epsm
     variant, pi, dlduv, dldp, ref = load_golden(path)
     fp, lg, dg = epsm.calc_grad(variant, _gpu(pi, dev), dlduv.to(dev), dldp.to(dev))
@@ -36,8 +38,11 @@ def test_hip_matches_reference_golden(path, dev):
     yard = torch.cat([ref["ref32_param"], ref["ref32_light"], ref["ref32_diffuse"]]).double()
     assert not torch.isnan(mine).any()
     rep = parity_report(mine, truth, yard)
-    assert rep["frac_bad"] <= 0.02, rep
+    assert rep["frac_bad"] <= 0.01, rep
     assert rep["median_rel"] < 1e-4, rep
+    from oracle.binding import oracle_cond
+    gated = gated_parity_report(mine, truth, oracle_cond(variant, pi, dlduv, dldp))
+    assert gated["n_bad_inside"] <= max(1, int(0.005 * truth.shape[1])), gated
     # masked paths must be EXACT zeros: wherever the float64 reference is
     # zero for a whole path, so are we
     dead = (truth == 0).all(dim=2).all(dim=0)
@@ -51,15 +56,20 @@ def test_hip_matches_reference_golden(path, dev):
 def test_hip_matches_oracle_synthetic(variant, profile, K, dev):
     import epsm_mitsuba3_amd as epsm
     from epsm_mitsuba3_amd.synth import synth_path_info
-    from oracle.binding import oracle_calc_grad
+    from oracle.binding import oracle_calc_grad, oracle_cond
     N = 20000
     pi, dlduv, dldp = synth_path_info(N, K, seed=40 + K, profile=profile, tangent_scale=2e-5)
     fp, lg, dg = epsm.calc_grad(variant, _gpu(pi, dev), dlduv.to(dev), dldp.to(dev))
     t = oracle_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float64)
     y = oracle_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float32)
     rep = parity_report(stack3(fp, lg, dg), stack3(*t[:3]), stack3(*y[:3]))
-    assert rep["frac_bad"] <= 0.01, rep
+    assert rep["frac_bad"] <= 0.005, rep
     assert rep["median_rel"] < 1e-4, rep
+    # inside cond_2 < 1e4 at most 0.5 % of the paths beyond scale * max(2e-4, 4 eps cond), no yardstick;
+    # the fraction outside the gate is reported (pytest -s), not bounded
+    gated = gated_parity_report(stack3(fp, lg, dg), stack3(*t[:3]), oracle_cond(variant, pi, dlduv, dldp))
+    print(variant, profile, K, gated)
+    assert gated["frac_bad_inside"] <= 0.005, gated
 
 
 def test_ragged_and_tiny_sizes(dev):

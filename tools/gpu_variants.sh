@@ -3,5 +3,5 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 run() { python bench.py --steps 4 --warmup 1 --no-cpu-baseline $2 2>/dev/null | tail -1 | python -c "
 import sys,json
-d=json.loads(sys.stdin.read()); print('[$1 $2]', 'kernel %.3f ms'%d['stages_ms']['grad'], 'frac %.3f'%d['roofline']['frac'])"; }
+d=json.loads(sys.stdin.read()); print('[$1 $2]', 'kernel %.3f ms'%d['stages_ms']['grad'], 'frac %.3f'%d['roofline']['frac'], 'dense kernel %.3f ms'%d.get('standalone_grad_kernel',{}).get('kernel_ms',0))"; }
 for k in "$@"; do for p in "--max-resident-gb 45" "--config 2" "--config 3 --max-resident-gb 30"; do EPSM_LIB_NAME=libepsm_$k.so run "$k" "$p"; done; done
