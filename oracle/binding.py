@@ -141,3 +141,31 @@ def oracle_scatter(variant, path_info, scatter_info, out_param, out_light, out_d
                                     gp.data_ptr(), gn.data_ptr(), ga.data_ptr(), V, B)
     assert rc == 0
     return gp, gn, ga[:B]
+
+
+# ---------------------------------------------------------------------------
+# brute-force float64 intersector (oracle/epsm_oracle_trace.c; the tracer's non-self oracle)
+# ---------------------------------------------------------------------------
+def oracle_intersect(o, d, tri_verts, tmin=0.0, tmax=float("inf"), skip=None, any_hit=False):
+    """Every ray against every triangle in float64.  ``o, d``: (n,3); ``tri_verts``: (T,3,3) = p0,p1,p2;
+    ``tmin`` / ``tmax``: scalars or (n); ``skip``: (n) triangle to ignore per ray (-1 none).
+    Returns dict(tri (n) int64 [-1 = miss], t, u, v, second_t (n) float64): mesh.h:343-365's (t, u, v)."""
+    l = lib()
+    if not hasattr(l, "_trace_ready"):
+        l.epsm_oracle_intersect.restype = C.c_int
+        l.epsm_oracle_intersect.argtypes = [C.c_int64] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        l._trace_ready = True
+    f = lambda t: torch.as_tensor(t).detach().to("cpu", torch.float64).contiguous()
+    o, d = f(o).reshape(-1, 3), f(d).reshape(-1, 3)
+    n = o.shape[0]
+    tv = f(tri_verts).reshape(-1, 9)
+    lo = f(tmin).expand(n).contiguous() if f(tmin).dim() == 0 else f(tmin)
+    hi = f(tmax).expand(n).contiguous() if f(tmax).dim() == 0 else f(tmax)
+    sk = None if skip is None else torch.as_tensor(skip).detach().to("cpu", torch.int64).contiguous()
+    tri = torch.empty(n, dtype=torch.int64)
+    t, u, v, s2 = (torch.empty(n, dtype=torch.float64) for _ in range(4))
+    rc = l.epsm_oracle_intersect(n, o.data_ptr(), d.data_ptr(), lo.data_ptr(), hi.data_ptr(), tv.shape[0], tv.data_ptr(),
+                                 sk.data_ptr() if sk is not None else None, int(bool(any_hit)),
+                                 tri.data_ptr(), t.data_ptr(), u.data_ptr(), v.data_ptr(), s2.data_ptr())
+    assert rc == 0
+    return {"tri": tri, "t": t, "u": u, "v": v, "second_t": s2}
