@@ -16,7 +16,20 @@
 //   hipcc -O2 -std=c++17 --offload-arch=gfx950 -Iinclude examples/epsm_host_driver.cpp \
 //         -Lepsm_mitsuba3_amd -lepsm_hip -Wl,-rpath,'$ORIGIN/../../epsm_mitsuba3_amd' -o examples/build/epsm_host_driver
 //   examples/build/epsm_host_driver [paths=1048576] [K=5] [variant=0|1] [V=100000]
+//
+// Multi-GPU (BASELINE.json north_star: "host C++ calls HIP through a thin C-ABI ... RCCL reduce over xGMI into the
+// shared parameter-gradient buffer"), still without Python or torch:
+//   examples/build/epsm_host_driver --ranks R [paths] [K] [variant] [V]
+// starts R processes (one per GPU; the parent forks BEFORE any HIP call), rank r runs epsm_backward_pass on the r-th
+// contiguous shard of the wavefront into ONE flat buffer [grad_pos | grad_nrm | grad_alpha | grad_origin], the ranks
+// sum it with a single ncclAllReduce(float, sum), and every rank checks the result against the whole wavefront
+// processed on its own GPU alone.  (R = 1 runs the same code over a one-rank communicator.)
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <string>
 
 #include <cmath>
 #include <cstdint>
@@ -165,9 +178,84 @@ struct Timer {
     float stop_ms() { HIP_OK(hipEventRecord(b, nullptr)); HIP_OK(hipEventSynchronize(b)); float ms = 0; HIP_OK(hipEventElapsedTime(&ms, a, b)); return ms; }
 };
 
+#define NCCL_OK(call)                                                                                  \
+    do {                                                                                               \
+        ncclResult_t r_ = (call);                                                                      \
+        if (r_ != ncclSuccess) { std::fprintf(stderr, "%s: %s\n", #call, ncclGetErrorString(r_)); std::exit(4); } \
+    } while (0)
+
+// Parent of the multi-GPU mode: no HIP call has been made in this process, so it may fork.  Children re-exec this
+// binary with EPSM_RANK / EPSM_RANKS / EPSM_ID_FILE set.
+int launch_ranks(int ranks, char **argv) {
+    char idfile[64];
+    std::snprintf(idfile, sizeof(idfile), "/tmp/epsm_nccl_id_%d", (int) getpid());
+    unlink(idfile);
+    std::vector<pid_t> pids;
+    for (int r = 0; r < ranks; ++r) {
+        const pid_t pid = fork();
+        if (pid < 0) { std::perror("fork"); return 1; }
+        if (pid == 0) {
+            setenv("EPSM_RANK", std::to_string(r).c_str(), 1);
+            setenv("EPSM_RANKS", std::to_string(ranks).c_str(), 1);
+            setenv("EPSM_ID_FILE", idfile, 1);
+            setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);          // dmabuf IPC (the only one this pool's driver supports)
+            execv("/proc/self/exe", argv);
+            std::perror("execv");
+            _exit(127);
+        }
+        pids.push_back(pid);
+    }
+    int worst = 0;
+    for (pid_t pid : pids) {
+        int st = 0;
+        waitpid(pid, &st, 0);
+        const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
+        if (rc > worst) worst = rc;
+    }
+    unlink(idfile);
+    std::printf("%s\n", worst == 0 ? "OK" : "MISMATCH");
+    return worst;
+}
+
+// rank 0 publishes the communicator id through a file (written whole, then renamed), the others wait for it
+ncclUniqueId exchange_id(int rank, const char *path) {
+    ncclUniqueId id;
+    if (rank == 0) {
+        NCCL_OK(ncclGetUniqueId(&id));
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE *f = std::fopen(tmp.c_str(), "wb");
+        if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) { std::perror("id file"); std::exit(5); }
+        std::fclose(f);
+        std::rename(tmp.c_str(), path);
+    } else {
+        for (int tries = 0;; ++tries) {
+            FILE *f = std::fopen(path, "rb");
+            if (f) { const size_t got = std::fread(&id, sizeof(id), 1, f); std::fclose(f); if (got == 1) break; }
+            if (tries > 600) { std::fprintf(stderr, "rank %d: no communicator id after 60 s\n", rank); std::exit(5); }
+            usleep(100000);
+        }
+    }
+    return id;
+}
+
 }  // namespace
 
+static int run_rank(int rank, int ranks, const char *idfile, int64_t N, int K, int variant, int64_t V);
+
 int main(int argc, char **argv) {
+    // ---- multi-GPU mode: decided before anything touches the GPU
+    int ranks = 0;
+    std::vector<char *> pos;
+    for (int a = 1; a < argc; ++a) {
+        if (std::strcmp(argv[a], "--ranks") == 0 && a + 1 < argc) { ranks = std::atoi(argv[++a]); continue; }
+        pos.push_back(argv[a]);
+    }
+    if (ranks > 0) {
+        if (!getenv("EPSM_RANK")) return launch_ranks(ranks, argv);
+        return run_rank(std::atoi(getenv("EPSM_RANK")), std::atoi(getenv("EPSM_RANKS")), getenv("EPSM_ID_FILE"),
+                        pos.size() > 0 ? std::atoll(pos[0]) : (1ll << 20), pos.size() > 1 ? std::atoi(pos[1]) : 5,
+                        pos.size() > 2 ? std::atoi(pos[2]) : EPSM_VARIANT_MANIFOLD, pos.size() > 3 ? std::atoll(pos[3]) : 100000);
+    }
     const int64_t N = argc > 1 ? std::atoll(argv[1]) : (1ll << 20);
     const int K = argc > 2 ? std::atoi(argv[2]) : 5;
     const int variant = argc > 3 ? std::atoi(argv[3]) : EPSM_VARIANT_MANIFOLD;
@@ -285,4 +373,83 @@ int main(int argc, char **argv) {
                     mo > 0 && eo <= 1e-3 * mo;
     std::printf("%s\n", ok ? "OK" : "MISMATCH");
     return ok ? 0 : 1;
+}
+
+
+// One rank of the multi-GPU mode.
+static int run_rank(int rank, int ranks, const char *idfile, int64_t N, int K, int variant, int64_t V) {
+    const int64_t B = 4;
+    const int spp = 64;
+    int res = 1; while ((int64_t) res * res * spp < N) ++res;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < ranks) {
+        std::fprintf(stderr, "rank %d: %d rank(s) need %d GPUs, %d visible (one process per GPU)\n", rank, ranks, ranks, n_dev);
+        return 1;
+    }
+    HIP_OK(hipSetDevice(rank));
+    ncclComm_t comm;
+    const ncclUniqueId id = exchange_id(rank, idfile);
+    NCCL_OK(ncclCommInitRank(&comm, ranks, id, rank));
+
+    // the same records on every rank (seeded generator); a rank only READS its shard in the sharded pass
+    std::vector<uint8_t> alive(N, 1);
+    std::vector<VertexArrays> verts;
+    for (int k = 1; k <= K; ++k) verts.push_back(make_vertex(N, k, V, res, spp, alive, 42));
+    DeviceArray<uint32_t> table(make_triangle_table(V));
+    const int64_t T = (int64_t) table.n / 4;
+    Rng r(7);
+    std::vector<float> ray_o(3 * N), ray_d(3 * N), ray_dx(3 * N), ray_dy(3 * N), grad_img((size_t) res * res * 5);
+    for (auto &g : grad_img) g = 1e-3f * r.gauss();
+    {
+        std::vector<float> p0 = verts[0].p[0].download(), p1 = verts[0].p[1].download(), p2 = verts[0].p[2].download();
+        std::vector<float> b0 = verts[0].b0.download(), b1 = verts[0].b1.download();
+        for (int64_t i = 0; i < N; ++i) {
+            float d[3];
+            for (int c = 0; c < 3; ++c) {
+                const float x = p0[3 * i + c] * b0[i] + p1[3 * i + c] * b1[i] + p2[3 * i + c] * (1.f - b0[i] - b1[i]);
+                ray_o[3 * i + c] = c == 2 ? 5.f : 0.f;
+                d[c] = x - ray_o[3 * i + c];
+            }
+            normalize3(d);
+            float dx[3] = {d[0] + 1e-3f, d[1], d[2]}, dy[3] = {d[0], d[1] + 1e-3f, d[2]};
+            normalize3(dx); normalize3(dy);
+            std::memcpy(&ray_d[3 * i], d, 12); std::memcpy(&ray_dx[3 * i], dx, 12); std::memcpy(&ray_dy[3 * i], dy, 12);
+        }
+    }
+    DeviceArray<float> d_o(ray_o), d_d(ray_d), d_dx(ray_dx), d_dy(ray_dy), d_img(grad_img);
+    // [grad_pos (3V) | grad_nrm (3V) | grad_alpha (B) | grad_origin (3)]: one buffer, one collective
+    const size_t flat_n = (size_t) (6 * V + B + 3);
+    DeviceArray<float> flat(flat_n), whole(flat_n);
+    auto records = [&](int64_t lo, std::vector<EpsmVertexRecord> &vr, std::vector<EpsmScatterRecord> &sr) {
+        vr.resize(K); sr.resize(K);
+        for (int k = 0; k < K; ++k) {
+            const VertexArrays &v = verts[k];
+            vr[k] = EpsmVertexRecord{v.p[0].ptr + 3 * lo, v.p[1].ptr + 3 * lo, v.p[2].ptr + 3 * lo, v.n[0].ptr + 3 * lo,
+                                     v.n[1].ptr + 3 * lo, v.n[2].ptr + 3 * lo, v.b0.ptr + lo, v.b1.ptr + lo, v.eta.ptr + lo,
+                                     v.hf.ptr + 3 * lo, v.light.ptr + 3 * lo, v.bsdf.ptr + lo, v.active.ptr + lo,
+                                     v.active_em.ptr + lo, v.ismesh.ptr + lo};
+            sr[k] = EpsmScatterRecord{v.tri.ptr + lo, v.aux.ptr + 4 * lo, v.emit.ptr + 4 * lo, nullptr};
+        }
+    };
+    auto pass = [&](int64_t lo, int64_t n, float *buf) {
+        std::vector<EpsmVertexRecord> vr; std::vector<EpsmScatterRecord> sr;
+        records(lo, vr, sr);
+        EPSM_CALL(epsm_backward_pass(variant, n, K, lo, spp, res, d_o.ptr + 3 * lo, d_d.ptr + 3 * lo, d_dx.ptr + 3 * lo,
+                                     d_dy.ptr + 3 * lo, d_img.ptr, res, 5, vr.data(), sr.data(), table.ptr, T, 0.1f,
+                                     buf, buf + 3 * V, buf + 6 * V, buf + 6 * V + B, V, B, nullptr));
+    };
+    const int64_t lo = N * rank / ranks, hi = N * (rank + 1) / ranks;
+    pass(lo, hi - lo, flat.ptr);                                                  // this rank's shard
+    NCCL_OK(ncclAllReduce(flat.ptr, flat.ptr, flat_n, ncclFloat, ncclSum, comm, nullptr));   // the ONE collective of a backward pass
+    pass(0, N, whole.ptr);                                                         // the single-GPU answer, for the check
+    HIP_OK(hipDeviceSynchronize());
+    const std::vector<float> a = flat.download(), b = whole.download();
+    const double m = max_abs(b), e = max_diff(a, b);
+    int count = 0;
+    NCCL_OK(ncclCommCount(comm, &count));
+    std::printf("epsm_host_driver rank %d/%d (RCCL communicator of %d): shard [%lld, %lld) of %lld paths, all-reduce of %zu floats; "
+                "max |sum over ranks - single GPU| = %.3g of %.3g\n", rank, ranks, count, (long long) lo, (long long) hi,
+                (long long) N, flat_n, e, m);
+    NCCL_OK(ncclCommDestroy(comm));
+    return (count == ranks && m > 0 && e <= 2e-4 * m) ? 0 : 1;
 }

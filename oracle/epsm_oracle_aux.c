@@ -24,6 +24,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -91,7 +92,12 @@ int epsm_oracle_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, in
     return 0;
 }
 
+/* Sums go either straight into the caller's buffers with an atomic add (one thread, or buffers too large to copy
+ * per thread) or into a PRIVATE copy per thread that is reduced at the end -- what a CPU implementation that wants to
+ * be fast does when every path hits the same few emitter rows. */
+static int g_private = 0;
 static void add1(double *p, double x) {
+    if (g_private) { *p += x; return; }
 #pragma omp atomic
     *p += x;
 }
@@ -118,7 +124,29 @@ int epsm_oracle_scatter(int variant, int64_t N, int K,
                         const double *out_param, const double *out_light, const double *out_diffuse,
                         double *grad_pos, double *grad_nrm, double *grad_alpha, int64_t V, int64_t B) {
     const int P = variant == EPSM_VARIANT_MANIFOLD_CAUSTIC ? 5 * K - 2 : 5 * K;
-#pragma omp parallel for schedule(static)
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    const int64_t per_thread = 6 * V + (grad_alpha ? B : 0);
+    double *priv = 0;
+    g_private = 0;
+    if (nthreads > 1 && per_thread * nthreads <= (int64_t) 1 << 28) {          /* <= 2 GiB of private copies */
+        priv = (double *) calloc((size_t) (per_thread * nthreads), sizeof(double));
+        g_private = priv != 0;
+    }
+    double *const out_pos = grad_pos, *const out_nrm = grad_nrm, *const out_alpha = grad_alpha;
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+    const int tid = omp_get_thread_num();
+#else
+    const int tid = 0;
+#endif
+    double *grad_pos = priv ? priv + (int64_t) tid * per_thread : out_pos;                 /* shadow the arguments */
+    double *grad_nrm = priv ? grad_pos + 3 * V : out_nrm;
+    double *grad_alpha = priv ? (out_alpha ? grad_pos + 6 * V : 0) : out_alpha;
+#pragma omp for schedule(static)
     for (int64_t i = 0; i < N; ++i) {
         for (int it = 0; it < K; ++it) {
             const EpsmVertexRecord *v = &verts[it];
@@ -202,6 +230,19 @@ int epsm_oracle_scatter(int variant, int64_t N, int K,
                 }
             }
         }
+    }
+    }   /* omp parallel */
+    if (priv) {
+        g_private = 0;
+#pragma omp parallel for schedule(static)
+        for (int64_t j = 0; j < per_thread; ++j) {
+            double s = 0.0;
+            for (int t = 0; t < nthreads; ++t) s += priv[(int64_t) t * per_thread + j];
+            if (j < 3 * V) out_pos[j] += s;
+            else if (j < 6 * V) out_nrm[j - 3 * V] += s;
+            else out_alpha[j - 6 * V] += s;
+        }
+        free(priv);
     }
     return 0;
 }

@@ -23,3 +23,20 @@ def test_cxx_host_driver(n, K, variant):
     r = subprocess.run([_exe(), str(n), str(K), str(variant), "20000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("OK")
+
+
+def test_cxx_host_driver_rccl_mode_one_rank():
+    """`--ranks R`: one process per GPU started by a parent that never touches the GPU, ONE ncclAllReduce(float, sum) of
+    the flat parameter-gradient buffer, self-check against the single-GPU sum.  A one-GPU box can only run R = 1 (RCCL
+    wants one device per rank): the launcher, the id exchange, the communicator, the collective and the check are the
+    code the R = 8 run uses."""
+    r = subprocess.run([_exe(), "--ranks", "1", "200000", "5", "0", "20000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RCCL communicator of 1" in r.stdout and r.stdout.strip().endswith("OK")
+
+
+def test_cxx_host_driver_rccl_mode_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([_exe(), "--ranks", str(n + 1), "1000", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "need" in r.stderr
