@@ -79,27 +79,42 @@ class Matcher:
         (g,) = torch.autograd.grad(loss * self.resolution * self.resolution, [render])                 # matcher.py:60
         return g
 
-    def match_sliced_wasserstein(self, render_point: torch.Tensor, gt_rgb: torch.Tensor, generator=None) -> torch.Tensor:
+    def match_sliced_wasserstein(self, render_point: torch.Tensor, gt_rgb: torch.Tensor, generator=None,
+                                 pca_V: torch.Tensor = None, directions: torch.Tensor = None) -> torch.Tensor:
         """matcher.py:76-116 (the reference's geomloss-free alternative): both point clouds (r,g,b,x,y) are
-        projected onto ``num_vectors`` random unit directions of the (principal colour axes + position) space,
-        each projection is matched by sorting, and the gradient of the summed squared differences w.r.t. the
-        rendered points is returned, (res^2, 5)."""
+        projected onto ``num_vectors`` random unit directions of the (principal colour axes of the target + position)
+        space, each projection is matched by sorting, and the gradient of the summed squared differences w.r.t. the
+        rendered points is returned, (res^2, 5).
+
+        The gradient is written in closed form (the reference differentiates the sorted projections with autograd):
+        with P = X D the projections of the rendered points X onto the directions D and e the differences of the
+        sorted columns, dL/dP puts 2 e back at the rows the sort took them from and dL/dX = (dL/dP) D^T, the colour
+        part going back through the PCA basis.  Random draws happen in the reference's order (``torch.pca_lowrank``,
+        then ``torch.rand`` for the directions), so a call under the same torch seed reproduces the reference --
+        pinned by tests/golden/matcher_sliced_*.npz (tests/test_matcher.py); ``pca_V`` / ``directions`` inject the
+        draws instead."""
         w = self.rgb_weight
         target = torch.cat([gt_rgb.clamp(0, 1).to(self.device, torch.float32) * w, self.pos], dim=1)
-        render = torch.cat([render_point.clamp(0, 1).to(self.device, torch.float32).detach() * w, self.pos], dim=1).requires_grad_(True)
+        render = torch.cat([render_point.clamp(0, 1).to(self.device, torch.float32).detach() * w, self.pos], dim=1)
         q = self.num_principle_vectors
         if q > 0:
             assert q <= 3
-            _, _, Vp = torch.pca_lowrank(target[:, :3], q=3)                       # colour axes of the TARGET
-            t_pts = torch.cat([target[:, :3] @ Vp[:, :q], target[:, 3:]], dim=1)
-            r_pts = torch.cat([render[:, :3] @ Vp[:, :q], render[:, 3:]], dim=1)
+            if pca_V is None:
+                _, _, pca_V = torch.pca_lowrank(target[:, :3], q=3)                  # colour axes of the TARGET
+            Vp = pca_V.to(self.device, torch.float32)[:, :q]
+            t_pts = torch.cat([target[:, :3] @ Vp, target[:, 3:]], dim=1)
+            r_pts = torch.cat([render[:, :3] @ Vp, render[:, 3:]], dim=1)
         else:
-            t_pts, r_pts = target, render
+            Vp, t_pts, r_pts = None, target, render
         dim = 2 + (q if q > 0 else 3)
-        dirs = torch.rand((dim, self.num_vectors), device=self.device, generator=generator) * 2.0 - 1.0
-        dirs = torch.nn.functional.normalize(dirs, p=2, dim=0)
-        pr, _ = torch.sort(r_pts @ dirs, dim=0, stable=True)
+        if directions is None:
+            directions = torch.rand((dim, self.num_vectors), device=self.device, generator=generator)
+        dirs = torch.nn.functional.normalize(directions.to(self.device, torch.float32) * 2.0 - 1.0, p=2, dim=0)
+        pr, order = torch.sort(r_pts @ dirs, dim=0, stable=True)
         pt, _ = torch.sort(t_pts @ dirs, dim=0, stable=True)
-        (g,) = torch.autograd.grad(((pr - pt) ** 2).sum(), [render])
+        gP = torch.zeros_like(pr).scatter_(0, order, 2.0 * (pr - pt))            # d/dP of sum (sorted_r - sorted_t)^2
+        gX = gP @ dirs.t()                                                        # (N, dim)
+        g_rgb = gX[:, :q] @ Vp.t() if q > 0 else gX[:, :3]
+        g = torch.cat([g_rgb, gX[:, -2:]], dim=1)
         g[:, :3] /= w
         return g

@@ -55,3 +55,48 @@ def test_sliced_wasserstein_moves_a_blob_towards_its_target():
     bright = a[:, 0] > 0.5
     assert float(g[bright, 3].mean()) < 0                               # -g points to +x
     assert abs(float(g[bright, 4].mean())) < 0.3 * abs(float(g[bright, 3].mean()))
+
+
+import glob
+import os
+
+import numpy as np
+import pytest
+
+_SLICED = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "matcher_sliced_*.npz")))
+
+
+@pytest.mark.parametrize("path", _SLICED, ids=[os.path.basename(p) for p in _SLICED])
+def test_sliced_wasserstein_matches_the_reference(path):
+    """``match_sliced_wasserstein`` against the reference's own function (EPSM/utils/matcher.py:76-116) run in place
+    by tests/golden/gen_matcher_golden.py: (1) with the reference's random draws injected -- the closed-form gradient
+    against the reference's autograd; (2) under the same torch seed -- the draws are made in the same order."""
+    z = np.load(path)
+    res = int(z["res"])
+    m = Matcher(res, "cpu")
+    assert m.num_vectors == int(z["num_vectors"]) and m.num_principle_vectors == int(z["num_principle_vectors"])
+    rd, gt, want = torch.from_numpy(z["render"]), torch.from_numpy(z["target"]), torch.from_numpy(z["grad"])
+    g = m.match_sliced_wasserstein(rd, gt, pca_V=torch.from_numpy(z["pca_V"]), directions=torch.from_numpy(z["rand"]))
+    scale = float(want.abs().max())
+    assert tuple(g.shape) == (res * res, 5) and scale > 0.1
+    assert float((g - want).abs().max()) <= 2e-5 * scale
+    torch.manual_seed(int(z["seed"]))
+    g2 = m.match_sliced_wasserstein(rd, gt)
+    assert float((g2 - want).abs().max()) <= 1e-3 * scale
+
+
+def test_sliced_wasserstein_gradient_is_the_autograd_gradient():
+    g0 = torch.Generator().manual_seed(5)
+    res = 12
+    m = Matcher(res, "cpu")
+    rd, gt = torch.rand((res * res, 3), generator=g0), torch.rand((res * res, 3), generator=g0)
+    V = torch.linalg.qr(torch.randn((3, 3), generator=g0))[0]
+    D = torch.rand((5, m.num_vectors), generator=g0)
+    g = m.match_sliced_wasserstein(rd, gt, pca_V=V, directions=D)
+    x = torch.cat([rd.clamp(0, 1), m.pos], dim=1).requires_grad_(True)
+    t = torch.cat([gt.clamp(0, 1), m.pos], dim=1)
+    dirs = torch.nn.functional.normalize(D * 2 - 1, p=2, dim=0)
+    proj = lambda p: torch.cat([p[:, :3] @ V, p[:, 3:]], dim=1) @ dirs
+    loss = ((torch.sort(proj(x), dim=0, stable=True)[0] - torch.sort(proj(t), dim=0, stable=True)[0]) ** 2).sum()
+    (want,) = torch.autograd.grad(loss, [x])
+    assert torch.allclose(g, want, rtol=1e-4, atol=1e-6)

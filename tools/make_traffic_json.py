@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, as the
+MI355X guide prescribes): HBM bytes per launch of the fused backward kernel = 2 x FETCH_SIZE (gfx950 tallies the 128-B
+requests of wide streaming reads at 64 B: MI355X_MICROARCH.md "HBM"; re-checked here on epsm_tangent_kernel, whose reads
+are known) + WRITE_SIZE (exact for stores and float atomics).  Every entry is stamped with the fingerprint of the kernel
+sources it was measured on (bench.kernel_source_hash); bench.py refuses entries of other sources.
+
+    python tools/make_traffic_json.py FETCH_DIR WRITE_DIR [CALIB_FETCH_DIR] --paths N --K 5 --variant manifold --profile bathroom --tag r02_b
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def counters(root, name):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == name:
+                acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return acc
+
+
+def pick(acc, needle):
+    for k, v in acc.items():
+        if needle in k:
+            return k, v
+    return None, []
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_dir"); ap.add_argument("write_dir"); ap.add_argument("calib_dir", nargs="?")
+    ap.add_argument("--paths", type=int, default=1 << 24); ap.add_argument("--K", type=int, default=5)
+    ap.add_argument("--variant", default="manifold"); ap.add_argument("--profile", default="bathroom")
+    ap.add_argument("--tag", default="r02")
+    a = ap.parse_args()
+    import bench
+    fk, fv = pick(counters(a.fetch_dir, "FETCH_SIZE"), "epsm_grad_scatter_kernel")
+    wk, wv = pick(counters(a.write_dir, "WRITE_SIZE"), "epsm_grad_scatter_kernel")
+    if not fv or not wv:
+        raise SystemExit("no FETCH_SIZE / WRITE_SIZE rows for epsm_grad_scatter_kernel")
+    fetch_kb, write_kb = sum(fv) / len(fv), sum(wv) / len(wv)          # rocprofv3 reports both in KB
+    note = ""
+    if a.calib_dir:
+        ck, cv = pick(counters(a.calib_dir, "FETCH_SIZE"), "epsm_tangent_kernel")
+        if cv:
+            known = 85 * a.paths                                    # o, d, dx, dy, p0, p1, p2 (7 x 12 B) + active (1 B) per path
+            note = (f"; calibration in the same session: epsm_tangent_kernel reads {known / 1e9:.3f} GB, FETCH_SIZE reported "
+                    f"{sum(cv) / len(cv) * 1024 / 1e9:.3f} GB")
+    total = int(2 * fetch_kb * 1024 + write_kb * 1024)
+    entry = {"kernel": "epsm_backward_pass", "paths": a.paths, "K": a.K, "variant": a.variant, "profile": a.profile,
+             "hbm_bytes_per_launch": total, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+             "dispatches": [len(fv), len(wv)], "src_hash": bench.kernel_source_hash(),
+             "source": f"profiles/{a.tag}_pmc_traffic.txt ({fk[:60]}...): FETCH_SIZE {fetch_kb:,.0f} KB x 2 (gfx950 half-count) + "
+                       f"WRITE_SIZE {write_kb:,.0f} KB (stores + float atomics, exact); separate rocprofv3 --pmc passes{note}"}
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    old = json.load(open(path)) if os.path.isfile(path) else []
+    old = [e for e in old if not all(e.get(k) == entry[k] for k in ("kernel", "paths", "K", "variant", "profile"))]
+    json.dump([entry] + old, open(path, "w"), indent=1)
+    print(json.dumps(entry, indent=1))
+
+
+if __name__ == "__main__":
+    main()
