@@ -84,6 +84,9 @@ def parse(argv=None):
     ap.add_argument("--scene-vertices", type=int, default=None, help="override: size V of the scatter target")
     ap.add_argument("--separate-tangent", action="store_true",
                     help="tangent kernel + fused gradient/scatter kernel instead of the single epsm_backward_pass launch")
+    ap.add_argument("--soa", action="store_true",
+                    help="records in the reference's tensor layout (one (N,3) array per field) instead of the native packed "
+                         "log (one 128-byte record per path vertex)")
     ap.add_argument("--two-stage", action="store_true",
                     help="calc_grad lists + separate scatter (the reference's shape) instead of the fused kernel")
     ap.add_argument("--max-resident-gb", type=float, default=0.0,
@@ -323,7 +326,7 @@ def main():
 
     import epsm_mitsuba3_amd as epsm
     from epsm_mitsuba3_amd import dist as edist
-    from epsm_mitsuba3_amd.records import PackedRecords, PackedScatter, num_param_grads
+    from epsm_mitsuba3_amd.records import PackedLog, PackedRecords, PackedScatter, num_param_grads
 
     N_image = res * res * spp                                   # paths of ONE gradient image (all ranks together)
     slab_paths = min(SLAB_PATHS, N_image)
@@ -331,6 +334,7 @@ def main():
     my_slabs = list(range(rank, n_slabs, world))               # strong scaling: slab s -> rank s % world
     fused = not args.two_stage
     one_launch = fused and not args.separate_tangent
+    packed_log = one_launch and not args.soa
     scene = epsm.SyntheticScene(res=res, n_vertices=K, n_scene_vertices=V, n_bsdfs=B,
                                 profile=profile, device=dev, tile_paths=slab_paths)
     integ = epsm.load_dict({"type": variant, "max_depth": 8, "fused": fused, "fuse_tangent": not args.separate_tangent})
@@ -345,7 +349,13 @@ def main():
             break                                               # the rest re-uses the resident ones (reported below)
         lo, hi = s * slab_paths, min((s + 1) * slab_paths, N_image)
         trace = scene.tile(s, lo, hi, seed=0, spp=spp, K=K, lean=True)
-        packed = (PackedRecords(trace.path_info, device=dev), PackedScatter(trace.scatter_info, device=dev, table=scene.triangle_table()))
+        if packed_log:
+            keep_soa = rank == 0 and not slabs            # slab 0 of rank 0 also feeds the CPU baseline and the dense-kernel leg
+            packed = PackedLog.from_trace(trace, device=dev, table=scene.triangle_table(), free=not keep_soa)
+            if not keep_soa:
+                trace.ray_o = trace.ray_dx = trace.ray_dy = None; trace.ray_d = trace.ray_d[:0]
+        else:
+            packed = (PackedRecords(trace.path_info, device=dev), PackedScatter(trace.scatter_info, device=dev, table=scene.triangle_table()))
         slabs.append((trace, packed))
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
@@ -358,7 +368,7 @@ def main():
     P = num_param_grads(variant, K)
     out = None
     if args.two_stage:
-        n0 = slabs[0][0].ray_d.shape[0]
+        n0 = slab_paths
         out = (torch.empty((P, n0, 3), device=dev), torch.empty((K, n0, 3), device=dev), torch.empty((K, n0, 3), device=dev))
     g = torch.Generator(device=dev).manual_seed(1)
     grad_in = torch.randn((res, res, 5), generator=g, device=dev) * 1e-3
@@ -422,17 +432,18 @@ def main():
     # secondary figure, outside the timed region: the stand-alone gradient kernel (calc_grad's
     # dense lists, 32+200K B/path) -- the reference-shaped first stage of --two-stage
     dense_ms = None
-    n_slab0 = slabs[0][0].ray_d.shape[0]
+    n_slab0 = min(slab_paths, N_image)
     if rank == 0 and not args.two_stage and torch.cuda.mem_get_info(dev)[0] > 1.3 * (P + 2 * K) * n_slab0 * 12:
         from epsm_mitsuba3_amd.manifold_grad import manifold_grad_packed
         d2 = torch.randn((n_slab0, 2), generator=g, device=dev) * 1e-3
         p3 = torch.randn((n_slab0, 3), generator=g, device=dev) * 1e-3
         dout = (torch.empty((P, n_slab0, 3), device=dev), torch.empty((K, n_slab0, 3), device=dev), torch.empty((K, n_slab0, 3), device=dev))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        manifold_grad_packed(variant, slabs[0][1][0], d2, p3, dlduv_cols=2, out=dout)
+        rec0 = PackedRecords(slabs[0][0].path_info, device=dev) if packed_log else slabs[0][1][0]
+        manifold_grad_packed(variant, rec0, d2, p3, dlduv_cols=2, out=dout)
         e0.record()
         for _ in range(5):
-            manifold_grad_packed(variant, slabs[0][1][0], d2, p3, dlduv_cols=2, out=dout)
+            manifold_grad_packed(variant, rec0, d2, p3, dlduv_cols=2, out=dout)
         e1.record()
         torch.cuda.synchronize()
         dense_ms = e0.elapsed_time(e1) / 5
@@ -447,7 +458,7 @@ def main():
         alg = per_path * n_slab0
         kernel_ms = stage_ms["grad"]
         achieved = alg / (kernel_ms * 1e-3) / 1e9
-        kname = "epsm_backward_pass" if one_launch else ("epsm_grad_scatter_kernel" if fused else "epsm_grad_kernel")
+        kname = ("epsm_backward_pass_packed" if packed_log else "epsm_backward_pass") if one_launch else ("epsm_grad_scatter_kernel" if fused else "epsm_grad_kernel")
         traffic, traffic_src = lookup_traffic(kname, n_slab0, K, variant, profile)
         distinct = len(slabs) == n_my
         result = {
@@ -466,7 +477,10 @@ def main():
                        "sharding": f"{world} rank(s), one all-reduce of the {params.flat.numel() * 4} B "
                                    f"parameter-gradient buffer per step"},
             "stages_ms": stage_ms,
-            "pipeline": ("one launch per slab (epsm_backward_pass)" if one_launch else "tangent + fused") if fused else "two-stage",
+            "pipeline": (("one launch per slab (epsm_backward_pass_packed, native log)" if packed_log else
+                          "one launch per slab (epsm_backward_pass)") if one_launch else "tangent + fused") if fused else "two-stage",
+            "record_layout": "packed: one 128-byte record per (path, vertex) + rays (N,12) + flag word" if packed_log
+                             else "reference tensors: one (N,3) array per field",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("epsm_grad_scatter_kernel<tangents in kernel> (epsm_backward_pass: tangent + calc_grad + scatter)"

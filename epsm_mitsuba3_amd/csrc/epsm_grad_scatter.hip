@@ -47,6 +47,11 @@ struct FusedArgs {
     int P, K;
     TangentIn tin;                   // epsm_backward_pass: the first-vertex tangent is computed in the kernel
     float *grad_o_sum;
+    // epsm_backward_pass_packed: the native log (include/epsm.h, EpsmPackedLog) instead of the per-array records
+    const float *pk_rays;            // (N,12)  o, d, d_x, d_y
+    const uint32_t *pk_flags;        // (N)     5 bits per vertex
+    const float *pk_verts;           // (N,K,32) one 128-byte record per (path, vertex)
+    const uint32_t *pk_shadow;       // (N,4) or null
 };
 // where the tangents of a path come from
 enum { kTangentsTwoColumns = 0, kTangentsFullRows = 1, kTangentsInKernel = 2 };
@@ -59,7 +64,48 @@ struct PtrTable {
     VertexPtrs<float> v[kMaxVertices];
     ScatterPtrs<float> s[kMaxVertices];
 };
-template <bool FLAGS_IN_LDS, int DMODE> struct LdsArgs {
+// 16-byte global load of quad q of a packed vertex record
+typedef float F4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ F4v ldq(const float *rec, int q) {
+    return *(const __attribute__((address_space(1))) F4v *) (rec + 4 * q);
+}
+// EpsmPackedLog vertex record (32 words): p0 p1 p2 n0 n1 n2 | b0 b1 eta light(3) | etri eb0 eb1 ew | tri dhf(3)
+constexpr int kRecWords = 32;
+__device__ __forceinline__ Geo<float> geo_from(F4v q0, F4v q1, F4v q2, float b0, float b1) {
+    Geo<float> g;
+    const V3<float> p0 = mk3<float>(q0.x, q0.y, q0.z), p1 = mk3<float>(q0.w, q1.x, q1.y), p2 = mk3<float>(q1.z, q1.w, q2.x);
+    g.b0 = b0; g.b1 = b1;
+    g.x = p0 * b0 + p1 * b1 + p2 * (1.f - b0 - b1);
+    g.e1 = p0 - p2; g.e2 = p1 - p2;
+    return g;
+}
+__device__ __forceinline__ Nrm<float> nrm_from(F4v q2, F4v q3, F4v q4, float b0, float b1) {
+    Nrm<float> o;
+    const V3<float> n0 = mk3<float>(q2.y, q2.z, q2.w), n1 = mk3<float>(q3.x, q3.y, q3.z), n2 = mk3<float>(q3.w, q4.x, q4.y);
+    o.n = n0 * b0 + n1 * b1 + n2 * (1.f - b0 - b1);
+    o.dn1 = n0 - n2; o.dn2 = n1 - n2;
+    return o;
+}
+
+// epsm.py:250-272 on the packed log: rays = this path's 12 floats (o, d, d_x, d_y), rec1 = its first vertex record
+__device__ __forceinline__ Tangent first_vertex_tangent_packed(const TangentIn &A, int64_t i, const float *rays,
+                                                               const float *rec1, bool active) {
+    const int64_t pix = (A.path_offset + i) / A.spp;
+    const int64_t y = pix / A.res, x = pix % A.res;
+    const auto *g = gl(A.grad_img) + (y * A.img_width + x) * A.img_channels;
+    const float gx = g[3], gy = g[4];
+    const F4v r0 = ldq(rays, 0), r1 = ldq(rays, 1), r2 = ldq(rays, 2);
+    const V3<float> o = mk3<float>(r0.x, r0.y, r0.z), d = mk3<float>(r0.w, r1.x, r1.y), dx = mk3<float>(r1.z, r1.w, r2.x),
+                    dy = mk3<float>(r2.y, r2.z, r2.w);
+    V3<float> p0 = zero3<float>(), p1 = p0, p2 = p0;
+    if (active) {
+        const F4v q0 = ldq(rec1, 0), q1 = ldq(rec1, 1), q2 = ldq(rec1, 2);
+        p0 = mk3<float>(q0.x, q0.y, q0.z); p1 = mk3<float>(q0.w, q1.x, q1.y); p2 = mk3<float>(q1.z, q1.w, q2.x);
+    }
+    return tangent_from(o, d, dx, dy, gx, gy, p0, p1, p2, active);
+}
+
+template <bool FLAGS_IN_LDS, int DMODE, bool PACKED> struct LdsArgs {
     int64_t N;
     const float *cam, *dlduv, *dldp;
     int64_t dlduv_stride;
@@ -68,11 +114,16 @@ template <bool FLAGS_IN_LDS, int DMODE> struct LdsArgs {
     const PtrTable *tab;             // LDS
     const uint32_t *win_flags;       // LDS: packed flags of the current window's paths, indexed by path - win_base
     int64_t win_base;
+    const float *pk_rays, *pk_verts; // PACKED: the native log
+    const uint32_t *pk_flags;
+    int pk_K;
     __device__ __forceinline__ const VertexPtrs<float> &vtx(int k) const { return tab->v[k]; }
+    __device__ __forceinline__ const float *rec(int k, int64_t i) const { return pk_verts + (i * pk_K + (k - 1)) * kRecWords; }
     // manifold: the window's flags are parked in LDS and a slot starts without a global round trip (-3 %);
     // caustic: re-reading them from the record arrays measured 7 % FASTER than the LDS copy, so it keeps that
     template <int K> __device__ __forceinline__ Flags<K> flags(int64_t i) const {
         if (FLAGS_IN_LDS) return unpack_flags<K>(win_flags[i - win_base]);
+        if (PACKED) return unpack_flags<K>(lds_(pk_flags, i));
         return load_flags<float, K>(*this, i);
     }
     __device__ __forceinline__ V3<float> dldp_at(int64_t i) const {
@@ -82,6 +133,37 @@ template <bool FLAGS_IN_LDS, int DMODE> struct LdsArgs {
     template <bool FULL_D> __device__ __forceinline__ V2<float> d_at(int64_t i, int k, int dcols) const {
         if (DMODE == kTangentsInKernel) return k == 1 ? lane_d : mk2<float>(0.f, 0.f);
         return load_d<float, FULL_D>(*this, i, k, dcols);
+    }
+    // ---- the record of vertex k of path i (epsm_path_core.h: Raw)
+    __device__ __forceinline__ V3<float> cam_at(int64_t i) const {
+        if (PACKED) { const F4v q = ldq(pk_rays + 12 * i, 0); return mk3<float>(q.x, q.y, q.z); }
+        return load3(cam, i);
+    }
+    __device__ __forceinline__ Raw<float> raw(int k, int64_t i) const {
+        if (!PACKED) return soa_raw<float>(*this, k, i);
+        const float *r = rec(k, i);
+        const F4v q0 = ldq(r, 0), q1 = ldq(r, 1), q2 = ldq(r, 2), q3 = ldq(r, 3), q4 = ldq(r, 4), q5 = ldq(r, 5);
+        Raw<float> o;
+        o.g = geo_from(q0, q1, q2, q4.z, q4.w);
+        o.nr = nrm_from(q2, q3, q4, q4.z, q4.w);
+        o.eta = q5.x;
+        o.light = mk3<float>(q5.y, q5.z, q5.w);
+        return o;
+    }
+    __device__ __forceinline__ Geo<float> geo(int k, int64_t i) const {
+        if (!PACKED) return load_geo(vtx(k - 1), i);
+        const float *r = rec(k, i);
+        const F4v q4 = ldq(r, 4);
+        return geo_from(ldq(r, 0), ldq(r, 1), ldq(r, 2), q4.z, q4.w);
+    }
+    __device__ __forceinline__ Nrm<float> nrm(int k, int64_t i, float b0, float b1) const {
+        if (!PACKED) return load_nrm(vtx(k - 1), i, b0, b1);
+        const float *r = rec(k, i);
+        return nrm_from(ldq(r, 2), ldq(r, 3), ldq(r, 4), b0, b1);
+    }
+    __device__ __forceinline__ float eta(int k, int64_t i) const {
+        if (!PACKED) return lds_(vtx(k - 1).eta, i);
+        return lds_(rec(k, i), 20);
     }
 };
 
@@ -95,7 +177,7 @@ template <bool FLAGS_IN_LDS, int DMODE> struct LdsArgs {
 // (measured on the bathroom / specular / pool profiles: 4, 8, 16, 32 for the triangle rows)
 constexpr int kMinMergeLanes = 16, kMinMergeLanesAlpha = 4;
 
-template <typename Table> struct ScatterOut {
+template <typename Table, bool PACKED> struct ScatterOut {
     const FusedArgs &F;
     const PtrTable &P;
     const Table &T;
@@ -154,6 +236,7 @@ template <typename Table> struct ScatterOut {
         }
     }
 
+    __device__ __forceinline__ const float *rec(int k) const { return F.pk_verts + (i * F.K + (k - 1)) * kRecWords; }
     struct Id { uint32_t v; };
     struct Tri { uint32_t vi[3]; uint32_t mode; };
     struct Emit { uint32_t etri; float eb0, eb1, ew; };
@@ -169,7 +252,9 @@ template <typename Table> struct ScatterOut {
 #ifdef EPSM_KO_NOADDR
         live = false;
 #endif
-        if (live && ok) d.v = lds_(P.s[k - 1].tri, i);
+        // (packed log: reading word 0 of the record along with the id, so that both cache lines of every record the
+        // path will need are on their way from the start, measured +0..2 %: the kernel is not waiting for HBM latency)
+        if (live && ok) d.v = PACKED ? __float_as_uint(lds_(rec(k), 28)) : lds_(P.s[k - 1].tri, i);
         return d;
     }
     // parameter addressing of vertex k, fetched ahead of the step that needs it: the triangle's row of the scene
@@ -198,10 +283,15 @@ template <typename Table> struct ScatterOut {
         live = live && i == -5;
 #endif
         if (live && ok) {
-            const uint32_t *p = P.s[k - 1].emit;
-            if (p) {
-                const U4 e4 = load_u4(p, i);
-                e.etri = e4.x; e.eb0 = bits_to_float(e4.y); e.eb1 = bits_to_float(e4.z); e.ew = bits_to_float(e4.w);
+            if (PACKED) {
+                const F4v q = ldq(rec(k), 6);
+                e.etri = __float_as_uint(q.x); e.eb0 = q.y; e.eb1 = q.z; e.ew = q.w;
+            } else {
+                const uint32_t *p = P.s[k - 1].emit;
+                if (p) {
+                    const U4 e4 = load_u4(p, i);
+                    e.etri = e4.x; e.eb0 = bits_to_float(e4.y); e.eb1 = bits_to_float(e4.z); e.ew = bits_to_float(e4.w);
+                }
             }
         }
         return e;
@@ -214,14 +304,21 @@ template <typename Table> struct ScatterOut {
         live = false;
 #endif
         if (live && ok) {
-            const ScatterPtrs<float> &s = P.s[k - 1];
+            if (PACKED) {
+                if (F.galpha) {                      // (the alpha slot comes with the triangle's table row: vertex())
+                    const F4v q = ldq(rec(k), 7);
+                    a.dhf = mk3<float>(q.y, q.z, q.w);
+                }
+            } else {
+                const ScatterPtrs<float> &s = P.s[k - 1];
 #ifndef EPSM_KO_NOAUX
-            if (s.aux && F.galpha) {
+                if (s.aux && F.galpha) {
 #else
-            if (s.aux && F.galpha && i == -5) {
+                if (s.aux && F.galpha && i == -5) {
 #endif
-                const U4 a4 = load_u4(s.aux, i);
-                a.bid = a4.x; a.dhf = mk3<float>(bits_to_float(a4.y), bits_to_float(a4.z), bits_to_float(a4.w));
+                    const U4 a4 = load_u4(s.aux, i);
+                    a.bid = a4.x; a.dhf = mk3<float>(bits_to_float(a4.y), bits_to_float(a4.z), bits_to_float(a4.w));
+                }
             }
             a.er = table_row(F.tab, e.etri);
         }
@@ -280,11 +377,12 @@ template <typename Table> struct ScatterOut {
         // group B: bsdf_sample.hf * path_grad[5it+4]  and  si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627, 645)
         {
             gm = fin(gm);
-            const bool a_ok = ok && has_nm && nz3(gm) && a.bid < (uint64_t) F.B;
+            const uint32_t bid = PACKED ? (t.mode >> 8) - 1u : a.bid;          // packed log: alpha slot + 1 in the table row
+            const bool a_ok = ok && has_nm && nz3(gm) && bid < (uint64_t) F.B;
             const bool e_ok = ok && nz3(glight) && er.x < (uint64_t) F.V && er.y < (uint64_t) F.V && er.z < (uint64_t) F.V && (er.w & kModePos);
             const V3<float> gl = e_ok ? glight * a.ew : zero3<float>();
             const uint32_t keys[4] = {e_ok ? er.x : 0u, e_ok ? er.y : 0u, e_ok ? er.z : 0u,
-                                      a_ok ? 2u * (uint32_t) F.V + a.bid : 0u};
+                                      a_ok ? 2u * (uint32_t) F.V + bid : 0u};
             V3<float> vals[4] = {gl * a.eb0, gl * a.eb1, gl * (1.f - a.eb0 - a.eb1),
                                  mk3<float>(a_ok ? dot(gm, a.dhf) : 0.f, 0.f, 0.f)};
             bool e_any = e_ok, a_any = a_ok;
@@ -306,11 +404,15 @@ template <typename Table> struct ScatterOut {
         g = fin(g);
         Tri t = pre_tri(1, nz3(g), id);
         float b0 = 0.f, b1 = 0.f;
-        if (ok && nz3(g)) { b0 = lds_(P.v[0].b0, i); b1 = lds_(P.v[0].b1, i); }
+        if (ok && nz3(g)) {
+            if (PACKED) { const F4v q = ldq(rec(1), 4); b0 = q.z; b1 = q.w; }
+            else { b0 = lds_(P.v[0].b0, i); b1 = lds_(P.v[0].b1, i); }
+        }
         diffuse(0, g, b0, b1, t);
         // occluder of the first vertex's emitter sample: si_direct.p * diffuse_grad[0] * dis (epsm.py:609-620)
-        if (P.s[0].shadow) {
-            ShadowItems<float> sh = shadow_items<float>(P.s[0].shadow, F.tab, i, ok ? g : zero3<float>(), F.V);
+        const uint32_t *shadow = PACKED ? F.pk_shadow : P.s[0].shadow;
+        if (shadow) {
+            ShadowItems<float> sh = shadow_items<float>(shadow, F.tab, i, ok ? g : zero3<float>(), F.V);
             merge_equal<3, 2>(sh.ok, sh.si, sh.val);
             push<3>(sh.ok, sh.si, sh.val);
         }
@@ -325,7 +427,7 @@ template <typename Table> struct ScatterOut {
 
 namespace {
 
-template <int K, int VARIANT, int DMODE>
+template <int K, int VARIANT, int DMODE, bool PACKED>
 // waves-per-SIMD 2: without it hipcc budgets 128 VGPRs from the LDS-derived occupancy and spills 720 B/lane
 __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, int dcols, int64_t chunks_per_block) {
     typedef LdsTable<VARIANT == EPSM_VARIANT_MANIFOLD ? kBits : kRowsCaustic,
@@ -338,11 +440,12 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
     __shared__ PtrTable s_ptrs;
     const Table T{s_keys, s_vals, &s_used, F.gpos, F.gnrm, F.galpha, (uint32_t) F.V};
     WaveQueue<kQueueCap> Q{s_queue[threadIdx.x >> 6], 0};
-    if (threadIdx.x < K) { s_ptrs.v[threadIdx.x] = F.g.v[threadIdx.x]; s_ptrs.s[threadIdx.x] = F.s[threadIdx.x]; }
+    if (!PACKED && threadIdx.x < K) { s_ptrs.v[threadIdx.x] = F.g.v[threadIdx.x]; s_ptrs.s[threadIdx.x] = F.s[threadIdx.x]; }
     __shared__ uint32_t s_flags[VARIANT == EPSM_VARIANT_MANIFOLD ? 1024 : 1];
     constexpr bool FULL_D = DMODE == kTangentsFullRows;
-    LdsArgs<VARIANT == EPSM_VARIANT_MANIFOLD, DMODE> A{F.g.N, F.g.cam, F.g.dlduv, F.g.dldp, F.g.dlduv_stride,
-                                                       mk2<float>(0.f, 0.f), zero3<float>(), &s_ptrs, s_flags, 0};
+    LdsArgs<VARIANT == EPSM_VARIANT_MANIFOLD, DMODE, PACKED> A{F.g.N, F.g.cam, F.g.dlduv, F.g.dldp, F.g.dlduv_stride,
+                                                               mk2<float>(0.f, 0.f), zero3<float>(), &s_ptrs, s_flags, 0,
+                                                               F.pk_rays, F.pk_verts, F.pk_flags, F.K};
     V3<float> gd_acc = zero3<float>();           // kTangentsInKernel: sum of grad_d over this lane's paths
     T.clear();                                   // ends with a barrier: the table of pointers is visible too
     // A workgroup takes WINDOWS of 1024 consecutive paths (16 pixels at 64 spp share triangles), dealt round-robin
@@ -375,7 +478,8 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
 #pragma unroll
             for (int j = 0; j < kSub; ++j) {
                 const int64_t p = base + j * 256 + threadIdx.x;
-                fl[j] = load_flags<float, K>(A, p < F.g.N ? p : F.g.N - 1);
+                const int64_t pc = p < F.g.N ? p : F.g.N - 1;
+                fl[j] = PACKED ? unpack_flags<K>(lds_(F.pk_flags, pc)) : load_flags<float, K>(A, pc);
             }
             if (VARIANT == EPSM_VARIANT_MANIFOLD) {
 #pragma unroll
@@ -446,10 +550,12 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
             const int64_t i0 = base + s_perm[slot * 64 + lane];
             const bool ok = i0 < F.g.N;
             const int64_t i = ok ? i0 : F.g.N - 1;     // lanes past the end recompute the last path and add nothing
-            const ScatterOut<Table> out{F, s_ptrs, T, Q, i, ok};
+            const ScatterOut<Table, PACKED> out{F, s_ptrs, T, Q, i, ok};
             if (DMODE == kTangentsInKernel) {              // epsm.py:250-272 for this path, in registers
-                const Tangent t = first_vertex_tangent(F.tin, i, s_ptrs.v[0].p0, s_ptrs.v[0].p1, s_ptrs.v[0].p2,
-                                                       gl(s_ptrs.v[0].active)[i] != 0);
+                const Tangent t = PACKED
+                    ? first_vertex_tangent_packed(F.tin, i, F.pk_rays + 12 * i, A.rec(1, i), (lds_(F.pk_flags, i) & 4u) != 0)
+                    : first_vertex_tangent(F.tin, i, s_ptrs.v[0].p0, s_ptrs.v[0].p1, s_ptrs.v[0].p2,
+                                           gl(s_ptrs.v[0].active)[i] != 0);
                 A.lane_d = mk2<float>(t.db0, t.db1);
                 A.lane_dp = t.dp;
                 if (ok) gd_acc = gd_acc + t.gd;
@@ -477,24 +583,24 @@ __global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, 
     }
 }
 
-template <int K, int VARIANT, int DMODE>
+template <int K, int VARIANT, int DMODE, bool PACKED = false>
 hipError_t launch(const FusedArgs &F, int dcols, hipStream_t s) {
     const int64_t chunks = (F.g.N + 255) / 256;
     const int64_t blocks = chunks < kFusedBlocks ? chunks : kFusedBlocks;
     int64_t per = (chunks + blocks - 1) / blocks;
     per = (per + 15) / 16 * 16;              // whole groups
-    hipLaunchKernelGGL((epsm_grad_scatter_kernel<K, VARIANT, DMODE>), dim3((unsigned) blocks), dim3(256), 0, s,
+    hipLaunchKernelGGL((epsm_grad_scatter_kernel<K, VARIANT, DMODE, PACKED>), dim3((unsigned) blocks), dim3(256), 0, s,
                        F, dcols, per);
     return hipGetLastError();
 }
-template <int VARIANT, int DMODE>
+template <int VARIANT, int DMODE, bool PACKED = false>
 hipError_t launch_k(int K, const FusedArgs &F, int dcols, hipStream_t s) {
     switch (K) {
-        case 1: return launch<1, VARIANT, DMODE>(F, dcols, s);
-        case 2: return launch<2, VARIANT, DMODE>(F, dcols, s);
-        case 3: return launch<3, VARIANT, DMODE>(F, dcols, s);
-        case 4: return launch<4, VARIANT, DMODE>(F, dcols, s);
-        default: return launch<5, VARIANT, DMODE>(F, dcols, s);
+        case 1: return launch<1, VARIANT, DMODE, PACKED>(F, dcols, s);
+        case 2: return launch<2, VARIANT, DMODE, PACKED>(F, dcols, s);
+        case 3: return launch<3, VARIANT, DMODE, PACKED>(F, dcols, s);
+        case 4: return launch<4, VARIANT, DMODE, PACKED>(F, dcols, s);
+        default: return launch<5, VARIANT, DMODE, PACKED>(F, dcols, s);
     }
 }
 
@@ -599,5 +705,46 @@ extern "C" int epsm_backward_pass(int variant, int64_t N, int K, int64_t path_of
     const hipError_t e = variant == EPSM_VARIANT_MANIFOLD ? launch_k<EPSM_VARIANT_MANIFOLD, kTangentsInKernel>(K, F, 2, s)
                                                           : launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, kTangentsInKernel>(K, F, 2, s);
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_backward_pass", e);
+    return EPSM_OK;
+}
+
+
+// The same pass on the native log (include/epsm.h: EpsmPackedLog): one 128-byte record per (path, vertex), the
+// rays and the flag word per path.
+extern "C" int epsm_backward_pass_packed(int variant, int64_t N, int K, int64_t path_offset, int spp, int res,
+                                         const EpsmPackedLog *log, const float *grad_img, int img_width, int img_channels,
+                                         const uint32_t *tri_table, int64_t T, float clip,
+                                         float *grad_pos, float *grad_nrm, float *grad_alpha, float *grad_o_sum,
+                                         int64_t V, int64_t B, void *stream) {
+    epsm_host::err_buf()[0] = 0;
+    if (variant != EPSM_VARIANT_MANIFOLD && variant != EPSM_VARIANT_MANIFOLD_CAUSTIC) return fail(EPSM_EINVAL, "epsm_backward_pass_packed: unknown variant");
+    if (K < 1 || K > EPSM_MAX_VERTICES) return fail(EPSM_EINVAL, "epsm_backward_pass_packed: K must be in 1..5");
+    if (N == 0) return EPSM_OK;
+    if (N < 0 || !log || !log->rays || !log->flags || !log->verts || !grad_img || !grad_pos || !grad_nrm)
+        return fail(EPSM_EINVAL, "epsm_backward_pass_packed: NULL argument / bad N");
+    if ((((uintptr_t) log->rays) | ((uintptr_t) log->verts) | ((uintptr_t) log->shadow) | ((uintptr_t) tri_table)) & 15)
+        return fail(EPSM_EINVAL, "epsm_backward_pass_packed: rays / verts / shadow / tri_table must be 16-byte aligned");
+    if (V < 0 || B < 0 || 2 * V + B >= 0xFFFFFFFFLL || T < 0 || (T > 0 && !tri_table))
+        return fail(EPSM_EINVAL, "epsm_backward_pass_packed: bad buffer sizes");
+    if (spp < 1 || res < 1 || img_width < res || img_channels < 5)
+        return fail(EPSM_EINVAL, "epsm_backward_pass_packed: need spp>=1, res>=1, img_width>=res, img_channels>=5");
+    if (path_offset < 0 || (int64_t) res * res * spp < path_offset + N)
+        return fail(EPSM_EINVAL, "epsm_backward_pass_packed: path_offset + N exceeds res*res*spp");
+    FusedArgs F;
+    memset(&F, 0, sizeof(F));
+    F.tab = TriTable{tri_table, T};
+    F.g.N = N;
+    F.g.clip = (clip > 0.0f && clip <= 3.402823466e+38f) ? clip : 3.402823466e+38f;
+    F.gpos = grad_pos; F.gnrm = grad_nrm; F.galpha = grad_alpha;
+    F.V = V; F.B = grad_alpha ? B : 0;
+    F.P = epsm_num_param_grads(variant, K);
+    F.K = K;
+    F.pk_rays = log->rays; F.pk_flags = log->flags; F.pk_verts = (const float *) log->verts; F.pk_shadow = log->shadow;
+    F.tin = TangentIn{path_offset, spp, res, img_width, img_channels, nullptr, nullptr, nullptr, nullptr, grad_img};
+    F.grad_o_sum = grad_o_sum;
+    hipStream_t s = (hipStream_t) stream;
+    const hipError_t e = variant == EPSM_VARIANT_MANIFOLD ? launch_k<EPSM_VARIANT_MANIFOLD, kTangentsInKernel, true>(K, F, 2, s)
+                                                          : launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, kTangentsInKernel, true>(K, F, 2, s);
+    if (e != hipSuccess) return epsm_host::hip_fail("epsm_backward_pass_packed", e);
     return EPSM_OK;
 }

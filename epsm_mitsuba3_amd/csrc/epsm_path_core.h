@@ -149,6 +149,12 @@ template <typename R> struct GradArgs {
     R *out_diffuse;          // (K,N,3)
     EPSM_HD const VertexPtrs<R> &vtx(int k) const { return v[k]; }
     template <int K> EPSM_HD Flags<K> flags(int64_t i) const;      // from the record arrays (defined below load_flags)
+    // the record of vertex k (1-based) of path i: see Raw / soa_raw below
+    EPSM_HD V3<R> cam_at(int64_t i) const;
+    EPSM_HD auto raw(int k, int64_t i) const;
+    EPSM_HD auto geo(int k, int64_t i) const;
+    EPSM_HD auto nrm(int k, int64_t i, R b0, R b1) const;
+    EPSM_HD R eta(int k, int64_t i) const;
     // the tangents of the first vertex (dldp) and of vertex k (columns 2(k-1), 2(k-1)+1 of dlduv)
     EPSM_HD V3<R> dldp_at(int64_t i) const { const R *p = dldp + 3 * i; return mk3<R>(p[0], p[1], p[2]); }
     template <bool FULL_D> EPSM_HD V2<R> d_at(int64_t i, int k, int dcols) const;      // defined below load_d
@@ -277,6 +283,20 @@ template <typename R> EPSM_HD Nrm<R> load_nrm(const VertexPtrs<R> &v, int64_t i,
     o.dn1 = n0 - n2;
     o.dn2 = n1 - n2;
     return o;
+}
+
+// Everything one logged vertex contributes to the solve.  The path functions ask their argument object for it
+// (A.raw / A.geo / A.nrm / A.eta / A.cam_at), so that the same code runs on the reference's tensor layout (nine
+// (N,3) arrays per vertex: soa_* below) and on the packed per-vertex records of the native pipeline
+// (epsm_grad_scatter.hip, PackedArgs).
+template <typename R> struct Raw { Geo<R> g; Nrm<R> nr; R eta; V3<R> light; };
+template <typename R, typename Args> EPSM_HD Raw<R> soa_raw(const Args &A, int kk, int64_t i) {
+    Raw<R> r;
+    r.g = load_geo(A.vtx(kk - 1), i);
+    r.nr = load_nrm(A.vtx(kk - 1), i, r.g.b0, r.g.b1);
+    r.eta = lds_(A.vtx(kk - 1).eta, i);
+    r.light = load3(A.vtx(kk - 1).light, i);
+    return r;
 }
 
 // local frame of epsm.py:746-756: rows t, n^ x t, n^;  t = normalize(0,-n^_z,n^_y)
@@ -421,6 +441,11 @@ template <int K> EPSM_HD Flags<K> unpack_flags(uint32_t w) {
     return f;
 }
 template <typename R> template <int K> EPSM_HD Flags<K> GradArgs<R>::flags(int64_t i) const { return load_flags<R, K>(*this, i); }
+template <typename R> EPSM_HD V3<R> GradArgs<R>::cam_at(int64_t i) const { return load3(cam, i); }
+template <typename R> EPSM_HD auto GradArgs<R>::raw(int k, int64_t i) const { return soa_raw<R>(*this, k, i); }
+template <typename R> EPSM_HD auto GradArgs<R>::geo(int k, int64_t i) const { return load_geo(v[k - 1], i); }
+template <typename R> EPSM_HD auto GradArgs<R>::nrm(int k, int64_t i, R b0, R b1) const { return load_nrm(v[k - 1], i, b0, b1); }
+template <typename R> EPSM_HD R GradArgs<R>::eta(int k, int64_t i) const { return lds_(v[k - 1].eta, i); }
 
 // Scalar type the 2x2 block recursion of `manifold` is COMPUTED in (pivots, forward vectors, adjoint seeds; they are
 // kept between the steps in the working precision R).  The reference inverts `cur` with a pivoted LU
@@ -514,30 +539,21 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
     // Everything a vertex contributes to pass 1, fetched ONE STEP AHEAD of its use: with two
     // waves per SIMD a load consumed in the step that issued it is a fully exposed HBM
     // round trip (the kernel was latency-bound at 35 % VALU utilisation before this).
-    struct Raw { Geo<R> g; Nrm<R> nr; R eta; V3<R> light; };
-    auto load_raw = [&](int kk) EPSM_LAMBDA {
-        Raw r;
-        r.g = load_geo(A.vtx(kk - 1), i);
-        r.nr = load_nrm(A.vtx(kk - 1), i, r.g.b0, r.g.b1);
-        r.eta = lds_(A.vtx(kk - 1).eta, i);
-        r.light = load3(A.vtx(kk - 1).light, i);
-        return r;
-    };
-    const V3<R> cam = load3(A.cam, i);
-    Raw rnext;
-    if (nv >= 1) rnext = load_raw(1);
+    const V3<R> cam = A.cam_at(i);
+    Raw<R> rnext;
+    if (nv >= 1) rnext = A.raw(1, i);
     M2<Q> Aup;                        // A^C_{k-1,k}: continuing row k-1, column block k
     Aup.a = Aup.b = Aup.c = Aup.d = Q(0);
 
     static_for_up<1, K>([&](auto kc) EPSM_LAMBDA {
         constexpr int k = decltype(kc)::value;
         if (k <= nv) {
-            const Raw r = rnext;
+            const Raw<R> r = rnext;
             const Geo<R> g = r.g;
             const Nrm<R> nr = r.nr;
             kp[k].x = g.x; kp[k].e1 = g.e1; kp[k].e2 = g.e2; kp[k].b0 = g.b0; kp[k].b1 = g.b1;
             const bool has_next = (k < K) && (k + 1 <= nv);
-            if (has_next) rnext = load_raw(k < K ? k + 1 : K);
+            if (has_next) rnext = A.raw(k < K ? k + 1 : K, i);
             kp[k].n = nr.n;
             kp[k].eta = r.eta;
             kp[k].light = r.light;
@@ -688,9 +704,9 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
 
     if (!undo) out.diffuse_first(fl.diffuse[1] ? A.dldp_at(i) : zero3<R>(), tid[1]);   // epsm.py:998-1000
 
-    const V3<R> cam = load3(A.cam, i);
+    const V3<R> cam = A.cam_at(i);
     Geo<R> gcur, gnext;
-    if (nv >= 1) gnext = load_geo(A.vtx(0), i);
+    if (nv >= 1) gnext = A.geo(1, i);
     typename Out::Tri tri_prev = out.pre_tri(1, false, tid[0]), tri_cur = out.pre_tri(1, nv >= 1, tid[1]);
     V3<R> n_prev = zero3<R>();
     V2<R> vprev = mk2<R>(R(0), R(0)), vcur = vprev;   // v_{k-1}, v_k   (v_1 = 0)
@@ -711,11 +727,11 @@ EPSM_HD void caustic_path(const Args &A, int64_t i, int dcols, const Out &out) {
         const typename Out::Aux aux_prev = out.pre_aux(k >= 2 ? k - 1 : 1, k >= 2 && (k - 1) <= idstar, out.pre_emit(1, false));   // (light_grad == 0)
         if (live) {
             gcur = gnext;
-            gnext = load_geo(A.vtx(k < K ? k : K - 1), i);
+            gnext = A.geo(k < K ? k + 1 : K, i);
             b0 = gcur.b0; b1 = gcur.b1;
-            const Nrm<R> nr = load_nrm(A.vtx(k - 1), i, gcur.b0, gcur.b1);
+            const Nrm<R> nr = A.nrm(k, i, gcur.b0, gcur.b1);
             ncur = nr.n;
-            const R eta = lds_(A.vtx(k - 1).eta, i);
+            const R eta = A.eta(k, i);
             const Frame<R> fr = make_frame(nr.n);
             const HalfVec<R> h = halfvec_fwd(xprev, gcur.x, gnext.x, fr, eta);
             const V2<R> dk = A.template d_at<FULL_D>(i, k, dcols);

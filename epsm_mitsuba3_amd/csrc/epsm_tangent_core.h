@@ -18,20 +18,14 @@ struct TangentIn {
 };
 struct Tangent { float db0, db1; V3<float> dp, gd; };     // d b0, d b1, d si.p, grad_d
 
-EPSM_HD Tangent first_vertex_tangent(const TangentIn &A, int64_t i, const float *p0a, const float *p1a, const float *p2a,
-                                     bool active) {
-    const int64_t pix = (A.path_offset + i) / A.spp;
-    const int64_t y = pix / A.res, x = pix % A.res;
-    const auto *g = gl(A.grad_img) + (y * A.img_width + x) * A.img_channels;
-    const float gx = g[3], gy = g[4];
-    const V3<float> d = load3(A.d, i), dx = load3(A.dx, i), dy = load3(A.dy, i);
+// the arithmetic, on values
+EPSM_HD Tangent tangent_from(V3<float> o, V3<float> d, V3<float> dx, V3<float> dy, float gx, float gy,
+                             V3<float> p0, V3<float> p1, V3<float> p2, bool active) {
     Tangent t;
     t.gd = (dx - d) * gx + (dy - d) * gy;
     t.db0 = t.db1 = 0.f;
     t.dp = zero3<float>();
     if (active) {
-        const V3<float> o = load3(A.o, i);
-        const V3<float> p0 = load3(p0a, i), p1 = load3(p1a, i), p2 = load3(p2a, i);
         const V3<float> e1 = p1 - p0, e2 = p2 - p0;               // mesh.h:349
         const V3<float> pvec = cross(d, e2);
         const float inv_det = rcp_(dot(e1, pvec));
@@ -49,6 +43,18 @@ EPSM_HD Tangent first_vertex_tangent(const TangentIn &A, int64_t i, const float 
         t.dp = e1 * du + e2 * dv;                                  // d (p0 b0 + p1 b1 + p2 b2)
     }
     return t;
+}
+
+EPSM_HD Tangent first_vertex_tangent(const TangentIn &A, int64_t i, const float *p0a, const float *p1a, const float *p2a,
+                                     bool active) {
+    const int64_t pix = (A.path_offset + i) / A.spp;
+    const int64_t y = pix / A.res, x = pix % A.res;
+    const auto *g = gl(A.grad_img) + (y * A.img_width + x) * A.img_channels;
+    const float gx = g[3], gy = g[4];
+    const V3<float> d = load3(A.d, i), dx = load3(A.dx, i), dy = load3(A.dy, i);
+    V3<float> o = zero3<float>(), p0 = o, p1 = o, p2 = o;
+    if (active) { o = load3(A.o, i); p0 = load3(p0a, i); p1 = load3(p1a, i); p2 = load3(p2a, i); }
+    return tangent_from(o, d, dx, dy, gx, gy, p0, p1, p2, active);
 }
 
 }  // namespace epsm

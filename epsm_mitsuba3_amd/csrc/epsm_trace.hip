@@ -248,12 +248,15 @@ static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene
         return bad("K_log must be <= min(max_depth, 5)");
     if (path_offset + N > (int64_t) sensor->width * sensor->height * spp || path_offset + N > 0xFFFFFFFFLL)
         return bad("path range exceeds width*height*spp (or 2^32, common.py:468-475)");
-    if (!ray_o || !ray_d || !ray_dx || !ray_dy || (K_log > 0 && !recs)) return bad("NULL output");
+    const bool packed = (flags & EPSM_TRACE_PACKED_LOG) != 0;
+    if (!ray_o || (!packed && (!ray_d || !ray_dx || !ray_dy)) || (K_log > 0 && !recs)) return bad("NULL output");
+    if (packed && ((((uintptr_t) ray_o) & 15) || (K_log > 0 && (!recs[0].packed || !recs[0].pflags || (((uintptr_t) recs[0].packed) & 15)))))
+        return bad("EPSM_TRACE_PACKED_LOG needs 16-byte aligned ray_o (N,12), recs[0].packed and recs[0].pflags");
     if (scene->n_triangles > 0 && (!scene->positions || !scene->normals || !scene->tri || !scene->tri_mesh ||
                                    !scene->meshes || !scene->bsdfs || !scene->bvh || !scene->prim_index || !scene->tri_verts))
         return bad("NULL scene array");
     if (scene->n_emitters > 0 && !scene->emitters) return bad("NULL emitters");
-    if (flags & ~(uint32_t) EPSM_TRACE_SPARSE_LOG) return bad("unknown flag");
+    if (flags & ~(uint32_t) (EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG)) return bad("unknown flag");
     memset(&A, 0, sizeof(A));
     A.flags = flags;
     A.S = *scene; A.C = *sensor;
@@ -263,6 +266,7 @@ static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene
     A.film_pos = film_pos; A.radiance = radiance; A.valid = valid;
     for (int k = 0; k < K_log; ++k) {
         const EpsmRecordOut &r = recs[k];
+        if (packed) { A.rec[k] = r; continue; }
         if (!r.p0 || !r.p1 || !r.p2 || !r.n0 || !r.n1 || !r.n2 || !r.b0 || !r.b1 || !r.eta || !r.hf || !r.light ||
             !r.bsdf || !r.active || !r.active_em || !r.ismesh || !r.tri || !r.aux || !r.emit)
             return bad("NULL pointer in a record (p / normal may be NULL)");

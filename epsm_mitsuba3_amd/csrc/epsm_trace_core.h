@@ -651,6 +651,45 @@ EPSM_HD void write_record(const EpsmRecordOut &R, int64_t i, bool active, const 
     st1(e, es.tri); st1(e + 1, f2u(es.b0)); st1(e + 2, f2u(es.b1)); st1(e + 3, f2u(eweight));
 }
 
+// EPSM_TRACE_PACKED_LOG: the same record as ONE 128-byte row of the native log (include/epsm.h, EpsmPackedLog): eight
+// 16-byte stores instead of twenty scattered ones, plus this bounce's five flag bits in the path's flag word (the
+// path's lane is its only writer: bounce 0 sets the word, later bounces OR into it).
+EPSM_HD void st4(float *p, float a, float b, float c, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float F4s __attribute__((ext_vector_type(4)));
+    F4s v; v.x = a; v.y = b; v.z = c; v.w = d;
+#if defined(EPSM_TRACE_NT_STORES) && defined(EPSM_TRACE_NT_PACKED)
+    __builtin_nontemporal_store(v, (F4s *) p);
+#else
+    *(F4s *) p = v;      // a lane writes the eight quads of its record back to back: left to L2 to combine into full lines
+#endif
+#else
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+#endif
+}
+EPSM_HD float u2f(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
+EPSM_HD void write_record_packed(float *packed, uint32_t *pflags, int K_log, int64_t i, int iteration, bool active,
+                                 const SurfHit &h, uint32_t flags, const EmitterSample &es, bool active_em,
+                                 const BsdfSample &bs, float eweight) {
+    const bool mesh = h.valid && (h.mesh_flags & EPSM_MESH_IS_MESH);
+    const F3 z = zero3<float>();
+    const F3 p0 = mesh ? h.p0 : z, p1 = mesh ? h.p1 : z, p2 = mesh ? h.p2 : z, n0 = mesh ? h.n0 : z, n1 = mesh ? h.n1 : z,
+             n2 = mesh ? h.n2 : z;
+    float *r = packed + (i * K_log + iteration) * 32;
+    st4(r + 0, p0.x, p0.y, p0.z, p1.x);
+    st4(r + 4, p1.y, p1.z, p2.x, p2.y);
+    st4(r + 8, p2.z, n0.x, n0.y, n0.z);
+    st4(r + 12, n1.x, n1.y, n1.z, n2.x);
+    st4(r + 16, n2.y, n2.z, mesh ? h.b0 : 0.f, mesh ? h.b1 : 0.f);
+    st4(r + 20, bs.eta, es.p.x, es.p.y, es.p.z);
+    st4(r + 24, u2f(es.tri), es.b0, es.b1, eweight);
+    st4(r + 28, u2f(mesh ? h.tri : kNoIndex), bs.dhf.x, bs.dhf.y, bs.dhf.z);
+    const uint32_t bits = ((flags & 0x6u) ? 1u : 0u) | ((flags & 0x1u) ? 2u : 0u) | (active ? 4u : 0u) | (active_em ? 8u : 0u) |
+                          (mesh ? 16u : 0u);
+    if (iteration == 0) pflags[i] = bits;
+    else pflags[i] |= bits << (5 * iteration);
+}
+
 // EPSM_TRACE_SPARSE_LOG: a bounce the path did not reach leaves only the fields the gradient kernels' masks read
 EPSM_HD void write_dead_masks(const EpsmRecordOut &R, int64_t i) {
     st1(R.bsdf + i, 0u);
@@ -693,7 +732,14 @@ EPSM_HD PathState path_begin(const TraceArgs &A, int64_t i) {
     PathState s;
     s.rng = seed_sampler(A.seed, (uint32_t) widx);                        // common.py:475 sampler.seed(seed, wavefront_size)
     const PrimaryRay pr = sample_primary_ray(A.C, widx, A.spp, s.rng);
-    st3(A.ray_o, i, pr.ray.o); st3(A.ray_d, i, pr.ray.d); st3(A.ray_dx, i, pr.dx); st3(A.ray_dy, i, pr.dy);
+    if (A.flags & EPSM_TRACE_PACKED_LOG) {                                // (N,12): o, d, d_x, d_y side by side
+        float *r = A.ray_o + 12 * i;
+        st4(r, pr.ray.o.x, pr.ray.o.y, pr.ray.o.z, pr.ray.d.x);
+        st4(r + 4, pr.ray.d.y, pr.ray.d.z, pr.dx.x, pr.dx.y);
+        st4(r + 8, pr.dx.z, pr.dy.x, pr.dy.y, pr.dy.z);
+    } else {
+        st3(A.ray_o, i, pr.ray.o); st3(A.ray_d, i, pr.ray.d); st3(A.ray_dx, i, pr.dx); st3(A.ray_dy, i, pr.dy);
+    }
     if (A.film_pos) { A.film_pos[2 * i] = pr.px; A.film_pos[2 * i + 1] = pr.py; }
     s.ray = pr.ray;
     s.L = zero3<float>(); s.beta = f3(1.f, 1.f, 1.f); s.prev_p = zero3<float>();
@@ -752,11 +798,16 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
     const BsdfSample bs = bsdf_sample(bsdf, si.wi, s1, s2x, s2y, active_next);
     // ---- log (epsm.py:648-654)
     if (iteration < A.K_log) {
-        if (s.active || !(A.flags & EPSM_TRACE_SPARSE_LOG))
+        if (A.flags & EPSM_TRACE_PACKED_LOG) {
+            if (s.active || iteration == 0)                                // (every path passes bounce 0: its flag word exists)
+                write_record_packed(A.rec[0].packed, A.rec[0].pflags, A.K_log, i, iteration, s.active && si.valid, si, flags, es,
+                                    active_em, bs, Lr_dir.x + Lr_dir.y + Lr_dir.z);
+        } else if (s.active || !(A.flags & EPSM_TRACE_SPARSE_LOG)) {
             write_record(A.rec[iteration], i, s.active && si.valid, si, flags, es, active_em, bs,
                          Lr_dir.x + Lr_dir.y + Lr_dir.z, bsdf.alpha_slot);
-        else
+        } else {
             write_dead_masks(A.rec[iteration], i);
+        }
     }
     // ---- update (epsm.py:658-683)
     if (s.active) vis.direct(s.L, Le, Lr_dir);

@@ -27,7 +27,6 @@
 namespace epsm {
 
 struct alignas(16) W4 { uint32_t x, y, z, w; };
-EPSM_HD float u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
 EPSM_HD W4 pack4(F3 v, float w) { W4 o; o.x = f2u(v.x); o.y = f2u(v.y); o.z = f2u(v.z); o.w = f2u(w); return o; }
 EPSM_HD W4 pack4u(F3 v, uint32_t w) { W4 o; o.x = f2u(v.x); o.y = f2u(v.y); o.z = f2u(v.z); o.w = w; return o; }
 EPSM_HD F3 xyz(const W4 &q) { return f3(u2f(q.x), u2f(q.y), u2f(q.z)); }
@@ -192,6 +191,11 @@ EPSM_HD void wf_shadow_begin(const TraceArgs &A, const WfState &W, int64_t i, Wf
     J.i = i; J.phase = 0;
     trav_begin(J.T, A.S, sr);
 }
+// ds.p of the first bounce, as logged (per-field array or packed record)
+EPSM_HD F3 wf_logged_light0(const TraceArgs &A, int64_t i) {
+    if (A.flags & EPSM_TRACE_PACKED_LOG) return ld3(A.rec[0].packed + i * A.K_log * 32 + 21);
+    return ld3(A.rec[0].light + 3 * i);
+}
 EPSM_HD bool wf_shadow_round(const TraceArgs &A, const WfState &W, int iteration, WfJob &J, uint32_t *lds, int stride) {
     const BvhStack st = wf_stack(W, J.i, lds, stride);
     const int64_t i = J.i;
@@ -199,7 +203,10 @@ EPSM_HD bool wf_shadow_round(const TraceArgs &A, const WfState &W, int iteration
         if (!trav_done(J.T)) trav_round<true>(J.T, A.S, st);
         if (!trav_done(J.T)) return false;
         if (J.T.best.hit) {                                              // occluded
-            if (iteration < A.K_log) A.rec[iteration].emit[4 * i + 3] = 0u;   // Lr_dir = 0: the logged weight with it
+            if (iteration < A.K_log) {                                       // Lr_dir = 0: the logged weight with it
+                if (A.flags & EPSM_TRACE_PACKED_LOG) A.rec[0].packed[(i * A.K_log + iteration) * 32 + 27] = 0.f;
+                else A.rec[iteration].emit[4 * i + 3] = 0u;
+            }
         } else {
             const W4 l = W.L[i];
             const F3 L = xyz(l) + xyz(W.sh_L[i]);                        // (L + Le) + Lr_dir, epsm.py:658
@@ -208,7 +215,7 @@ EPSM_HD bool wf_shadow_round(const TraceArgs &A, const WfState &W, int iteration
         if (!(W.sh_d[i].w & kWfOccluder)) return true;
         // iteration 0, max_depth <= 3, K_log > 0: si.p is the path's prev_p by now, ds.p was logged as the vertex's
         // light point; ds.d as in sample_emitter_direction, the origin of spawn_ray(si, ds.d) is that of the visibility ray
-        const F3 sip = xyz(W.prev_p[i]), esp = ld3(A.rec[0].light + 3 * i);
+        const F3 sip = xyz(W.prev_p[i]), esp = wf_logged_light0(A, i);
         const F3 dd = esp - sip;
         const float dist = sqrtf(dot(dd, dd));
         Ray r2; r2.o = xyz(W.sh_o[i]); r2.d = dd * (1.f / dist); r2.maxt = kInf;
@@ -218,7 +225,7 @@ EPSM_HD bool wf_shadow_round(const TraceArgs &A, const WfState &W, int iteration
     }
     if (!trav_done(J.T)) trav_round<false>(J.T, A.S, st);
     if (!trav_done(J.T)) return false;
-    const F3 sip = xyz(W.prev_p[i]), esp = ld3(A.rec[0].light + 3 * i);
+    const F3 sip = xyz(W.prev_p[i]), esp = wf_logged_light0(A, i);
     const F3 dd = esp - sip;
     const float dist = sqrtf(dot(dd, dd));
     Ray r2; r2.o = xyz(W.sh_o[i]); r2.d = dd * (1.f / dist); r2.maxt = kInf;
@@ -251,7 +258,9 @@ EPSM_HD void wf_finish(const TraceArgs &A, const WfState &W, int64_t i) {
     st3(A.radiance, i, xyz(l));
     if (A.valid) A.valid[i] = (l.w & 0xFFu) != 0;
     const int done = (int) (l.w >> 16);
-    if (A.flags & EPSM_TRACE_SPARSE_LOG) {
+    if (A.flags & EPSM_TRACE_PACKED_LOG) {
+        // nothing: the flag word of the path says which records exist
+    } else if (A.flags & EPSM_TRACE_SPARSE_LOG) {
         for (int k = done; k < A.K_log; ++k) write_dead_masks(A.rec[k], i);
     } else {
         for (int k = done; k < A.K_log; ++k) write_dead_record(A.rec[k], i);

@@ -25,8 +25,9 @@ import torch
 from . import dist as _dist
 from .manifold_grad import OUTLIER_CLIP, calc_grad as _calc_grad, manifold_grad_packed
 from .params import ParamGrads
-from .records import PackedRecords, PackedScatter
-from .tangent_scatter import backward_pass, first_vertex_tangent, manifold_grad_scatter, scatter
+from .records import PackedLog, PackedRecords, PackedScatter
+from .tangent_scatter import (backward_pass, backward_pass_packed, first_vertex_tangent, manifold_grad_scatter,
+                              scatter)
 
 
 @dataclass
@@ -43,6 +44,7 @@ class PathTrace:
     scatter_info: List[dict]      # K entries (EpsmScatterRecord fields)
     path_offset: int = 0          # first path of this shard within the full wavefront
     n_paths_total: Optional[int] = None
+    log: Optional[PackedLog] = None   # the native log (then path_info / scatter_info may be None)
 
 
 class EPSMIntegrator:
@@ -67,6 +69,9 @@ class EPSMIntegrator:
         # True: calc_grad and the scatter run as ONE kernel (no dense per-path gradient lists);
         # False: the reference's two-stage shape (calc_grad lists, then scatter)
         self.fused = props.get("fused", True)
+        # True: render_backward asks the tracer for the native packed log (one 128-byte record per path vertex) and runs
+        # epsm_backward_pass_packed on it; False: the reference's per-field tensors all the way
+        self.packed_log = bool(props.get("packed_log", True))
 
     def to_string(self):
         md = 0xFFFFFFFF if self.max_depth < 0 else self.max_depth
@@ -110,9 +115,13 @@ class EPSMIntegrator:
         # ranks (or the caller's own data) and must not be multiplied by the world size.
         target = params.scratch() if world > 1 else params
         tracer = getattr(scene, "iter_traces", None) or scene.trace_paths      # a generator: one tile resident at a time
+        kw = {}
+        if self.fused and self.fuse_tangent and self.packed_log and getattr(scene, "supports_packed_log", False):
+            kw["packed_log"] = True        # the tracer writes the backward kernel's native layout (EpsmPackedLog)
         traces = tracer(sensor=self.backward_sensor, seed=seed, spp=self.backward_spp,
                         max_depth=self.tracer_depth(), max_log_depth=self.max_log_depth, rank=rank, world_size=world,
-                        sparse_log=True)   # the log is consumed here and nowhere else: skip the zeros of dead bounces
+                        sparse_log=True,   # the log is consumed here and nowhere else: skip the zeros of dead bounces
+                        **kw)
         if isinstance(traces, PathTrace):
             traces = [traces]
         for trace in traces:                       # this rank's pixel/sample tiles
@@ -133,10 +142,19 @@ class EPSMIntegrator:
         """Tangent -> gradient -> scatter for one tile.  ``packed`` = (PackedRecords, PackedScatter)
         built once for records that stay resident; ``out`` = reusable output tensors; ``mark(name)`` is
         called after each stage (bench.py records HIP events there)."""
+        mark = mark or (lambda name: None)
+        if isinstance(packed, PackedLog) or getattr(trace, "log", None) is not None:
+            # the native log (one 128-byte record per path vertex): one launch, nothing else
+            log = packed if isinstance(packed, PackedLog) else trace.log
+            mark("tangent")
+            backward_pass_packed(self.variant, log, grad_in, trace.spp, trace.res, params.pos, params.nrm,
+                                 params.alpha if params.B else None, params.cam_origin, clip=self.outlier_clip,
+                                 path_offset=trace.path_offset)
+            mark("grad"); mark("scatter")
+            return None
         dev = trace.ray_d.device
         rec, sc = packed if packed is not None else (PackedRecords(trace.path_info, device=dev),
                                                      PackedScatter(trace.scatter_info, device=dev))
-        mark = mark or (lambda name: None)
         fused = self.fused if fused is None else fused
         if fused and self.fuse_tangent:
             # one launch for the whole tile: tangents live in registers, gradients go into the parameter buffers

@@ -227,3 +227,82 @@ class PackedScatter:
 
     def table_ptr(self) -> int:
         return self.table.data_ptr()
+
+
+class EpsmPackedLog(C.Structure):
+    """Mirror of ``struct EpsmPackedLog`` (include/epsm.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("rays", "flags", "verts", "shadow")]
+
+
+FLAG_DIFFUSE, FLAG_NULL, FLAG_ACTIVE, FLAG_ACTIVE_EM, FLAG_ISMESH = 1, 2, 4, 8, 16
+REC_WORDS = 32
+
+
+class PackedLog:
+    """The native path log (``EpsmPackedLog``): rays ``(N,12)``, one flag word per path, ONE 128-byte record per
+    (path, vertex).  The tracer writes it directly (``Scene`` with ``packed_log``); ``from_trace`` builds it from the
+    per-array records of a ``PathTrace`` (synthetic wavefronts, tests) -- the triangle table must then carry the alpha
+    slots in bits 8.. of its mode words, because the packed record has no room for a per-vertex BSDF id."""
+
+    def __init__(self, rays, flags, verts, shadow, table, K):
+        self.rays, self.flags, self.verts, self.shadow, self.table, self.K = rays, flags, verts, shadow, table, int(K)
+        self.N = int(rays.shape[0])
+        self.T = int(table.shape[0])
+        self.device = rays.device
+        assert tuple(rays.shape) == (self.N, 12) and tuple(flags.shape) == (self.N,) and tuple(verts.shape) == (self.N, self.K, REC_WORDS)
+        for t in (rays, flags, verts, table) + ((shadow,) if shadow is not None else ()):
+            assert t.is_contiguous() and t.element_size() == 4
+        self.c = EpsmPackedLog(rays.data_ptr(), flags.data_ptr(), verts.data_ptr(), shadow.data_ptr() if shadow is not None else None)
+
+    def table_ptr(self) -> int:
+        return self.table.data_ptr()
+
+    @staticmethod
+    def from_trace(trace, device=None, table: Optional[torch.Tensor] = None, free: bool = False) -> "PackedLog":
+        dev = torch.device(device) if device is not None else trace.ray_d.device
+        f = lambda t: t.detach().to(dev, torch.float32)
+        pi, si = trace.path_info, trace.scatter_info
+        K = len(pi) - 1
+        N = trace.ray_d.shape[0]
+        rays = torch.cat([f(trace.ray_o), f(trace.ray_d), f(trace.ray_dx), f(trace.ray_dy)], dim=1).contiguous()
+        flags = torch.zeros(N, dtype=torch.int32, device=dev)
+        verts = torch.zeros((N, K, REC_WORDS), dtype=torch.float32, device=dev)
+        iview = verts.view(torch.int32)
+        shadow = None
+        if table is None:
+            table = si[0].get("table")
+        if table is None:
+            raise ValueError("PackedLog.from_trace needs the scene's triangle table")
+        table = table.detach().to(dev, torch.int32).contiguous()
+        for k in range(1, K + 1):
+            r, s = pi[k], si[k - 1]
+            b = _flags_tensor(r["bsdf"]).to(dev).to(torch.int64)
+            m = lambda t: (t.to(dev) > 0) if t.dtype != torch.bool else t.to(dev)
+            w = (((b & 6) != 0).to(torch.int32) * FLAG_DIFFUSE | ((b & 1) != 0).to(torch.int32) * FLAG_NULL |
+                 m(r["active"]).to(torch.int32) * FLAG_ACTIVE | m(r["active_em"]).to(torch.int32) * FLAG_ACTIVE_EM |
+                 m(r["ismesh"]).to(torch.int32) * FLAG_ISMESH)
+            flags |= w << (5 * (k - 1))
+            v = verts[:, k - 1]
+            for j in range(3):
+                v[:, 3 * j: 3 * j + 3] = f(r["points"][j])
+                v[:, 9 + 3 * j: 12 + 3 * j] = f(r["normals"][j])
+            v[:, 18], v[:, 19], v[:, 20] = f(r["uv"][0]), f(r["uv"][1]), f(r["eta"])
+            v[:, 21:24] = f(r["light"])
+            iv = iview[:, k - 1]
+            if s.get("emit") is not None:
+                iv[:, 24:28] = s["emit"].to(dev, torch.int32)
+            else:
+                iv[:, 24] = -1
+            tri = s["tri"].to(dev, torch.int32)
+            iv[:, 28] = tri
+            if s.get("aux") is not None:
+                aux = s["aux"].to(dev, torch.int32)
+                iv[:, 29:32] = aux[:, 1:4]
+                slot = torch.where(tri >= 0, (table[:, 3][tri.clamp_min(0).long()] >> 8) - 1, torch.full_like(tri, -1))
+                if not bool((torch.where(aux[:, 0] >= 0, aux[:, 0], torch.full_like(tri, -1)) == slot).all()):
+                    raise ValueError("PackedLog: aux[:,0] (alpha slot per vertex) disagrees with bits 8.. of the triangle table")
+            if k == 1 and s.get("shadow") is not None:
+                shadow = s["shadow"].to(dev, torch.int32).contiguous()
+            if free:
+                r.clear(); s.clear()
+        return PackedLog(rays, flags.contiguous(), verts, shadow, table, K)

@@ -43,6 +43,7 @@ IOR = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "bk7": 1.5046, "glass": 
 
 # ---------------------------------------------------------------------------- ctypes mirrors
 EPSM_TRACE_SPARSE_LOG = 0x1          # include/epsm_trace.h
+EPSM_TRACE_PACKED_LOG = 0x2
 
 
 class EpsmMesh(C.Structure):
@@ -77,7 +78,7 @@ class EpsmSceneC(C.Structure):
 class EpsmRecordOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "p0", "p1", "p2", "p", "n0", "n1", "n2", "normal", "b0", "b1", "eta", "hf", "light",
-        "bsdf", "active", "active_em", "ismesh", "tri", "aux", "emit", "shadow")]
+        "bsdf", "active", "active_em", "ismesh", "tri", "aux", "emit", "packed", "pflags", "shadow")]
 
 
 # ---------------------------------------------------------------------------- transforms
@@ -628,7 +629,8 @@ class Scene:
         self.emitter_cdf = f32(np.concatenate(cdf) if cdf else np.zeros(1))
         # the triangle table of include/epsm.h: row t = [v0, v1, v2, EPSM_MODE_* of the owning mesh]; the tracer logs
         # triangle ids, the gradient kernels look the vertex rows up here
-        mode = np.array([m.flags() & 0xF for m in self.meshes], dtype=np.int64)
+        # (+ bits 8..: alpha slot of the mesh's BSDF + 1, which the packed log does not carry per vertex)
+        mode = np.array([(m.flags() & 0xF) | ((self.alpha_slots.get(m.bsdf, -1) + 1) << 8) for m in self.meshes], dtype=np.int64)
         tm = np.concatenate(tri_mesh).astype(np.int64) if tri_mesh else np.zeros(0, np.int64)
         table = np.concatenate([TRI.reshape(-1, 3), mode[tm].reshape(-1, 1) if len(tm) else np.zeros((0, 1), np.int64)], axis=1)
         if table.shape[0] == 0:
@@ -668,6 +670,50 @@ class Scene:
             raise ValueError("Scene.tracer must be 'auto', 'mega' or 'wavefront'")
         return self.tracer == "wavefront" or (self.tracer == "auto" and self.T >= self.WAVEFRONT_MIN_TRIANGLES)
 
+    def _trace_packed(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int):
+        """The same trace with the vertex log in the NATIVE layout of the backward kernel (EPSM_TRACE_PACKED_LOG,
+        include/epsm.h EpsmPackedLog): the PathTrace carries ``log`` (a PackedLog) instead of per-field arrays."""
+        from .integrators import PathTrace
+        from .records import PackedLog, REC_WORDS
+        dev = self.device
+        if dev.type != "cuda" and self._backend is None:
+            raise _lib.EpsmError("the tracer runs on the GPU only (no CPU fallback)")
+        lib = self._backend if self._backend is not None else _lib.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+        sensor = self.sensors[sensor_index]
+        n = hi - lo
+        assert K >= 1
+        rays = torch.empty((n, 12), device=dev, dtype=torch.float32)
+        radiance = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        film_pos = torch.empty((n, 2), device=dev, dtype=torch.float32)
+        valid = torch.empty((n,), device=dev, dtype=torch.uint8)
+        flags = torch.empty((n,), device=dev, dtype=torch.int32)
+        verts = torch.empty((n, K, REC_WORDS), device=dev, dtype=torch.float32)
+        shadow = torch.empty((n, 4), device=dev, dtype=torch.int32) if max_depth <= 3 else None
+        recs = (EpsmRecordOut * K)()
+        recs[0].packed, recs[0].pflags = verts.data_ptr(), flags.data_ptr()
+        recs[0].shadow = shadow.data_ptr() if shadow is not None else None
+        cs = sensor.c_struct()
+        args = [C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
+                C.c_int64(lo), C.c_int64(n), K, C.c_void_p(rays.data_ptr()), None, None, None,
+                C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()), C.c_void_p(valid.data_ptr()),
+                C.c_void_p(C.addressof(recs)), C.c_uint32(EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG)]
+        if self.use_wavefront() and n > 0:
+            need = int(lib.epsm_trace_workspace_bytes(C.c_int64(n)))
+            ws = self._wf_workspace.get(stream)
+            if ws is None or ws.numel() < need:
+                ws = self._wf_workspace[stream] = torch.empty(need, device=dev, dtype=torch.uint8)
+            rc = lib.epsm_trace_paths_wavefront(*args, C.c_void_p(ws.data_ptr()), C.c_size_t(need), C.c_void_p(stream))
+        else:
+            rc = lib.epsm_trace_paths(*args, C.c_void_p(stream))
+        if rc != 0:
+            _lib.check(rc, "epsm_trace_paths") if self._backend is None else (_ for _ in ()).throw(RuntimeError(f"host tracer rc={rc}"))
+        tr = PathTrace(res=sensor.width, spp=spp, ray_o=rays[:, 0:3], ray_d=rays[:, 3:6], ray_dx=rays[:, 6:9], ray_dy=rays[:, 9:12],
+                       path_info=None, scatter_info=None, path_offset=lo, n_paths_total=sensor.width * sensor.height * spp)
+        tr.film_pos, tr.radiance, tr.valid = film_pos, radiance, valid
+        tr.log = PackedLog(rays, flags, verts, shadow, self.tri_table, K)
+        return tr
+
     def _trace(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int,
                want_radiance: bool = True, sparse_log: bool = False):
         from .integrators import PathTrace
@@ -704,6 +750,8 @@ class Scene:
             shadow = quad[2 * K] if (k == 0 and want_shadow) else None
             r = recs[k]
             for name, _ in EpsmRecordOut._fields_:
+                if name in ("packed", "pflags"):
+                    continue
                 setattr(r, name, t[name].data_ptr() if name != "shadow" else (shadow.data_ptr() if shadow is not None else None))
             info.append({"it": k, "active": t["active"], "bsdf": t["bsdf"], "ismesh": t["ismesh"], "light": t["light"],
                          "active_em": t["active_em"], "points": [t["p0"], t["p1"], t["p2"], t["p"]],
@@ -735,7 +783,10 @@ class Scene:
         tr.film_pos, tr.radiance, tr.valid = film_pos, radiance, valid
         return tr
 
-    def iter_traces(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1, sparse_log=False):
+    supports_packed_log = True
+
+    def iter_traces(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1, sparse_log=False,
+                    packed_log=False):
         """Generator over this rank's tiles of the backward wavefront of ``sensors[sensor]`` (epsm.py:142-181): a tile
         is traced when the consumer asks for it, so ``render_backward`` holds ONE tile's records (~0.8 KB per path at
         K = 5) at a time whatever the size of the wavefront.  ``sparse_log``: EPSM_TRACE_SPARSE_LOG -- bounces a path
@@ -754,7 +805,10 @@ class Scene:
             tile = max(self.tile_paths, min(self.WAVEFRONT_TILE_PATHS, per_rank))
         tiles = _dist.tile_ranges(n_total, tile)
         for t in _dist.my_tiles(len(tiles), rank, world_size):
-            yield self._trace(si, seed, spp, max_depth, K, *tiles[t], sparse_log=sparse_log)
+            if packed_log and K >= 1:
+                yield self._trace_packed(si, seed, spp, max_depth, K, *tiles[t])
+            else:
+                yield self._trace(si, seed, spp, max_depth, K, *tiles[t], sparse_log=sparse_log)
 
     def trace_paths(self, *args, **kw):
         """All of this rank's tiles at once (``list(iter_traces(...))``): for small wavefronts and the tests."""

@@ -221,12 +221,13 @@ def synth_first_hit_triangles(o, d, seed: int = 0):
     return p0, p0 + e1, p0 + e2, (1 - u - v)[:, 0], u[:, 0]
 
 
-def synth_triangle_table(n_scene_vertices: int, device="cpu", n_emitter_tris: int = 32) -> torch.Tensor:
+def synth_triangle_table(n_scene_vertices: int, device="cpu", n_emitter_tris: int = 32, n_bsdfs: int = 4) -> torch.Tensor:
     """The synthetic scene's triangle table ``(T,4) int32 [v0, v1, v2, mode]`` (include/epsm.h): V surface triangles
     -- triangle t uses vertex rows (t, t+1, t+G) mod V, G = sqrt(2V) -- followed by ``n_emitter_tris`` emitter triangles
     on the last 3 * n_emitter_tris vertex rows.  Modes per triangle (a fixed pseudo-random function of V): 60 % smooth
-    and attached, 25 % flat meshes, 10 % with flipped normals, 5 % detached.  Depends only on its arguments, so every
-    tile / rank / slab of a scene shares it."""
+    and attached, 25 % flat meshes, 10 % with flipped normals, 5 % detached; bits 8.. of the mode word carry the alpha
+    slot of the triangle's BSDF + 1 (uniform over none, 0..n_bsdfs-1), as the packed log wants it (include/epsm.h).
+    Depends only on its arguments, so every tile / rank / slab of a scene shares it."""
     import math
     V = int(n_scene_vertices)
     dev = torch.device(device)
@@ -237,6 +238,8 @@ def synth_triangle_table(n_scene_vertices: int, device="cpu", n_emitter_tris: in
     mode = torch.where(r < 0.25, torch.tensor(4), mode)                                 # flat mesh
     mode = torch.where((r >= 0.25) & (r < 0.35), torch.tensor(4 | 8 | 1 | 2), mode)     # flipped normals
     mode = torch.where((r >= 0.35) & (r < 0.40), torch.tensor(1), mode)                 # detached
+    slot = torch.randint(-1, max(0, int(n_bsdfs)), (V,), generator=gen) if n_bsdfs > 0 else torch.full((V,), -1)
+    mode = mode | ((slot + 1) << 8)
     t = torch.arange(V)
     rows = [torch.stack([t, (t + 1) % V, (t + G) % V, mode], dim=1)]
     if n_emitter_tris > 0 and V >= 3 * n_emitter_tris:
@@ -266,7 +269,7 @@ def synth_scatter_info(n_paths: int, n_vertices: int, n_scene_vertices: int, see
     gen = torch.Generator(device=dev)
     gen.manual_seed(99991 + int(seed))
     if table is None:
-        table = synth_triangle_table(V, dev, n_emitter_tris)
+        table = synth_triangle_table(V, dev, n_emitter_tris, n_bsdfs)
     has_emitters = table.shape[0] > V
     idx = torch.arange(N, device=dev) + int(path_offset)
     import math
@@ -306,7 +309,8 @@ def synth_scatter_info(n_paths: int, n_vertices: int, n_scene_vertices: int, see
             sdis = torch.where(torch.rand((N,), generator=gen, device=dev) < 0.3, torch.zeros_like(sdis), sdis)
             rec["shadow"] = torch.stack([stri, bits(_u(gen, (N,), 0.0, 0.5, dev, dtype)), bits(_u(gen, (N,), 0.0, 0.5, dev, dtype)),
                                          bits(sdis)], dim=1)
-        bsdf_id = torch.randint(-1, n_bsdfs, (N,), generator=gen, device=dev).to(torch.int32)
+        # the alpha slot belongs to the triangle's BSDF (mode word of its table row, bits 8..); none without a triangle
+        bsdf_id = torch.where(tri >= 0, (table[:, 3][tri.clamp_min(0).long()] >> 8) - 1, none).to(torch.int32)
         rec["aux"] = torch.cat([bsdf_id[:, None], bits(_u(gen, (N, 3), -1.0, 1.0, dev, dtype))], dim=1)
         del bsdf_id
         rec["emit"] = torch.stack([etri, bits(_u(gen, (N,), 0.0, 0.5, dev, dtype)), bits(_u(gen, (N,), 0.0, 0.5, dev, dtype)),

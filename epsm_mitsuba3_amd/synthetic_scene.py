@@ -27,7 +27,7 @@ class SyntheticScene:
     def triangle_table(self) -> torch.Tensor:
         """The scene's ``(T,4) [v0, v1, v2, mode]`` table (include/epsm.h), shared by all tiles."""
         if self._table is None:
-            self._table = synth_triangle_table(self.V, self.device)
+            self._table = synth_triangle_table(self.V, self.device, n_bsdfs=self.B)
         return self._table
 
     def tile(self, t: int, lo: int, hi: int, seed: int, spp: int, K: int, shadow: bool = False, lean: bool = False) -> PathTrace:

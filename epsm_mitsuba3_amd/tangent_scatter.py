@@ -9,7 +9,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from .records import PackedRecords, PackedScatter, VARIANTS, num_param_grads
+from .records import PackedLog, PackedRecords, PackedScatter, VARIANTS, num_param_grads
 
 
 def _f32(t: torch.Tensor, dev, shape=None) -> torch.Tensor:
@@ -145,3 +145,32 @@ def backward_pass(variant: str, rec: PackedRecords, sc: PackedScatter, ray_o, ra
             grad_origin.data_ptr() if grad_origin is not None else None, V, B,
             torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "epsm_backward_pass")
+
+
+def backward_pass_packed(variant: str, log: PackedLog, grad_in: torch.Tensor, spp: int, res: int,
+                         grad_pos: torch.Tensor, grad_nrm: torch.Tensor, grad_alpha: Optional[torch.Tensor] = None,
+                         grad_origin: Optional[torch.Tensor] = None, clip: float = 0.1, path_offset: int = 0) -> None:
+    """``backward_pass`` on the native log (``epsm_backward_pass_packed``): one 128-byte record per (path, vertex)."""
+    dev = log.device
+    if dev.type != "cuda":
+        raise _lib.EpsmError("backward_pass_packed: the log must live on the GPU (no CPU fallback)")
+    g = _f32(grad_in, dev)
+    if g.dim() != 3 or g.shape[2] < 5 or g.shape[0] < res or g.shape[1] < res:
+        raise ValueError(f"grad_in must be (H>=res, W>=res, >=5), got {tuple(g.shape)}")
+    for t in (grad_pos, grad_nrm):
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.device == dev
+    V = grad_pos.shape[0]
+    assert tuple(grad_pos.shape) == (V, 3) and tuple(grad_nrm.shape) == (V, 3)
+    B = 0
+    if grad_alpha is not None:
+        assert grad_alpha.is_contiguous() and grad_alpha.dtype == torch.float32 and grad_alpha.device == dev
+        B = grad_alpha.numel()
+    if grad_origin is not None:
+        assert grad_origin.is_contiguous() and grad_origin.dtype == torch.float32 and grad_origin.numel() == 3
+    with torch.cuda.device(dev):
+        rc = _lib.lib().epsm_backward_pass_packed(
+            VARIANTS[variant], log.N, log.K, int(path_offset), int(spp), int(res), C.addressof(log.c), g.data_ptr(),
+            int(g.shape[1]), int(g.shape[2]), log.table_ptr(), log.T, float(clip), grad_pos.data_ptr(), grad_nrm.data_ptr(),
+            grad_alpha.data_ptr() if grad_alpha is not None else None,
+            grad_origin.data_ptr() if grad_origin is not None else None, V, B, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "epsm_backward_pass_packed")

@@ -236,6 +236,42 @@ int epsm_backward_pass(int variant, int64_t N, int K, int64_t path_offset, int s
                        float *grad_pos, float *grad_nrm, float *grad_alpha, float *grad_o_sum,
                        int64_t V, int64_t B, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * The NATIVE path log: what this library's tracer writes for this library's backward kernel (the per-array records
+ * above are the reference's tensors, kept for the calc_grad drop-in).  The backward kernel regroups the paths of a
+ * window by chain length, so a wave reads the records of 64 scattered paths: with one array per field that is nine
+ * 12-byte gathers per vertex from lines of which a fraction is wanted; here a (path, vertex) is ONE 128-byte record,
+ * a path's K records are contiguous, and vertices a path never reached are never touched (nor written).
+ *   rays   (N,12) f32   o, d, d_x, d_y of the primary ray (sample_ray_differential)
+ *   flags  (N)    u32   5 bits per logged vertex, vertex k at bits 5(k-1)..: 1 = bsdf has a Diffuse lobe, 2 = Null,
+ *                       4 = active, 8 = active_em, 16 = ismesh  (the masks of EpsmVertexRecord)
+ *   verts  (N,K,32) 32-bit words, record of vertex k of path i at word (i*K + k-1)*32:
+ *            0..8   p0 p1 p2          9..17  n0 n1 n2        18 19  b0 b1      20  eta      21..23  light
+ *            24..27 etri u32, eb0, eb1, eweight              (EpsmScatterRecord.emit)
+ *            28     tri u32 (row of the triangle table)      29..31 d hf / d alpha
+ *          the alpha slot of the vertex's BSDF travels with the triangle: bits 8.. of the table row's mode word hold
+ *          slot + 1 (0 = none)
+ *   shadow (N,4) as EpsmScatterRecord.shadow, or NULL
+ * epsm_backward_pass_packed = epsm_backward_pass on this log (same sums, same arguments otherwise).
+ * ------------------------------------------------------------------------- */
+typedef struct EpsmPackedLog {
+    const float *rays;
+    const uint32_t *flags;
+    const void *verts;
+    const uint32_t *shadow;
+} EpsmPackedLog;
+#define EPSM_FLAG_DIFFUSE   1u
+#define EPSM_FLAG_NULL      2u
+#define EPSM_FLAG_ACTIVE    4u
+#define EPSM_FLAG_ACTIVE_EM 8u
+#define EPSM_FLAG_ISMESH    16u
+
+int epsm_backward_pass_packed(int variant, int64_t N, int K, int64_t path_offset, int spp, int res,
+                              const EpsmPackedLog *log, const float *grad_img, int img_width, int img_channels,
+                              const uint32_t *tri_table, int64_t T, float clip,
+                              float *grad_pos, float *grad_nrm, float *grad_alpha, float *grad_o_sum,
+                              int64_t V, int64_t B, void *stream);
+
 /* Human-readable text of the last failure on the calling thread ("" if none). */
 const char *epsm_last_error(void);
 

@@ -50,6 +50,14 @@ enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
  *   (path, bounce).  The reference logs masked lanes as zeros (epsm.py:551, 648-654) and so does the default; the
  *   zeros are 203 B per dead (path, bounce) that epsm_manifold_grad / _scatter / epsm_backward_pass never read. */
 #define EPSM_TRACE_SPARSE_LOG 0x1u
+/* EPSM_TRACE_PACKED_LOG: the vertex log is written in the NATIVE layout of the backward kernel (include/epsm.h,
+ * EpsmPackedLog) instead of the per-field arrays: recs[0].packed = (N, K_log, 32) words, one 128-byte record per
+ * (path, bounce) written with eight 16-byte stores, recs[0].pflags = (N) flag words (5 bits per bounce); bounces a path
+ * did not reach are not touched (the flag word says so).  ray_o must then point to an (N,12) array that receives
+ * o, d, d_x, d_y of a path side by side (ray_d / ray_dx / ray_dy are ignored); only `shadow` of the per-field pointers is
+ * still used.  The alpha slot of a vertex's BSDF is NOT in the record: the consumer takes it from the triangle table
+ * (bits 8.. of the mode word). */
+#define EPSM_TRACE_PACKED_LOG 0x2u
 
 typedef struct EpsmMesh {
     uint32_t tri_begin, tri_count;   /* this mesh's range in the triangle arrays */
@@ -122,6 +130,8 @@ typedef struct EpsmRecordOut {
     uint32_t *bsdf;                  /* (N) */
     uint8_t *active, *active_em, *ismesh;  /* (N) */
     uint32_t *tri, *aux, *emit;      /* (N) (N,4) (N,4): EpsmScatterRecord (tri = triangle id, emit = [etri, eb0, eb1, ew]) */
+    float *packed;                   /* EPSM_TRACE_PACKED_LOG, recs[0] only: (N, K_log, 32) words */
+    uint32_t *pflags;                /* EPSM_TRACE_PACKED_LOG, recs[0] only: (N) flag words */
     uint32_t *shadow;                /* (N,4): EpsmScatterRecord.shadow [stri, sb0, sb1, dis]; written for the first logged vertex only and
                                         only meaningful when max_depth <= 3 (epsm.py:610); may be NULL */
 } EpsmRecordOut;
@@ -135,7 +145,7 @@ typedef struct EpsmRecordOut {
  *   ray_o/d/dx/dy (N,3), film_pos (N,2), radiance (N,3), valid (N) u8: outputs (any may be NULL
  *                                    except ray_*); radiance = L of epsm.py:658, valid = depth != 0
  *   recs                             K_log records to fill (all fields written for every path)
- *   flags                            0 or EPSM_TRACE_SPARSE_LOG
+ *   flags                            0 or EPSM_TRACE_SPARSE_LOG and / or EPSM_TRACE_PACKED_LOG
  * ------------------------------------------------------------------------- */
 int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor,
                      uint32_t seed, int spp, int max_depth, int rr_depth,

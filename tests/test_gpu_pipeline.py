@@ -245,3 +245,33 @@ def test_full_size_wavefront_of_config_2():
     assert float((bufs[0] - bufs[1]).abs().max()) <= 1e-5 * m                   # run to run: order of the atomics only
     assert float((bufs[0] - bufs[2]).abs().max()) <= 1e-3 * m                   # one launch vs three stages
     assert abs(float(bufs[0].sum() - bufs[2].sum())) <= 1e-4 * float(bufs[0].abs().sum())   # checksum of the whole buffer
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("kind,profile,max_depth", [("manifold", "bathroom", 8), ("manifold", "mixed", 3),
+                                                    ("manifold_caustic", "pool", 8), ("manifold_caustic", "mixed", 3)])
+def test_packed_log_gives_the_sums_of_the_per_array_records(kind, profile, K, max_depth):
+    """The native log (EpsmPackedLog: one 128-byte record per path vertex, rays (N,12), one flag word per path) through
+    ``epsm_backward_pass_packed`` against the same trace in the reference's tensor layout through ``epsm_backward_pass``:
+    the same sums (float order aside), camera-origin gradient included; max_depth = 3 adds the occluder record."""
+    import epsm_mitsuba3_amd as epsm
+    from epsm_mitsuba3_amd.records import PackedLog
+    dev = torch.device("cuda", 0)
+    res, spp, V, B = 24, 16, 900, 3
+    scene = epsm.SyntheticScene(res=res, n_vertices=K, n_scene_vertices=V, n_bsdfs=B, profile=profile, device=dev,
+                                tile_paths=res * res * spp)
+    g = torch.Generator().manual_seed(6)
+    grad_in = (torch.randn((res, res, 5), generator=g) * 1e-3).to(dev)
+    integ = epsm.load_dict({"type": kind, "max_depth": max_depth})
+    (trace,) = scene.trace_paths(seed=4, spp=spp, max_depth=max_depth)
+    a, b = epsm.ParamGrads(V, B, device=dev), epsm.ParamGrads(V, B, device=dev)
+    integ.backward_from_trace(trace, a, grad_in)
+    log = PackedLog.from_trace(trace)
+    assert (log.shadow is not None) == (max_depth <= 3)
+    integ.backward_from_trace(trace, b, grad_in, packed=log)
+    torch.cuda.synchronize()
+    for x, y, name in ((a.pos, b.pos, "pos"), (a.nrm, b.nrm, "nrm"), (a.alpha, b.alpha, "alpha"), (a.cam_origin, b.cam_origin, "cam")):
+        m = float(x.abs().max())
+        if name in ("pos", "cam"):
+            assert m > 0, name
+        assert float((x - y).abs().max()) <= 2e-4 * m + 1e-12, name

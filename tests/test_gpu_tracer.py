@@ -238,3 +238,41 @@ def test_film_splat_matches_host(res, spp, n_cut, rfilter):
     torch.cuda.synchronize()
     assert float(want.abs().max()) > 0
     assert torch.allclose(got.cpu(), want, rtol=2e-4, atol=2e-4 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("tracer", ["mega", "wavefront"])
+@pytest.mark.parametrize("max_depth", [5, 3])
+def test_render_backward_on_the_native_packed_log(tracer, max_depth):
+    """render_backward asks the tracer for the backward kernel's native layout (EPSM_TRACE_PACKED_LOG -> one launch of
+    epsm_backward_pass_packed per tile) by default; ``packed_log=False`` keeps the reference's per-field tensors
+    (-> epsm_backward_pass).  Same gradients -- positions, normals, alpha (its slot now comes from the triangle table),
+    camera origin; NaN poison in fresh allocations shows that records of bounces a path never reached are not read."""
+    import epsm_mitsuba3_amd as epsm
+    from test_tracer_wavefront_host import _rich_scene
+    dev = torch.device("cuda", 0)
+    res, spp = 32, 16
+    sc = _rich_scene(res, spp, point_light=True, occluder=max_depth <= 3, device=dev)
+    sc.attach("floor", positions=True)
+    sc.tracer = tracer
+    sc.tile_paths = 5000                                   # several ragged tiles
+    g = torch.Generator().manual_seed(0)
+    grad_in = torch.zeros((res, res, 5)); grad_in[..., 3:] = torch.randn((res, res, 2), generator=g) * 1e-2
+    grad_in = grad_in.to(dev)
+    for variant in ("manifold", "manifold_caustic"):
+        out = []
+        for packed in (False, True):
+            integ = epsm.load_dict({"type": variant, "max_depth": max_depth, "packed_log": packed, "backward_sensor": 0})
+            integ.backward_spp = spp
+            poison = [torch.full((res * res * spp * 40,), float("nan"), device=dev) for _ in range(4)]
+            del poison
+            p = sc.param_grads()
+            integ.render_backward(sc, p, grad_in, seed=2)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(p.flat).all())
+            out.append(p.flat.clone())
+        m = float(out[0].abs().max())
+        assert m > 0
+        assert float((out[0] - out[1]).abs().max()) <= 2e-4 * m, variant
+    tiles = list(sc.iter_traces(sensor=0, seed=2, spp=spp, max_depth=max_depth, packed_log=True))
+    assert len(tiles) == -(-res * res * spp // (max(5000, 1))) or sc.use_wavefront()
+    assert all(t.log is not None and t.path_info is None for t in tiles)

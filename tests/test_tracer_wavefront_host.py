@@ -181,3 +181,33 @@ def test_wavefront_tiles_follow_the_sharding():
     assert torch.equal(both, one[0].radiance)
     sc.tracer = "mega"                                   # the one-launch form keeps the sharding unit
     assert len(sc.trace_paths(sensor=0, seed=1, spp=8, max_depth=3)) == n_total // 64
+
+
+@pytest.mark.parametrize("tracer", ["mega", "wavefront"])
+@pytest.mark.parametrize("max_depth,K,occluder", [(5, 4, False), (3, 3, True), (2, 1, True)])
+def test_packed_log_is_the_per_field_log_in_another_layout(tracer, max_depth, K, occluder):
+    """EPSM_TRACE_PACKED_LOG: the tracer writes the backward kernel's native layout (one 128-byte record per path
+    vertex, rays (N,12), one flag word per path: include/epsm.h EpsmPackedLog).  Bit for bit the per-field log repacked
+    by PackedLog.from_trace wherever a vertex is live; the flag words agree everywhere."""
+    from epsm_mitsuba3_amd.records import PackedLog
+    res, spp = 12, 8
+    sc = _rich_scene(res, spp, point_light=True, occluder=occluder)
+    sc.tracer = tracer
+    n = res * res * spp
+    a = sc._trace(0, seed=5, spp=spp, max_depth=max_depth, K=K, lo=0, hi=n)
+    b = sc._trace_packed(0, seed=5, spp=spp, max_depth=max_depth, K=K, lo=0, hi=n)
+    want = PackedLog.from_trace(a)
+    got = b.log
+    assert torch.equal(want.rays.view(torch.int32), got.rays.view(torch.int32))
+    assert torch.equal(want.flags, got.flags)
+    assert torch.equal(a.radiance, b.radiance) and torch.equal(a.film_pos, b.film_pos) and torch.equal(a.valid, b.valid)
+    live_total = 0
+    for k in range(K):
+        live = ((got.flags >> (5 * k)) & 4) != 0
+        live_total += int(live.sum())
+        assert torch.equal(want.verts[live, k].view(torch.int32), got.verts[live, k].view(torch.int32)), k
+    assert live_total > n // 2
+    if max_depth <= 3:
+        assert torch.equal(want.shadow, got.shadow)
+    else:
+        assert got.shadow is None
