@@ -169,7 +169,8 @@ def loose_from_packed(rec: dict, table: Optional[torch.Tensor] = None) -> dict:
         ids = ids.to(torch.int64) & 0xFFFFFFFF
         ok = ids < T
         r = table[torch.where(ok, ids, torch.zeros_like(ids))]
-        return torch.where(ok[:, None], r[:, :3], torch.full_like(r[:, :3], -1)), torch.where(ok, r[:, 3], torch.zeros_like(ids))
+        # (bits 8.. of the mode word are the alpha slot + 1 of the triangle's BSDF, for the packed log: not a mode bit)
+        return torch.where(ok[:, None], r[:, :3], torch.full_like(r[:, :3], -1)), torch.where(ok, r[:, 3] & 0xF, torch.zeros_like(ids))
     f = lambda t: t.contiguous().view(torch.float32)
     out = {}
     out["vidx"], out["mode"] = rows(rec["tri"])

@@ -153,7 +153,9 @@ int epsm_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, int res,
 #define EPSM_MODE_NRM_ATTACHED   0x8u  /* vertex normals of this mesh receive gradients */
 
 /* The scene's triangles: row t = [v0, v1, v2, mode] -- the rows of triangle t's vertices in the flat (V,3) position /
- * normal buffers and the EPSM_MODE_* bits of its mesh.  One table per scene (16 B per triangle; it stays in L2 / MALL),
+ * normal buffers and, in the mode word, the EPSM_MODE_* bits of its mesh (bits 0..3) and the alpha slot of the mesh's
+ * BSDF + 1 (bits 8.., 0 = no attached BSDF parameter; read by epsm_backward_pass_packed, whose log has no per-vertex
+ * `aux` slot).  One table per scene (16 B per triangle; it stays in L2 / MALL),
  * rebuilt when a mesh is attached or detached.  A ray tracer reports a hit as a primitive index, so the per-path log
  * below carries triangle IDS (4 B) instead of vertex triples.
  * Passed to the scatter entry points as `tri_table` ((T,4) u32, 16-byte aligned) and `T`. */
