@@ -81,6 +81,9 @@ def declare_tracer(lib):
     lib.epsm_trace_paths.argtypes = trace_args + [C.c_void_p]
     lib.epsm_trace_paths_wavefront.restype = C.c_int
     lib.epsm_trace_paths_wavefront.argtypes = trace_args + [C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.epsm_trace_paths_color.restype = C.c_int
+    lib.epsm_trace_paths_color.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.epsm_trace_workspace_bytes.restype = C.c_size_t
     lib.epsm_trace_workspace_bytes.argtypes = [C.c_int64]
     lib.epsm_film_splat.restype = C.c_int

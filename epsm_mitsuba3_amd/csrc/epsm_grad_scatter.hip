@@ -33,9 +33,15 @@ namespace {
 // wave drains a few items with most lanes idle; the table is flushed when a census finds it half full, and a window
 // of 1024 paths leaves ~1250 distinct rows on config 2).  Re-measured with the drain inlined: 2304/576 4.5-4.6,
 // 2432/544, 2560/512, 2816/448 4.7 (specular 14.5 / 13.3 / 11.7 against 15.9), 2048/640 5.25.
-constexpr int kBits = 2304;                // manifold: table rows, 16 B each (float sums) = 36 KB
-constexpr int kRowsCaustic = 1280;         // manifold_caustic: rows of 28 B (64-bit fixed-point sums, epsm_wave_scatter.h) = 35 KB
-constexpr int kQueueCap = 576;             // items per wave queue: 4 x 9 KB
+#ifndef EPSM_TABLE_ROWS
+#define EPSM_TABLE_ROWS 2304
+#define EPSM_TABLE_ROWS_CAUSTIC 1280
+#define EPSM_QUEUE_CAP 576
+#define EPSM_WAVES_PER_SIMD 2
+#endif
+constexpr int kBits = EPSM_TABLE_ROWS;                // manifold: table rows, 16 B each (float sums) = 36 KB
+constexpr int kRowsCaustic = EPSM_TABLE_ROWS_CAUSTIC; // manifold_caustic: rows of 28 B (64-bit fixed-point sums, epsm_wave_scatter.h) = 35 KB
+constexpr int kQueueCap = EPSM_QUEUE_CAP;             // items per wave queue: 4 x 9 KB
 constexpr int kFusedBlocks = 2048;             // 512 / 1024 / 8192 measured within 2 %
 
 struct FusedArgs {
@@ -429,7 +435,7 @@ namespace {
 
 template <int K, int VARIANT, int DMODE, bool PACKED>
 // waves-per-SIMD 2: without it hipcc budgets 128 VGPRs from the LDS-derived occupancy and spills 720 B/lane
-__global__ __launch_bounds__(256, 2) void epsm_grad_scatter_kernel(FusedArgs F, int dcols, int64_t chunks_per_block) {
+__global__ __launch_bounds__(256, EPSM_WAVES_PER_SIMD) void epsm_grad_scatter_kernel(FusedArgs F, int dcols, int64_t chunks_per_block) {
     typedef LdsTable<VARIANT == EPSM_VARIANT_MANIFOLD ? kBits : kRowsCaustic,
                      typename std::conditional<VARIANT == EPSM_VARIANT_MANIFOLD, AccFloat, AccFixed64>::type> Table;
     constexpr int kTableSize = Table::kTableSize;

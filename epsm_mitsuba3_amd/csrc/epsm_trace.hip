@@ -293,6 +293,30 @@ extern "C" int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor
     return EPSM_OK;
 }
 
+extern "C" int epsm_trace_paths_color(const EpsmScene *scene, const EpsmSensor *sensor,
+                                      uint32_t seed, int spp, int max_depth, int rr_depth,
+                                      int64_t path_offset, int64_t N,
+                                      float *film_pos, float *radiance, uint8_t *valid,
+                                      float *color_sum, int n_color, void *stream) {
+    epsm_host::err_buf()[0] = 0;
+    if (scene && sensor && N == 0) return EPSM_OK;
+    if (!color_sum || n_color < 1 || n_color > 4 || !radiance)
+        return fail(EPSM_EINVAL, "epsm_trace_paths_color: need color_sum, radiance and 1 <= n_color <= 4");
+    TraceArgs A;
+    static float dummy_rays[12];                               // (the rays are not wanted: fill_trace_args only checks for NULL)
+    const int rc = fill_trace_args(A, "epsm_trace_paths_color", scene, sensor, seed, spp, max_depth, rr_depth, path_offset, N, 0,
+                                   dummy_rays, dummy_rays, dummy_rays, dummy_rays, film_pos, radiance, valid, nullptr, 0);
+    if (rc != EPSM_OK) return rc;
+    A.ray_o = A.ray_d = A.ray_dx = A.ray_dy = nullptr;
+    A.color_sum = color_sum; A.n_color = n_color;
+    hipError_t e = hipMemsetAsync(color_sum, 0, (size_t) N * n_color * 3 * sizeof(float), (hipStream_t) stream);
+    if (e != hipSuccess) return epsm_host::hip_fail("epsm_trace_paths_color", e);
+    hipLaunchKernelGGL(epsm_trace_kernel, dim3((unsigned) ((N + 127) / 128)), dim3(128), 0, (hipStream_t) stream, A);
+    e = hipGetLastError();
+    if (e != hipSuccess) return epsm_host::hip_fail("epsm_trace_paths_color", e);
+    return EPSM_OK;
+}
+
 extern "C" size_t epsm_trace_workspace_bytes(int64_t N) { return N > 0 ? wf_workspace_bytes(N) : 0; }
 
 extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSensor *sensor,

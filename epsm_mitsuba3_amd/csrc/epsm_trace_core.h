@@ -485,6 +485,7 @@ struct EmitterSample {
     float pdf, dist;
     bool delta, valid;
     uint32_t tri; float b0, b1;      // triangle id + barycentrics of the sampled point (parameter addressing)
+    int emitter;                     // index of the sampled emitter
 };
 EPSM_HD F3 emitter_normal(const EpsmScene &S, const EpsmMesh &m, const uint32_t *iv, float w0, float w1, float w2, F3 q0, F3 q1, F3 q2) {
     F3 n = normalize3(cross(q1 - q0, q2 - q0));
@@ -499,7 +500,7 @@ EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit
                                                Vis &vis) {
     EmitterSample e;
     e.p = e.n = e.d = e.weight = zero3<float>(); e.pdf = 0.f; e.dist = 0.f; e.delta = false; e.valid = false;
-    e.tri = kNoIndex; e.b0 = e.b1 = 0.f;
+    e.tri = kNoIndex; e.b0 = e.b1 = 0.f; e.emitter = -1;
     if (!active || S.n_emitters <= 0) return e;
     // scene.cpp:233-246: uniform emitter choice, the sample is re-used
     const int count = S.n_emitters;
@@ -511,6 +512,7 @@ EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit
         emitter_weight = (float) count;
     }
     const EpsmEmitter em = S.emitters[index];
+    e.emitter = (int) index;
     F3 radiance = ld3(em.radiance);
     if (em.type == EPSM_EMITTER_POINT) {                                  // point.cpp:96-115
         e.p = ld3(em.position);
@@ -630,6 +632,8 @@ struct TraceArgs {
     float *ray_o, *ray_d, *ray_dx, *ray_dy, *film_pos, *radiance;
     uint8_t *valid;
     EpsmRecordOut rec[kMaxVertices];
+    float *color_sum;                // epsm_trace_paths_color: (N, n_color, 3), else null
+    int n_color;
 };
 
 EPSM_HD void write_record(const EpsmRecordOut &R, int64_t i, bool active, const SurfHit &h, uint32_t flags,
@@ -724,6 +728,7 @@ struct PathState {
     int depth;
     bool active, prev_bsdf_delta;
     Pcg32 rng;
+    uint32_t cnt;                    // colour adjoint: vertices passed so far per BSDF colour slot, 8 bits each
 };
 
 // sample_rays (common.py:291-422) + the initial loop state
@@ -746,6 +751,7 @@ EPSM_HD PathState path_begin(const TraceArgs &A, int64_t i) {
     s.eta = 1.f; s.prev_bsdf_pdf = 1.f;
     s.depth = 0;
     s.active = true; s.prev_bsdf_delta = true;
+    s.cnt = 0u;
     return s;
 }
 EPSM_HD int path_max_depth(const TraceArgs &A) { return A.max_depth < 6 ? A.max_depth : 6; }   // epsm.py:549
@@ -765,7 +771,7 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
     bsdf.type = EPSM_BSDF_DIFFUSE_T; bsdf.twosided = 0; bsdf.distr = 0; bsdf.sample_visible = 1; bsdf.alpha = 0.1f;
     bsdf.reflectance[0] = bsdf.reflectance[1] = bsdf.reflectance[2] = 0.f;
     bsdf.eta[0] = bsdf.eta[1] = bsdf.eta[2] = 0.f; bsdf.k[0] = bsdf.k[1] = bsdf.k[2] = 1.f;
-    bsdf.int_ior = 1.5046f; bsdf.ext_ior = 1.000277f; bsdf.alpha_slot = -1; bsdf.pad = 0;
+    bsdf.int_ior = 1.5046f; bsdf.ext_ior = 1.000277f; bsdf.alpha_slot = -1; bsdf.color_slot = -1;
     uint32_t flags = 0;
     if (si.valid && si.bsdf >= 0) { bsdf = S.bsdfs[si.bsdf]; flags = bsdf_flags(bsdf); }
 
@@ -808,6 +814,26 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
         } else {
             write_dead_masks(A.rec[iteration], i);
         }
+    }
+    // ---- colour adjoint (epsm_trace_paths_color; needs the final Lr_dir, i.e. the one-launch form): this path's row of
+    //      color_sum gets, per BSDF slot j, (vertices of j the term passed) x term, and per emitter slot the term itself
+    if (A.color_sum && s.active) {
+        float *G = A.color_sum + i * A.n_color * 3;
+        const int here = (si.valid && bsdf.color_slot >= 0 && bsdf.color_slot < A.n_color) ? bsdf.color_slot : -1;
+        for (int j = 0; j < A.n_color; ++j) {
+            const float n = (float) ((s.cnt >> (8 * j)) & 0xFFu);
+            const float nd = n + (j == here ? 1.f : 0.f);                  // the emitter-sample term includes this vertex's BSDF
+            G[3 * j] += n * Le.x + nd * Lr_dir.x; G[3 * j + 1] += n * Le.y + nd * Lr_dir.y; G[3 * j + 2] += n * Le.z + nd * Lr_dir.z;
+        }
+        if (si.valid && si.emitter >= 0) {
+            const int se = S.emitters[si.emitter].color_slot;
+            if (se >= 0 && se < A.n_color) { G[3 * se] += Le.x; G[3 * se + 1] += Le.y; G[3 * se + 2] += Le.z; }
+        }
+        if (es.emitter >= 0) {
+            const int se = S.emitters[es.emitter].color_slot;
+            if (se >= 0 && se < A.n_color) { G[3 * se] += Lr_dir.x; G[3 * se + 1] += Lr_dir.y; G[3 * se + 2] += Lr_dir.z; }
+        }
+        if (here >= 0 && bs.valid) s.cnt += 1u << (8 * here);              // the sampled direction carries one more factor rho_j
     }
     // ---- update (epsm.py:658-683)
     if (s.active) vis.direct(s.L, Le, Lr_dir);

@@ -194,6 +194,101 @@ class ManifoldCausticIntegrator(EPSMIntegrator):
     variant = "manifold_caustic"
 
 
+def film_adjoint(film_pos: torch.Tensor, grad_img: torch.Tensor, weight_img: torch.Tensor, rfilter: int) -> torch.Tensor:
+    """Adjoint of ImageBlock::put + film.develop (``epsm_film_splat`` / ``epsm_film_develop``) w.r.t. the radiance of
+    every sample: image[p] = sum_i w_ip L_i / W_p, so dL_i = sum_p grad[p] w_ip / W_p -- the box filter touches the
+    pixel under the sample, the gaussian (stddev 0.5, radius 2, src/rfilters/gaussian.cpp) its 5x5 window.
+    ``film_pos (n,2)``, ``grad_img (H,W,3)``, ``weight_img (H,W)`` = W_p of the primal pass; returns ``(n,3)``."""
+    H, W = weight_img.shape
+    g = grad_img[..., :3] / weight_img.clamp_min(1e-30)[..., None]
+    g = torch.where((weight_img > 0)[..., None], g, torch.zeros_like(g))
+    px, py = film_pos[:, 0], film_pos[:, 1]
+    X, Y = torch.floor(px).long(), torch.floor(py).long()
+    if rfilter == 0:                                      # EPSM_RFILTER_BOX
+        ok = (X >= 0) & (Y >= 0) & (X < W) & (Y < H)
+        return g[Y.clamp(0, H - 1), X.clamp(0, W - 1)] * ok[:, None]
+    radius, alpha = 2.0, -1.0 / (2.0 * 0.5 * 0.5)
+    bias = math.exp(alpha * radius * radius)
+    off = torch.arange(-2, 3, device=film_pos.device)
+    xs, ys = X[:, None] + off[None, :], Y[:, None] + off[None, :]             # (n,5)
+    dx, dy = (xs.float() + 0.5) - px[:, None], (ys.float() + 0.5) - py[:, None]
+    wx = torch.where(dx.abs() <= radius, (torch.exp(alpha * dx * dx) - bias).clamp_min(0), torch.zeros_like(dx))
+    wy = torch.where(dy.abs() <= radius, (torch.exp(alpha * dy * dy) - bias).clamp_min(0), torch.zeros_like(dy))
+    wx = wx * ((xs >= 0) & (xs < W)); wy = wy * ((ys >= 0) & (ys < H))
+    gw = g[ys.clamp(0, H - 1)[:, :, None], xs.clamp(0, W - 1)[:, None, :]]      # (n,5,5,3)
+    return (gw * (wy[:, :, None] * wx[:, None, :])[..., None]).sum(dim=(1, 2))
+
+
+class PRBIntegrator:
+    """Second phase of the reference's ``*_hybrid`` scheme (EPSM/optim.py:87-94, 113-119 switch to ``prb_reparam`` after
+    ``thres`` iterations): a 3-channel image and the COLOUR adjoint -- ``render_backward`` takes ``grad_in (H,W,3)``
+    (the branch of epsm.py:230-234) and accumulates d sum(image * grad_in) / d theta for the colour parameters attached
+    to the scene (``Scene.attach_color``: diffuse reflectances, ``Scene.attach_radiance``: emitters) into
+    ``params.color``.  Path replay with detached sampling as in prb.py: one pass of ``epsm_trace_paths_color`` under the
+    primal pass's seed returns, per path, the radiance and its derivative sums; the film's adjoint turns ``grad_in``
+    into the adjoint radiance of every sample.  What ``prb_reparam`` adds on top -- the warp field that makes
+    visibility differentiable, i.e. gradients of vertex positions through silhouettes (ad/reparam.py) -- is NOT
+    implemented: ``reparam`` is False and geometry receives nothing in this phase."""
+    reparam = False
+
+    def __init__(self, props: Optional[dict] = None):
+        props = dict(props or {})
+        max_depth = props.get("max_depth", 6)
+        if max_depth < 0 and max_depth != -1:
+            raise Exception("\"max_depth\" must be set to -1 (infinite) or a value >= 0")
+        self.max_depth = max_depth
+        self.rr_depth = props.get("rr_depth", 5)
+
+    def _depth(self) -> int:
+        return 1 << 20 if self.max_depth < 0 else int(self.max_depth)
+
+    def to_string(self):
+        return f"PRBIntegrator[max_depth = {self.max_depth}, rr_depth = {self.rr_depth}, reparam = False]"
+
+    __repr__ = to_string
+
+    def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True):
+        if not develop:
+            raise Exception("develop=True must be specified when invoking AD integrators")
+        self.primal_image = scene.render_primal(sensor=sensor, seed=seed, spp=spp, max_depth=self._depth())[..., :3]
+        return self.primal_image
+
+    def render_backward(self, scene, params: ParamGrads, grad_in: torch.Tensor, sensor=0, seed: int = 0, spp: int = 0) -> None:
+        """Accumulates into ``params.color`` (one all-reduce of this call's contribution when there are several ranks)."""
+        if not getattr(scene, "color_slots", None):
+            return                                  # nothing this phase can differentiate (geometry needs the warp field)
+        si = min(sensor, len(scene.sensors) - 1)
+        s = scene.sensors[si]
+        spp = spp or s.spp
+        n_total = s.width * s.height * spp
+        rank, world = _dist.world()
+        lib = scene._backend if scene._backend is not None else __import__("epsm_mitsuba3_amd")._lib.lib()
+        stream = torch.cuda.current_stream(scene.device).cuda_stream if scene.device.type == "cuda" else None
+        import ctypes as C
+        accum = torch.zeros((s.height, s.width, 4), device=scene.device, dtype=torch.float32)
+        tiles = _dist.tile_ranges(n_total, scene.tile_paths)
+        kept = []
+        for t in _dist.my_tiles(len(tiles), rank, world):
+            lo, hi = tiles[t]
+            film_pos, radiance, sums = scene.trace_color(si, seed, spp, min(self._depth(), 6), lo, hi)
+            rc = lib.epsm_film_splat(C.c_int64(hi - lo), C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()),
+                                     s.width, s.height, s.rfilter, C.c_void_p(accum.data_ptr()), C.c_void_p(stream))
+            assert rc == 0, "epsm_film_splat failed"
+            kept.append((film_pos, sums))
+        if world > 1:
+            _dist.allreduce_param_grads(accum)
+        g = grad_in.to(scene.device, torch.float32)[: s.height, : s.width, :3]
+        values = scene.color_values()                                   # (C,3)
+        contrib = torch.zeros_like(values)
+        for film_pos, sums in kept:
+            dL = film_adjoint(film_pos, g, accum[..., 3], s.rfilter)    # (n,3)
+            contrib += (sums * dL[:, None, :]).sum(dim=0)
+        contrib = contrib / values.clamp_min(1e-12)
+        if world > 1:
+            _dist.allreduce_param_grads(contrib)
+        params.color += contrib
+
+
 # -- plugin registry (mi.register_integrator / mi.load_dict) -------------------
 _REGISTRY: Dict[str, Callable[[dict], EPSMIntegrator]] = {}
 
@@ -212,3 +307,5 @@ def load_dict(d: dict) -> EPSMIntegrator:
 
 register_integrator("manifold", lambda props: ManifoldIntegrator(props))                  # epsm.py:948
 register_integrator("manifold_caustic", lambda props: ManifoldCausticIntegrator(props))   # epsm.py:1202
+register_integrator("prb", lambda props: PRBIntegrator(props))
+register_integrator("prb_reparam", lambda props: PRBIntegrator(props))    # EPSM/optim.py:89-92 asks for this name; colour adjoint only

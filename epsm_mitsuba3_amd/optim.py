@@ -5,8 +5,12 @@
 render (H,W,5) -> tone-map + resize to ``match_res`` -> Sinkhorn matcher -> 5-channel gradient image tiled
 back to the film size (optim.py:130-135) -> ``render_backward`` -> chain rule into the optimised leaves
 -> NaN scrub (optim.py:143-154) -> Adam step (torch, as the reference's optim_human.py does).
-The ``*_hybrid`` second phase (prb_reparam after ``thres`` iterations, optim.py:87-94,113-119) is not
-built: a hybrid METHOD runs its manifold phase only and says so.
+``*_hybrid`` (optim.py:87-94, 113-119): after ``tasks.thres`` iterations the optimiser state is reset and the loop
+switches to the ``prb_reparam`` integrator on sensor 0 with the L2 image loss of optim.py:137-141
+(``grad_in = 2 (img - ref) / len(img)``, 3 channels).  That integrator's backward pass here is the COLOUR adjoint
+only (integrators.PRBIntegrator: diffuse reflectances / emitter radiances attached with Scene.attach_color /
+attach_radiance); the reparameterised visibility gradients of vertex positions are not built, so geometric
+parameters stop moving in the second phase -- the loop says so.
 """
 from __future__ import annotations
 
@@ -40,9 +44,13 @@ def chain_vertex_grads(vertices: torch.Tensor, vertex_grad: torch.Tensor) -> Non
 
 def run(method: str, exp: str, device="cuda", iterations=None, lr=0.02, log=print):
     tasks = importlib.import_module(f"epsm_mitsuba3_amd.exp.{exp}")
-    if method.endswith("hybrid"):
+    thres, integrator2 = 10000, None                                            # optim.py:93-94
+    if method.endswith("hybrid"):                                               # optim.py:87-92
         method = method[:-7]
-        log("hybrid: the prb_reparam phase is not built; running the manifold phase for all iterations")
+        integrator2 = load_dict({"type": "prb_reparam", "max_depth": tasks.max_depth})
+        thres = getattr(tasks, "thres", 10000)
+        log(f"hybrid: switching to {integrator2} after {thres} iterations (colour adjoint only: geometry gradients of "
+            f"prb_reparam's warp field are not built)")
     scene = tasks.load_scene(device)
     integrator = load_dict({"type": method, "max_depth": tasks.max_depth})
     sensor_id = 1 if method.startswith("manifold") else 0                      # optim.py:103-106
@@ -56,12 +64,23 @@ def run(method: str, exp: str, device="cuda", iterations=None, lr=0.02, log=prin
     rep = tasks.resolution // tasks.match_res
     for it in range(iterations or tasks.it):
         apply_transformation(scene, opt)                                        # optim.py:112
-        img = integrator.render(scene, sensor=sensor_id, seed=it, spp=tasks.spp)             # (H,W,5)
-        render_low = resize(to_ldr(img[..., :3]), tasks.match_res)
-        grad_ = matcher.match_Sinkhorn(render_low.reshape(-1, 3), gt_low.reshape(-1, 3))
-        grad = grad_.reshape(tasks.match_res, tasks.match_res, 5).repeat(rep, rep, 1)         # optim.py:133-135
+        if it < thres:
+            integ, sid = integrator, sensor_id
+        else:
+            if it == thres:                                                     # optim.py:116-118: opt.reset(key)
+                optimizer = torch.optim.Adam(list(opt.values()), lr=lr)
+            integ, sid = integrator2, 0
+        img = integ.render(scene, sensor=sid, seed=it, spp=tasks.spp)           # (H,W,5) or (H,W,3)
+        params = scene.param_grads() if params.flat.numel() != scene.param_grads().flat.numel() else params
         params.zero_()
-        integrator.render_backward(scene, params, grad, sensor=sensor_id, seed=it, spp=tasks.spp)   # dr.backward(img*grad)
+        if img.shape[-1] == 5:                                                  # optim.py:130-136
+            render_low = resize(to_ldr(img[..., :3]), tasks.match_res)
+            grad_ = matcher.match_Sinkhorn(render_low.reshape(-1, 3), gt_low.reshape(-1, 3))
+            grad = grad_.reshape(tasks.match_res, tasks.match_res, 5).repeat(rep, rep, 1)         # optim.py:133-135
+        else:                                                                   # optim.py:137-141: L2 against the reference
+            ref = gt if tuple(gt.shape[:2]) == tuple(img.shape[:2]) else resize(gt, img.shape[0])
+            grad = 2.0 * (img - ref[..., :3]) / img.shape[0]
+        integ.render_backward(scene, params, grad, sensor=sid, seed=it, spp=tasks.spp)   # dr.backward(img*grad) / dr.backward(loss)
         backward(opt, params)
         for p in opt.values():                                                  # optim.py:143-154
             if p.grad is not None:

@@ -54,11 +54,12 @@ class EpsmMesh(C.Structure):
 class EpsmBsdf(C.Structure):
     _fields_ = [("type", C.c_uint32), ("twosided", C.c_uint32), ("distr", C.c_uint32), ("sample_visible", C.c_uint32),
                 ("reflectance", C.c_float * 3), ("alpha", C.c_float), ("eta", C.c_float * 3), ("k", C.c_float * 3),
-                ("int_ior", C.c_float), ("ext_ior", C.c_float), ("alpha_slot", C.c_int32), ("pad", C.c_uint32)]
+                ("int_ior", C.c_float), ("ext_ior", C.c_float), ("alpha_slot", C.c_int32), ("color_slot", C.c_int32)]
 
 
 class EpsmEmitter(C.Structure):
-    _fields_ = [("type", C.c_uint32), ("mesh", C.c_int32), ("radiance", C.c_float * 3), ("position", C.c_float * 3)]
+    _fields_ = [("type", C.c_uint32), ("mesh", C.c_int32), ("radiance", C.c_float * 3), ("position", C.c_float * 3),
+                ("color_slot", C.c_int32), ("pad", C.c_uint32)]
 
 
 class EpsmSensor(C.Structure):
@@ -424,6 +425,7 @@ class Scene:
         self.device = torch.device(device)
         self.tile_paths = tile_paths
         self.alpha_slots: Dict[int, int] = {}
+        self.color_slots: List[tuple] = []         # colour parameters attached for the colour adjoint: ("bsdf" | "emitter", index)
         self.rr_depth = 5
         # test hook: tests/host_harness compiles the tracer's per-path code for the CPU and plugs
         # its entry points in here; the product path (None) is the HIP library and needs a GPU
@@ -540,6 +542,41 @@ class Scene:
         self._upload()
         return self.alpha_slots[i]
 
+    def attach_color(self, bsdf_name: str) -> int:
+        """``dr.enable_grad(params['<bsdf>.reflectance.value'])`` for the colour adjoint (PRBIntegrator): diffuse BSDFs."""
+        i = self.bsdf_names.index(bsdf_name)
+        if self.bsdf_desc[i]["type"] != 0:
+            raise ValueError("attach_color: only the reflectance of a diffuse BSDF is a colour parameter here")
+        if ("bsdf", i) not in self.color_slots:
+            if len(self.color_slots) >= 4:
+                raise ValueError("at most 4 colour parameters")
+            self.color_slots.append(("bsdf", i))
+            self._upload()
+        return self.color_slots.index(("bsdf", i))
+
+    def attach_radiance(self, mesh_or_index) -> int:
+        """``dr.enable_grad(params['<emitter>.radiance.value'])``: by emitting mesh name (area light) or emitter index."""
+        i = mesh_or_index if isinstance(mesh_or_index, int) else self.mesh(mesh_or_index).emitter
+        if not (0 <= i < len(self.emitter_desc)):
+            raise ValueError("attach_radiance: not an emitter")
+        if ("emitter", i) not in self.color_slots:
+            if len(self.color_slots) >= 4:
+                raise ValueError("at most 4 colour parameters")
+            self.color_slots.append(("emitter", i))
+            self._upload()
+        return self.color_slots.index(("emitter", i))
+
+    def color_values(self) -> torch.Tensor:
+        """(C,3) current values of the attached colour parameters, slot order."""
+        rows = [self.bsdf_desc[i]["reflectance"] if kind == "bsdf" else self.emitter_desc[i]["radiance"] for kind, i in self.color_slots]
+        return torch.tensor([[float(x) for x in r] for r in rows], dtype=torch.float32, device=self.device).reshape(-1, 3)
+
+    def set_color(self, slot: int, rgb):
+        """``params[...] = rgb; params.update()`` for colour slot ``slot``."""
+        kind, i = self.color_slots[slot]
+        (self.bsdf_desc[i] if kind == "bsdf" else self.emitter_desc[i])["reflectance" if kind == "bsdf" else "radiance"] = [float(x) for x in rgb]
+        self._upload()
+
     def set_alpha(self, bsdf_name: str, alpha: float):
         """``params['<bsdf>.alpha.value'] = alpha; params.update()``: only the BSDF table is rewritten (in place)."""
         self.bsdf_desc[self.bsdf_names.index(bsdf_name)]["alpha"] = float(alpha)
@@ -555,6 +592,7 @@ class Scene:
             c.eta[:] = [float(x) for x in b["eta"]]; c.k[:] = [float(x) for x in b["k"]]
             c.int_ior, c.ext_ior = float(b["int_ior"]), float(b["ext_ior"])
             c.alpha_slot = self.alpha_slots.get(i, -1)
+            c.color_slot = self.color_slots.index(("bsdf", i)) if ("bsdf", i) in self.color_slots else -1
         return bs
 
     def set_vertex_positions(self, mesh_name: str, v):
@@ -594,7 +632,8 @@ class Scene:
         return self.positions[lo:hi]
 
     def param_grads(self) -> ParamGrads:
-        return ParamGrads(self.V, len(self.alpha_slots), device=self.device, mesh_slices=self.mesh_slices)
+        return ParamGrads(self.V, len(self.alpha_slots), device=self.device, mesh_slices=self.mesh_slices,
+                          n_colors=len(self.color_slots))
 
     # -- upload ----------------------------------------------------------------------------------
     def _upload(self):
@@ -646,6 +685,7 @@ class Scene:
             c = em[i]
             c.type, c.mesh = e["type"], e["mesh"]
             c.radiance[:] = [float(x) for x in e["radiance"]]; c.position[:] = [float(x) for x in e["position"]]
+            c.color_slot = self.color_slots.index(("emitter", i)) if ("emitter", i) in self.color_slots else -1
         as_dev = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self._mesh_buf, self._bsdf_buf, self._em_buf = as_dev(mesh_c), as_dev(bs), as_dev(em)
         s = EpsmSceneC()
@@ -669,6 +709,30 @@ class Scene:
         if self.tracer not in ("auto", "mega", "wavefront"):
             raise ValueError("Scene.tracer must be 'auto', 'mega' or 'wavefront'")
         return self.tracer == "wavefront" or (self.tracer == "auto" and self.T >= self.WAVEFRONT_MIN_TRIANGLES)
+
+    def trace_color(self, sensor_index: int, seed: int, spp: int, max_depth: int, lo: int, hi: int):
+        """``epsm_trace_paths_color``: film positions, radiance and the per-path colour sums (n, C, 3) of paths [lo, hi)."""
+        dev = self.device
+        if dev.type != "cuda" and self._backend is None:
+            raise _lib.EpsmError("the tracer runs on the GPU only (no CPU fallback)")
+        lib = self._backend if self._backend is not None else _lib.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+        n, Cn = hi - lo, len(self.color_slots)
+        if Cn == 0:
+            raise ValueError("no colour parameter attached (Scene.attach_color / attach_radiance)")
+        film_pos = torch.empty((n, 2), device=dev, dtype=torch.float32)
+        radiance = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        valid = torch.empty((n,), device=dev, dtype=torch.uint8)
+        sums = torch.empty((n, Cn, 3), device=dev, dtype=torch.float32)
+        cs = self.sensors[sensor_index].c_struct()
+        fn = lib.epsm_trace_paths_color
+        fn.restype = C.c_int
+        rc = fn(C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
+                C.c_int64(lo), C.c_int64(n), C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()),
+                C.c_void_p(valid.data_ptr()), C.c_void_p(sums.data_ptr()), int(Cn), C.c_void_p(stream))
+        if rc != 0:
+            _lib.check(rc, "epsm_trace_paths_color") if self._backend is None else (_ for _ in ()).throw(RuntimeError(f"host tracer rc={rc}"))
+        return film_pos, radiance, sums
 
     def _trace_packed(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int):
         """The same trace with the vertex log in the NATIVE layout of the backward kernel (EPSM_TRACE_PACKED_LOG,

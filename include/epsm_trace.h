@@ -79,7 +79,8 @@ typedef struct EpsmBsdf {
     float eta[3], k[3];              /* conductor complex IOR; eta = 0,k = 1 is the '100 % reflecting mirror' */
     float int_ior, ext_ior;          /* dielectric */
     int32_t alpha_slot;              /* slot of this BSDF's alpha in grad_alpha, -1 = not optimised */
-    uint32_t pad;
+    int32_t color_slot;              /* diffuse: slot of `reflectance` in the colour adjoint of epsm_trace_paths_color,
+                                        -1 = not optimised */
 } EpsmBsdf;
 
 typedef struct EpsmEmitter {
@@ -87,6 +88,8 @@ typedef struct EpsmEmitter {
     int32_t mesh;                    /* area: emitting mesh */
     float radiance[3];               /* area: radiance; point: intensity */
     float position[3];               /* point */
+    int32_t color_slot;              /* slot of `radiance` in the colour adjoint, -1 = not optimised */
+    uint32_t pad;
 } EpsmEmitter;
 
 typedef struct EpsmBvhNode {         /* 64 bytes: one load brings the boxes of BOTH children */
@@ -173,6 +176,24 @@ int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSensor *sensor,
                                float *ray_o, float *ray_d, float *ray_dx, float *ray_dy,
                                float *film_pos, float *radiance, uint8_t *valid,
                                const EpsmRecordOut *recs, uint32_t flags, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * epsm_trace_paths_color -- epsm_trace_paths (no vertex log) that also returns, per path, the derivative of its
+ *   radiance w.r.t. the COLOUR parameters attached to the scene (EpsmBsdf.color_slot: diffuse reflectance;
+ *   EpsmEmitter.color_slot: emitted radiance / intensity) -- the colour adjoint of the reference's hybrid phase
+ *   (3-channel grad_in: epsm.py:230-234 -> prb-style backward, src/python/python/ad/integrators/prb.py) for parameters
+ *   the radiance is multiplicative in.  Sampling is detached as in PRB: a term T of the estimator that passed n_j
+ *   vertices of BSDF j satisfies dT/d rho_j,c = n_j T_c / rho_j,c, and dT/dE_e,c = T_c / E_e,c for the emitter it ends on.
+ *     color_sum   (N, n_color, 3) f32, written: sum over the path's terms of n_j T_c (BSDF slots) / T_c (emitter
+ *                 slots); the caller divides by the parameter value and contracts with the adjoint radiance
+ *     n_color     number of slots, <= 4
+ *   One-launch form only.  Visibility / geometry derivatives (prb_reparam's warp field) are NOT part of it.
+ * ------------------------------------------------------------------------- */
+int epsm_trace_paths_color(const EpsmScene *scene, const EpsmSensor *sensor,
+                           uint32_t seed, int spp, int max_depth, int rr_depth,
+                           int64_t path_offset, int64_t N,
+                           float *film_pos, float *radiance, uint8_t *valid,
+                           float *color_sum, int n_color, void *stream);
 
 /* epsm_film_splat -- ImageBlock::put + weight division (film.develop): accumulates
  * radiance with the reconstruction filter into accum (height,width,4) [r,g,b,w] (atomics);

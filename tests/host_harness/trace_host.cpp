@@ -29,6 +29,25 @@ extern "C" int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor
     return 0;
 }
 
+extern "C" int epsm_trace_paths_color(const EpsmScene *scene, const EpsmSensor *sensor, uint32_t seed, int spp, int max_depth,
+                                      int rr_depth, int64_t path_offset, int64_t N, float *film_pos, float *radiance,
+                                      uint8_t *valid, float *color_sum, int n_color, void *) {
+    TraceArgs A;
+    memset(&A, 0, sizeof(A));
+    A.S = *scene; A.C = *sensor;
+    A.seed = seed; A.spp = spp; A.max_depth = max_depth; A.rr_depth = rr_depth; A.K_log = 0;
+    A.path_offset = path_offset; A.N = N;
+    A.film_pos = film_pos; A.radiance = radiance; A.valid = valid;
+    A.color_sum = color_sum; A.n_color = n_color;
+    memset(color_sum, 0, (size_t) N * n_color * 3 * sizeof(float));
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < N; ++i) {
+        uint32_t stack[kBvhStack];
+        trace_one_path(A, i, BvhStack{stack, 1});
+    }
+    return 0;
+}
+
 // The wavefront form, stage by stage as the device launches them (serial loops in place of the kernels; the queues
 // are appended in path order here, on the device in the order the waves arrive -- per-path results do not depend on it).
 extern "C" size_t epsm_trace_workspace_bytes(int64_t N) { return N > 0 ? wf_workspace_bytes(N) : 0; }
