@@ -10,9 +10,12 @@ rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "epsm" --output-format csv -d 
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "epsm" --output-format csv -d ${T}_pmc_write -- $B > ${T}_pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "epsm" --output-format csv -d ${T}_pmc_calib -- $B --separate-tangent > ${T}_pmc3.log 2>&1
 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-include-regex "epsm" --output-format csv -d ${T}_pmc_req -- $B > ${T}_pmc4.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-include-regex "epsm_grad" --output-format csv -d ${T}_pmc_sq -- $B > ${T}_pmc5.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU --kernel-include-regex "epsm_grad" --output-format csv -d ${T}_pmc_sq -- $B > ${T}_pmc5.log 2>&1
+(cd tools/micro && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o gather128 gather128.hip > /dev/null 2>&1)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d ${T}_pmc_gather -- tools/micro/gather128 > ${T}_pmc6.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d ${T}_pmc_gather5 -- tools/micro/gather128 5 > ${T}_pmc7.log 2>&1
 python tools/summarize_rocprof.py ${T}_trace > ${T}_kernel_stats.txt 2>&1
-{ for d in fetch write calib req sq; do python tools/summarize_rocprof.py ${T}_pmc_$d; done; } > ${T}_pmc_traffic.txt 2>&1
-python tools/make_traffic_json.py ${T}_pmc_fetch ${T}_pmc_write ${T}_pmc_calib --tag ${2:-r02_b} > ${T}_traffic_entry.json 2>&1
+{ for d in fetch write calib req sq gather gather5; do python tools/summarize_rocprof.py ${T}_pmc_$d; done; } > ${T}_pmc_traffic.txt 2>&1
+python tools/make_traffic_json.py ${T}_pmc_fetch ${T}_pmc_write ${T}_pmc_calib --tag ${2:-r02_c} --packed --gather-calib ${T}_pmc_gather > ${T}_traffic_entry.json 2>&1
 cp profiles/traffic.json ${T}_traffic.json
-head -12 ${T}_kernel_stats.txt; tail -12 ${T}_traffic_entry.json
+head -8 ${T}_kernel_stats.txt; tail -14 ${T}_traffic_entry.json; grep -A3 gather128 ${T}_pmc_traffic.txt | head -12

@@ -6,6 +6,9 @@ are known) + WRITE_SIZE (exact for stores and float atomics).  Every entry is st
 sources it was measured on (bench.kernel_source_hash); bench.py refuses entries of other sources.
 
     python tools/make_traffic_json.py FETCH_DIR WRITE_DIR [CALIB_FETCH_DIR] --paths N --K 5 --variant manifold --profile bathroom --tag r02_b
+    [--packed --gather-calib DIR]   the run was on the native packed log (kernel <..., true>); DIR = FETCH_SIZE of
+                                    tools/micro/gather128 (N x 128 B read by per-lane 16-byte gathers), which fixes the
+                                    factor for THAT access pattern instead of the x2 of wide coalesced reads
 """
 import argparse
 import csv
@@ -41,10 +44,12 @@ def main():
     ap.add_argument("--paths", type=int, default=1 << 24); ap.add_argument("--K", type=int, default=5)
     ap.add_argument("--variant", default="manifold"); ap.add_argument("--profile", default="bathroom")
     ap.add_argument("--tag", default="r02")
+    ap.add_argument("--packed", action="store_true"); ap.add_argument("--gather-calib", default=None)
     a = ap.parse_args()
     import bench
-    fk, fv = pick(counters(a.fetch_dir, "FETCH_SIZE"), "epsm_grad_scatter_kernel")
-    wk, wv = pick(counters(a.write_dir, "WRITE_SIZE"), "epsm_grad_scatter_kernel")
+    needle = "true>" if a.packed else "epsm_grad_scatter_kernel"
+    fk, fv = pick({k: v for k, v in counters(a.fetch_dir, "FETCH_SIZE").items() if "epsm_grad_scatter_kernel" in k}, needle)
+    wk, wv = pick({k: v for k, v in counters(a.write_dir, "WRITE_SIZE").items() if "epsm_grad_scatter_kernel" in k}, needle)
     if not fv or not wv:
         raise SystemExit("no FETCH_SIZE / WRITE_SIZE rows for epsm_grad_scatter_kernel")
     fetch_kb, write_kb = sum(fv) / len(fv), sum(wv) / len(wv)          # rocprofv3 reports both in KB
@@ -55,11 +60,19 @@ def main():
             known = 85 * a.paths                                    # o, d, dx, dy, p0, p1, p2 (7 x 12 B) + active (1 B) per path
             note = (f"; calibration in the same session: epsm_tangent_kernel reads {known / 1e9:.3f} GB, FETCH_SIZE reported "
                     f"{sum(cv) / len(cv) * 1024 / 1e9:.3f} GB")
-    total = int(2 * fetch_kb * 1024 + write_kb * 1024)
-    entry = {"kernel": "epsm_backward_pass", "paths": a.paths, "K": a.K, "variant": a.variant, "profile": a.profile,
+    factor, fnote = 2.0, "x 2 (gfx950 half-count of wide coalesced reads)"
+    if a.packed and a.gather_calib:
+        gk, gv = pick(counters(a.gather_calib, "FETCH_SIZE"), "gather128")
+        if gv:
+            known = (1 << 23) * 128
+            factor = known / (sum(gv) / len(gv) * 1024)
+            fnote = (f"x {factor:.3f} (calibrated on tools/micro/gather128: {known / 1e9:.3f} GB read by per-lane 16-byte gathers of "
+                     f"128-byte records, FETCH_SIZE reported {sum(gv) / len(gv) * 1024 / 1e9:.3f} GB)")
+    total = int(factor * fetch_kb * 1024 + write_kb * 1024)
+    entry = {"kernel": "epsm_backward_pass_packed" if a.packed else "epsm_backward_pass", "paths": a.paths, "K": a.K, "variant": a.variant, "profile": a.profile,
              "hbm_bytes_per_launch": total, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
              "dispatches": [len(fv), len(wv)], "src_hash": bench.kernel_source_hash(),
-             "source": f"profiles/{a.tag}_pmc_traffic.txt ({fk[:60]}...): FETCH_SIZE {fetch_kb:,.0f} KB x 2 (gfx950 half-count) + "
+             "source": f"profiles/{a.tag}_pmc_traffic.txt ({fk[:60]}...): FETCH_SIZE {fetch_kb:,.0f} KB {fnote} + "
                        f"WRITE_SIZE {write_kb:,.0f} KB (stores + float atomics, exact); separate rocprofv3 --pmc passes{note}"}
     path = os.path.join(ROOT, "profiles", "traffic.json")
     old = json.load(open(path)) if os.path.isfile(path) else []

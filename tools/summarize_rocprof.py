@@ -34,7 +34,7 @@ def main(root):
             meta[k] = (row.get("VGPR_Count", "?"), row.get("SGPR_Count", "?"), row.get("LDS_Block_Size", "?"),
                        row.get("Grid_Size", "?"), row.get("Workgroup_Size", "?"))
         for k, counters in acc.items():
-            if "epsm" not in k:
+            if "epsm" not in k and "gather128" not in k:
                 continue
             v = meta[k]
             print(f"kernel {k}\n  vgpr={v[0]} sgpr={v[1]} lds={v[2]} grid={v[3]} wg={v[4]}")
