@@ -341,13 +341,20 @@ def main():
 
     # -- this rank's slabs, resident in HBM (content depends only on the slab index) ------------------------
     free_b, total_b = torch.cuda.mem_get_info(dev)
-    budget = min(free_b * 0.85, args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else float("inf"))
+    cap = args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else float("inf")
+    # bytes a slab keeps (its final layout) and the most its construction needs on top (the generator's per-field
+    # records, before they are repacked / trimmed)
+    keep_per_path = (52 + 128 * K) if packed_log else (48 + K * 139)
+    build_per_path = 48 + K * 200
     slabs, used0 = [], torch.cuda.memory_allocated(dev)
-    per_slab = None
     for s in my_slabs:
-        if per_slab is not None and (len(slabs) + 1) * per_slab + 2 * per_slab * 0.25 > budget:
-            break                                               # the rest re-uses the resident ones (reported below)
         lo, hi = s * slab_paths, min((s + 1) * slab_paths, N_image)
+        n_s = hi - lo
+        torch.cuda.empty_cache()
+        resident_now = torch.cuda.memory_allocated(dev) - used0
+        if slabs and (torch.cuda.mem_get_info(dev)[0] < 1.1 * n_s * (keep_per_path + build_per_path) + (2 << 30)
+                      or resident_now + n_s * keep_per_path > cap):
+            break                                               # the rest re-uses the resident ones (reported below)
         trace = scene.tile(s, lo, hi, seed=0, spp=spp, K=K, lean=True)
         if packed_log:
             keep_soa = rank == 0 and not slabs            # slab 0 of rank 0 also feeds the CPU baseline and the dense-kernel leg
@@ -358,9 +365,6 @@ def main():
             packed = (PackedRecords(trace.path_info, device=dev), PackedScatter(trace.scatter_info, device=dev, table=scene.triangle_table()))
         slabs.append((trace, packed))
         torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-        if per_slab is None:
-            per_slab = torch.cuda.memory_allocated(dev) - used0
     if not slabs:
         raise SystemExit("bench.py: not even one slab fits into HBM")
     resident_bytes = torch.cuda.memory_allocated(dev) - used0
