@@ -276,3 +276,22 @@ def test_render_backward_on_the_native_packed_log(tracer, max_depth):
     tiles = list(sc.iter_traces(sensor=0, seed=2, spp=spp, max_depth=max_depth, packed_log=True))
     assert len(tiles) == -(-res * res * spp // (max(5000, 1))) or sc.use_wavefront()
     assert all(t.log is not None and t.path_info is None for t in tiles)
+
+
+def test_unlimited_depth_integrator_renders_and_differentiates():
+    """``max_depth = -1`` (common.py:31-37: infinite) used to reach the tracer as 0xFFFFFFFF -> EINVAL.  The
+    logging trace stops at 6 bounces whatever the integrator says (epsm.py:549); the primal pass goes as deep as the
+    tracer does."""
+    import epsm_mitsuba3_amd as epsm
+    dev = torch.device("cuda", 0)
+    sc = _scene(dev)
+    integ = epsm.load_dict({"type": "manifold", "max_depth": -1})
+    assert integ.tracer_depth() == 6 and "4294967295" in repr(integ)
+    img = integ.render(sc, sensor=0, seed=1, spp=4)
+    assert tuple(img.shape) == (32, 32, 5) and bool(torch.isfinite(img).all()) and float(img[..., :3].max()) > 0
+    p = sc.param_grads()
+    g = torch.zeros((32, 32, 5), device=dev); g[..., 3:] = 1e-2
+    integ.backward_sensor = 0
+    integ.render_backward(sc, p, g, seed=1)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(p.flat).all()) and float(p.flat.abs().max()) > 0
