@@ -495,9 +495,11 @@ EPSM_HD F3 emitter_normal(const EpsmScene &S, const EpsmMesh &m, const uint32_t 
     if (m.flags & EPSM_MESH_FLIP_NORMALS) n = -n;
     return n;
 }
+// `test_now` = false leaves the visibility test (scene.cpp:270-275) to the caller, which may know that the sample
+// contributes nothing whatever the test says (path_bounce).
 template <class Vis>
 EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit &ref, float u, float v, bool active,
-                                               Vis &vis) {
+                                               Vis &vis, bool test_now = true) {
     EmitterSample e;
     e.p = e.n = e.d = e.weight = zero3<float>(); e.pdf = 0.f; e.dist = 0.f; e.delta = false; e.valid = false;
     e.tri = kNoIndex; e.b0 = e.b1 = 0.f; e.emitter = -1;
@@ -551,7 +553,7 @@ EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit
     e.pdf /= emitter_weight;                                              // scene.cpp:262-266
     e.weight = e.weight * emitter_weight;
     e.valid = e.pdf != 0.f;
-    if (e.valid) {                                                        // scene.cpp:270-275 test_visibility
+    if (e.valid && test_now) {                                            // scene.cpp:270-275 test_visibility
         float dist;
         const Ray sr = spawn_ray_to(ref, e.p, dist);
         if (vis.occluded(S, sr)) e.weight = zero3<float>();
@@ -786,7 +788,7 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
     bool active_next = (s.depth + 1 < A.max_depth) && si.valid;
     bool active_em = active_next && (flags & kFlSmooth);
     const float e1 = s.rng.next_1d(), e2 = s.rng.next_1d();              // sampler.next_2d()
-    const EmitterSample es = sample_emitter_direction(S, si, e1, e2, active_em, vis);
+    const EmitterSample es = sample_emitter_direction(S, si, e1, e2, active_em, vis, false);
     active_em = active_em && es.pdf != 0.f;                               // :590
     F3 Lr_dir = zero3<float>();
     if (active_em) {
@@ -795,6 +797,16 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
         bsdf_eval_pdf(bsdf, si.wi, wo, bval, bpdf);
         const float mis_em = es.delta ? 1.f : mis_weight(es.pdf, bpdf);
         Lr_dir = mul3(mul3(s.beta, bval), es.weight) * mis_em;            // :605
+        // The visibility ray of scene.cpp:270-275, AFTER the BSDF value is known: an occluded sample only zeroes
+        // ds.weight, i.e. Lr_dir and the logged emitter weight -- when they are zero already (emitter below the
+        // surface's horizon: half of the samples on a convex object) the ray decides nothing and is not traced.
+        // (The occluder record of the first vertex rides on this ray in the wavefront form: always traced then.)
+        const bool occluder_wanted = iteration == 0 && A.K_log > 0 && A.rec[0].shadow && A.max_depth <= 3;
+        if (es.valid && (Lr_dir.x != 0.f || Lr_dir.y != 0.f || Lr_dir.z != 0.f || occluder_wanted)) {
+            float dist;
+            const Ray sr = spawn_ray_to(si, es.p, dist);
+            if (vis.occluded(S, sr)) Lr_dir = zero3<float>();
+        }
     }
     // ---- occluder of the first vertex's emitter sample (epsm.py:609-620)
     if (iteration == 0 && A.K_log > 0 && A.rec[0].shadow) vis.occluder(A, i, si, es, active_em);
