@@ -598,6 +598,9 @@ EPSM_HD void manifold_path(const Args &A, int64_t i, int dcols, const Out &out) 
     });
 
     // ---- pass 2: backward recursion of the adjoint seeds + seeded sweeps
+    // (Tried: keeping the two unit-seed sweeps of the LAST vertex's light-sampling constraint in registers across the
+    // pass boundary -- pass 2 starts at that vertex and its seeded sweep there is their linear combination, ~200 of the
+    // ~700 VALU instructions of the step.  24 more live floats: fused kernel 3.95 -> 4.46 ms, dense 2.87 -> 3.09 ms.)
     V2<Q> carry = mk2<Q>(Q(0), Q(0));  // sum over deeper terms of their y_k
     int W = 0;                         // number of live terms with depth > k
     V3<R> GP = zero3<R>();             // d/dx_k through constraint k+1 (x_k as previous vertex)
