@@ -33,15 +33,17 @@ namespace {
 // wave drains a few items with most lanes idle; the table is flushed when a census finds it half full, and a window
 // of 1024 paths leaves ~1250 distinct rows on config 2).  Re-measured with the drain inlined: 2304/576 4.5-4.6,
 // 2432/544, 2560/512, 2816/448 4.7 (specular 14.5 / 13.3 / 11.7 against 15.9), 2048/640 5.25.
-#ifndef EPSM_TABLE_ROWS
-#define EPSM_TABLE_ROWS 2304
-#define EPSM_TABLE_ROWS_CAUSTIC 1280
-#define EPSM_QUEUE_CAP 576
-#define EPSM_WAVES_PER_SIMD 2
-#endif
-constexpr int kBits = EPSM_TABLE_ROWS;                // manifold: table rows, 16 B each (float sums) = 36 KB
-constexpr int kRowsCaustic = EPSM_TABLE_ROWS_CAUSTIC; // manifold_caustic: rows of 28 B (64-bit fixed-point sums, epsm_wave_scatter.h) = 35 KB
-constexpr int kQueueCap = EPSM_QUEUE_CAP;             // items per wave queue: 4 x 9 KB
+// Short chains (K <= 2 logged vertices: the reference's own backward size, exp/human.py max_depth 3) need <= 168
+// VGPRs, so THREE waves per SIMD are possible if three workgroups' LDS fits a CU: a smaller table and queues there.
+// Measured at 2^24 paths (config 2 with --vertices K; ms): K = 2: 2.84 -> 2.53, K = 1: 1.43 -> 1.30; from K = 3 on
+// the third wave costs spills (K = 3: 168 VGPRs + 240 B of scratch, 3.73 -> 4.21) and the large configuration stays.
+template <int K> struct Shape {
+    static constexpr bool kSmall = K <= 2;
+    static constexpr int kRows = kSmall ? 1408 : 2304;         // manifold: table rows, 16 B each (float sums)
+    static constexpr int kRowsCaustic = kSmall ? 800 : 1280;   // manifold_caustic: rows of 28 B (64-bit fixed-point sums)
+    static constexpr int kQueueCap = kSmall ? 384 : 576;       // items per wave queue (a push is at most 6 rows x 64 lanes)
+    static constexpr int kWaves = kSmall ? 3 : 2;              // waves per SIMD the register budget is set for
+};
 constexpr int kFusedBlocks = 2048;             // 512 / 1024 / 8192 measured within 2 %
 
 struct FusedArgs {
@@ -183,7 +185,7 @@ template <bool FLAGS_IN_LDS, int DMODE, bool PACKED> struct LdsArgs {
 // (measured on the bathroom / specular / pool profiles: 4, 8, 16, 32 for the triangle rows)
 constexpr int kMinMergeLanes = 16, kMinMergeLanesAlpha = 4;
 
-template <typename Table, bool PACKED> struct ScatterOut {
+template <typename Table, bool PACKED, int kQueueCap> struct ScatterOut {
     const FusedArgs &F;
     const PtrTable &P;
     const Table &T;
@@ -435,8 +437,9 @@ namespace {
 
 template <int K, int VARIANT, int DMODE, bool PACKED>
 // waves-per-SIMD 2: without it hipcc budgets 128 VGPRs from the LDS-derived occupancy and spills 720 B/lane
-__global__ __launch_bounds__(256, EPSM_WAVES_PER_SIMD) void epsm_grad_scatter_kernel(FusedArgs F, int dcols, int64_t chunks_per_block) {
-    typedef LdsTable<VARIANT == EPSM_VARIANT_MANIFOLD ? kBits : kRowsCaustic,
+__global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kernel(FusedArgs F, int dcols, int64_t chunks_per_block) {
+    constexpr int kQueueCap = Shape<K>::kQueueCap;
+    typedef LdsTable<VARIANT == EPSM_VARIANT_MANIFOLD ? Shape<K>::kRows : Shape<K>::kRowsCaustic,
                      typename std::conditional<VARIANT == EPSM_VARIANT_MANIFOLD, AccFloat, AccFixed64>::type> Table;
     constexpr int kTableSize = Table::kTableSize;
     __shared__ uint32_t s_keys[kTableSize];
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(256, EPSM_WAVES_PER_SIMD) void epsm_grad_scatter_ke
             const int64_t i0 = base + s_perm[slot * 64 + lane];
             const bool ok = i0 < F.g.N;
             const int64_t i = ok ? i0 : F.g.N - 1;     // lanes past the end recompute the last path and add nothing
-            const ScatterOut<Table, PACKED> out{F, s_ptrs, T, Q, i, ok};
+            const ScatterOut<Table, PACKED, kQueueCap> out{F, s_ptrs, T, Q, i, ok};
             if (DMODE == kTangentsInKernel) {              // epsm.py:250-272 for this path, in registers
                 const Tangent t = PACKED
                     ? first_vertex_tangent_packed(F.tin, i, F.pk_rays + 12 * i, A.rec(1, i), (lds_(F.pk_flags, i) & 4u) != 0)
