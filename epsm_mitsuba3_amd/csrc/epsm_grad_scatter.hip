@@ -44,7 +44,10 @@ template <int K> struct Shape {
     static constexpr int kQueueCap = kSmall ? 384 : 576;       // items per wave queue (a push is at most 6 rows x 64 lanes)
     static constexpr int kWaves = kSmall ? 3 : 2;              // waves per SIMD the register budget is set for
 };
-constexpr int kFusedBlocks = 2048;             // 512 / 1024 / 8192 measured within 2 %
+#ifndef EPSM_FUSED_BLOCKS
+#define EPSM_FUSED_BLOCKS 2048
+#endif
+constexpr int kFusedBlocks = EPSM_FUSED_BLOCKS;             // 512 / 1024 / 8192 measured within 2 %
 
 struct FusedArgs {
     GradArgs<float> g;
@@ -457,8 +460,8 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
                                                                F.pk_rays, F.pk_verts, F.pk_flags, F.K};
     V3<float> gd_acc = zero3<float>();           // kTangentsInKernel: sum of grad_d over this lane's paths
     T.clear();                                   // ends with a barrier: the table of pointers is visible too
-    // A workgroup takes WINDOWS of 1024 consecutive paths (16 pixels at 64 spp share triangles), dealt round-robin
-    // over the workgroups.  Each 256-path sub-chunk of a window is counting-sorted (stable) by the number of
+    // A workgroup takes WINDOWS of 1024 consecutive paths (16 pixels at 64 spp share triangles), a contiguous range
+    // of them per workgroup.  Each 256-path sub-chunk of a window is counting-sorted (stable) by the number of
     // vertices its paths are live in and cut into four 64-path slots; in step g the four waves take the four
     // slots of sub-chunk g, rotated so that every wave meets each length class once per window.  A wave then
     // holds paths of (nearly) ONE length -- a step nobody needs is skipped by the whole wave (the flags are
@@ -474,7 +477,11 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll 1
     for (int64_t wi = 0; wi < windows_per_block; ++wi) {
-        const int64_t win = wi * gridDim.x + blockIdx.x;
+        // a workgroup walks a CONTIGUOUS range of windows: neighbouring pixels keep hitting the triangles whose rows
+        // the table already holds, so it fills more slowly and a flushed row carries more (dealt round-robin over the
+        // workgroups, as in round 1: +1.5..2.5 %; with the flush threshold at 6/8 instead of 4/8: headline slab
+        // 4.01 -> 3.77 ms, config 2 4.46 -> 4.33; the flush atomics are 0.46 ms of the kernel)
+        const int64_t win = (int64_t) blockIdx.x * windows_per_block + wi;
         if (win >= n_windows) break;                   // workgroup-uniform
         const int64_t base = win * kWindow;
         A.win_base = base;
@@ -577,7 +584,13 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
         }
         // workgroup-uniform census (three barriers) once per window; a table that fills up in between sends
         // the overflow straight to HBM (LdsTable::add)
-        if (T.crowded()) T.flush();
+#if defined(EPSM_KO_NOCENSUS)
+        if ((wi & 3) == 3) T.flush();                 // (knock-out: no census, flush every 4th window)
+#elif defined(EPSM_KO_FLUSHALWAYS)
+        T.flush();                                    // (knock-out: no census, flush every window)
+#else
+        if (T.crowded(6)) T.flush();
+#endif
     }
     T.flush();
     if (DMODE == kTangentsInKernel && F.grad_o_sum) {      // epsm.py:260-261: d/d ray.o = -sum grad_d, one atomic triple per workgroup
