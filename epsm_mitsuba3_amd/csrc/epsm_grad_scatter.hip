@@ -481,6 +481,9 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
         // the table already holds, so it fills more slowly and a flushed row carries more (dealt round-robin over the
         // workgroups, as in round 1: +1.5..2.5 %; with the flush threshold at 6/8 instead of 4/8: headline slab
         // 4.01 -> 3.77 ms, config 2 4.46 -> 4.33; the flush atomics are 0.46 ms of the kernel)
+        // (also tried: PINNED rows -- emitter vertices and alpha slots, the targets every path adds to, kept in the table
+        // across the periodic flushes so that they cost one same-address global atomic per workgroup instead of one per
+        // flush: 3.67 -> 3.66 ms, nothing.)
         const int64_t win = (int64_t) blockIdx.x * windows_per_block + wi;
         if (win >= n_windows) break;                   // workgroup-uniform
         const int64_t base = win * kWindow;
