@@ -359,8 +359,10 @@ def main():
         if packed_log:
             keep_soa = rank == 0 and not slabs            # slab 0 of rank 0 also feeds the CPU baseline and the dense-kernel leg
             packed = PackedLog.from_trace(trace, device=dev, table=scene.triangle_table(), free=not keep_soa)
-            if not keep_soa:
-                trace.ray_o = trace.ray_dx = trace.ray_dy = None; trace.ray_d = trace.ray_d[:0]
+            if not keep_soa:                              # only the log stays resident: the per-field arrays are released
+                trace = epsm.PathTrace(res=trace.res, spp=trace.spp, ray_o=None, ray_d=None, ray_dx=None, ray_dy=None,
+                                       path_info=None, scatter_info=None, path_offset=trace.path_offset,
+                                       n_paths_total=trace.n_paths_total)
         else:
             packed = (PackedRecords(trace.path_info, device=dev), PackedScatter(trace.scatter_info, device=dev, table=scene.triangle_table()))
         slabs.append((trace, packed))

@@ -262,9 +262,10 @@ class PRBIntegrator:
         spp = spp or s.spp
         n_total = s.width * s.height * spp
         rank, world = _dist.world()
-        lib = scene._backend if scene._backend is not None else __import__("epsm_mitsuba3_amd")._lib.lib()
-        stream = torch.cuda.current_stream(scene.device).cuda_stream if scene.device.type == "cuda" else None
         import ctypes as C
+        from . import _lib
+        lib = scene._backend if scene._backend is not None else _lib.lib()
+        stream = torch.cuda.current_stream(scene.device).cuda_stream if scene.device.type == "cuda" else None
         accum = torch.zeros((s.height, s.width, 4), device=scene.device, dtype=torch.float32)
         tiles = _dist.tile_ranges(n_total, scene.tile_paths)
         kept = []
