@@ -9,6 +9,7 @@
 // same triangles return -> they stay in the table) and flush to HBM with float
 // atomics when the table fills and once at the end.
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 #include <stdio.h>
 #include <string.h>
@@ -47,6 +48,10 @@ template <int K> struct Shape {
 #ifndef EPSM_FUSED_BLOCKS
 #define EPSM_FUSED_BLOCKS 2048
 #endif
+#ifndef EPSM_SMALL_WAVEFRONT
+#define EPSM_SMALL_WAVEFRONT (1 << 20)
+#endif
+constexpr int64_t kSmallWavefront = EPSM_SMALL_WAVEFRONT;
 constexpr int kFusedBlocks = EPSM_FUSED_BLOCKS;             // 512 / 1024 / 8192 measured within 2 %
 
 struct FusedArgs {
@@ -58,6 +63,10 @@ struct FusedArgs {
     int P, K;
     TangentIn tin;                   // epsm_backward_pass: the first-vertex tangent is computed in the kernel
     float *grad_o_sum;
+    // small wavefronts: workgroup b adds to replica b % replicas of the four buffers (launch(), reduce_replicas_kernel)
+    float *rep;                      // replicas x rep_stride floats, each [pos 3V | nrm 3V | alpha B | o_sum 3]; null: none
+    int replicas;
+    int64_t rep_stride;
     // epsm_backward_pass_packed: the native log (include/epsm.h, EpsmPackedLog) instead of the per-array records
     const float *pk_rays;            // (N,12)  o, d, d_x, d_y
     const uint32_t *pk_flags;        // (N)     5 bits per vertex
@@ -438,22 +447,31 @@ template <typename Table, bool PACKED, int kQueueCap> struct ScatterOut {
 
 namespace {
 
-template <int K, int VARIANT, int DMODE, bool PACKED>
+template <int K, int VARIANT, int DMODE, bool PACKED, int kWindow>
 // waves-per-SIMD 2: without it hipcc budgets 128 VGPRs from the LDS-derived occupancy and spills 720 B/lane
-__global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kernel(FusedArgs F, int dcols, int64_t chunks_per_block) {
+__global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kernel(FusedArgs F, int dcols, int64_t windows_per_block) {
     constexpr int kQueueCap = Shape<K>::kQueueCap;
-    typedef LdsTable<VARIANT == EPSM_VARIANT_MANIFOLD ? Shape<K>::kRows : Shape<K>::kRowsCaustic,
-                     typename std::conditional<VARIANT == EPSM_VARIANT_MANIFOLD, AccFloat, AccFixed64>::type> Table;
+    // float rows only where the window's distinct rows need the larger table (epsm_wave_scatter.h, AccFixed64): a 256-path
+    // window of a small wavefront fills a few hundred rows, and the integer atomic inserts ~18x faster
+#ifdef EPSM_AB_SMALL_FLOAT
+    constexpr bool kFloatRows = VARIANT == EPSM_VARIANT_MANIFOLD;
+#else
+    constexpr bool kFloatRows = VARIANT == EPSM_VARIANT_MANIFOLD && kWindow == 1024;
+#endif
+    typedef LdsTable<kFloatRows ? Shape<K>::kRows : Shape<K>::kRowsCaustic,
+                     typename std::conditional<kFloatRows, AccFloat, AccFixed64>::type> Table;
     constexpr int kTableSize = Table::kTableSize;
     __shared__ uint32_t s_keys[kTableSize];
     __shared__ typename Table::Val s_vals[kTableSize * 3];
     __shared__ int s_used;
     __shared__ QItem s_queue[4][kQueueCap];
     __shared__ PtrTable s_ptrs;
-    const Table T{s_keys, s_vals, &s_used, F.gpos, F.gnrm, F.galpha, (uint32_t) F.V};
+    float *const my_rep = F.rep ? F.rep + (blockIdx.x % (unsigned) F.replicas) * F.rep_stride : nullptr;
+    const Table T{s_keys, s_vals, &s_used, my_rep ? my_rep : F.gpos, my_rep ? my_rep + 3 * F.V : F.gnrm,
+                  my_rep ? my_rep + 6 * F.V : F.galpha, (uint32_t) F.V};
     WaveQueue<kQueueCap> Q{s_queue[threadIdx.x >> 6], 0};
     if (!PACKED && threadIdx.x < K) { s_ptrs.v[threadIdx.x] = F.g.v[threadIdx.x]; s_ptrs.s[threadIdx.x] = F.s[threadIdx.x]; }
-    __shared__ uint32_t s_flags[VARIANT == EPSM_VARIANT_MANIFOLD ? 1024 : 1];
+    __shared__ uint32_t s_flags[VARIANT == EPSM_VARIANT_MANIFOLD ? kWindow : 1];
     constexpr bool FULL_D = DMODE == kTangentsFullRows;
     LdsArgs<VARIANT == EPSM_VARIANT_MANIFOLD, DMODE, PACKED> A{F.g.N, F.g.cam, F.g.dlduv, F.g.dldp, F.g.dlduv_stride,
                                                                mk2<float>(0.f, 0.f), zero3<float>(), &s_ptrs, s_flags, 0,
@@ -468,12 +486,11 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
     // independent per path in the worst case: 41 % lane utilisation unsorted) -- the four SIMDs stay balanced
     // without a barrier between steps, and the cache lines of a sub-chunk are touched by the four waves at about
     // the same time (sorting the whole window at once re-fetched every line ~2x: 19 GB instead of 10.8 GB).
-    constexpr int kWindow = 1024, kSlots = kWindow / 64, kKeys = K + 1, kSub = kWindow / 256;
+    constexpr int kSlots = kWindow / 64, kKeys = K + 1, kSub = kWindow / 256;
     __shared__ uint16_t s_perm[kWindow];
     __shared__ int s_sort;
     __shared__ int s_cnt[kKeys * kSub * 4];            // [key][sub-chunk j][wave w]: histogram, then offsets
     const int64_t n_windows = (F.g.N + kWindow - 1) / kWindow;
-    const int64_t windows_per_block = (chunks_per_block + kSub - 1) / kSub;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll 1
     for (int64_t wi = 0; wi < windows_per_block; ++wi) {
@@ -565,7 +582,8 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
         // -- the wave's four slots
 #pragma unroll 1
         for (int g = 0; g < kSlots / 4; ++g) {
-            const int slot = g * 4 + ((wv + g) & 3);   // sub-chunk g, quartile rotated: every wave gets each length class once
+            // sub-chunk g, quartile rotated: every wave gets each length class once (one-sub-chunk windows: rotated by window)
+            const int slot = g * 4 + ((wv + (kSub > 1 ? g : (int) win)) & 3);
             const int64_t i0 = base + s_perm[slot * 64 + lane];
             const bool ok = i0 < F.g.N;
             const int64_t i = ok ? i0 : F.g.N - 1;     // lanes past the end recompute the last path and add nothing
@@ -604,18 +622,95 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
         if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6][0] = sx; s_part[threadIdx.x >> 6][1] = sy; s_part[threadIdx.x >> 6][2] = sz; }
         __syncthreads();
         if (threadIdx.x < 3)
-            atomicAdd(F.grad_o_sum + threadIdx.x, s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+            atomicAdd((my_rep ? my_rep + 6 * F.V + F.B : F.grad_o_sum) + threadIdx.x, s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
     }
 }
 
+// Sums the replicas of a small wavefront into the caller's buffers and leaves the workspace zero for the next launch.
+__global__ __launch_bounds__(256) void reduce_replicas_kernel(float *rep, int replicas, int64_t stride, int64_t V, int64_t B,
+                                                              float *gpos, float *gnrm, float *galpha, float *go) {
+    const int64_t e = (int64_t) blockIdx.x * 256 + threadIdx.x, n = 6 * V + B + 3;
+    if (e >= n) return;
+    float sum = 0.f;
+    for (int r = 0; r < replicas; ++r) { sum += rep[r * stride + e]; rep[r * stride + e] = 0.f; }
+    float *dst = e < 3 * V ? gpos + e : e < 6 * V ? gnrm + (e - 3 * V) : e < 6 * V + B ? (galpha ? galpha + (e - 6 * V) : nullptr)
+                                                                                      : (go ? go + (e - 6 * V - B) : nullptr);
+    if (dst && sum != 0.f) *dst += sum;
+}
+
+// Why replicas: the workgroups of a small wavefront all flush at the same moment, and every one of them holds the rows
+// every path adds to (the emitter's vertices, the alpha slots, the camera origin).  Global float atomics on ONE 12-byte row
+// retire at 12.7 ns each, on 96 rows at 0.86 G rows/s, on rows drawn from >= 15 000 at 18.6 G rows/s
+// (tools/micro/global_atomics.hip): 512 workgroups x 96 emitter rows = 57 us of a 190 us kernel (config 5), 2048
+// workgroups four times that.  With the rows of workgroup b in replica b % R the same atomics spread over R x as many
+// rows; one small kernel sums the replicas afterwards.  The workspace is the library's, one per (device, stream), kept
+// zero between launches.
+struct Workspace { int dev; hipStream_t stream; float *p; size_t bytes; };
+static Workspace g_ws[16];
+static int g_ws_n = 0;
+static std::mutex g_ws_mutex;
+constexpr size_t kReplicaBudget = 48u << 20;
+static hipError_t workspace(hipStream_t s, size_t bytes, float **out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    Workspace *w = nullptr;
+    for (int i = 0; i < g_ws_n; ++i) if (g_ws[i].dev == dev && g_ws[i].stream == s) w = &g_ws[i];
+    if (!w) {
+        if (g_ws_n == 16) { *out = nullptr; return hipSuccess; }          // no replicas for a 17th stream
+        w = &g_ws[g_ws_n++];
+        *w = Workspace{dev, s, nullptr, 0};
+    }
+    if (w->bytes < bytes) {
+        if (w->p) { e = hipFree(w->p); w->p = nullptr; w->bytes = 0; if (e != hipSuccess) return e; }
+        e = hipMalloc((void **) &w->p, kReplicaBudget);
+        if (e != hipSuccess) { w->p = nullptr; return e; }
+        w->bytes = kReplicaBudget;
+        e = hipMemsetAsync(w->p, 0, kReplicaBudget, s);
+        if (e != hipSuccess) return e;
+    }
+    *out = w->p;
+    return hipSuccess;
+}
+
 template <int K, int VARIANT, int DMODE, bool PACKED = false>
-hipError_t launch(const FusedArgs &F, int dcols, hipStream_t s) {
-    const int64_t chunks = (F.g.N + 255) / 256;
-    const int64_t blocks = chunks < kFusedBlocks ? chunks : kFusedBlocks;
-    int64_t per = (chunks + blocks - 1) / blocks;
-    per = (per + 15) / 16 * 16;              // whole groups
-    hipLaunchKernelGGL((epsm_grad_scatter_kernel<K, VARIANT, DMODE, PACKED>), dim3((unsigned) blocks), dim3(256), 0, s,
-                       F, dcols, per);
+hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
+    FusedArgs F = F0;
+    // the unit of work is a 1024-path window; a small wavefront gets one window per workgroup (round 1 rounded the share
+    // up to four windows: the 2^19 paths of the reference's own backward size ran on 128 workgroups, half the chip idle)
+    // A wave works through its slots of a window one after the other, so a wavefront of few windows is bound by that
+    // latency and leaves SIMDs idle: up to 2^20 paths (the reference's own backward sizes: 16 384 .. 524 288) the windows
+    // are 256 paths, one slot per wave.
+    // (EPSM_SMALL_WAVEFRONT=<paths> in the environment moves the switch: the tests run both forms at every size)
+    int64_t small_limit = kSmallWavefront;
+    if (const char *e = getenv("EPSM_SMALL_WAVEFRONT")) small_limit = atoll(e);
+    const bool small = F.g.N <= small_limit;
+    const int64_t windows = small ? (F.g.N + 255) / 256 : (F.g.N + 1023) / 1024;
+    const int64_t blocks = windows < kFusedBlocks ? windows : kFusedBlocks;
+    const int64_t per = (windows + blocks - 1) / blocks;
+    F.rep = nullptr; F.replicas = 1; F.rep_stride = 0;
+    if (small) {
+        const int64_t stride = (6 * F.V + F.B + 3 + 63) / 64 * 64;        // floats; replicas start on 256-byte boundaries
+        int64_t R = blocks / 16;
+        if (R > 32) R = 32;
+        if (R * stride * 4 > (int64_t) kReplicaBudget) R = (int64_t) kReplicaBudget / (stride * 4);
+        const char *off = getenv("EPSM_NO_REPLICAS");
+        if (R >= 4 && !(off && off[0] == '1')) {
+            const hipError_t e = workspace(s, (size_t) (R * stride * 4), &F.rep);
+            if (e != hipSuccess) return e;
+            if (F.rep) { F.replicas = (int) R; F.rep_stride = stride; }
+        }
+    }
+    if (small)
+        hipLaunchKernelGGL((epsm_grad_scatter_kernel<K, VARIANT, DMODE, PACKED, 256>), dim3((unsigned) blocks), dim3(256), 0, s, F, dcols, per);
+    else
+        hipLaunchKernelGGL((epsm_grad_scatter_kernel<K, VARIANT, DMODE, PACKED, 1024>), dim3((unsigned) blocks), dim3(256), 0, s, F, dcols, per);
+    if (F.rep) {
+        const int64_t n = 6 * F.V + F.B + 3;
+        hipLaunchKernelGGL(reduce_replicas_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, F.rep, F.replicas, F.rep_stride,
+                           F.V, F.B, F.gpos, F.gnrm, F.galpha, F.grad_o_sum);
+    }
     return hipGetLastError();
 }
 template <int VARIANT, int DMODE, bool PACKED = false>
