@@ -42,8 +42,11 @@ def chain_vertex_grads(vertices: torch.Tensor, vertex_grad: torch.Tensor) -> Non
     (vertices * vertex_grad.detach().to(vertices.device, vertices.dtype)).sum().backward()
 
 
-def run(method: str, exp: str, device="cuda", iterations=None, lr=0.02, log=print):
+def run(method: str, exp: str, device="cuda", iterations=None, lr=None, log=print):
     tasks = importlib.import_module(f"epsm_mitsuba3_amd.exp.{exp}")
+    lr = getattr(tasks, "lr", 0.02) if lr is None else lr
+    # the reference's Matcher has both (utils/matcher.py:51-63 and :76-180); an experiment may name the sort-based one
+    match_name = "match_" + getattr(tasks, "matcher", "Sinkhorn")
     thres, integrator2 = 10000, None                                            # optim.py:93-94
     if method.endswith("hybrid"):                                               # optim.py:87-92
         method = method[:-7]
@@ -75,7 +78,7 @@ def run(method: str, exp: str, device="cuda", iterations=None, lr=0.02, log=prin
         params.zero_()
         if img.shape[-1] == 5:                                                  # optim.py:130-136
             render_low = resize(to_ldr(img[..., :3]), tasks.match_res)
-            grad_ = matcher.match_Sinkhorn(render_low.reshape(-1, 3), gt_low.reshape(-1, 3))
+            grad_ = getattr(matcher, match_name)(render_low.reshape(-1, 3), gt_low.reshape(-1, 3))
             grad = grad_.reshape(tasks.match_res, tasks.match_res, 5).repeat(rep, rep, 1)         # optim.py:133-135
         else:                                                                   # optim.py:137-141: L2 against the reference
             ref = gt if tuple(gt.shape[:2]) == tuple(img.shape[:2]) else resize(gt, img.shape[0])

@@ -1,7 +1,7 @@
-"""The skinned stand-in for SMPL (exp/human.py): rest pose, rigid root, differentiable pose."""
+"""The skinned stand-in for SMPL (exp/human_tube.py): rest pose, rigid root, differentiable pose."""
 import torch
 
-from epsm_mitsuba3_amd.exp.human import SkinnedTube, _rodrigues
+from epsm_mitsuba3_amd.exp.human_tube import SkinnedTube, _rodrigues
 
 
 def test_rodrigues_and_skinning():

@@ -251,7 +251,7 @@ def test_vertex_update_refits_the_bvh_and_recomputes_normals():
     """params.update(): `set_vertex_positions` overwrites the rows of the flat buffers on the device, recomputes
     the vertex normals and refits the BVH (same topology); tracing then sees exactly what a scene built from
     the moved vertices sees."""
-    from epsm_mitsuba3_amd.exp.human import SkinnedTube
+    from epsm_mitsuba3_amd.exp.human_tube import SkinnedTube
     m = SkinnedTube("cpu", rings=12, sectors=10)
     fv, ff = quad(0.0, 4.0, up=True)
     lv, lf = quad(5.0, 0.3, up=False)
