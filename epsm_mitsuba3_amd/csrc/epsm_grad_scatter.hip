@@ -455,6 +455,8 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
     // window of a small wavefront fills a few hundred rows, and the integer atomic inserts ~18x faster
 #ifdef EPSM_AB_SMALL_FLOAT
     constexpr bool kFloatRows = VARIANT == EPSM_VARIANT_MANIFOLD;
+#elif defined(EPSM_AB_ALLFIXED)
+    constexpr bool kFloatRows = false;
 #else
     constexpr bool kFloatRows = VARIANT == EPSM_VARIANT_MANIFOLD && kWindow == 1024;
 #endif
