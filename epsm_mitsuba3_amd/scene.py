@@ -703,7 +703,11 @@ class Scene:
 
     # -- tracing ---------------------------------------------------------------------------------
     WAVEFRONT_MIN_TRIANGLES = 60000      # measured break-even on MI355X with the sparse log (64 k triangles: 4.02 / 3.93 ms per 4.2 M paths)
-    WAVEFRONT_TILE_PATHS = 1 << 22       # the wavefront form is 26 launches per tile: tiles as large as the sharding over the ranks allows
+    # The wavefront form is 26 launches per tile and its later bounces carry a fraction of the paths (20 % at the fourth
+    # bounce of the 128 k-triangle scene): tiles as large as the sharding over the ranks allows.  512x512 @ 64 spp on that
+    # scene, whole gradient image: 26.7 / 21.6 / 18.8 / 16.9 / 16.7 ms with tiles of 2^20 .. 2^24 paths (0.9 KB of log and
+    # workspace per path: 14.7 GB at 2^24, of 288).
+    WAVEFRONT_TILE_PATHS = 1 << 24
 
     def use_wavefront(self) -> bool:
         if self.tracer not in ("auto", "mega", "wavefront"):
@@ -864,7 +868,7 @@ class Scene:
         K = min(max_log_depth, max_depth, 5)
         n_total = s.width * s.height * spp
         tile = self.tile_paths
-        if self.use_wavefront():       # as large as the sharding allows: every rank still gets a tile, none larger than 2^22 paths
+        if self.use_wavefront():       # as large as the sharding allows: every rank still gets a tile, none larger than 2^24 paths
             per_rank = -(-n_total // max(1, world_size))
             tile = max(self.tile_paths, min(self.WAVEFRONT_TILE_PATHS, per_rank))
         tiles = _dist.tile_ranges(n_total, tile)

@@ -295,3 +295,30 @@ def test_unlimited_depth_integrator_renders_and_differentiates():
     integ.render_backward(sc, p, g, seed=1)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(p.flat).all()) and float(p.flat.abs().max()) > 0
+
+
+def test_gradient_image_does_not_depend_on_the_tile_size():
+    """512 x 512 @ 64 spp on the 128 004-triangle scene: one tile of 2^24 paths (8.6 GB of packed log: 64-bit offsets
+    everywhere) against sixteen tiles of 2^20 -- the same paths, the same sums up to the order of the atomics."""
+    import epsm_mitsuba3_amd as epsm
+    from epsm_mitsuba3_amd.exp import clutter
+    dev = torch.device("cuda", 0)
+    res, spp = 512, 64
+    sc = clutter.load_scene(dev, n_spheres=100, res=res, spp=spp)
+    for i in range(0, 100, 7):
+        sc.attach(f"s{i}", positions=True, normals=True)
+    sc.tracer = "wavefront"
+    g = torch.Generator().manual_seed(4)
+    grad_in = (torch.randn((res, res, 5), generator=g) * 1e-3).to(dev)
+    integ = epsm.load_dict({"type": "manifold", "max_depth": clutter.max_depth})
+    integ.backward_spp = spp
+    out = []
+    for tile in (1 << 24, 1 << 20):
+        sc.WAVEFRONT_TILE_PATHS = tile
+        assert len(list(t.path_offset for t in sc.iter_traces(sensor=2, seed=3, spp=spp, max_depth=clutter.max_depth, packed_log=True))) == (1 << 24) // tile
+        p = sc.param_grads()
+        integ.render_backward(sc, p, grad_in, seed=3)
+        torch.cuda.synchronize()
+        out.append(p.flat.double().cpu())
+    m = float(out[0].abs().max())
+    assert m > 0 and float((out[0] - out[1]).abs().max()) <= 2e-4 * m
