@@ -64,32 +64,42 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_shade_kernel(TraceArgs A, Wf
     if (threadIdx.x < 2)
         W.chunk_counts[threadIdx.x * W.chunks + blockIdx.x] = s_n[threadIdx.x][0] + s_n[threadIdx.x][1] + s_n[threadIdx.x][2] + s_n[threadIdx.x][3];
 }
-// Exclusive scan of the chunk counts of both queues (<= 65 536 chunks each at 2^24 paths), ONE workgroup: thread t
-// sums a strip, the strips' sums are scanned over the workgroup, the strip is rewritten as offsets.  Also
-// publishes the two queue lengths of the next stages.
+// Exclusive scan of the chunk counts of both queues (<= 65 536 chunks each at 2^24 paths), one workgroup PER QUEUE:
+// thread t sums a strip, the strips' sums are scanned over the workgroup, the strip is rewritten as offsets.  Also
+// publishes the queue length of the next stage.  A strip is read in batches of 16 independent loads (as a loop of
+// dependent-looking loads the 64-element strips of a 2^24-path tile took 209 us per bounce, four bounces per tile).
 __global__ __launch_bounds__(1024) void epsm_wf_scan_kernel(TraceArgs A, WfState W, int b) {
     const int64_t count = wf_count(A, W, b), n = (count + kWfChunk - 1) / kWfChunk;
     const int64_t strip = (n + 1023) / 1024, lo = (int64_t) threadIdx.x * strip, hi = lo + strip < n ? lo + strip : n;
-    __shared__ uint32_t s_w[2][16];
-    uint32_t total[2];
+    __shared__ uint32_t s_w[16];
+    const int which = blockIdx.x;
+    uint32_t *c = W.chunk_counts + which * W.chunks;
+    constexpr int kBatch = 16;
+    uint32_t sum = 0;
+    for (int64_t k0 = lo; k0 < hi; k0 += kBatch) {
+        uint32_t v[kBatch];
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        uint32_t *c = W.chunk_counts + which * W.chunks;
-        uint32_t sum = 0;
-        for (int64_t k = lo; k < hi; ++k) sum += c[k];
-        uint32_t inc = sum;                                       // inclusive scan over the wave, then over the 16 waves
+        for (int j = 0; j < kBatch; ++j) v[j] = k0 + j < hi ? c[k0 + j] : 0u;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t) __shfl_up((int) inc, off); if ((int) (threadIdx.x & 63) >= off) inc += t; }
-        if ((threadIdx.x & 63) == 63) s_w[which][threadIdx.x >> 6] = inc;
-        __syncthreads();
-        uint32_t before = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { const uint32_t v = s_w[which][w]; if (w < (int) (threadIdx.x >> 6)) before += v; all += v; }
-        uint32_t run = before + inc - sum;
-        for (int64_t k = lo; k < hi; ++k) { const uint32_t v = c[k]; c[k] = run; run += v; }
-        total[which] = all;
+        for (int j = 0; j < kBatch; ++j) sum += v[j];
     }
-    if (threadIdx.x == 0) { W.counters[b + 1] = total[0]; W.counters[8 + b] = total[1]; }
+    uint32_t inc = sum;                                           // inclusive scan over the wave, then over the 16 waves
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t) __shfl_up((int) inc, off); if ((int) (threadIdx.x & 63) >= off) inc += t; }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const uint32_t v = s_w[w]; if (w < (int) (threadIdx.x >> 6)) before += v; all += v; }
+    uint32_t run = before + inc - sum;
+    for (int64_t k0 = lo; k0 < hi; k0 += kBatch) {
+        uint32_t v[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) v[j] = k0 + j < hi ? c[k0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) { if (k0 + j < hi) c[k0 + j] = run; run += v[j]; }
+    }
+    if (threadIdx.x == 0) W.counters[which == 0 ? b + 1 : 8 + b] = all;
 }
 // Writes the queue of bounce b + 1 and the shadow queue of bounce b, in path order (stable).
 // (Tried: grouping the survivors of a chunk by the octant of their new direction, 8-bucket counting sort in LDS --
@@ -347,7 +357,7 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
         // surplus workgroups leave at once (no host round trip between the bounces)
         hipLaunchKernelGGL(epsm_wf_extend_kernel, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_shade_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
-        hipLaunchKernelGGL(epsm_wf_scan_kernel, dim3(1), dim3(1024), 0, s, A, W, b);
+        hipLaunchKernelGGL(epsm_wf_scan_kernel, dim3(2), dim3(1024), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_compact_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_shadow_kernel, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
     }
