@@ -68,6 +68,8 @@ def _declare(lib):
     lib.epsm_backward_pass_packed.argtypes = [
         C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
         C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    lib.epsm_release_workspace.restype = C.c_int
+    lib.epsm_release_workspace.argtypes = []
     declare_tracer(lib)
     return lib
 

@@ -676,6 +676,22 @@ static hipError_t workspace(hipStream_t s, size_t bytes, float **out) {
     return hipSuccess;
 }
 
+static hipError_t release_workspaces() {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    hipError_t first = hipSuccess;
+    int here = 0;
+    (void) hipGetDevice(&here);
+    for (int i = 0; i < g_ws_n; ++i) {
+        if (!g_ws[i].p) continue;
+        hipError_t e = hipSetDevice(g_ws[i].dev);
+        if (e == hipSuccess) e = hipFree(g_ws[i].p);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    g_ws_n = 0;
+    (void) hipSetDevice(here);
+    return first;
+}
+
 template <int K, int VARIANT, int DMODE, bool PACKED = false>
 hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
     FusedArgs F = F0;
@@ -767,6 +783,13 @@ static int fill_args(FusedArgs &F, const char *who, int variant, int64_t N, int 
     F.V = V; F.B = grad_alpha ? B : 0;
     F.P = epsm_num_param_grads(variant, K);
     F.K = K;
+    return EPSM_OK;
+}
+
+extern "C" int epsm_release_workspace(void) {
+    epsm_host::err_buf()[0] = 0;
+    const hipError_t e = release_workspaces();
+    if (e != hipSuccess) return epsm_host::hip_fail("epsm_release_workspace", e);
     return EPSM_OK;
 }
 

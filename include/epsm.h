@@ -274,6 +274,19 @@ int epsm_backward_pass_packed(int variant, int64_t N, int K, int64_t path_offset
                               float *grad_pos, float *grad_nrm, float *grad_alpha, float *grad_o_sum,
                               int64_t V, int64_t B, void *stream);
 
+/* Small wavefronts (N <= 2^20 paths) of the three fused entry points above -- epsm_manifold_grad_scatter,
+ * epsm_backward_pass, epsm_backward_pass_packed -- accumulate into REPLICAS of the gradient buffers, which one more small
+ * kernel on the same stream sums into grad_pos / grad_nrm / grad_alpha / grad_o_sum ("Small wavefronts": the
+ * workgroups of a small launch all flush at once, and same-address global atomics retire one at a time).  The replicas
+ * live in a workspace of 48 MB that the library allocates on first use per (device, stream) -- at most 16 of them; further
+ * streams go without replicas -- and keeps zeroed between launches.  Consequences for the caller: the first small launch on
+ * a stream calls hipMalloc (do it outside a stream capture); results are complete when the stream reaches the end of the
+ * call's work, as before; launches on ONE stream from several host threads must be serialised by the caller, as any use
+ * of a stream.  epsm_release_workspace frees every workspace (call it when no launch is in flight; they come back on
+ * demand).  EPSM_NO_REPLICAS=1 in the environment turns the replicas off.
+ * There is no reference counterpart: Dr.Jit's scatter_reduce goes straight to global atomics. */
+int epsm_release_workspace(void);
+
 /* Human-readable text of the last failure on the calling thread ("" if none). */
 const char *epsm_last_error(void);
 

@@ -197,6 +197,13 @@ def test_small_wavefront_forms_agree(kind, profile, K, res, spp, V, monkeypatch)
         integ.render_backward(scene, params, grad_in, seed=1)
         torch.cuda.synchronize()
         bufs[name] = params.flat.double().cpu()
+        if name == "replicas again":               # the workspace can be given back and comes back on demand
+            from epsm_mitsuba3_amd import _lib
+            assert _lib.lib().epsm_release_workspace() == 0
+            params.zero_()
+            integ.render_backward(scene, params, grad_in, seed=1)
+            torch.cuda.synchronize()
+            bufs["replicas after a release"] = params.flat.double().cpu()
     ref = bufs["two stages"]
     m = float(ref.abs().max())
     assert m > 0
