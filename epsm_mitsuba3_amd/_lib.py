@@ -24,12 +24,33 @@ class EpsmError(RuntimeError):
     pass
 
 
+class build_lock:
+    """One build of a directory at a time across processes (the ranks of a multi-process run all check their libraries on
+    start-up; two `make`s in one directory write the same files, and a third process may dlopen a half-written one)."""
+
+    def __init__(self, directory: str):
+        self.path = os.path.join(directory, ".build.lock")
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(self.path, "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+        return False
+
+
 def build(force: bool = False) -> str:
     """Compiles the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    if force:
-        subprocess.run(["make", "-C", src_dir, "-s", "clean"], check=True)
-    subprocess.run(["make", "-C", src_dir, "-s"], check=True)
+    with build_lock(src_dir):
+        if force:
+            subprocess.run(["make", "-C", src_dir, "-s", "clean"], check=True)
+        subprocess.run(["make", "-C", src_dir, "-s"], check=True)
     return LIB_PATH
 
 

@@ -117,7 +117,8 @@ struct LdsTable {
     // LDS atomic rates on MI355X (tools/micro/lds_atomics.hip; lane-ops per clock and CU, scattered rows / 16 hot rows):
     // ds_add_f32 0.33 / 0.42, read + ds_cmpst float-add loop 3.3 / 0.47, ds_add_u64 6.1 / 3.4, ds_add_u32 11.4 / 4.3,
     // ds_cmpst_rtn 5.6.  Both alternatives to ds_add_f32 were tried here: the cmpst loop lost (5.4 against 5.0 ms on
-    // config 2: a drain iteration carries several items of one row); 64-bit fixed-point rows with ds_add_u64 (28 B
+    // config 2: a drain iteration carries several items of one row; again in round 2 with the wave merges in place:
+    // headline slab 3.73 -> 3.80 ms, config 2 4.31 -> 5.00 ms); 64-bit fixed-point rows with ds_add_u64 (28 B
     // per row, so 1728 rows in the workgroup's LDS share instead of 2048) came out mixed -- at equal row counts
     // (1024) 5.19 against 5.67 ms, but with 1728 rows bathroom 5.15 (float, 2048 rows: 4.96), pool 4.55 (5.01),
     // specular 22.0 (18.0), V = 7 829: 4.88 (4.31), V = 10^6: 5.52 (5.68) -- and was not kept.

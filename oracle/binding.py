@@ -18,7 +18,9 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)    # make decides what is stale
+    from epsm_mitsuba3_amd._lib import build_lock
+    with build_lock(_HERE):             # the two ranks of a gloo test both come here; the link step renames into place
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)    # make decides what is stale
     return _LIB_PATH
 
 

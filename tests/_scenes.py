@@ -19,9 +19,12 @@ def host_tracer():
         src = os.path.join(_DIR, "trace_host.cpp")
         csrc = os.path.join(_DIR, "..", "..", "epsm_mitsuba3_amd", "csrc")
         hdrs = [os.path.join(csrc, h) for h in ("epsm_trace_core.h", "epsm_trace_wavefront.h")]
-        if (not os.path.isfile(_SO)) or any(os.path.getmtime(p) > os.path.getmtime(_SO) for p in [src] + hdrs):
-            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wno-unknown-pragmas",
-                            "-ffp-contract=off", "-o", _SO, src], check=True)
+        from epsm_mitsuba3_amd._lib import build_lock
+        with build_lock(_DIR):
+            if (not os.path.isfile(_SO)) or any(os.path.getmtime(p) > os.path.getmtime(_SO) for p in [src] + hdrs):
+                subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wno-unknown-pragmas",
+                                "-ffp-contract=off", "-o", _SO + ".tmp", src], check=True)
+                os.replace(_SO + ".tmp", _SO)
         _lib = C.CDLL(_SO)
         for n in ("epsm_trace_paths", "epsm_trace_paths_wavefront", "epsm_film_splat", "epsm_film_develop"):
             getattr(_lib, n).restype = C.c_int
