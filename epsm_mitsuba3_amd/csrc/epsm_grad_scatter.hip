@@ -38,12 +38,25 @@ namespace {
 // VGPRs, so THREE waves per SIMD are possible if three workgroups' LDS fits a CU: a smaller table and queues there.
 // Measured at 2^24 paths (config 2 with --vertices K; ms): K = 2: 2.84 -> 2.53, K = 1: 1.43 -> 1.30; from K = 3 on
 // the third wave costs spills (K = 3: 168 VGPRs + 240 B of scratch, 3.73 -> 4.21) and the large configuration stays.
+// K >= 3, sizes within the 80 KB a workgroup may hold for two per CU (round 2, end): 384-item queues -- the minimum, a push
+// is at most 6 rows x 64 lanes -- instead of 576 and the 12 KB they free given to the table: 3072 float rows (2304
+// before) / 1920 fixed-point rows (1280): headline slab 3.73 -> 3.67 ms, config 2 4.31 -> 4.19, pool caustic 3.85 -> 3.79.
+// (EPSM_AB_*: A/B switches of tools/build_variant.sh.)
+#ifndef EPSM_AB_ROWS_FLOAT
+#define EPSM_AB_ROWS_FLOAT 3072
+#endif
+#ifndef EPSM_AB_ROWS_FIXED
+#define EPSM_AB_ROWS_FIXED 1920
+#endif
+#ifndef EPSM_AB_QUEUE
+#define EPSM_AB_QUEUE 384
+#endif
 template <int K> struct Shape {
     static constexpr bool kSmall = K <= 2;
-    static constexpr int kRows = kSmall ? 1408 : 2304;         // manifold: table rows, 16 B each (float sums)
-    static constexpr int kRowsCaustic = kSmall ? 800 : 1280;   // manifold_caustic: rows of 28 B (64-bit fixed-point sums)
-    static constexpr int kQueueCap = kSmall ? 384 : 576;       // items per wave queue (a push is at most 6 rows x 64 lanes)
-    static constexpr int kWaves = kSmall ? 3 : 2;              // waves per SIMD the register budget is set for
+    static constexpr int kRows = kSmall ? 1408 : EPSM_AB_ROWS_FLOAT;        // manifold: table rows, 16 B each (float sums)
+    static constexpr int kRowsCaustic = kSmall ? 800 : EPSM_AB_ROWS_FIXED;  // manifold_caustic: rows of 28 B (64-bit fixed-point sums)
+    static constexpr int kQueueCap = kSmall ? 384 : EPSM_AB_QUEUE;          // items per wave queue
+    static constexpr int kWaves = kSmall ? 3 : 2;                           // waves per SIMD the register budget is set for
 };
 #ifndef EPSM_FUSED_BLOCKS
 #define EPSM_FUSED_BLOCKS 2048
