@@ -625,7 +625,10 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
 #elif defined(EPSM_KO_FLUSHALWAYS)
         T.flush();                                    // (knock-out: no census, flush every window)
 #else
-        if (T.crowded(6)) T.flush();
+#ifndef EPSM_AB_CROWD
+#define EPSM_AB_CROWD 6
+#endif
+        if (T.crowded(EPSM_AB_CROWD)) T.flush();
 #endif
     }
     T.flush();
