@@ -122,29 +122,35 @@ struct LdsTable {
     // per row, so 1728 rows in the workgroup's LDS share instead of 2048) came out mixed -- at equal row counts
     // (1024) 5.19 against 5.67 ms, but with 1728 rows bathroom 5.15 (float, 2048 rows: 4.96), pool 4.55 (5.01),
     // specular 22.0 (18.0), V = 7 829: 4.88 (4.31), V = 10^6: 5.52 (5.68) -- and was not kept.
-    __device__ __forceinline__ void add(uint32_t key, float x, float y, float z) const {
-        if (x == 0.f && y == 0.f && z == 0.f) return;
+    static constexpr uint32_t kStep = Acc::kBucketed ? 4u : 1u;
+    __device__ __forceinline__ static uint32_t home(uint32_t key) {
         // Fixed-point tables: four consecutive keys share a BUCKET of four consecutive slots (probing moves by whole
         // buckets).  The flush walks the table in slot order, so the rows of neighbouring vertices -- a triangle's, its
         // neighbours' -- leave in the same wave instruction and, where they share a 64-byte line, as ONE atomic request
         // (the rate of scattered row atomics is 18.6 G/s, of rows that arrive line by line 108 G/s:
         // tools/micro/global_atomics.hip).  Pool caustic slab 4.04 -> 3.82 ms, config 5 0.155 -> 0.123 ms.  The float
         // table gains nothing from it (headline slab 3.73 -> 3.78 ms) and keeps one hash per key.
-        constexpr uint32_t kStep = Acc::kBucketed ? 4u : 1u;
         static_assert(kTableSize % kStep == 0, "whole buckets");
-        uint32_t slot = Acc::kBucketed
+        return Acc::kBucketed
             ? (uint32_t) (((unsigned long long) ((key >> 2) * 2654435761u) * (unsigned long long) (kTableSize / 4)) >> 32) * 4u + (key & 3u)
             : (uint32_t) (((unsigned long long) (key * 2654435761u) * (unsigned long long) kTableSize) >> 32);
+    }
+    __device__ __forceinline__ static uint32_t next(uint32_t slot) {
+        return slot + kStep >= (uint32_t) kTableSize ? slot + kStep - (uint32_t) kTableSize : slot + kStep;
+    }
+    __device__ __forceinline__ void add_at(uint32_t slot, float x, float y, float z) const {
+        if (x != 0.f) Acc::add(&vals[3 * slot + 0], x);
+        if (y != 0.f) Acc::add(&vals[3 * slot + 1], y);
+        if (z != 0.f) Acc::add(&vals[3 * slot + 2], z);
+    }
+    __device__ __forceinline__ void add(uint32_t key, float x, float y, float z) const {
+        if (x == 0.f && y == 0.f && z == 0.f) return;
+        uint32_t slot = home(key);
 #pragma unroll 1
         for (int probe = 0; probe < kMaxProbe; ++probe) {
             const uint32_t prev = atomicCAS(&keys[slot], kEmptyKey, key);
-            if (prev == kEmptyKey || prev == key) {
-                if (x != 0.f) Acc::add(&vals[3 * slot + 0], x);
-                if (y != 0.f) Acc::add(&vals[3 * slot + 1], y);
-                if (z != 0.f) Acc::add(&vals[3 * slot + 2], z);
-                return;
-            }
-            slot = slot + kStep >= (uint32_t) kTableSize ? slot + kStep - (uint32_t) kTableSize : slot + kStep;
+            if (prev == kEmptyKey || prev == key) { add_at(slot, x, y, z); return; }
+            slot = next(slot);
         }
         global_add(key, x, y, z);          // crowded neighbourhood: go straight to HBM
     }
@@ -297,6 +303,8 @@ __device__ __forceinline__ void drain_queue(const QItem *q, int n, Table T) {
     // prefetched -- at each drain.
     typedef __attribute__((address_space(3))) const uint32_t LdsWord;
     LdsWord *ql = (LdsWord *) q;
+    // (Two items per lane and turn, their compare-and-swaps in flight together -- a probe is an LDS round trip the lane
+    // waits for -- was slower: headline slab 3.67 -> 4.16 ms, config 2 4.19 -> 4.73, pool caustic 3.79 -> 4.03.)
 #pragma unroll 1
     for (int idx = lane_id(); idx < n; idx += 64) {
         QItem it;
