@@ -603,6 +603,8 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
             const bool ok = i0 < F.g.N;
             const int64_t i = ok ? i0 : F.g.N - 1;     // lanes past the end recompute the last path and add nothing
             const ScatterOut<Table, PACKED, kQueueCap> out{F, s_ptrs, T, Q, i, ok};
+            // (Tried: the first lines of the NEXT slot's paths -- rays, record 1 -- requested here, a slot ahead of their use:
+            // two more live registers, headline slab 3.74 -> 3.90 ms.)
             if (DMODE == kTangentsInKernel) {              // epsm.py:250-272 for this path, in registers
                 const Tangent t = PACKED
                     ? first_vertex_tangent_packed(F.tin, i, F.pk_rays + 12 * i, A.rec(1, i), (lds_(F.pk_flags, i) & 4u) != 0)
