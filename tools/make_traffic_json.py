@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--packed", action="store_true"); ap.add_argument("--gather-calib", default=None)
     a = ap.parse_args()
     import bench
-    needle = "true>" if a.packed else "epsm_grad_scatter_kernel"
+    needle = ", true, " if a.packed else "epsm_grad_scatter_kernel"        # <K, VARIANT, DMODE, PACKED, window>
     fk, fv = pick({k: v for k, v in counters(a.fetch_dir, "FETCH_SIZE").items() if "epsm_grad_scatter_kernel" in k}, needle)
     wk, wv = pick({k: v for k, v in counters(a.write_dir, "WRITE_SIZE").items() if "epsm_grad_scatter_kernel" in k}, needle)
     if not fv or not wv:
