@@ -99,6 +99,10 @@ def parse(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher + process group + one all-reduce of the parameter-gradient buffer only (gloo on a box "
                          "without GPU): what tests/test_bench_launcher.py runs")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="with --gpus N: all N ranks on GPU 0 and the collectives by gloo through the host -- runs the "
+                         "sharded path (launcher, slab s -> rank s mod N, scratch buffers, one all-reduce per step) on a "
+                         "one-GPU box; the line it prints says so and is not a measurement")
     return ap.parse_args(argv)
 
 
@@ -318,11 +322,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path to measure)")
+    if args.rehearse_one_gpu:
+        local_rank = 0                       # every rank on GPU 0, collectives by gloo through the host: NOT a measurement
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def all_reduce_(t, op=dist.ReduceOp.SUM):
+        if args.rehearse_one_gpu:
+            h = t.cpu(); dist.all_reduce(h, op=op); t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
 
     import epsm_mitsuba3_amd as epsm
     from epsm_mitsuba3_amd import dist as edist
@@ -421,12 +436,14 @@ def main():
     rccl_ranks = 1
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         probe = torch.ones(1, device=dev)
-        dist.all_reduce(probe)                                   # the number of ranks RCCL actually summed over
+        all_reduce_(probe)                                       # the number of ranks RCCL actually summed over
         rccl_ranks = int(round(float(probe.item())))
         assert rccl_ranks == dist.get_world_size() == world
+    # what the last step left in the parameter-gradient buffer (already summed over the ranks): the same image whatever N
+    grad_abs_sum = float(params.flat.double().abs().sum())
     ms_per_step = elapsed / args.steps * 1e3
     value = N_image * args.steps / elapsed
 
@@ -472,7 +489,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "grad_image_ms": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks,
+            "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks, "grad_abs_sum": grad_abs_sum,
+            **({"rehearsal": f"{world} ranks SHARING GPU 0, collectives by gloo through the host: exercises the sharded path, "
+                             "measures nothing"} if args.rehearse_one_gpu else {}),
             "config": {"workload": f"{label}: {profile}-like synthetic path records, {variant}, {res}x{res} @ {spp} spp = "
                                    f"{N_image} paths per gradient image, K={K} logged vertices, scatter target V={V} "
                                    f"vertices; {n_slabs} slab(s) of {slab_paths} paths, slab s on rank s % {world}",

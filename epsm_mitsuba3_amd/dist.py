@@ -62,5 +62,11 @@ def my_tiles(n_tiles: int, rank: Optional[int] = None, world_size: Optional[int]
 def allreduce_param_grads(flat: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum of the flat parameter-gradient buffer over all ranks."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            # a gloo group over device buffers (rehearsals of the multi-rank path on one GPU): through the host
+            host = flat.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
