@@ -630,7 +630,8 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
 #ifndef EPSM_AB_CROWD
 #define EPSM_AB_CROWD 6
 #endif
-        if (T.crowded(EPSM_AB_CROWD)) T.flush();
+        // (not after the workgroup's last window: the final flush follows at once)
+        if (wi + 1 < windows_per_block && win + 1 < n_windows && T.crowded(EPSM_AB_CROWD)) T.flush();
 #endif
     }
     T.flush();
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(256) void reduce_replicas_kernel(float *rep, int re
     for (int r = 0; r < replicas; ++r) { sum += rep[r * stride + e]; rep[r * stride + e] = 0.f; }
     float *dst = e < 3 * V ? gpos + e : e < 6 * V ? gnrm + (e - 3 * V) : e < 6 * V + B ? (galpha ? galpha + (e - 6 * V) : nullptr)
                                                                                       : (go ? go + (e - 6 * V - B) : nullptr);
-    if (dst && sum != 0.f) *dst += sum;
+    if (dst && sum != 0.f) atomicAdd(dst, sum);      // atomic like every other add into the caller's buffers: launches on other streams may share them
 }
 
 // Why replicas: the workgroups of a small wavefront all flush at the same moment, and every one of them holds the rows
