@@ -630,8 +630,11 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
 #ifndef EPSM_AB_CROWD
 #define EPSM_AB_CROWD 6
 #endif
-        // (not after the workgroup's last window: the final flush follows at once)
-        if (wi + 1 < windows_per_block && win + 1 < n_windows && T.crowded(EPSM_AB_CROWD)) T.flush();
+        // (small form: not after the workgroup's last window, the final flush follows at once.  In the large form the two
+        // extra live values cost the K = 5 kernel five more spilled registers, 3.74 -> 3.78 ms.  The kernel sits on that
+        // edge: 256 VGPRs + 4 spilled; keeping the sum of grad_d per wave in LDS instead of three registers per lane came
+        // out of the register allocator with 24 spilled.)
+        if ((kWindow == 1024 || (wi + 1 < windows_per_block && win + 1 < n_windows)) && T.crowded(EPSM_AB_CROWD)) T.flush();
 #endif
     }
     T.flush();
