@@ -27,9 +27,6 @@ constexpr int kWfMaxBlocks = 16384;
 __device__ __forceinline__ int64_t wf_count(const TraceArgs &A, const WfState &W, int b) {
     return b == 0 ? A.N : (int64_t) W.counters[b];
 }
-__global__ __launch_bounds__(256) void epsm_wf_generate_kernel(TraceArgs A, WfState W) {
-    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < A.N; i += (int64_t) gridDim.x * 256) wf_generate(A, W, i);
-}
 // Traversal kernels: 8 KB of LDS stacks per workgroup, 47-50 registers: 8 waves per SIMD.
 // (Tried and dropped: persistent waves whose idle lanes fetch new rays between two traversal rounds -- from a shared
 // queue head the ~10^5 same-address atomics serialise, from a static share per wave the primary rays lose their
@@ -38,11 +35,14 @@ __global__ __launch_bounds__(256) void epsm_wf_generate_kernel(TraceArgs A, WfSt
 // the unfinished lanes (the while-while loops run for the slowest lane: 27 % of the VALU lanes busy).  Same hits;
 // 5.6-5.7 ms against 5.3-5.4 ms at 128 k triangles, 8.7 against 8.9 ms at 512 k: the step-wise traversal state
 // (leaf cursor kept across turns) costs the while-while form 5-7 % where both share it, so it was not kept.)
+// FIRST: bounce 0, whose rays are the primary rays (derived from the path index, nothing read); its own instantiation so
+// that the later bounces keep their 47 registers.
+template <bool FIRST>
 __global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_kernel(TraceArgs A, WfState W, int b) {
     __shared__ uint32_t s_stack[kWfStackLds * kWfThreads];
     const int64_t count = wf_count(A, W, b);
     for (int64_t q = (int64_t) blockIdx.x * kWfThreads + threadIdx.x; q < count; q += (int64_t) gridDim.x * kWfThreads)
-        wf_extend(A, W, b == 0 ? q : (int64_t) W.queue[b & 1][q], s_stack + threadIdx.x, kWfThreads);
+        wf_extend(A, W, FIRST ? q : (int64_t) W.queue[b & 1][q], s_stack + threadIdx.x, kWfThreads, FIRST ? 0 : 1);
 }
 // (160 registers, 3 waves per SIMD; capped at 128 for 4 waves it spills 96 B/lane and is no faster.)
 // One 256-slot chunk of the queue per workgroup.  Appending the survivors to the next queue with one atomic per
@@ -349,13 +349,13 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
     hipError_t e = hipMemsetAsync(W.counters, 0, kWfCounters * sizeof(uint32_t), s);
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_trace_paths_wavefront", e);
     auto blocks = [&](int threads) { const int64_t b = (N + threads - 1) / threads; return dim3((unsigned) (b < kWfMaxBlocks ? b : kWfMaxBlocks)); };
-    hipLaunchKernelGGL(epsm_wf_generate_kernel, blocks(256), dim3(256), 0, s, A, W);
     const int depth = path_max_depth(A);
     const dim3 chunks((unsigned) W.chunks);
     for (int b = 0; b < depth; ++b) {
         // the queue lengths of bounce b live on the device: every stage is launched for the worst case and its
         // surplus workgroups leave at once (no host round trip between the bounces)
-        hipLaunchKernelGGL(epsm_wf_extend_kernel, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
+        if (b == 0) hipLaunchKernelGGL(epsm_wf_extend_kernel<true>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
+        else hipLaunchKernelGGL(epsm_wf_extend_kernel<false>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_shade_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_scan_kernel, dim3(2), dim3(1024), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_compact_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);

@@ -734,12 +734,15 @@ struct PathState {
 };
 
 // sample_rays (common.py:291-422) + the initial loop state
-EPSM_HD PathState path_begin(const TraceArgs &A, int64_t i) {
+// `log = false`: the ray only, nothing written (the wavefront tracer's first closest-hit stage re-derives the primary ray
+// instead of reading a stored one)
+EPSM_HD PathState path_begin(const TraceArgs &A, int64_t i, bool log = true) {
     const int64_t widx = A.path_offset + i;
     PathState s;
     s.rng = seed_sampler(A.seed, (uint32_t) widx);                        // common.py:475 sampler.seed(seed, wavefront_size)
     const PrimaryRay pr = sample_primary_ray(A.C, widx, A.spp, s.rng);
-    if (A.flags & EPSM_TRACE_PACKED_LOG) {                                // (N,12): o, d, d_x, d_y side by side
+    if (!log) {
+    } else if (A.flags & EPSM_TRACE_PACKED_LOG) {                         // (N,12): o, d, d_x, d_y side by side
         float *r = A.ray_o + 12 * i;
         st4(r, pr.ray.o.x, pr.ray.o.y, pr.ray.o.z, pr.ray.d.x);
         st4(r + 4, pr.ray.d.y, pr.ray.d.z, pr.dx.x, pr.dx.y);
@@ -747,7 +750,7 @@ EPSM_HD PathState path_begin(const TraceArgs &A, int64_t i) {
     } else {
         st3(A.ray_o, i, pr.ray.o); st3(A.ray_d, i, pr.ray.d); st3(A.ray_dx, i, pr.dx); st3(A.ray_dy, i, pr.dy);
     }
-    if (A.film_pos) { A.film_pos[2 * i] = pr.px; A.film_pos[2 * i + 1] = pr.py; }
+    if (log && A.film_pos) { A.film_pos[2 * i] = pr.px; A.film_pos[2 * i + 1] = pr.py; }
     s.ray = pr.ray;
     s.L = zero3<float>(); s.beta = f3(1.f, 1.f, 1.f); s.prev_p = zero3<float>();
     s.eta = 1.f; s.prev_bsdf_pdf = 1.f;

@@ -113,11 +113,9 @@ EPSM_HD PathState wf_load(const WfState &W, int64_t i) {
     return s;
 }
 
-// ---- stage: generate (sample_rays).  Every path is alive into bounce 0, the queue of bounce 0 is the identity.
-EPSM_HD void wf_generate(const TraceArgs &A, const WfState &W, int64_t i) {
-    const PathState s = path_begin(A, i);
-    wf_store(W, i, s, 0);
-}
+// ---- (no generate stage: every path is alive into bounce 0, the queue of bounce 0 is the identity, and both stages of
+//      bounce 0 derive the primary ray from the path index -- sample_rays, ~100 instructions -- instead of one kernel
+//      writing 96 bytes of state per path for the next two to read back: 0.45 ms + 0.2 ms per 2^24 paths)
 
 // ---- stage: extend.  Closest hit of path i's ray, as a resumable job (begin, traversal rounds until done).
 struct WfJob {
@@ -125,9 +123,14 @@ struct WfJob {
     int phase;                     // shadow stage: 0 = visibility (any hit), 1 = occluder record (closest hit)
     Traversal T;
 };
-EPSM_HD void wf_extend_begin(const TraceArgs &A, const WfState &W, int64_t i, WfJob &J) {
-    const W4 o = W.ray_o[i], d = W.ray_d[i];
-    Ray r; r.o = xyz(o); r.maxt = u2f(o.w); r.d = xyz(d);
+EPSM_HD void wf_extend_begin(const TraceArgs &A, const WfState &W, int64_t i, WfJob &J, int iteration) {
+    Ray r;
+    if (iteration == 0) {
+        r = path_begin(A, i, false).ray;
+    } else {
+        const W4 o = W.ray_o[i], d = W.ray_d[i];
+        r.o = xyz(o); r.maxt = u2f(o.w); r.d = xyz(d);
+    }
     J.i = i; J.phase = 0;
     trav_begin(J.T, A.S, r);
 }
@@ -140,9 +143,9 @@ EPSM_HD bool wf_extend_round(const TraceArgs &A, const WfState &W, WfJob &J, uin
     W.hit[J.i] = h;
     return true;
 }
-EPSM_HD void wf_extend(const TraceArgs &A, const WfState &W, int64_t i, uint32_t *lds, int stride) {
+EPSM_HD void wf_extend(const TraceArgs &A, const WfState &W, int64_t i, uint32_t *lds, int stride, int iteration) {
     WfJob J;
-    wf_extend_begin(A, W, i, J);
+    wf_extend_begin(A, W, i, J, iteration);
     while (!wf_extend_round(A, W, J, lds, stride)) {}
 }
 
@@ -162,7 +165,7 @@ struct DeferredVis {
 // ---- stage: shade.  Returns through `alive` / `shadow` whether path i goes on to bounce `iteration + 1` / has a
 //      visibility ray pending; the caller compacts.
 EPSM_HD void wf_shade(const TraceArgs &A, const WfState &W, int64_t i, int iteration, bool &alive, bool &shadow) {
-    PathState s = wf_load(W, i);
+    PathState s = iteration == 0 ? path_begin(A, i) : wf_load(W, i);
     const W4 h = W.hit[i];
     TriHit th; th.hit = h.x != kNoIndex; th.tri = th.hit ? h.x : 0u; th.t = u2f(h.y); th.u = u2f(h.z); th.v = u2f(h.w);
     DeferredVis vis; vis.pending = false; vis.want_occluder = false; vis.Lr = zero3<float>();

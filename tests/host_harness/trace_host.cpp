@@ -68,10 +68,9 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
     const WfState W = wf_carve(workspace, N);
     memset(W.counters, 0, kWfCounters * sizeof(uint32_t));
     uint32_t stack[kWfStackLds];
-    for (int64_t i = 0; i < N; ++i) wf_generate(A, W, i);
     for (int b = 0; b < path_max_depth(A); ++b) {
         const int64_t count = b == 0 ? N : (int64_t) W.counters[b];
-        for (int64_t q = 0; q < count; ++q) wf_extend(A, W, b == 0 ? q : (int64_t) W.queue[b & 1][q], stack, 1);
+        for (int64_t q = 0; q < count; ++q) wf_extend(A, W, b == 0 ? q : (int64_t) W.queue[b & 1][q], stack, 1, b);
         for (int64_t q = 0; q < count; ++q) {
             const int64_t i = b == 0 ? q : (int64_t) W.queue[b & 1][q];
             bool alive, shadow;
