@@ -120,16 +120,16 @@ EPSM_HD bool moeller_trumbore(const Ray &r, F3 p0, F3 p1, F3 p2, float &t, float
     t = dot(e2, qvec) * inv_det;
     return u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t <= r.maxt;
 }
-// slab test; `tnear` is the entry distance (used to visit the nearer child first)
+// slab test; `tnear` is the entry distance (used to visit the nearer child first).  Per axis two subtractions, two
+// products, a min and a max; then max3 / min3 (v_max3_f32 / v_min3_f32) -- 23 instructions instead of the 33 of the
+// compare-and-swap form with its three scaled far planes (scaling the smallest far distance once is the same number:
+// rounding is monotonic).  `inv_d` is finite (trav_begin), so no 0 * inf turns up here.
 EPSM_HD bool hit_box(const float *lo, const float *hi, F3 o, F3 inv_d, float maxt, float &tnear) {
-    float t0 = 0.f, t1 = maxt;
-    const float oo[3] = {o.x, o.y, o.z}, id[3] = {inv_d.x, inv_d.y, inv_d.z};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float ta = (lo[a] - oo[a]) * id[a], tb = (hi[a] - oo[a]) * id[a];
-        if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; }
-        t0 = fmaxf(t0, ta); t1 = fminf(t1, tb * 1.0000004f);
-    }
+    const float ax = (lo[0] - o.x) * inv_d.x, bx = (hi[0] - o.x) * inv_d.x;
+    const float ay = (lo[1] - o.y) * inv_d.y, by = (hi[1] - o.y) * inv_d.y;
+    const float az = (lo[2] - o.z) * inv_d.z, bz = (hi[2] - o.z) * inv_d.z;
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+    const float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f, maxt);
     tnear = t0;
     return t0 <= t1;
 }
@@ -172,7 +172,9 @@ struct Traversal {
 EPSM_HD void trav_begin(Traversal &T, const EpsmScene &S, const Ray &r) {
     T.r = r;
     T.best.hit = false; T.best.tri = 0; T.best.t = r.maxt; T.best.u = T.best.v = 0.f;
-    T.inv_d = f3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+    // finite reciprocals: a ray parallel to a slab sees its planes at +-1e18 x distance (or at 0 when it lies IN one,
+    // which counts as inside) instead of +-inf / NaN
+    T.inv_d = f3(fminf(fmaxf(1.f / r.d.x, -1e18f), 1e18f), fminf(fmaxf(1.f / r.d.y, -1e18f), 1e18f), fminf(fmaxf(1.f / r.d.z, -1e18f), 1e18f));
     T.best_e = -1;
     T.cur = S.n_nodes > 0 ? 0 : kBvhNone;
     T.sp = 0;
