@@ -703,7 +703,7 @@ class Scene:
 
     # -- tracing ---------------------------------------------------------------------------------
     WAVEFRONT_MIN_TRIANGLES = 60000      # measured break-even on MI355X with the sparse log (64 k triangles: 4.02 / 3.93 ms per 4.2 M paths)
-    # The wavefront form is 26 launches per tile and its later bounces carry a fraction of the paths (20 % at the fourth
+    # The wavefront form is 5 launches per bounce + 1 per tile and its later bounces carry a fraction of the paths (20 % at the fourth
     # bounce of the 128 k-triangle scene): tiles as large as the sharding over the ranks allows.  512x512 @ 64 spp on that
     # scene, whole gradient image: 26.7 / 21.6 / 18.8 / 16.9 / 16.7 ms with tiles of 2^20 .. 2^24 paths (0.9 KB of log and
     # workspace per path: 14.7 GB at 2^24, of 288).
