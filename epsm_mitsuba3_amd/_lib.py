@@ -89,6 +89,13 @@ def _declare(lib):
     lib.epsm_backward_pass_packed.argtypes = [
         C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
         C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    lib.epsm_sinkhorn_splits.restype = C.c_int
+    lib.epsm_sinkhorn_splits.argtypes = [C.c_int64, C.c_int64]
+    lib.epsm_sinkhorn_scratch_bytes.restype = C.c_size_t
+    lib.epsm_sinkhorn_scratch_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int]
+    lib.epsm_sinkhorn_softmin.restype = C.c_int
+    lib.epsm_sinkhorn_softmin.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.epsm_release_workspace.restype = C.c_int
     lib.epsm_release_workspace.argtypes = []
     declare_tracer(lib)

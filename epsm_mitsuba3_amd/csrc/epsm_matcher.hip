@@ -1,0 +1,156 @@
+// The Sinkhorn matcher's inner operation on the GPU (outer loop, row f2; EPSM/utils/matcher.py:51-63 calls
+// geomloss.SamplesLoss("sinkhorn", p = 2, blur = 0.01, scaling = 0.9), whose "online" backend never forms the cost matrix):
+//
+//     out_i = -eps * log sum_j exp( h_j - |x_i - y_j|^2 / (2 eps) )              ("softmin" of the dual update)
+//     w_i   = sum_j p_ij y_j,   p_ij = softmax_j( h_j - |x_i - y_j|^2 / (2 eps) )  (optional: d out_i / d x_i = x_i - w_i)
+//
+// for two point clouds of n and m points in D <= 8 dimensions (the matcher's are 5-D: r, g, b, x, y).  The plain-torch
+// restatement (epsm_mitsuba3_amd/matcher.py) forms four n x m matrices -- 17 GB each at the 256 x 256 matching resolution
+// of exp/human.py and exp/glassslab.py, ~200 passes over them per call, 6.7 s -- this streams y through LDS and keeps a
+// running (max, sum) per row: nothing but x, y, h is read, 4.3e9 pair evaluations per call at that size.
+//
+// Decomposition: a workgroup owns 256 rows (one per lane) and ONE of S column ranges, so that small clouds fill the chip
+// too; the S partial (max, sum, weighted sum) triples of a row are merged by a second small kernel.  The column tile of
+// 256 points sits in LDS as 8 floats per point (coordinates, then h in the last word): every lane reads the SAME point at
+// the same time -- a broadcast, two ds_read_b128 per pair -- and does ~20 VALU operations on it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/epsm.h"
+#include "epsm_common.h"
+
+using epsm_host::fail;
+
+namespace {
+
+constexpr int kMaxD = 7;                 // coordinates per point (word 7 of a staged point is h)
+constexpr float kLow = -1e30f;           // "minus infinity" that survives subtraction
+
+template <int D, bool WSUM>
+__global__ __launch_bounds__(256) void softmin_partial_kernel(int64_t n, int64_t m, const float *x, const float *y, const float *h,
+                                                              float inv_2eps, int64_t cols_per_split, float *part) {
+    __shared__ float s_y[256 * 8];
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int64_t j0 = (int64_t) blockIdx.y * cols_per_split, j1 = j0 + cols_per_split < m ? j0 + cols_per_split : m;
+    float xi[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) xi[k] = i < n ? x[i * D + k] : 0.f;
+    float mx = kLow, sum = 0.f, w[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) w[k] = 0.f;
+    for (int64_t t0 = j0; t0 < j1; t0 += 256) {
+        __syncthreads();
+        {
+            const int64_t j = t0 + threadIdx.x;
+            float *dst = s_y + threadIdx.x * 8;
+#pragma unroll
+            for (int k = 0; k < D; ++k) dst[k] = j < j1 ? y[j * D + k] : 0.f;
+            dst[7] = j < j1 ? h[j] : kLow;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int jj = 0; jj < 256; ++jj) {
+            const float *p = s_y + jj * 8;
+            float d = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) { const float c = xi[k] - p[k]; d = fmaf(c, c, d); }
+            const float v = fmaf(-d, inv_2eps, p[7]);
+            const float mn = fmaxf(mx, v);
+            const float a = __expf(mx - mn), b = __expf(v - mn);      // one of the two is exp(0)
+            sum = fmaf(sum, a, b);
+            if (WSUM) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) w[k] = fmaf(w[k], a, b * p[k]);
+            }
+            mx = mn;
+        }
+    }
+    if (i < n) {
+        constexpr int kStride = WSUM ? 2 + D : 2;
+        float *o = part + ((int64_t) blockIdx.y * n + i) * kStride;
+        o[0] = mx; o[1] = sum;
+        if (WSUM) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) o[2 + k] = w[k];
+        }
+    }
+}
+
+template <int D, bool WSUM>
+__global__ __launch_bounds__(256) void softmin_merge_kernel(int64_t n, int splits, const float *part, float eps, float *out, float *wsum) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    constexpr int kStride = WSUM ? 2 + D : 2;
+    float M = kLow;
+    for (int s = 0; s < splits; ++s) M = fmaxf(M, part[((int64_t) s * n + i) * kStride]);
+    float S = 0.f, W[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) W[k] = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        const float *p = part + ((int64_t) s * n + i) * kStride;
+        const float a = __expf(p[0] - M);
+        S = fmaf(p[1], a, S);
+        if (WSUM) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) W[k] = fmaf(p[2 + k], a, W[k]);
+        }
+    }
+    out[i] = -eps * (M + __logf(S));
+    if (WSUM) {
+        const float r = 1.f / S;
+#pragma unroll
+        for (int k = 0; k < D; ++k) wsum[i * D + k] = W[k] * r;
+    }
+}
+
+template <int D, bool WSUM>
+hipError_t run(int64_t n, int64_t m, const float *x, const float *y, const float *h, float eps, float *out, float *wsum,
+               float *scratch, int splits, hipStream_t s) {
+    const int64_t row_blocks = (n + 255) / 256;
+    const int64_t cols = ((m + splits - 1) / splits + 255) / 256 * 256;
+    hipLaunchKernelGGL((softmin_partial_kernel<D, WSUM>), dim3((unsigned) row_blocks, (unsigned) splits), dim3(256), 0, s,
+                       n, m, x, y, h, 0.5f / eps, cols, scratch);
+    hipLaunchKernelGGL((softmin_merge_kernel<D, WSUM>), dim3((unsigned) row_blocks), dim3(256), 0, s, n, splits, scratch, eps, out, wsum);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int epsm_sinkhorn_splits(int64_t n, int64_t m) {
+    // enough workgroups for four per CU, no column range shorter than one tile
+    const int64_t row_blocks = (n + 255) / 256, tiles = (m + 255) / 256;
+    int64_t s = (1024 + row_blocks - 1) / (row_blocks > 0 ? row_blocks : 1);
+    if (s > tiles) s = tiles;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int) s;
+}
+
+extern "C" size_t epsm_sinkhorn_scratch_bytes(int64_t n, int64_t m, int D) {
+    return (size_t) epsm_sinkhorn_splits(n, m) * (size_t) n * (size_t) (2 + D) * sizeof(float);
+}
+
+extern "C" int epsm_sinkhorn_softmin(int64_t n, int64_t m, int D, const float *x, const float *y, const float *h, float eps,
+                                     float *out, float *wsum, void *scratch, size_t scratch_bytes, void *stream) {
+    epsm_host::err_buf()[0] = 0;
+    if (n < 0 || m < 0 || D < 1 || D > kMaxD) return fail(EPSM_EINVAL, "epsm_sinkhorn_softmin: need n, m >= 0 and 1 <= D <= 7");
+    if (n == 0) return EPSM_OK;
+    if (m == 0) return fail(EPSM_EINVAL, "epsm_sinkhorn_softmin: empty second cloud");
+    if (!x || !y || !h || !out || !scratch) return fail(EPSM_EINVAL, "epsm_sinkhorn_softmin: NULL argument");
+    if (!(eps > 0.f)) return fail(EPSM_EINVAL, "epsm_sinkhorn_softmin: eps must be positive");
+    if (scratch_bytes < epsm_sinkhorn_scratch_bytes(n, m, D)) return fail(EPSM_EINVAL, "epsm_sinkhorn_softmin: scratch too small (epsm_sinkhorn_scratch_bytes)");
+    const int splits = epsm_sinkhorn_splits(n, m);
+    hipStream_t s = (hipStream_t) stream;
+    float *sc = (float *) scratch;
+    hipError_t e = hipSuccess;
+#define EPSM_SOFTMIN_CASE(DD) case DD: e = wsum ? run<DD, true>(n, m, x, y, h, eps, out, wsum, sc, splits, s) \
+                                                : run<DD, false>(n, m, x, y, h, eps, out, nullptr, sc, splits, s); break;
+    switch (D) {
+        EPSM_SOFTMIN_CASE(1) EPSM_SOFTMIN_CASE(2) EPSM_SOFTMIN_CASE(3) EPSM_SOFTMIN_CASE(4)
+        EPSM_SOFTMIN_CASE(5) EPSM_SOFTMIN_CASE(6) EPSM_SOFTMIN_CASE(7)
+    }
+#undef EPSM_SOFTMIN_CASE
+    if (e != hipSuccess) return epsm_host::hip_fail("epsm_sinkhorn_softmin", e);
+    return EPSM_OK;
+}

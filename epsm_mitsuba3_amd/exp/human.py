@@ -9,9 +9,9 @@ the reference's wrapper interface (``model.gen_mesh(pose, shape) -> (1, 7829, 3)
 diffuse, lit by a tiny far light, seen directly and through its shadow on the floor, with ``max_depth = 3``: the
 gradients arrive through ``si_follow.p * diffuse_grad[0]`` (the figure itself, epsm.py:561-562) and through the occluder
 term (its shadow, epsm.py:609-620).  The backward sensor is 256 x 256 at 8 spp = 524 288 paths, BASELINE.json's configs[4].
-At that matching resolution the 5-D clouds have 65 536 points.  The dense Sinkhorn restatement of matcher.py does run
-there on an MI355X -- four 17 GB cost matrices, ~100 GB with the temporaries, 6.7 s per call (`matcher = "Sinkhorn"`; the
-reference goes through geomloss's online kernels) -- and brings the vertices to 53 % of their initial distance; the default
+At that matching resolution the 5-D clouds have 65 536 points: as dense torch the Sinkhorn matcher is four 17 GB cost
+matrices and 6.7 s per call; on ``epsm_sinkhorn_softmin`` (csrc/epsm_matcher.hip, what ``Matcher`` uses on a GPU) it is
+0.46 s and no matrix (`matcher = "Sinkhorn"`), and brings the vertices to 53 % of their initial distance.  The default
 here is the reference's own sort-based ``match_sliced_wasserstein`` (utils/matcher.py:76-180): 0.1 s per call, 34 %.
 
 exp/human_tube.py keeps round 1's three-bone tube (large bends, coarse image)."""

@@ -9,6 +9,11 @@ diameter down to blur^2 by ``scaling^2`` per step, symmetric averaged updates, g
 last extrapolation step with detached duals).  PARITY UNPINNED (no geomloss here to compare with);
 pinned by properties in tests/test_matcher.py: zero gradient for identical clouds, gradient =
 displacement for a translated cloud, descent reduces the divergence.
+
+On the GPU the same iteration runs on ``epsm_sinkhorn_softmin`` (csrc/epsm_matcher.hip, include/epsm.h): the softmin of a
+dual update evaluated online -- no n x m cost matrix, which is 17 GB at the 256 x 256 matching resolution of exp/human.py --
+and the gradient of the last extrapolation in closed form (d softmin_i / d x_i = x_i - sum_j p_ij y_j).  Checked against
+this file's dense torch form in tests/test_gpu_matcher.py.
 """
 from __future__ import annotations
 
@@ -60,6 +65,69 @@ def sinkhorn_divergence(x: torch.Tensor, y: torch.Tensor, blur: float = 0.01, sc
     return (f_ba - f_aa_new).mean() + (g_ab_new - g_bb_new).mean()
 
 
+_scratch = {}
+
+
+def softmin_hip(eps: float, x: torch.Tensor, y: torch.Tensor, h: torch.Tensor, want_wsum: bool = False):
+    """``-eps * logsumexp_j(h_j - |x_i - y_j|^2 / (2 eps))`` for CUDA float32 clouds x (n,D), y (m,D), h (m): (n,) and,
+    with ``want_wsum``, ``sum_j softmax_ij y_j`` (n,D).  Fails loudly without the HIP library."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.lib()
+    assert x.is_cuda and y.is_cuda and h.is_cuda, "softmin_hip takes device tensors"
+    x, y, h = x.detach().contiguous().float(), y.detach().contiguous().float(), h.detach().contiguous().float()
+    n, D = x.shape
+    m = y.shape[0]
+    assert y.shape[1] == D and h.shape == (m,)
+    need = int(lib.epsm_sinkhorn_scratch_bytes(n, m, D))
+    key = (x.device.index, need)
+    sc = _scratch.get(key)
+    if sc is None:
+        _scratch.clear()
+        sc = _scratch[key] = torch.empty((max(need, 4) + 3) // 4, dtype=torch.float32, device=x.device)
+    out = torch.empty((n,), dtype=torch.float32, device=x.device)
+    w = torch.empty((n, D), dtype=torch.float32, device=x.device) if want_wsum else None
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _lib.check(lib.epsm_sinkhorn_softmin(n, m, D, x.data_ptr(), y.data_ptr(), h.data_ptr(), float(eps), out.data_ptr(),
+                                         w.data_ptr() if want_wsum else None, sc.data_ptr(), sc.numel() * 4, C.c_void_p(stream)),
+               "epsm_sinkhorn_softmin")
+    return (out, w) if want_wsum else out
+
+
+def sinkhorn_divergence_and_grad_hip(x: torch.Tensor, y: torch.Tensor, blur: float = 0.01, scaling: float = 0.9):
+    """The iteration of ``sinkhorn_divergence`` on the HIP softmin: returns (divergence, d divergence / d x)."""
+    with torch.no_grad():
+        x, y = x.detach().float().contiguous(), y.detach().float().contiguous()
+        n, m = x.shape[0], y.shape[0]
+        a_log = torch.full((n,), -math.log(n), device=x.device)
+        b_log = torch.full((m,), -math.log(m), device=x.device)
+        mins = torch.minimum(x.min(0).values, y.min(0).values)
+        maxs = torch.maximum(x.max(0).values, y.max(0).values)
+        diameter = float((maxs - mins).norm().clamp_min(1e-12))
+        eps_list = [diameter ** 2]
+        e = 2 * math.log(diameter)
+        while e > 2 * math.log(blur):
+            eps_list.append(math.exp(e)); e += 2 * math.log(scaling)
+        eps_list.append(blur ** 2)
+        eps = eps_list[0]
+        f_aa, g_bb = softmin_hip(eps, x, x, a_log), softmin_hip(eps, y, y, b_log)
+        g_ab, f_ba = softmin_hip(eps, y, x, a_log), softmin_hip(eps, x, y, b_log)
+        for eps in eps_list:
+            ft_ba = softmin_hip(eps, x, y, b_log + g_ab / eps)
+            gt_ab = softmin_hip(eps, y, x, a_log + f_ba / eps)
+            f_ba, g_ab = 0.5 * (f_ba + ft_ba), 0.5 * (g_ab + gt_ab)
+            f_aa = 0.5 * (f_aa + softmin_hip(eps, x, x, a_log + f_aa / eps))
+            g_bb = 0.5 * (g_bb + softmin_hip(eps, y, y, b_log + g_bb / eps))
+        eps = eps_list[-1]
+        f_ba, w_ba = softmin_hip(eps, x, y, b_log + g_ab / eps, want_wsum=True)
+        f_aa_new, w_aa = softmin_hip(eps, x, x, a_log + f_aa / eps, want_wsum=True)
+        g_ab_new = softmin_hip(eps, y, x, a_log + f_ba / eps)
+        g_bb_new = softmin_hip(eps, y, y, b_log + g_bb / eps)
+        loss = (f_ba - f_aa_new).mean() + (g_ab_new - g_bb_new).mean()
+        grad = (w_aa - w_ba) / n                  # d/dx_i of mean_i( softmin over y - softmin over (detached) x )
+    return loss, grad
+
+
 class Matcher:
     """``Matcher(res, device).match_Sinkhorn(render_rgb (res^2,3), gt_rgb (res^2,3)) -> (res^2, 5)``."""
 
@@ -70,11 +138,16 @@ class Matcher:
         # matcher.py:14-17: pos[..., 0] = x (column), pos[..., 1] = y (row)
         self.pos = torch.stack([gx, gy], dim=2).reshape(-1, 2).to(self.device)
         self.blur, self.scaling = 0.01, 0.9
+        self.backend = "hip"                    # on a GPU: csrc/epsm_matcher.hip; "torch": the dense form below (the checker)
         self.num_vectors, self.num_principle_vectors, self.rgb_weight = 50, 3, 1.0       # matcher.py:22-25
 
     def match_Sinkhorn(self, render_point: torch.Tensor, gt_rgb: torch.Tensor) -> torch.Tensor:
         target = torch.cat([gt_rgb.clamp(0, 1).to(self.device, torch.float32), self.pos], dim=1)      # matcher.py:52-54
-        render = torch.cat([render_point.clamp(0, 1).to(self.device, torch.float32), self.pos], dim=1).requires_grad_(True)
+        render = torch.cat([render_point.clamp(0, 1).to(self.device, torch.float32), self.pos], dim=1)
+        if self.device.type == "cuda" and self.backend == "hip":
+            _, g = sinkhorn_divergence_and_grad_hip(render, target, self.blur, self.scaling)
+            return g * (self.resolution * self.resolution)                                             # matcher.py:60
+        render.requires_grad_(True)
         loss = sinkhorn_divergence(render, target, self.blur, self.scaling)
         (g,) = torch.autograd.grad(loss * self.resolution * self.resolution, [render])                 # matcher.py:60
         return g

@@ -23,6 +23,7 @@
 #ifndef EPSM_H
 #define EPSM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -286,6 +287,19 @@ int epsm_backward_pass_packed(int variant, int64_t N, int K, int64_t path_offset
  * demand).  EPSM_NO_REPLICAS=1 in the environment turns the replicas off.
  * There is no reference counterpart: Dr.Jit's scatter_reduce goes straight to global atomics. */
 int epsm_release_workspace(void);
+
+/* The Sinkhorn matcher's inner operation (outer loop).  EPSM/utils/matcher.py:51-63 calls
+ * geomloss.SamplesLoss("sinkhorn", p=2, blur=0.01, scaling=0.9) on two 5-D point clouds (r,g,b,x,y); geomloss's online
+ * backend evaluates, per dual update, the "softmin"
+ *     out[i]  = -eps * log sum_j exp( h[j] - |x_i - y_j|^2 / (2 eps) )                    i < n, j < m
+ *     wsum[i] = sum_j p_ij y_j,  p_ij = softmax_j( h[j] - |x_i - y_j|^2 / (2 eps) )        (optional, (n,D); d out[i] / d x_i = x_i - wsum[i])
+ * without forming the n x m cost matrix.  x (n,D), y (m,D) row-major floats, 1 <= D <= 7, h (m) = log-weight + dual / eps;
+ * scratch: device memory of at least epsm_sinkhorn_scratch_bytes(n, m, D) bytes (partial results of the column ranges
+ * a row is split into: epsm_sinkhorn_splits).  epsm_mitsuba3_amd/matcher.py drives it (epsilon-scaling loop, debiasing). */
+int epsm_sinkhorn_splits(int64_t n, int64_t m);
+size_t epsm_sinkhorn_scratch_bytes(int64_t n, int64_t m, int D);
+int epsm_sinkhorn_softmin(int64_t n, int64_t m, int D, const float *x, const float *y, const float *h, float eps,
+                          float *out, float *wsum, void *scratch, size_t scratch_bytes, void *stream);
 
 /* Human-readable text of the last failure on the calling thread ("" if none). */
 const char *epsm_last_error(void);

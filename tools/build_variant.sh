@@ -7,4 +7,4 @@ F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=fast -fno-slp-vector
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-sched-strategy=max-ilp $2 -c -o build/epsm_grad_scatter_$1.o epsm_grad_scatter.hip &
 /opt/rocm/bin/hipcc $F $2 -c -o build/epsm_grad_$1.o epsm_grad.hip &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libepsm_$1.so build/epsm_grad_$1.o build/epsm_tangent.o build/epsm_scatter.o build/epsm_grad_scatter_$1.o build/epsm_trace.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libepsm_$1.so build/epsm_grad_$1.o build/epsm_tangent.o build/epsm_scatter.o build/epsm_grad_scatter_$1.o build/epsm_trace.o build/epsm_matcher.o
