@@ -96,6 +96,9 @@ def _declare(lib):
     lib.epsm_sinkhorn_softmin.restype = C.c_int
     lib.epsm_sinkhorn_softmin.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.epsm_sinkhorn_update.restype = C.c_int
+    lib.epsm_sinkhorn_update.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.epsm_release_workspace.restype = C.c_int
     lib.epsm_release_workspace.argtypes = []
     declare_tracer(lib)

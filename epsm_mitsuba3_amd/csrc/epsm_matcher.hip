@@ -42,6 +42,7 @@ constexpr int kRows = 4;
 
 template <int D, bool WSUM>
 __global__ __launch_bounds__(256) void softmin_partial_kernel(int64_t n, int64_t m, const float *x, const float *y, const float *h,
+                                                              const float *dual, float logw, float inv_eps,
                                                               float s, int64_t cols_per_split, float *part) {
     __shared__ float s_y[256 * 8];
     const int64_t i0 = (int64_t) blockIdx.x * (256 * kRows) + threadIdx.x;       // rows i0 + 256 r
@@ -62,7 +63,9 @@ __global__ __launch_bounds__(256) void softmin_partial_kernel(int64_t n, int64_t
             float yy = 0.f;
 #pragma unroll
             for (int k = 0; k < D; ++k) { const float v = j < j1 ? y[j * D + k] : 0.f; dst[k] = v; yy = fmaf(v, v, yy); }
-            dst[7] = j < j1 ? fmaf(h[j], kLog2e, -0.5f * s * yy) : kLow;
+            // h given, or h = log-weight + dual / eps of a Sinkhorn update (epsm_sinkhorn_update)
+            const float hj = j < j1 ? (h ? h[j] : (dual ? fmaf(dual[j], inv_eps, logw) : logw)) : 0.f;
+            dst[7] = j < j1 ? fmaf(hj, kLog2e, -0.5f * s * yy) : kLow;
         }
         __syncthreads();
 #pragma unroll 1
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void softmin_partial_kernel(int64_t n, int64_t
 
 template <int D, bool WSUM>
 __global__ __launch_bounds__(256) void softmin_merge_kernel(int64_t n, int splits, const float *part, const float *x, float s, float eps,
-                                                            float *out, float *wsum) {
+                                                            const float *prev, float *out, float *wsum) {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     constexpr int kStride = WSUM ? 2 + D : 2;
@@ -151,7 +154,8 @@ __global__ __launch_bounds__(256) void softmin_merge_kernel(int64_t n, int split
     float xx = 0.f;
 #pragma unroll
     for (int k = 0; k < D; ++k) { const float v = x[i * D + k]; xx = fmaf(v, v, xx); }
-    out[i] = -eps * kLn2 * (M - 0.5f * s * xx + __builtin_amdgcn_logf(S));       // v_log_f32 is log2
+    const float val = -eps * kLn2 * (M - 0.5f * s * xx + __builtin_amdgcn_logf(S));       // v_log_f32 is log2
+    out[i] = prev ? 0.5f * (prev[i] + val) : val;                                           // the symmetric update averages
     if (WSUM) {
         const float r = 1.f / S;
 #pragma unroll
@@ -160,13 +164,13 @@ __global__ __launch_bounds__(256) void softmin_merge_kernel(int64_t n, int split
 }
 
 template <int D, bool WSUM>
-hipError_t run(int64_t n, int64_t m, const float *x, const float *y, const float *h, float eps, float *out, float *wsum,
-               float *scratch, int splits, hipStream_t s) {
+hipError_t run(int64_t n, int64_t m, const float *x, const float *y, const float *h, const float *dual, float logw, const float *prev,
+               float eps, float *out, float *wsum, float *scratch, int splits, hipStream_t s) {
     const int64_t row_blocks = (n + 255) / 256, row_groups = (n + 256 * kRows - 1) / (256 * kRows);
     const int64_t cols = ((m + splits - 1) / splits + 255) / 256 * 256;
     hipLaunchKernelGGL((softmin_partial_kernel<D, WSUM>), dim3((unsigned) row_groups, (unsigned) splits), dim3(256), 0, s,
-                       n, m, x, y, h, kLog2e / eps, cols, scratch);
-    hipLaunchKernelGGL((softmin_merge_kernel<D, WSUM>), dim3((unsigned) row_blocks), dim3(256), 0, s, n, splits, scratch, x, kLog2e / eps, eps, out, wsum);
+                       n, m, x, y, h, dual, logw, 1.f / eps, kLog2e / eps, cols, scratch);
+    hipLaunchKernelGGL((softmin_merge_kernel<D, WSUM>), dim3((unsigned) row_blocks), dim3(256), 0, s, n, splits, scratch, x, kLog2e / eps, eps, prev, out, wsum);
     return hipGetLastError();
 }
 
@@ -186,26 +190,39 @@ extern "C" size_t epsm_sinkhorn_scratch_bytes(int64_t n, int64_t m, int D) {
     return (size_t) epsm_sinkhorn_splits(n, m) * (size_t) n * (size_t) (2 + D) * sizeof(float);
 }
 
-extern "C" int epsm_sinkhorn_softmin(int64_t n, int64_t m, int D, const float *x, const float *y, const float *h, float eps,
-                                     float *out, float *wsum, void *scratch, size_t scratch_bytes, void *stream) {
+static int softmin_entry(const char *who, int64_t n, int64_t m, int D, const float *x, const float *y, const float *h, const float *dual,
+                         float logw, const float *prev, float eps, float *out, float *wsum, void *scratch, size_t scratch_bytes, void *stream) {
     epsm_host::err_buf()[0] = 0;
-    if (n < 0 || m < 0 || D < 1 || D > kMaxD) return fail(EPSM_EINVAL, "epsm_sinkhorn_softmin: need n, m >= 0 and 1 <= D <= 7");
+    char msg[160];
+    auto bad = [&](const char *what) { snprintf(msg, sizeof(msg), "%s: %s", who, what); return fail(EPSM_EINVAL, msg); };
+    if (n < 0 || m < 0 || D < 1 || D > kMaxD) return bad("need n, m >= 0 and 1 <= D <= 7");
     if (n == 0) return EPSM_OK;
-    if (m == 0) return fail(EPSM_EINVAL, "epsm_sinkhorn_softmin: empty second cloud");
-    if (!x || !y || !h || !out || !scratch) return fail(EPSM_EINVAL, "epsm_sinkhorn_softmin: NULL argument");
-    if (!(eps > 0.f)) return fail(EPSM_EINVAL, "epsm_sinkhorn_softmin: eps must be positive");
-    if (scratch_bytes < epsm_sinkhorn_scratch_bytes(n, m, D)) return fail(EPSM_EINVAL, "epsm_sinkhorn_softmin: scratch too small (epsm_sinkhorn_scratch_bytes)");
+    if (m == 0) return bad("empty second cloud");
+    if (!x || !y || !out || !scratch) return bad("NULL argument");
+    if (!(eps > 0.f)) return bad("eps must be positive");
+    if (scratch_bytes < epsm_sinkhorn_scratch_bytes(n, m, D)) return bad("scratch too small (epsm_sinkhorn_scratch_bytes)");
     const int splits = epsm_sinkhorn_splits(n, m);
     hipStream_t s = (hipStream_t) stream;
     float *sc = (float *) scratch;
     hipError_t e = hipSuccess;
-#define EPSM_SOFTMIN_CASE(DD) case DD: e = wsum ? run<DD, true>(n, m, x, y, h, eps, out, wsum, sc, splits, s) \
-                                                : run<DD, false>(n, m, x, y, h, eps, out, nullptr, sc, splits, s); break;
+#define EPSM_SOFTMIN_CASE(DD) case DD: e = wsum ? run<DD, true>(n, m, x, y, h, dual, logw, prev, eps, out, wsum, sc, splits, s) \
+                                                : run<DD, false>(n, m, x, y, h, dual, logw, prev, eps, out, nullptr, sc, splits, s); break;
     switch (D) {
         EPSM_SOFTMIN_CASE(1) EPSM_SOFTMIN_CASE(2) EPSM_SOFTMIN_CASE(3) EPSM_SOFTMIN_CASE(4)
         EPSM_SOFTMIN_CASE(5) EPSM_SOFTMIN_CASE(6) EPSM_SOFTMIN_CASE(7)
     }
 #undef EPSM_SOFTMIN_CASE
-    if (e != hipSuccess) return epsm_host::hip_fail("epsm_sinkhorn_softmin", e);
+    if (e != hipSuccess) return epsm_host::hip_fail(who, e);
     return EPSM_OK;
+}
+
+extern "C" int epsm_sinkhorn_softmin(int64_t n, int64_t m, int D, const float *x, const float *y, const float *h, float eps,
+                                     float *out, float *wsum, void *scratch, size_t scratch_bytes, void *stream) {
+    if (!h && n > 0 && m > 0) { epsm_host::err_buf()[0] = 0; return fail(EPSM_EINVAL, "epsm_sinkhorn_softmin: NULL argument"); }
+    return softmin_entry("epsm_sinkhorn_softmin", n, m, D, x, y, h, nullptr, 0.f, nullptr, eps, out, wsum, scratch, scratch_bytes, stream);
+}
+
+extern "C" int epsm_sinkhorn_update(int64_t n, int64_t m, int D, const float *x, const float *y, const float *dual, float log_weight,
+                                    float eps, const float *prev, float *out, float *wsum, void *scratch, size_t scratch_bytes, void *stream) {
+    return softmin_entry("epsm_sinkhorn_update", n, m, D, x, y, nullptr, dual, log_weight, prev, eps, out, wsum, scratch, scratch_bytes, stream);
 }

@@ -94,13 +94,38 @@ def softmin_hip(eps: float, x: torch.Tensor, y: torch.Tensor, h: torch.Tensor, w
     return (out, w) if want_wsum else out
 
 
+def update_hip(eps: float, x: torch.Tensor, y: torch.Tensor, dual, log_weight: float, prev=None, want_wsum: bool = False):
+    """One dual update in one call (``epsm_sinkhorn_update``): softmin over y with h = log_weight + dual / eps, averaged with
+    ``prev`` when given.  x (n,D), y (m,D), dual (m) or None, prev (n) or None: contiguous CUDA float32."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.lib()
+    n, D = x.shape
+    m = y.shape[0]
+    need = int(lib.epsm_sinkhorn_scratch_bytes(n, m, D))
+    key = (x.device.index, need)
+    sc = _scratch.get(key)
+    if sc is None:
+        if len(_scratch) > 8:
+            _scratch.clear()
+        sc = _scratch[key] = torch.empty((max(need, 4) + 3) // 4, dtype=torch.float32, device=x.device)
+    out = torch.empty((n,), dtype=torch.float32, device=x.device)
+    w = torch.empty((n, D), dtype=torch.float32, device=x.device) if want_wsum else None
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _lib.check(lib.epsm_sinkhorn_update(n, m, D, x.data_ptr(), y.data_ptr(), dual.data_ptr() if dual is not None else None,
+                                        float(log_weight), float(eps), prev.data_ptr() if prev is not None else None, out.data_ptr(),
+                                        w.data_ptr() if want_wsum else None, sc.data_ptr(), sc.numel() * 4, C.c_void_p(stream)),
+               "epsm_sinkhorn_update")
+    return (out, w) if want_wsum else out
+
+
 def sinkhorn_divergence_and_grad_hip(x: torch.Tensor, y: torch.Tensor, blur: float = 0.01, scaling: float = 0.9):
-    """The iteration of ``sinkhorn_divergence`` on the HIP softmin: returns (divergence, d divergence / d x)."""
+    """The iteration of ``sinkhorn_divergence`` on the HIP kernel, one call per dual update (h = log-weight + dual / eps and
+    the averaging happen inside): returns (divergence, d divergence / d x)."""
     with torch.no_grad():
         x, y = x.detach().float().contiguous(), y.detach().float().contiguous()
         n, m = x.shape[0], y.shape[0]
-        a_log = torch.full((n,), -math.log(n), device=x.device)
-        b_log = torch.full((m,), -math.log(m), device=x.device)
+        la, lb = -math.log(n), -math.log(m)
         mins = torch.minimum(x.min(0).values, y.min(0).values)
         maxs = torch.maximum(x.max(0).values, y.max(0).values)
         diameter = float((maxs - mins).norm().clamp_min(1e-12))
@@ -110,19 +135,19 @@ def sinkhorn_divergence_and_grad_hip(x: torch.Tensor, y: torch.Tensor, blur: flo
             eps_list.append(math.exp(e)); e += 2 * math.log(scaling)
         eps_list.append(blur ** 2)
         eps = eps_list[0]
-        f_aa, g_bb = softmin_hip(eps, x, x, a_log), softmin_hip(eps, y, y, b_log)
-        g_ab, f_ba = softmin_hip(eps, y, x, a_log), softmin_hip(eps, x, y, b_log)
+        f_aa, g_bb = update_hip(eps, x, x, None, la), update_hip(eps, y, y, None, lb)
+        g_ab, f_ba = update_hip(eps, y, x, None, la), update_hip(eps, x, y, None, lb)
         for eps in eps_list:
-            ft_ba = softmin_hip(eps, x, y, b_log + g_ab / eps)
-            gt_ab = softmin_hip(eps, y, x, a_log + f_ba / eps)
-            f_ba, g_ab = 0.5 * (f_ba + ft_ba), 0.5 * (g_ab + gt_ab)
-            f_aa = 0.5 * (f_aa + softmin_hip(eps, x, x, a_log + f_aa / eps))
-            g_bb = 0.5 * (g_bb + softmin_hip(eps, y, y, b_log + g_bb / eps))
+            f_new = update_hip(eps, x, y, g_ab, lb, prev=f_ba)          # both from the OLD duals (symmetric update)
+            g_new = update_hip(eps, y, x, f_ba, la, prev=g_ab)
+            f_ba, g_ab = f_new, g_new
+            f_aa = update_hip(eps, x, x, f_aa, la, prev=f_aa)
+            g_bb = update_hip(eps, y, y, g_bb, lb, prev=g_bb)
         eps = eps_list[-1]
-        f_ba, w_ba = softmin_hip(eps, x, y, b_log + g_ab / eps, want_wsum=True)
-        f_aa_new, w_aa = softmin_hip(eps, x, x, a_log + f_aa / eps, want_wsum=True)
-        g_ab_new = softmin_hip(eps, y, x, a_log + f_ba / eps)
-        g_bb_new = softmin_hip(eps, y, y, b_log + g_bb / eps)
+        f_ba, w_ba = update_hip(eps, x, y, g_ab, lb, want_wsum=True)
+        f_aa_new, w_aa = update_hip(eps, x, x, f_aa, la, want_wsum=True)
+        g_ab_new = update_hip(eps, y, x, f_ba, la)
+        g_bb_new = update_hip(eps, y, y, g_bb, lb)
         loss = (f_ba - f_aa_new).mean() + (g_ab_new - g_bb_new).mean()
         grad = (w_aa - w_ba) / n                  # d/dx_i of mean_i( softmin over y - softmin over (detached) x )
     return loss, grad

@@ -300,6 +300,12 @@ int epsm_sinkhorn_splits(int64_t n, int64_t m);
 size_t epsm_sinkhorn_scratch_bytes(int64_t n, int64_t m, int D);
 int epsm_sinkhorn_softmin(int64_t n, int64_t m, int D, const float *x, const float *y, const float *h, float eps,
                           float *out, float *wsum, void *scratch, size_t scratch_bytes, void *stream);
+/* One dual update of the Sinkhorn loop in one call: h[j] = log_weight + dual[j] / eps (dual NULL: h = log_weight, the
+ * initialisation), out[i] = prev ? (prev[i] + softmin_i) / 2 : softmin_i (the symmetric, averaged update of geomloss's
+ * sinkhorn_loop).  `out` is written by the second of the two kernels, after every read of `dual` and element-wise after
+ * `prev`: it may alias either (the caller still needs the OLD dual of the other cloud for its own update). */
+int epsm_sinkhorn_update(int64_t n, int64_t m, int D, const float *x, const float *y, const float *dual, float log_weight,
+                         float eps, const float *prev, float *out, float *wsum, void *scratch, size_t scratch_bytes, void *stream);
 
 /* Human-readable text of the last failure on the calling thread ("" if none). */
 const char *epsm_last_error(void);

@@ -85,3 +85,19 @@ def test_matcher_at_the_reference_resolutions():
         print(f"match_Sinkhorn at {res} x {res}: {dt * 1e3:.1f} ms")
         assert grad.shape == (res * res, 5) and bool(torch.isfinite(grad).all()) and float(grad.abs().max()) > 0
         assert dt < (3.0 if res == 256 else 1.0)
+
+
+def test_update_is_the_softmin_with_h_and_averaging_inside():
+    from epsm_mitsuba3_amd.matcher import softmin_hip, update_hip
+    dev = torch.device("cuda", 0)
+    x, y, dual = _clouds(3000, 2000, 5, 7, dev)
+    prev = torch.randn(3000, device=dev)
+    for eps in (1.0, 1e-3):
+        lw = -math.log(2000)
+        ref = softmin_hip(eps, x, y, lw + dual / eps)
+        assert torch.allclose(update_hip(eps, x, y, dual, lw), ref, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(update_hip(eps, x, y, dual, lw, prev=prev), 0.5 * (prev + ref), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(update_hip(eps, x, y, None, lw), softmin_hip(eps, x, y, torch.full((2000,), lw, device=dev)), rtol=1e-5, atol=1e-6)
+        o, w = update_hip(eps, x, y, dual, lw, want_wsum=True)
+        o2, w2 = softmin_hip(eps, x, y, lw + dual / eps, want_wsum=True)
+        assert torch.allclose(w, w2, rtol=1e-4, atol=1e-5)
