@@ -37,8 +37,13 @@ constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
 // A staged point is read by every lane at the same time, and a broadcast ds_read_b128 still occupies the LDS for the
 // full 64 x 16 bytes: with one row per lane the kernel was bound by exactly that (two reads per pair = 16 LDS clocks per
-// wave and pair: 0.36 s of the 0.385 s per matcher call at 256 x 256).  kRows rows per lane share each read.
+// wave and pair: 0.36 s of the 0.385 s per matcher call at 256 x 256).  kRows rows per lane share each read: 0.23 s; with
+// the chunk loop unrolled twice 0.214 s.  What bounds it now is the vector ALU: per 64 pairs the loop issues 160
+// v_pk_fma_f32 (4 clocks each), 73 v_exp_f32 (8), ~290 subtractions / additions / maxima / moves (2): ~1 800 SIMD clocks,
+// i.e. 0.77 ms of the 1.0 ms one softmin of 65 536^2 pairs takes (eight rows per lane, scalar instead of packed
+// multiply-adds: no change).
 constexpr int kRows = 4;
+typedef float F2 __attribute__((ext_vector_type(2)));
 
 template <int D, bool WSUM>
 __global__ __launch_bounds__(256) void softmin_partial_kernel(int64_t n, int64_t m, const float *x, const float *y, const float *h,
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(256) void softmin_partial_kernel(int64_t n, int64_t
             dst[7] = j < j1 ? fmaf(hj, kLog2e, -0.5f * s * yy) : kLow;
         }
         __syncthreads();
-#pragma unroll 1
+#pragma unroll 2
         for (int jj = 0; jj < 256; jj += 8) {
             float v[kRows][8];
 #pragma unroll
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(256) void softmin_partial_kernel(int64_t n, int64_t
 #pragma unroll
                 for (int k = 0; k < D; ++k) pk[k] = p[k];
                 const float ph = p[7];
+#ifdef EPSM_AB_MATCHER_SCALAR_FMA
 #pragma unroll
                 for (int r = 0; r < kRows; ++r) {
                     float a = ph;
@@ -85,6 +91,16 @@ __global__ __launch_bounds__(256) void softmin_partial_kernel(int64_t n, int64_t
                     for (int k = 0; k < D; ++k) a = fmaf(xs[r][k], pk[k], a);
                     v[r][c] = a;
                 }
+#else
+                // two rows per v_pk_fma_f32 (the point's coordinate goes to both halves through op_sel)
+#pragma unroll
+                for (int r = 0; r < kRows; r += 2) {
+                    F2 a = {ph, ph};
+#pragma unroll
+                    for (int k = 0; k < D; ++k) a = __builtin_elementwise_fma(F2{xs[r][k], xs[r + 1][k]}, F2{pk[k], pk[k]}, a);
+                    v[r][c] = a.x; v[r + 1][c] = a.y;
+                }
+#endif
             }
             float sc[kRows];
 #pragma unroll

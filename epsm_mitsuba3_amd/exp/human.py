@@ -11,7 +11,7 @@ gradients arrive through ``si_follow.p * diffuse_grad[0]`` (the figure itself, e
 term (its shadow, epsm.py:609-620).  The backward sensor is 256 x 256 at 8 spp = 524 288 paths, BASELINE.json's configs[4].
 At that matching resolution the 5-D clouds have 65 536 points: as dense torch the Sinkhorn matcher is four 17 GB cost
 matrices and 6.7 s per call; on ``epsm_sinkhorn_softmin`` (csrc/epsm_matcher.hip, what ``Matcher`` uses on a GPU) it is
-0.23 s and no matrix (`matcher = "Sinkhorn"`), and brings the vertices to 53 % of their initial distance.  The default
+0.21 s and no matrix (`matcher = "Sinkhorn"`), and brings the vertices to 53 % of their initial distance.  The default
 here is the reference's own sort-based ``match_sliced_wasserstein`` (utils/matcher.py:76-180): 0.1 s per call, 34 %.
 
 exp/human_tube.py keeps round 1's three-bone tube (large bends, coarse image)."""
