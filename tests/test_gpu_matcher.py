@@ -52,7 +52,7 @@ def test_softmin_rejects_bad_arguments():
     assert lib.epsm_sinkhorn_splits(65536, 65536) >= 4 and lib.epsm_sinkhorn_scratch_bytes(256, 256, 5) == 1 * 256 * 7 * 4
 
 
-@pytest.mark.parametrize("res", [16, 48])
+@pytest.mark.parametrize("res", [16, 48, 128])          # 128: the matching resolution of most of the reference's experiments
 def test_matcher_on_the_kernel_equals_the_dense_matcher(res):
     from epsm_mitsuba3_amd.matcher import Matcher
     dev = torch.device("cuda", 0)
