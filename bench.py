@@ -218,6 +218,36 @@ def cpu_baseline(trace, grad_in, variant, V, B, target_s):
                       f"threads, {dt1:.2f} s"}
 
 
+def secondary_config_leg(index, dev):
+    """BASELINE.json configs[index - 1] as a secondary figure next to the headline (round 1's driver line
+    was configs[1]): one resident slab, native packed log, the one-launch backward pass timed with events over 10 launches."""
+    import epsm_mitsuba3_amd as epsm
+    from epsm_mitsuba3_amd.records import PackedLog
+    label, variant, profile, res, spp, K, V = CONFIGS[index]
+    n = min(res * res * spp, SLAB_PATHS)
+    scene = epsm.SyntheticScene(res=res, n_vertices=K, n_scene_vertices=V, n_bsdfs=4, profile=profile, device=dev, tile_paths=n)
+    integ = epsm.load_dict({"type": variant, "max_depth": 8})
+    trace = scene.tile(0, 0, n, seed=0, spp=spp, K=K, lean=True)
+    log = PackedLog.from_trace(trace, device=dev, table=scene.triangle_table(), free=True)
+    trace = epsm.PathTrace(res=trace.res, spp=trace.spp, ray_o=None, ray_d=None, ray_dx=None, ray_dy=None, path_info=None,
+                           scatter_info=None, path_offset=trace.path_offset, n_paths_total=trace.n_paths_total)
+    g = torch.Generator(device=dev).manual_seed(1)
+    grad_in = torch.randn((res, res, 5), generator=g, device=dev) * 1e-3
+    params = epsm.ParamGrads(V, 4, device=dev)
+    for _ in range(2):
+        integ.backward_from_trace(trace, params, grad_in, packed=log)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        integ.backward_from_trace(trace, params, grad_in, packed=log)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    alg = (56 + 116 * K) * n
+    return {"workload": f"{label}: one slab of {n} paths, native packed log", "kernel_ms": ms, "paths_per_s": n / (ms * 1e-3),
+            "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_path": 56 + 116 * K,
+            "note": "secondary figure, outside the timed region"}
+
+
 def real_scene_leg(variant, res, spp, dev):
     """Secondary figure, outside the timed region: gradient image of a TRACED scene (epsm_mitsuba3_amd/exp/clutter.py,
     the stand-in for the bathroom asset the reference does not ship): render_backward = native tracer with vertex log
@@ -537,6 +567,8 @@ def main():
                                                 "note": "outside the timed region; first stage of --two-stage"}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(slabs[0][0], grad_in, variant, V, B, args.cpu_seconds)
+        if world == 1 and args.config == 0 and not (args.soa or args.two_stage or args.separate_tangent):
+            result["configs_1"] = secondary_config_leg(2, dev)          # BASELINE.json configs[1]: round 1's driver line
         if args.real_scene and world == 1:
             del slabs, out
             torch.cuda.empty_cache()
