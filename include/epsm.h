@@ -30,6 +30,8 @@
 extern "C" {
 #endif
 
+/* Changes when the meaning or signature of an existing entry point changes (4: triangle-id addressing, round 2).  Entry points
+ * added since without touching the others: epsm_backward_pass_packed, epsm_release_workspace, epsm_sinkhorn_*. */
 #define EPSM_ABI_VERSION 4
 
 /* BSDF flag bits tested by the hot path (include/mitsuba/render/bsdf.h:40-46,101). */
