@@ -39,8 +39,8 @@ POSE_CLAMP = 0.1                                                          # opti
 # after ~30 more steps the angles sit at the +-0.1 clamp with the image worse than at the start -- more slowly without the
 # occluder term (max_depth = 2).  It is not Adam: plain gradient steps do the same, with and without the occluder term, and
 # the matcher's own loss (Sinkhorn divergence of a 256-spp render from the target) rises with the image MSE after the
-# minimum -- the first-hit term (si_follow.p * diffuse_grad[0]) slides a visible point inside its tilted triangle, which has
-# a component along the view ray that nothing in the image restrains.  At the target pose the seed-averaged gradient is
+# minimum.  (A candidate, not established: the first-hit term, si_follow.p * diffuse_grad[0], slides a visible point inside
+# its tilted triangle, which has a component along the view ray that nothing in the image restrains.)  At the target pose the seed-averaged gradient is
 # 8 % of the one at the zero pose, so the descent direction itself is sound.  exp/human_tube.py, which frees only the angles the view determines, converges and
 # stays.  The test therefore checks the descent (tests/test_gpu_optim.py), not a fixed point.
 
