@@ -302,7 +302,7 @@ def kernel_source_hash() -> str:
     h = hashlib.sha256()
     d = os.path.join(ROOT, "epsm_mitsuba3_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")) and not name.startswith(("epsm_trace", "epsm_matcher")):
+        if (name.endswith((".hip", ".h")) and not name.startswith(("epsm_trace", "epsm_matcher"))) or name == "Makefile":   # flags count
             h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 

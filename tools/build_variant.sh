@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../epsm_mitsuba3_amd/csrc"
 make -s
 F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=fast -fno-slp-vectorize -Wall -Wno-unused-function"
-/opt/rocm/bin/hipcc $F -mllvm -amdgpu-sched-strategy=max-ilp $2 -c -o build/epsm_grad_scatter_$1.o epsm_grad_scatter.hip &
+/opt/rocm/bin/hipcc $F -mllvm -amdgpu-sched-strategy=iterative-maxocc $2 -c -o build/epsm_grad_scatter_$1.o epsm_grad_scatter.hip &
 /opt/rocm/bin/hipcc $F $2 -c -o build/epsm_grad_$1.o epsm_grad.hip &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libepsm_$1.so build/epsm_grad_$1.o build/epsm_tangent.o build/epsm_scatter.o build/epsm_grad_scatter_$1.o build/epsm_trace.o build/epsm_matcher.o
