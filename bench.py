@@ -99,6 +99,8 @@ def parse(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher + process group + one all-reduce of the parameter-gradient buffer only (gloo on a box "
                          "without GPU): what tests/test_bench_launcher.py runs")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the configs[1] leg after the timed region (the profiling runs want the headline launches only)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="with --gpus N: all N ranks on GPU 0 and the collectives by gloo through the host -- runs the "
                          "sharded path (launcher, slab s -> rank s mod N, scratch buffers, one all-reduce per step) on a "
@@ -571,7 +573,7 @@ def main():
                                                 "note": "outside the timed region; first stage of --two-stage"}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(slabs[0][0], grad_in, variant, V, B, args.cpu_seconds)
-        if world == 1 and args.config == 0 and not (args.soa or args.two_stage or args.separate_tangent):
+        if world == 1 and args.config == 0 and not (args.soa or args.two_stage or args.separate_tangent or args.no_secondary):
             result["configs_1"] = secondary_config_leg(2, dev)          # BASELINE.json configs[1]: round 1's driver line
         if args.real_scene and world == 1:
             del slabs, out

@@ -4,7 +4,7 @@ T=gpurun_out/${1:-r2h}
 timeout -k 10 1000 python -m pytest tests -m gpu -q > ${T}_pytest.log 2>&1; echo "pytest rc $?" >> ${T}_pytest.log; tail -4 ${T}_pytest.log
 timeout -k 10 300 python __graft_entry__.py smoke > ${T}_smoke.log 2>&1; tail -2 ${T}_smoke.log
 timeout -k 10 900 python bench.py > ${T}_bench.json 2> ${T}_bench.err; cut -c1-400 ${T}_bench.json; tail -2 ${T}_bench.err
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --max-resident-gb 45"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --max-resident-gb 45"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d ${T}_trace -- $B > ${T}_trace.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "epsm" --output-format csv -d ${T}_pmc_fetch -- $B > ${T}_pmc1.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "epsm" --output-format csv -d ${T}_pmc_write -- $B > ${T}_pmc2.log 2>&1
