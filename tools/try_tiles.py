@@ -22,7 +22,7 @@ def timed(fn, n=5):
         torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize()
         out.append((time.perf_counter() - t) * 1e3)
     return sorted(out)[n // 2]
-for lg in (20, 21, 22, 23, 24):
+for lg in ((24,) if os.environ.get("TILES_ONLY_24") else (20, 21, 22, 23, 24)):
     Scene.WAVEFRONT_TILE_PATHS = 1 << lg
     scene.WAVEFRONT_TILE_PATHS = 1 << lg
     t = timed(lambda: integ.render_backward(scene, params, grad_in, seed=1))
