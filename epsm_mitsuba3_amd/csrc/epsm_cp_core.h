@@ -1,0 +1,368 @@
+// epsm_cp_core.h -- the manifold-gradient arithmetic in CONSTRAINT-PARALLEL form.
+//
+// epsm_path_core.h gives one lane a whole light path: per-vertex state of up to five vertices lives in registers between
+// a forward and a backward pass (130 of the 256 VGPRs of the fused kernel), every half-vector constraint is evaluated
+// twice and its frame three times.  Here the unit of work is ONE CONSTRAINT VERTEX of one path:
+//
+//   eval      lane (path, k) loads vertex k and the positions / edges of its two neighbours, evaluates the projected
+//             half-vector constraint(s) of vertex k ONCE and keeps their unit-seed reverse sweeps -- the 2 x 12 Jacobian
+//             of C_k w.r.t. (x_{k-1}, x_k, x_{k+1}, n_k) -- in registers, together with the 2x2 blocks of `cur`
+//             (epsm.py:771, 826-833, 889-900) they contract to;
+//   recursion the block recursions of epsm_path_core.h (manifold: block LU forward, adjoint seeds backward;
+//             manifold_caustic: one forward recursion) run ACROSS the lanes of a path: step s is taken by the lanes
+//             with k == s, which receive ten-odd numbers from lane k-1 (k+1);
+//   finish    every output of vertex k is a linear combination of the lane's own unit sweeps with the seeds the
+//             recursion produced -- nothing is re-evaluated -- plus d/dx_k through constraint k+1, handed down by
+//             the neighbouring lane.
+//
+// Per-lane state no longer grows with the chain length, chains of different lengths keep all lanes busy, and the
+// vertex loops are real loops (the per-vertex arrays that forced compile-time unrolling are gone).
+//
+// What is computed is what epsm_path_core.h computes -- ManifoldIntegrator.calc_grad (epsm.py:745-946) and
+// ManifoldCausticIntegrator.calc_grad (epsm.py:952-1200) in adjoint form, same masks, same quirks, same NaN and clamp
+// rules; the derivation is in that file's header and in DESIGN.md section 2.  The frame derivative is written in closed
+// form here (epsm.py:746-756 differentiated by hand) instead of as the reverse sweep of the cross products.
+//
+// Plain C++ templated on the scalar type: hipcc compiles it into the gfx950 backward kernel (epsm_backward_cp.hip, lanes
+// = wave lanes, exchange = shuffles) and tests/host_harness compiles the SAME functions for the CPU (lanes = array
+// entries), so the algebra is checked against the reference's goldens and the oracle without a GPU.
+#pragma once
+
+#include "epsm_path_core.h"
+
+namespace epsm {
+namespace cp {
+
+// ----------------------------------------------------------------------------
+// plan of a path: which terms exist (from the flag word alone)
+// ----------------------------------------------------------------------------
+// Flag word: 5 bits per logged vertex (include/epsm.h EPSM_FLAG_*), vertex k at bits 5(k-1)..; vertices beyond K are 0.
+// Plan word:
+//   bits 0..4   manifold: wN[k] (light-sampling term at depth k)      caustic: wP[k] (epsm.py:1172-1174)
+//   bits 5..9   manifold: wC[k] (continuing term at depth k)          caustic: wD[k] (epsm.py:1180-1182)
+//   bits 10..12 nv: last vertex whose geometry is needed
+//   bits 13..15 manifold: bit 13 = the last vertex has a light-sampling term      caustic: id* (0 = none)
+//   bits 16..18 m: number of constraint vertices (lanes with a constraint); a path always gets max(m, 1) lanes,
+//               the first of which also carries the first-vertex tangent and diffuse_grad[0]
+//   bit  19     first logged vertex is diffuse
+//   bit  20     path index inside the wavefront (set by the caller)
+constexpr uint32_t kPlanInRange = 1u << 20;
+EPSM_HD int plan_nv(uint32_t p) { return (int) ((p >> 10) & 7u); }
+EPSM_HD int plan_m(uint32_t p) { return (int) ((p >> 16) & 7u); }
+EPSM_HD int plan_idstar(uint32_t p) { return (int) ((p >> 13) & 7u); }
+EPSM_HD bool plan_a(uint32_t p, int k) { return ((p >> (k - 1)) & 1u) != 0; }        // wN / wP
+EPSM_HD bool plan_b(uint32_t p, int k) { return ((p >> (4 + k)) & 1u) != 0; }        // wC / wD
+EPSM_HD bool plan_diffuse1(uint32_t p) { return ((p >> 19) & 1u) != 0; }
+
+EPSM_HD bool fbit(uint32_t w, int k, uint32_t bit) { return k >= 1 && k <= 5 && ((w >> (5 * (k - 1))) & bit) != 0; }
+
+// term masks of epsm.py:793-802, 852-855, 916-920 (manifold_path of epsm_path_core.h)
+EPSM_HD uint32_t manifold_plan(uint32_t w) {
+    bool valid = true;
+    int hasdiffuse = 0, nv = 0;
+    bool nvN = false;
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (int id = 1; id <= 5; ++id) {
+        valid = valid && fbit(w, id, 16u);
+        hasdiffuse += fbit(w, id, 1u) ? 1 : 0;
+        valid = valid && (hasdiffuse < 2);
+        const bool spec = valid && (hasdiffuse == 0);
+        const bool wN = spec && fbit(w, id, 4u) && fbit(w, id, 8u);
+        const bool wC = spec && fbit(w, id + 1, 4u) && fbit(w, id + 1, 1u);
+        if (wN) { nv = id; nvN = true; a |= 1u << (id - 1); }
+        if (wC) { nv = id + 1; nvN = false; b |= 1u << (id - 1); }
+    }
+    const int m = nvN ? nv : (nv > 0 ? nv - 1 : 0);
+    return a | (b << 5) | ((uint32_t) nv << 10) | (nvN ? 1u << 13 : 0u) | ((uint32_t) m << 16) | (fbit(w, 1, 1u) ? 1u << 19 : 0u);
+}
+// epsm.py:1172-1183 (caustic_path of epsm_path_core.h)
+EPSM_HD uint32_t caustic_plan(uint32_t w) {
+    bool valid = true;
+    int hasdiffuse = 0, nv = 0, idstar = 0;
+    uint32_t a = 0, b = 0;
+    const bool d1 = fbit(w, 1, 1u);
+#pragma unroll
+    for (int id = 1; id <= 5; ++id) {
+        valid = valid && fbit(w, id, 16u);
+        hasdiffuse += fbit(w, id, 1u) ? 1 : 0;
+        valid = valid && (hasdiffuse < 2);
+        const bool base = d1 && valid && fbit(w, id + 1, 4u);
+        const bool wP = base && fbit(w, id + 1, 1u);
+        const bool wD = base && (fbit(w, id + 1, 1u) || fbit(w, id + 1, 2u));
+        if (wD) { nv = id + 1; b |= 1u << (id - 1); }
+        if (wP) { idstar = id; a |= 1u << (id - 1); }
+    }
+    const int m = nv > 0 ? nv - 1 : 0;
+    return a | (b << 5) | ((uint32_t) nv << 10) | ((uint32_t) idstar << 13) | ((uint32_t) m << 16) | (d1 ? 1u << 19 : 0u);
+}
+
+// ----------------------------------------------------------------------------
+// geometry a lane holds
+// ----------------------------------------------------------------------------
+template <typename R> struct Own {      // vertex k itself
+    V3<R> x, e1, e2;                    // x = sum b_j p_j, e_j = dx/db_j   (epsm.py:758-759)
+    V3<R> n, dn1, dn2;                  // un-normalised interpolated normal and dn/db_j   (epsm.py:761-762)
+    R b0, b1, eta;
+    V3<R> light;                        // emitter sample point
+};
+template <typename R> struct Nbr { V3<R> x, e1, e2; };      // vertex k-1 / k+1 (the camera: e1 = e2 = 0)
+
+// local frame of epsm.py:746-756 in closed form: t = (0, ty, tz) = (0, -nn_z, nn_y) / sg,  bt = nn x t
+template <typename R> struct Frm { V3<R> nn, bt; R inv_n, ty, tz, isg; };
+template <typename R> EPSM_HD Frm<R> make_frm(V3<R> n) {
+    Frm<R> f;
+    f.inv_n = rsqrt_(dot(n, n));
+    f.nn = n * f.inv_n;
+    const R s2 = f.nn.y * f.nn.y + f.nn.z * f.nn.z;      // n || x: 0 -> isg non-finite -> the term is dropped (epsm.py:746-748, 856)
+    f.isg = rsqrt_(s2);
+    f.ty = -f.nn.z * f.isg;
+    f.tz = f.nn.y * f.isg;
+    f.bt = mk3<R>(s2 * f.isg, -f.nn.x * f.tz, f.nn.x * f.ty);
+    return f;
+}
+// d(t . w)/dn and d(bt . w)/dn for a vector w that does not depend on n (rows of the frame differentiated by hand,
+// then through nn = n / |n|)
+template <typename R> EPSM_HD void frame_grad(const Frm<R> &f, V3<R> w, R cx, V3<R> &g0, V3<R> &g1) {
+    const R x = f.nn.x, q = f.nn.y * w.y + f.nn.z * w.z, xi = x * f.isg, qi = q * f.isg;
+    const V3<R> G0 = mk3<R>(R(0), (w.z - cx * f.tz) * f.isg, (cx * f.ty - w.y) * f.isg);
+    const V3<R> G1 = mk3<R>(-qi, w.x * f.tz + xi * (qi * f.tz - w.y), -w.x * f.ty - xi * (w.z + qi * f.ty));
+    g0 = (G0 - f.nn * dot(f.nn, G0)) * f.inv_n;
+    g1 = (G1 - f.nn * dot(f.nn, G1)) * f.inv_n;
+}
+
+// Unit-seed reverse sweeps of one constraint: row r = gradient of component r.  d/dx_k = -(gxp + gxn).
+template <typename R> struct Jac { V3<R> gxp[2], gxn[2], gn[2]; };
+template <typename R> EPSM_HD Jac<R> zero_jac() {
+    Jac<R> j;
+    j.gxp[0] = j.gxp[1] = j.gxn[0] = j.gxn[1] = j.gn[0] = j.gn[1] = zero3<R>();
+    return j;
+}
+template <typename R> struct Dir { V3<R> w; R inv; };      // unit direction and 1/length
+template <typename R> EPSM_HD Dir<R> make_dir(V3<R> from, V3<R> to) {
+    Dir<R> d;
+    const V3<R> a = to - from;
+    d.inv = rsqrt_(dot(a, a));
+    d.w = a * d.inv;
+    return d;
+}
+// C = [ normalize(R wi + eta R wo) ]_xy   (epsm.py:809-821)
+template <typename R> EPSM_HD Jac<R> halfvec_jac(const Frm<R> &f, const Dir<R> &wi, const Dir<R> &wo, R eta) {
+    Jac<R> j;
+    const V3<R> u = madd(wi.w, wo.w, eta);
+    const R inv_u = rsqrt_(dot(u, u));
+    const V3<R> uh = u * inv_u;
+    const R cx = f.ty * uh.y + f.tz * uh.z, cy = dot(f.bt, uh);
+    // d C_r / d u
+    const V3<R> P0 = (mk3<R>(R(0), f.ty, f.tz) - uh * cx) * inv_u, P1 = (f.bt - uh * cy) * inv_u;
+    j.gxp[0] = (P0 - wi.w * dot(wi.w, P0)) * wi.inv;
+    j.gxp[1] = (P1 - wi.w * dot(wi.w, P1)) * wi.inv;
+    const R eb = eta * wo.inv;
+    j.gxn[0] = (P0 - wo.w * dot(wo.w, P0)) * eb;
+    j.gxn[1] = (P1 - wo.w * dot(wo.w, P1)) * eb;
+    frame_grad(f, uh, cx, j.gn[0], j.gn[1]);
+    return j;
+}
+// pseudo-constraint of manifold_caustic: wo2 = [R normalize(x_next - x)]_xy   (epsm.py:1028, 1116); gxp = 0
+template <typename R> EPSM_HD Jac<R> wo2_jac(const Frm<R> &f, const Dir<R> &wo) {
+    Jac<R> j;
+    const R cx = f.ty * wo.w.y + f.tz * wo.w.z, cy = dot(f.bt, wo.w);
+    j.gxp[0] = j.gxp[1] = zero3<R>();
+    j.gxn[0] = (mk3<R>(R(0), f.ty, f.tz) - wo.w * cx) * wo.inv;
+    j.gxn[1] = (f.bt - wo.w * cy) * wo.inv;
+    frame_grad(f, wo.w, cx, j.gn[0], j.gn[1]);
+    return j;
+}
+template <typename R> EPSM_HD V3<R> gxc(const Jac<R> &j, int r) { return -(j.gxp[r] + j.gxn[r]); }
+
+// seeded combination of the two rows
+template <typename R> EPSM_HD V3<R> lin(const V3<R> v[2], V2<R> s) { return v[0] * s.x + v[1] * s.y; }
+
+// 2x2 blocks of `cur`: rows = components of the constraint, columns = (b0, b1) of a vertex
+template <typename R> EPSM_HD M2<R> blk(const V3<R> g[2], V3<R> e1, V3<R> e2) { return block2(g[0], g[1], e1, e2); }
+template <typename R> EPSM_HD M2<R> blk_own(const Jac<R> &j, const Own<R> &o) {
+    const V3<R> c0 = gxc(j, 0), c1 = gxc(j, 1);
+    return madd2(block2(c0, c1, o.e1, o.e2), block2(j.gn[0], j.gn[1], o.dn1, o.dn2));
+}
+
+// ============================================================================
+// "manifold"
+// ============================================================================
+template <typename R> struct MEval {
+    Jac<R> jn, jc;                       // light-sampling / continuing version
+    M2<R> AkkN, AkmN, AkkC, AkmC, Aup;   // A_{k,k}, A_{k,k-1} of both versions; A^C_{k,k+1}
+};
+// lane (path, k): wN = plan_a(k), has_next = k + 1 <= nv
+template <typename R> EPSM_HD MEval<R> manifold_eval(const Own<R> &o, const Nbr<R> &prev, const Nbr<R> &next, bool wN, bool has_next) {
+    MEval<R> e;
+    const M2<R> z{R(0), R(0), R(0), R(0)};
+    e.jn = zero_jac<R>(); e.jc = e.jn;
+    e.AkkN = e.AkmN = e.AkkC = e.AkmC = e.Aup = z;
+    const Frm<R> f = make_frm(o.n);
+    const Dir<R> wi = make_dir(o.x, prev.x);
+    if (wN) {
+        e.jn = halfvec_jac(f, wi, make_dir(o.x, o.light), o.eta);
+        e.AkkN = blk_own(e.jn, o);
+        e.AkmN = blk(e.jn.gxp, prev.e1, prev.e2);
+    }
+    if (has_next) {
+        e.jc = halfvec_jac(f, wi, make_dir(o.x, next.x), o.eta);
+        e.AkkC = blk_own(e.jc, o);
+        e.AkmC = blk(e.jc.gxp, prev.e1, prev.e2);
+        e.Aup = blk(e.jc.gxn, next.e1, next.e2);
+    }
+    return e;
+}
+
+// what lane k hands to lane k+1 in the forward recursion / keeps for the backward one
+template <typename R> struct MFwd { V2<R> z, zN; M2<R> Sinv; };
+template <typename R> EPSM_HD MFwd<R> mfwd_zero() {
+    MFwd<R> f;
+    f.z = f.zN = mk2<R>(R(0), R(0));
+    f.Sinv = M2<R>{R(0), R(0), R(0), R(0)};
+    return f;
+}
+// forward step of lane k (block LU of the continuing rows; pass 1 of manifold_path).  `pf`, `pAup`: z, Sinv and
+// A^C_{k-1,k} of lane k-1 (ignored for k == 1).  Computed in RecType (float64, see epsm_path_core.h), kept in R.
+template <typename R>
+EPSM_HD MFwd<R> manifold_fwd(const MEval<R> &e, V2<R> dk, bool first, const MFwd<R> &pf, const M2<R> &pAup, bool wN, bool has_next) {
+    typedef typename RecType<R>::type Q;
+    MFwd<R> o = mfwd_zero<R>();
+    V2<Q> rhs = cvv<Q>(dk);
+    M2<Q> T{Q(0), Q(0), Q(0), Q(0)};
+    if (!first) {
+        const M2<Q> Au = cvm<Q>(pAup);
+        rhs = rhs - vmul(cvv<Q>(pf.z), Au);
+        T = mmul(cvm<Q>(pf.Sinv), Au);
+    }
+    if (wN) {
+        M2<Q> S = cvm<Q>(e.AkkN);
+        if (!first) S = msub(S, mmul(cvm<Q>(e.AkmN), T));
+        o.zN = cvv<R>(vmul(rhs, minv(S)));
+    }
+    if (has_next) {
+        M2<Q> S = cvm<Q>(e.AkkC);
+        if (!first) S = msub(S, mmul(cvm<Q>(e.AkmC), T));
+        const M2<Q> Si = minv(S);
+        o.Sinv = cvm<R>(Si);
+        o.z = cvv<R>(vmul(rhs, Si));
+    }
+    return o;
+}
+// what lane k hands to lane k-1 in the backward recursion
+template <typename R> struct MBwd { V3<R> GP; int W; };       // d/dx_{k-1} through constraint k; live terms of depth >= k
+// results of lane k
+template <typename R> struct MOut { V3<R> Gx, gn, gm, glight, gdiff; };
+// backward step of lane k (pass 2 of manifold_path): `nb` comes from lane k+1 (zero for the last lane)
+template <typename R>
+EPSM_HD MOut<R> manifold_bwd(const MEval<R> &e, const MFwd<R> &f, const Own<R> &o, const MBwd<R> &nb, bool wN, bool wC, bool has_next,
+                             MBwd<R> &mine) {
+    typedef typename RecType<R>::type Q;
+    MOut<R> out;
+    // carry = W z_k - (GP . [e1 e2]_k) Sinv_k : the sum over deeper terms of their y_k
+    V2<Q> carry = mk2<Q>(Q(0), Q(0));
+    if (nb.W > 0) {
+        const V2<Q> q = mk2<Q>(Q(dot(nb.GP, o.e1)), Q(dot(nb.GP, o.e2)));
+        carry = cvv<Q>(f.z) * Q(nb.W) - vmul(q, cvm<Q>(f.Sinv));
+    }
+    const bool fN = wN && finite2(f.zN);
+    const bool fC = wC && finite2(f.z);
+    const V2<R> sN = fN ? f.zN : mk2<R>(R(0), R(0));
+    V2<Q> sCq = carry;
+    if (fC) sCq = sCq + cvv<Q>(f.z);
+    const V2<R> sC = cvv<R>(sCq);
+    const bool useN = sN.x != R(0) || sN.y != R(0);
+    const bool useC = has_next && (sC.x != R(0) || sC.y != R(0));
+    const V3<R> z3 = zero3<R>();
+    const V3<R> a_p = useN ? lin(e.jn.gxp, sN) : z3, a_n = useN ? lin(e.jn.gxn, sN) : z3, a_g = useN ? lin(e.jn.gn, sN) : z3;
+    const V3<R> c_p = useC ? lin(e.jc.gxp, sC) : z3, c_n = useC ? lin(e.jc.gxn, sC) : z3, c_g = useC ? lin(e.jc.gn, sC) : z3;
+    // -(a.gxc + c.gxc + GP) with gxc = -(gxp + gxn)
+    out.Gx = (a_p + a_n) + (c_p + c_n) - nb.GP;
+    out.gn = -(a_g + c_g);
+    out.gm = has_next ? mk3<R>(sC.x, sC.y, R(0)) : z3;        // dC/dm = -I on continuing rows (epsm.py:883)
+    out.glight = -a_n;
+    out.gdiff = fC ? -c_n : z3;                               // carry == 0 whenever fC (a diffuse x_{k+1} ends the chain)
+    mine.GP = a_p + c_p;
+    mine.W = nb.W + (fN ? 1 : 0) + (fC ? 1 : 0);
+    return out;
+}
+
+// ============================================================================
+// "manifold_caustic"
+// ============================================================================
+template <typename R> struct CEval {
+    Jac<R> jc, jw;                  // half-vector constraint of vertex k (k >= 2), pseudo-constraint wo2 of depth k
+    M2<R> Akk, Akm, Aup, Wk;
+};
+template <typename R> EPSM_HD CEval<R> caustic_eval(const Own<R> &o, const Nbr<R> &prev, const Nbr<R> &next, bool first) {
+    CEval<R> e;
+    const M2<R> z{R(0), R(0), R(0), R(0)};
+    const Frm<R> f = make_frm(o.n);
+    const Dir<R> wo = make_dir(o.x, next.x);
+    e.jw = wo2_jac(f, wo);
+    e.Wk = blk_own(e.jw, o);
+    e.jc = zero_jac<R>();
+    e.Akk = e.Akm = e.Aup = z;
+    if (!first) {
+        e.jc = halfvec_jac(f, make_dir(o.x, prev.x), wo, o.eta);
+        e.Akm = blk(e.jc.gxp, prev.e1, prev.e2);
+        e.Akk = blk_own(e.jc, o);
+        e.Aup = blk(e.jc.gxn, next.e1, next.e2);
+    }
+    return e;
+}
+// forward recursion: v_k = r_{k-1} A_{k,k-1}^-1, r_k = d_k - v_k A_kk - v_{k-1} A_{k-1,k}, u_k = r_k W_k^-1
+template <typename R> struct CFwd { V2<R> v, r, u; bool fin; };
+template <typename R> EPSM_HD CFwd<R> cfwd_zero() {
+    CFwd<R> f;
+    f.v = f.r = f.u = mk2<R>(R(0), R(0));
+    f.fin = true;
+    return f;
+}
+template <typename R>
+EPSM_HD CFwd<R> caustic_fwd(const CEval<R> &e, V2<R> dk, bool first, const CFwd<R> &pf, const M2<R> &pAup) {
+    CFwd<R> o;
+    o.v = mk2<R>(R(0), R(0));
+    V2<R> rk = dk;
+    if (!first) {
+        o.v = vmul(pf.r, minv(e.Akm));
+        rk = dk - vmul(o.v, e.Akk) - vmul(pf.v, pAup);
+    }
+    o.r = rk;
+    o.u = vmul(rk, minv(e.Wk));
+    o.fin = finite2(o.u) && finite2(o.v);
+    return o;
+}
+template <typename R> struct COut { V3<R> Gx, gn, gm, gdiff, gxp_prev; };
+// lane k once the recursion has reached it; `inP` = k <= id*, `star` = k == id*, wD = plan_b(k).
+// gxp_prev: -(d/dx_{k-1}) through constraint k, to be ADDED to Gx of lane k-1.
+template <typename R> EPSM_HD COut<R> caustic_finish(const CEval<R> &e, const CFwd<R> &f, bool first, bool inP, bool star, bool wD) {
+    COut<R> o;
+    const V3<R> z3 = zero3<R>();
+    o.Gx = o.gn = o.gm = o.gdiff = o.gxp_prev = z3;
+    const V3<R> cs_p = lin(e.jc.gxp, f.v), cs_n = lin(e.jc.gxn, f.v), cs_g = lin(e.jc.gn, f.v);
+    const V3<R> ws_n = lin(e.jw.gxn, f.u), ws_g = lin(e.jw.gn, f.u);
+    if (inP) {
+        o.Gx = cs_p + cs_n;                       // -cs.gxc
+        o.gn = -cs_g;
+        if (!first) o.gm = mk3<R>(f.v.x, f.v.y, R(0));
+        o.gxp_prev = -cs_p;
+        if (star) {
+            o.Gx = o.Gx + ws_n;                   // -ws.gxc, gxc = -gxn
+            o.gn = o.gn - ws_g;
+        }
+    }
+    if (wD && f.fin) {
+        // epsm.py:1139-1157: row block id (gxn, plus the stale wo2[0] gradient on its second row) and the pseudo rows
+        if (!first) {
+            const V3<R> wx = e.jw.gxn[0] * (f.u.x + f.v.y) + e.jw.gxn[1] * f.u.y;
+            o.gdiff = -(wx + cs_n);
+        } else {
+            o.gdiff = -ws_n;
+        }
+    }
+    return o;
+}
+
+}  // namespace cp
+}  // namespace epsm

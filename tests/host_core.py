@@ -10,31 +10,38 @@ import torch
 from epsm_mitsuba3_amd.records import PackedRecords, VARIANTS, num_param_grads
 
 _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_harness")
-_SO = os.path.join(_DIR, "libpath_core_host.so")
-_SRC = os.path.join(_DIR, "path_core_host.cpp")
-_HDR = os.path.join(os.path.dirname(_DIR), "..", "epsm_mitsuba3_amd", "csrc", "epsm_path_core.h")
-_lib = None
+_CSRC = os.path.join(os.path.dirname(_DIR), "..", "epsm_mitsuba3_amd", "csrc")
+# core name -> (library, source, headers it compiles, entry-point stem)
+#   "path": epsm_path_core.h, one lane = one path (the dense calc_grad kernel)
+#   "cp":   epsm_cp_core.h, one lane = one (path, constraint vertex) (the fused backward kernel)
+CORES = {
+    "path": ("libpath_core_host.so", "path_core_host.cpp", ("epsm_path_core.h",), "epsm_host_core_grad"),
+    "cp": ("libcp_core_host.so", "cp_core_host.cpp", ("epsm_path_core.h", "epsm_cp_core.h"), "epsm_host_cp_grad"),
+}
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        stale = (not os.path.isfile(_SO)) or any(
-            os.path.getmtime(p) > os.path.getmtime(_SO) for p in (_SRC, _HDR))
+def lib(core="path"):
+    if core not in _libs:
+        so, src, hdrs, stem = CORES[core]
+        so, src = os.path.join(_DIR, so), os.path.join(_DIR, src)
+        deps = [src] + [os.path.join(_CSRC, h) for h in hdrs]
+        stale = (not os.path.isfile(so)) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in deps)
         if stale:
             subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-                            "-ffp-contract=off", "-o", _SO, _SRC], check=True)
-        _lib = C.CDLL(_SO)
-        for name in ("epsm_host_core_grad_f32", "epsm_host_core_grad_f64"):
+                            "-ffp-contract=off", "-o", so, src], check=True)
+        _lib = C.CDLL(so)
+        _libs[core] = _lib
+        for name in (stem + "_f32", stem + "_f64"):
             fn = getattr(_lib, name)
             fn.restype = C.c_int
             fn.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_double,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-    return _lib
+    return _libs[core]
 
 
-def host_core_calc_grad(variant, path_info, dlduv, dldp, clip=0.1, dtype=torch.float32, dlduv_cols=None):
+def host_core_calc_grad(variant, path_info, dlduv, dldp, clip=0.1, dtype=torch.float32, dlduv_cols=None, core="path"):
     rec = PackedRecords(path_info, device="cpu", float_dtype=dtype)
     N, K = rec.N, rec.K
     d = dlduv.detach().to("cpu", dtype).reshape(N, -1).contiguous()
@@ -47,7 +54,7 @@ def host_core_calc_grad(variant, path_info, dlduv, dldp, clip=0.1, dtype=torch.f
     out_p = torch.full((P, N, 3), float("nan"), dtype=dtype)
     out_l = torch.full((K, N, 3), float("nan"), dtype=dtype)
     out_d = torch.full((K, N, 3), float("nan"), dtype=dtype)
-    fn = lib().epsm_host_core_grad_f32 if dtype == torch.float32 else lib().epsm_host_core_grad_f64
+    fn = getattr(lib(core), CORES[core][3] + ("_f32" if dtype == torch.float32 else "_f64"))
     rc = fn(VARIANTS[variant], N, K, rec.cam.data_ptr(), C.addressof(rec.records),
             d.data_ptr(), d.shape[1], dlduv_cols, p.data_ptr(), float(clip),
             out_p.data_ptr(), out_l.data_ptr(), out_d.data_ptr(), 0)

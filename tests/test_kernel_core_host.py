@@ -1,7 +1,8 @@
-"""The per-path kernel code (epsm_mitsuba3_amd/csrc/epsm_path_core.h) compiled for
-the host CPU by tests/host_harness, against the reference goldens and the oracle.
-This checks the block-adjoint algebra the gfx950 kernels run without a GPU; the
-GPU tests (-m gpu) check the same code compiled by hipcc."""
+"""The kernels' arithmetic compiled for the host CPU by tests/host_harness, against the reference goldens and the
+oracle: epsm_mitsuba3_amd/csrc/epsm_path_core.h (core "path": one lane per path, the dense calc_grad kernel) and
+epsm_cp_core.h (core "cp": one lane per (path, constraint vertex), the fused backward kernel).  This checks the
+block-adjoint algebra the gfx950 kernels run without a GPU; the GPU tests (-m gpu) check the same code compiled by
+hipcc."""
 import pytest
 import torch
 
@@ -10,12 +11,14 @@ from host_core import host_core_calc_grad
 from oracle.binding import oracle_calc_grad, oracle_cond
 
 FILES = golden_files()
+CORES = ["path", "cp"]
 
 
+@pytest.mark.parametrize("core", CORES)
 @pytest.mark.parametrize("path", FILES, ids=golden_id)
-def test_core_f64_matches_reference_f64(path):
+def test_core_f64_matches_reference_f64(path, core):
     variant, pi, dlduv, dldp, ref = load_golden(path, dtype=torch.float64)
-    fp, lg, dg = host_core_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float64)
+    fp, lg, dg = host_core_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float64, core=core)
     mine = stack3(fp, lg, dg)
     truth = torch.cat([ref["ref64_param"], ref["ref64_light"], ref["ref64_diffuse"]]).double()
     assert not torch.isnan(mine).any()
@@ -25,10 +28,11 @@ def test_core_f64_matches_reference_f64(path):
     assert torch.equal(mine == 0, truth == 0)
 
 
+@pytest.mark.parametrize("core", CORES)
 @pytest.mark.parametrize("path", FILES, ids=golden_id)
-def test_core_f32_matches_reference(path):
+def test_core_f32_matches_reference(path, core):
     variant, pi, dlduv, dldp, ref = load_golden(path, dtype=torch.float32)
-    fp, lg, dg = host_core_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float32)
+    fp, lg, dg = host_core_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float32, core=core)
     truth = torch.cat([ref["ref64_param"], ref["ref64_light"], ref["ref64_diffuse"]]).double()
     yard = torch.cat([ref["ref32_param"], ref["ref32_light"], ref["ref32_diffuse"]]).double()
     rep = parity_report(stack3(fp, lg, dg), truth, yard)
@@ -60,10 +64,11 @@ def test_oracle_cond_against_the_reference_matrices(path):
 @pytest.mark.parametrize("variant,profile", [("manifold", "bathroom"), ("manifold", "specular"),
                                               ("manifold_caustic", "pool"), ("manifold_caustic", "mixed")])
 @pytest.mark.parametrize("K", [1, 3, 5])
-def test_core_f64_matches_oracle_synthetic(variant, profile, K):
+@pytest.mark.parametrize("core", CORES)
+def test_core_f64_matches_oracle_synthetic(variant, profile, K, core):
     from epsm_mitsuba3_amd.synth import synth_path_info
     pi, dlduv, dldp = synth_path_info(3000, K, seed=K, profile=profile, dtype=torch.float64, tangent_scale=1e-5)
-    fp, lg, dg = host_core_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float64)
+    fp, lg, dg = host_core_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float64, core=core)
     t = oracle_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float64)
     mine, truth = stack3(fp, lg, dg), stack3(*t[:3])
     scale = truth.abs().amax(dim=(0, 2)).clamp_min(1e-12)
@@ -74,12 +79,13 @@ def test_core_f64_matches_oracle_synthetic(variant, profile, K):
 
 @pytest.mark.parametrize("variant,profile", [("manifold", "bathroom"), ("manifold", "specular"), ("manifold", "mixed"),
                                               ("manifold_caustic", "pool"), ("manifold_caustic", "caustic")])
-def test_core_f32_inside_the_conditioning_gate(variant, profile):
+@pytest.mark.parametrize("core", CORES)
+def test_core_f32_inside_the_conditioning_gate(variant, profile, core):
     """N = 20 000, K = 5: inside cond_2 < 1e4 at most 0.5 % of the paths may leave
     scale * max(2e-4, 4 eps cond); the fraction outside the gate is reported, not bounded."""
     from epsm_mitsuba3_amd.synth import synth_path_info
     pi, dlduv, dldp = synth_path_info(20000, 5, seed=45, profile=profile, tangent_scale=2e-5)
-    fp, lg, dg = host_core_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float32)
+    fp, lg, dg = host_core_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float32, core=core)
     t = oracle_calc_grad(variant, pi, dlduv, dldp, dtype=torch.float64)
     cond = oracle_cond(variant, pi, dlduv, dldp)
     rep = gated_parity_report(stack3(fp, lg, dg), stack3(*t[:3]), cond)
