@@ -1,0 +1,753 @@
+// epsm_backward_cp.hip -- the backward pass (first-vertex tangent + calc_grad + parameter scatter, epsm.py:238-297) in
+// CONSTRAINT-PARALLEL form: one lane per (path, constraint vertex), arithmetic in epsm_cp_core.h.
+//
+// A persistent workgroup walks windows of consecutive paths.  Per window:
+//   plan    every path's flag word -> which terms exist and how many constraint vertices m it has (cp::*_plan);
+//   sort    the window's paths are counting-sorted by m (stable), so that a ROUND -- 64 lanes -- holds 64 / max(m,1)
+//           paths of ONE m, each path on max(m,1) adjacent lanes (lane = first lane of the path + k - 1);
+//   rounds  dealt round-robin to the waves, no barrier between them.  A lane loads vertex k and the geometry of its two
+//           neighbours, evaluates its constraint(s) once (unit-seed Jacobians stay in registers), the block recursions
+//           run across the path's lanes with shuffles, and every lane then emits the rows of ITS vertex: wave-level
+//           merge of equal targets (DPP), append to the wave's LDS queue, LDS accumulator table, float atomics on
+//           flush -- the scatter back end of epsm_grad_scatter.hip (epsm_wave_scatter.h), unchanged.
+// Against the one-lane-per-path kernel: no per-vertex state (256 -> ~half the VGPRs), every constraint evaluated once
+// instead of twice and its frame once instead of three times, all lanes busy whatever the chain length, vertex loops are
+// run-time loops (one instantiation per variant instead of one per K, a fraction of the code).
+#include <stdlib.h>
+#include <string.h>
+
+#include "epsm_fused.h"
+#include "epsm_cp_core.h"
+#include "epsm_wave_scatter.h"
+
+using namespace epsm;
+
+namespace {
+
+#ifndef EPSM_CP_THREADS
+#define EPSM_CP_THREADS 256
+#endif
+#ifndef EPSM_CP_OCC
+#define EPSM_CP_OCC 2                   // waves per SIMD the register budget is set for
+#endif
+#ifndef EPSM_CP_ROWS_FLOAT
+#define EPSM_CP_ROWS_FLOAT 3072
+#endif
+#ifndef EPSM_CP_ROWS_FIXED
+#define EPSM_CP_ROWS_FIXED 1728
+#endif
+#ifndef EPSM_CP_QUEUE
+#define EPSM_CP_QUEUE 384               // >= 4 rows x 64 lanes, the largest push
+#endif
+#ifndef EPSM_CP_BLOCKS
+#define EPSM_CP_BLOCKS 2048
+#endif
+constexpr int kThreads = EPSM_CP_THREADS, kWaves = kThreads / 64, kQueueCap = EPSM_CP_QUEUE;
+constexpr int kKeys = 6;                // m = 0..5
+
+// lane -> (path slot j, vertex k) inside a round of c lanes per path: j = lane / c without a division
+__device__ __forceinline__ int div_small(int lane, int c) {
+    const int inv = c == 1 ? 65536 : c == 2 ? 32768 : c == 3 ? 21846 : c == 4 ? 16384 : 13108;
+    return (lane * inv) >> 16;
+}
+
+template <typename T> __device__ __forceinline__ T up1(T v) { return __shfl_up(v, 1); }
+template <typename T> __device__ __forceinline__ T down1(T v) { return __shfl_down(v, 1); }
+__device__ __forceinline__ V2<float> up1(V2<float> v) { return mk2<float>(up1(v.x), up1(v.y)); }
+__device__ __forceinline__ M2<float> up1(M2<float> m) { M2<float> o; o.a = up1(m.a); o.b = up1(m.b); o.c = up1(m.c); o.d = up1(m.d); return o; }
+__device__ __forceinline__ V3<float> down1(V3<float> v) { return mk3<float>(down1(v.x), down1(v.y), down1(v.z)); }
+
+// ---- record access: the native packed log or the reference's per-field arrays
+template <bool PACKED> struct Records {
+    const FusedArgs &F;
+    const PtrTable &P;                   // LDS (per-field arrays)
+    int64_t i;
+    __device__ __forceinline__ const float *rec(int k) const { return F.pk_verts + (i * F.K + (k - 1)) * kRecWords; }
+    __device__ __forceinline__ cp::Own<float> own(int k) const {
+        cp::Own<float> o;
+        Raw<float> r;
+        if (PACKED) {
+            const float *p = rec(k);
+            const F4v q0 = ldq(p, 0), q1 = ldq(p, 1), q2 = ldq(p, 2), q3 = ldq(p, 3), q4 = ldq(p, 4), q5 = ldq(p, 5);
+            r.g = geo_from(q0, q1, q2, q4.z, q4.w);
+            r.nr = nrm_from(q2, q3, q4, q4.z, q4.w);
+            r.eta = q5.x;
+            r.light = mk3<float>(q5.y, q5.z, q5.w);
+        } else {
+            const VertexPtrs<float> &v = P.v[k - 1];
+            r.g = load_geo(v, i);
+            r.nr = load_nrm(v, i, r.g.b0, r.g.b1);
+            r.eta = lds_(v.eta, i);
+            r.light = load3(v.light, i);
+        }
+        o.x = r.g.x; o.e1 = r.g.e1; o.e2 = r.g.e2; o.b0 = r.g.b0; o.b1 = r.g.b1;
+        o.n = r.nr.n; o.dn1 = r.nr.dn1; o.dn2 = r.nr.dn2; o.eta = r.eta; o.light = r.light;
+        return o;
+    }
+    __device__ __forceinline__ Geo<float> geo(int k) const {
+        if (PACKED) {
+            const float *p = rec(k);
+            const F4v q4 = ldq(p, 4);
+            return geo_from(ldq(p, 0), ldq(p, 1), ldq(p, 2), q4.z, q4.w);
+        }
+        return load_geo(P.v[k - 1], i);
+    }
+    __device__ __forceinline__ V3<float> cam() const {
+        if (PACKED) { const F4v q = ldq(F.pk_rays + 12 * i, 0); return mk3<float>(q.x, q.y, q.z); }
+        return load3(F.g.cam, i);
+    }
+    __device__ __forceinline__ uint32_t tri_id(int k) const { return PACKED ? __float_as_uint(lds_(rec(k), 28)) : lds_(P.s[k - 1].tri, i); }
+    __device__ __forceinline__ void b0b1(int k, float &b0, float &b1) const {
+        if (PACKED) { const F4v q = ldq(rec(k), 4); b0 = q.z; b1 = q.w; }
+        else { b0 = lds_(P.v[k - 1].b0, i); b1 = lds_(P.v[k - 1].b1, i); }
+    }
+    // emitter-sample record [etri, eb0, eb1, eweight]
+    __device__ __forceinline__ bool emit(int k, uint32_t &etri, float &eb0, float &eb1, float &ew) const {
+        if (PACKED) {
+            const F4v q = ldq(rec(k), 6);
+            etri = __float_as_uint(q.x); eb0 = q.y; eb1 = q.z; ew = q.w;
+            return true;
+        }
+        const uint32_t *p = P.s[k - 1].emit;
+        if (!p) return false;
+        const U4 e4 = load_u4(p, i);
+        etri = e4.x; eb0 = bits_to_float(e4.y); eb1 = bits_to_float(e4.z); ew = bits_to_float(e4.w);
+        return true;
+    }
+    // BSDF record: alpha slot (per-field arrays only; the packed log carries it in the triangle's table row) and d hf / d alpha
+    __device__ __forceinline__ void aux(int k, uint32_t &bid, V3<float> &dhf) const {
+        bid = kNoIndex; dhf = zero3<float>();
+        if (!F.galpha) return;
+        if (PACKED) {
+            const F4v q = ldq(rec(k), 7);
+            dhf = mk3<float>(q.y, q.z, q.w);
+        } else if (P.s[k - 1].aux) {
+            const U4 a4 = load_u4(P.s[k - 1].aux, i);
+            bid = a4.x; dhf = mk3<float>(bits_to_float(a4.y), bits_to_float(a4.z), bits_to_float(a4.w));
+        }
+    }
+    __device__ __forceinline__ uint32_t flag_word() const {
+        if (PACKED) return lds_(F.pk_flags, i);
+        uint32_t w = 0;
+        for (int k = 1; k <= F.K; ++k) {
+            const VertexPtrs<float> &v = P.v[k - 1];
+            const uint32_t b = lds_(v.bsdf, i);
+            w |= (((b & kBsdfDiffuse) ? 1u : 0u) | ((b & kBsdfNull) ? 2u : 0u) | (lds_(v.active, i) ? 4u : 0u) |
+                  (lds_(v.active_em, i) ? 8u : 0u) | (lds_(v.ismesh, i) ? 16u : 0u)) << (5 * (k - 1));
+        }
+        return w;
+    }
+};
+
+// ---- emission: the rows of one vertex into the wave queue (clamp / NaN rule of calc_grad per (N,3) component first,
+// then the linear map of epsm_scatter_core.h: epsm.py:559-562, 622-627, 644-645).  All 64 lanes call every method.
+template <typename Table> struct Emitter {
+    const FusedArgs &F;
+    const Table &T;
+    WaveQueue<kQueueCap> &Q;
+
+    template <int ROWS>
+    __device__ __forceinline__ void push(bool valid, const uint32_t key[ROWS], const V3<float> val[ROWS]) const {
+#ifdef EPSM_CP_DIRECT                       // (A/B: rows straight into the table, no wave queue)
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) T.add(key[j], val[j].x, val[j].y, val[j].z);
+        }
+#else
+        Q.reserve(T, ROWS);
+        Q.template push_rows<ROWS>(valid, key, val);
+#endif
+    }
+    __device__ __forceinline__ V3<float> fin(V3<float> g) const {
+        return mk3<float>(finalize(g.x, F.g.clip), finalize(g.y, F.g.clip), finalize(g.z, F.g.clip));
+    }
+    __device__ __forceinline__ static bool tri_ok(const U4 &t, int64_t V) {
+        return t.x < (uint64_t) V && t.y < (uint64_t) V && t.z < (uint64_t) V;
+    }
+    // rows of the hit triangle t: d/dp_j = b_j Gx (+ the flat-normal part of d/dn), d/dn_j; `on`: this lane has a vertex to emit
+    __device__ __forceinline__ void triangle(bool on, V3<float> Gx, V3<float> gn, const cp::Own<float> &c, const U4 &t) const {
+        const float b0 = c.b0, b1 = c.b1, b2 = 1.f - b0 - b1;
+        V3<float> pos[3] = {fin(Gx * b0), fin(Gx * b1), fin(Gx * b2)};       // si.p_j * path_grad[5it+j]
+        V3<float> nrm[3] = {zero3<float>(), zero3<float>(), zero3<float>()};
+        gn = fin(gn);
+        const bool idx_ok = on && tri_ok(t, F.V);
+        const bool pos_v = idx_ok && (t.w & kModePos);
+        bool nrm_v = false;
+        if (idx_ok && nz3(gn)) {                                              // si_follow.sh_frame.n * path_grad[5it+3]
+            const float sgn = (t.w & kModeFlip) ? -1.f : 1.f;
+            if (t.w & kModeVertexNormals) {
+                if (t.w & kModeNrm) {
+                    // logged normals are post-flip: c.n = sum_j b_j n'_j; sh = normalize(c.n)   (mesh.cpp:784-790, 820-827)
+                    const float il = rsqrt_(dot(c.n, c.n));
+                    const V3<float> sh = c.n * il;
+                    const V3<float> pg = (gn - sh * dot(sh, gn)) * (il * sgn);
+                    nrm[0] = pg * b0; nrm[1] = pg * b1; nrm[2] = pg * b2;
+                    nrm_v = true;
+                }
+            } else if (pos_v) {
+                // flat: sh = sgn normalize(cross(p1-p0, p2-p0)) with p1-p0 = e2-e1, p2-p0 = -e1   (mesh.cpp:729, 811)
+                const V3<float> d0 = c.e2 - c.e1, d1 = -c.e1;
+                const V3<float> cr = cross(d0, d1);
+                const float il = rsqrt_(dot(cr, cr));
+                const V3<float> ch = cr * il;
+                const V3<float> cb = (gn - ch * dot(ch, gn)) * (il * sgn);
+                const V3<float> d0b = cross(d1, cb), d1b = cross(cb, d0);
+                pos[1] = pos[1] + d0b; pos[2] = pos[2] + d1b; pos[0] = pos[0] - (d0b + d1b);
+            }
+        }
+        const uint32_t V32 = (uint32_t) F.V;
+        const V3<float> z = zero3<float>();
+        V3<float> vals[6] = {pos_v ? pos[0] : z, pos_v ? pos[1] : z, pos_v ? pos[2] : z,
+                             nrm_v ? nrm[0] : z, nrm_v ? nrm[1] : z, nrm_v ? nrm[2] : z};
+        bool any = (pos_v && (nz3(pos[0]) || nz3(pos[1]) || nz3(pos[2]))) || nrm_v;
+        const uint32_t tri[3] = {t.x, t.y, t.z};
+        const bool some_nrm = __ballot(nrm_v) != 0ull;
+        merge_equal<6, 2>(any, tri, vals, some_nrm ? 6 : 3);
+        push<3>(any, tri, vals);
+        if (some_nrm) {
+            const uint32_t nk[3] = {V32 + tri[0], V32 + tri[1], V32 + tri[2]};
+            push<3>(any && (nz3(vals[3]) || nz3(vals[4]) || nz3(vals[5])), nk, vals + 3);     // (the carrier of a merge holds the others' rows)
+        }
+    }
+    // bsdf_sample.hf * path_grad[5it+4]  and  si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627, 645)
+    __device__ __forceinline__ void light_alpha(bool on, V3<float> gm, V3<float> glight, uint32_t bid, V3<float> dhf,
+                                                const U4 &er, float eb0, float eb1, float ew) const {
+        gm = fin(gm);
+        glight = fin(glight);
+        const bool a_ok = on && nz3(gm) && bid < (uint64_t) F.B;
+        const bool e_ok = on && nz3(glight) && tri_ok(er, F.V) && (er.w & kModePos);
+        const V3<float> gl = e_ok ? glight * ew : zero3<float>();
+        const uint32_t keys[4] = {e_ok ? er.x : 0u, e_ok ? er.y : 0u, e_ok ? er.z : 0u, a_ok ? 2u * (uint32_t) F.V + bid : 0u};
+        V3<float> vals[4] = {gl * eb0, gl * eb1, gl * (1.f - eb0 - eb1), mk3<float>(a_ok ? dot(gm, dhf) : 0.f, 0.f, 0.f)};
+        bool e_any = e_ok, a_any = a_ok;
+        merge_equal<3, 2>(e_any, keys, vals);                       // area lights are a handful of triangles
+        const uint32_t aid[3] = {keys[3], 0u, 0u};
+        merge_equal<1, 4>(a_any, aid, vals + 3);                    // a handful of materials
+        if (__ballot(a_any || e_any) != 0ull) push<4>(a_any || e_any, keys, vals);
+    }
+    // si_follow.p * diffuse_grad[it] with detached barycentrics (epsm.py:561-562): rows of triangle t, weights b_j
+    __device__ __forceinline__ void diffuse(bool on, V3<float> g, float b0, float b1, const U4 &t) const {
+        g = fin(g);
+        bool pos_v = on && nz3(g) && tri_ok(t, F.V) && (t.w & kModePos);
+        if (__ballot(pos_v) == 0ull) return;
+        V3<float> pos[3] = {g * b0, g * b1, g * (1.f - b0 - b1)};
+        const uint32_t tri[3] = {t.x, t.y, t.z};
+        merge_equal<3, 2>(pos_v, tri, pos);
+        push<3>(pos_v, tri, pos);
+    }
+    // occluder of the first vertex's emitter sample: si_direct.p * diffuse_grad[0] * dis (epsm.py:609-620);
+    // a = [stri, sb0, sb1, dis] (EpsmScatterRecord.shadow), row = the occluder triangle's row of the scene table
+    __device__ __forceinline__ void shadow(bool on, V3<float> g, const U4 &a, const U4 &row) const {
+        g = fin(g);
+        const float c0 = bits_to_float(a.y), c1 = bits_to_float(a.z), dis = bits_to_float(a.w);
+        bool v = on && nz3(g) && tri_ok(row, F.V) && (row.w & kModePos) && dis != 0.f;
+        if (__ballot(v) == 0ull) return;
+        const V3<float> gd = g * dis;
+        V3<float> val[3] = {gd * c0, gd * c1, gd * (1.f - c0 - c1)};
+        const uint32_t si[3] = {row.x, row.y, row.z};
+        merge_equal<3, 2>(v, si, val);
+        push<3>(v, si, val);
+    }
+};
+
+// ---- who a lane is in round r of the current window
+struct LaneId { int q, c, k; uint32_t plan; int loc; };      // plan == 0: no path on this lane
+struct Rounds {
+    int cls[kKeys + 1], rb[kKeys + 1];
+    const uint16_t *perm;            // LDS: the window's paths sorted by m
+    const uint32_t *plan;            // LDS
+    __device__ __forceinline__ LaneId lane_of(int r, int lane) const {
+        LaneId L;
+        int q = 0;
+#pragma unroll
+        for (int t = 1; t < kKeys; ++t) if (r >= rb[t]) q = t;
+        int cls_q = cls[0], n_q = cls[1] - cls[0], rb_q = rb[0];
+#pragma unroll
+        for (int t = 1; t < kKeys; ++t) if (q == t) { cls_q = cls[t]; n_q = cls[t + 1] - cls[t]; rb_q = rb[t]; }
+        const int c = q > 0 ? q : 1, ppr = 64 / c;
+        const int j = div_small(lane, c), k = lane - j * c + 1;
+        const int idx = (r - rb_q) * ppr + j;
+        const bool lane_on = r < rb[kKeys] && j < ppr && idx < n_q;
+        const int loc = lane_on ? (int) perm[cls_q + idx] : 0;
+        L.q = q; L.c = c; L.k = k; L.loc = loc;
+        L.plan = lane_on ? plan[loc] : 0u;               // (paths beyond the end of the wavefront have plan 0)
+        return L;
+    }
+};
+
+// ---- the first-level global loads of a round (native log), held in registers from their issue -- one round ahead, before
+// the previous round's emission -- to their use.  o: the lane's own record (words 24..27 emitter sample, 28 triangle id,
+// 29..31 d hf / d alpha); p: the first lane of a path holds its rays here (12 words), the others quads 0, 1, 2, 4 of
+// record k-1; n: quads 0, 1, 2, 4 of record k+1 and its triangle id; the image gradient of the path's pixel.
+struct Fetch {
+    F4v o[7];                        // own record, quads 0..6
+    uint32_t o_tid; float dhf[3];    // own record, word 28 and words 29..31
+    F4v p[3]; float p_b[2];          // first lane: the rays.  Others, of record k-1: quads 0, 1, word 8 (p[2].x), words 18, 19
+    F4v n[2]; float n_z, n_b[2];     // record k+1: quads 0, 1, word 8, words 18, 19 ...
+    uint32_t n_tid;                  // ... and its triangle id
+    float gx, gy;
+    U4 sh;                           // the first vertex's occluder record (max_depth <= 3 logs)
+};
+// (Only words that are USED are loaded: a register of a pending load's destination that nobody reads is free for the
+// register allocator, and the hardware's write to it then has to be waited for -- s_waitcnt in the middle of the emission.)
+typedef float F2v __attribute__((ext_vector_type(2)));
+typedef float F3v __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ F2v ld2(const float *p) { return *(const __attribute__((address_space(1))) F2v *) p; }
+__device__ __forceinline__ F3v ld3(const float *p) { return *(const __attribute__((address_space(1))) F3v *) p; }
+// x / d and x % d for 0 <= x < 2^24, d >= 1 (float reciprocal + one correction step each way)
+__device__ __forceinline__ void divmod24(uint32_t x, uint32_t d, float rcp_d, uint32_t &qo, uint32_t &ro) {
+    uint32_t q = (uint32_t) ((float) x * rcp_d);
+    int32_t r = (int32_t) x - (int32_t) (q * d);
+    if (r < 0) { --q; r += (int32_t) d; }
+    if (r >= (int32_t) d) { ++q; r -= (int32_t) d; }
+    qo = q; ro = (uint32_t) r;
+}
+template <int VARIANT, int DMODE, bool PACKED>
+__device__ __forceinline__ void fetch_issue(Fetch &X, const FusedArgs &F, const LaneId &L, int64_t base) {
+    if (!PACKED) return;             // per-field arrays: loaded where they are used (the reference's layout is not the fast path)
+    const int k = L.k;
+    const bool ok = L.plan != 0u;
+    const int64_t i = base + L.loc;
+    const bool first = k == 1, live = ok && L.q > 0;
+    const bool has_next = live && k + 1 <= cp::plan_nv(L.plan);
+    const bool d1 = ok && first && cp::plan_diffuse1(L.plan);
+    const float *rec = F.pk_verts + (i * F.K + (k - 1)) * kRecWords;
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) X.o[t] = ldq(rec, t);
+        X.o_tid = __float_as_uint(lds_(rec, 28));
+        if (F.galpha) { const F3v d = ld3(rec + 29); X.dhf[0] = d.x; X.dhf[1] = d.y; X.dhf[2] = d.z; }
+        if (VARIANT == EPSM_VARIANT_MANIFOLD && cp::plan_a(L.plan, k)) X.o[6] = ldq(rec, 6);
+    } else if (ok) {                 // a path without a constraint: its tangent and diffuse_grad[0] only
+        if (L.plan & cp::kPlanActive1) { X.o[0] = ldq(rec, 0); X.o[1] = ldq(rec, 1); X.o[2] = ldq(rec, 2); }
+        if (d1) { X.o[4] = ldq(rec, 4); X.o_tid = __float_as_uint(lds_(rec, 28)); }
+    }
+    if (ok && first) {
+        const float *rays = F.pk_rays + 12 * i;
+        X.p[0] = ldq(rays, 0); X.p[1] = ldq(rays, 1); X.p[2] = ldq(rays, 2);
+        // pixel of the path: (path_offset + i) / spp, row-major on the res x res crop (epsm.py:250)
+        const int64_t pix = (F.tin.path_offset + i) / F.tin.spp;
+        const int64_t y = pix / F.tin.res, x = pix - y * F.tin.res;
+        const F2v g = ld2(F.tin.grad_img + (y * F.tin.img_width + x) * F.tin.img_channels + 3);
+        X.gx = g.x; X.gy = g.y;
+        if (d1 && F.pk_shadow) X.sh = load_u4(F.pk_shadow, i);
+    } else if (live) {
+        const float *pr = rec - kRecWords;
+        X.p[0] = ldq(pr, 0); X.p[1] = ldq(pr, 1); X.p[2].x = lds_(pr, 8);
+        const F2v b = ld2(pr + 18); X.p_b[0] = b.x; X.p_b[1] = b.y;
+    }
+    if (has_next) {
+        const float *nx = rec + kRecWords;
+        X.n[0] = ldq(nx, 0); X.n[1] = ldq(nx, 1); X.n_z = lds_(nx, 8);
+        const F2v b = ld2(nx + 18); X.n_b[0] = b.x; X.n_b[1] = b.y;
+        X.n_tid = __float_as_uint(lds_(nx, 28));
+    }
+}
+
+// kWindow: the largest window (paths a workgroup plans, sorts and works through at a time); `window` <= kWindow, a multiple
+// of 64, is what this launch uses -- a small wavefront is cut into smaller windows so that every CU gets some (launch()).
+constexpr int kWindow = 1024;
+template <int VARIANT, int DMODE, bool PACKED, bool FLOAT_ROWS>
+__global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel(FusedArgs F, int dcols, int64_t windows_per_block, int window) {
+    // float rows where the window's distinct rows need the larger table (epsm_wave_scatter.h, AccFixed64)
+    // Rows of the accumulator table: 64-bit fixed point (epsm_wave_scatter.h, AccFixed64: the LDS integer atomic inserts an
+    // order of magnitude faster than ds_add_f32, and same-address lanes do not serialise as badly) unless the caller disabled
+    // the outlier clamp -- then the terms are unbounded and the sums stay in float.
+    constexpr bool kFloatRows = FLOAT_ROWS;
+    typedef LdsTable<kFloatRows ? EPSM_CP_ROWS_FLOAT : EPSM_CP_ROWS_FIXED, typename std::conditional<kFloatRows, AccFloat, AccFixed64>::type> Table;
+    constexpr int kTableSize = Table::kTableSize;
+    __shared__ uint32_t s_keys[kTableSize];
+    __shared__ typename Table::Val s_vals[kTableSize * 3];
+    __shared__ int s_used;
+#ifdef EPSM_CP_DIRECT
+    __shared__ QItem s_queue[kWaves][1];
+#else
+    __shared__ QItem s_queue[kWaves][kQueueCap];
+#endif
+    __shared__ PtrTable s_ptrs;
+    float *const my_rep = F.rep ? F.rep + (blockIdx.x % (unsigned) F.replicas) * F.rep_stride : nullptr;
+    const Table T{s_keys, s_vals, &s_used, my_rep ? my_rep : F.gpos, my_rep ? my_rep + 3 * F.V : F.gnrm,
+                  my_rep ? my_rep + 6 * F.V : F.galpha, (uint32_t) F.V};
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    WaveQueue<kQueueCap> Q{s_queue[wv], 0};
+    const Emitter<Table> E{F, T, Q};
+    if (!PACKED && threadIdx.x < F.K) { s_ptrs.v[threadIdx.x] = F.g.v[threadIdx.x]; s_ptrs.s[threadIdx.x] = F.s[threadIdx.x]; }
+    constexpr int kPer = (kWindow + kThreads - 1) / kThreads;        // paths a thread plans
+    constexpr int kStride = kPer * kWaves, kEntries = kKeys * kStride;
+    __shared__ uint32_t s_plan[kWindow];
+    __shared__ uint16_t s_perm[kWindow];
+    __shared__ int s_cnt[kEntries];                                  // [m][j][wave]: histogram, then offsets
+    __shared__ int s_cls[kKeys + 1];                                 // first sorted position of class m
+    V3<float> gd_acc = zero3<float>();                               // kTangentsInKernel: sum of grad_d over this lane's paths
+    Fetch X;                                                         // (all fields defined: a conditionally loaded, conditionally read struct
+    {                                                                //  otherwise carries undef through the round loop)
+        const F4v z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 7; ++t) X.o[t] = z4;
+        X.p[0] = X.p[1] = X.p[2] = X.n[0] = X.n[1] = z4;
+        X.o_tid = X.n_tid = kNoIndex;
+        X.dhf[0] = X.dhf[1] = X.dhf[2] = X.p_b[0] = X.p_b[1] = X.n_z = X.n_b[0] = X.n_b[1] = X.gx = X.gy = 0.f;
+        X.sh.x = kNoIndex; X.sh.y = X.sh.z = X.sh.w = 0u;
+    }
+    T.clear();                                                       // ends with a barrier: the table of pointers is visible too
+    const int64_t n_windows = (F.g.N + window - 1) / window;
+#pragma unroll 1
+    for (int64_t wi = 0; wi < windows_per_block; ++wi) {
+        // a workgroup walks a CONTIGUOUS range of windows: neighbouring pixels keep hitting the rows its table holds
+        const int64_t win = (int64_t) blockIdx.x * windows_per_block + wi;
+        if (win >= n_windows) break;                                 // workgroup-uniform
+        const int64_t base = win * window;
+        // ---- plan + histogram of m: thread t plans paths base + j*kThreads + t
+        int key[kPer], rank[kPer];
+        {
+            uint32_t fw[kPer];
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {                         // all flag loads first
+                const int64_t p = base + j * kThreads + threadIdx.x;
+                const Records<PACKED> R{F, s_ptrs, p < F.g.N ? p : F.g.N - 1};
+                fw[j] = (j * kThreads + (int) threadIdx.x < window) ? R.flag_word() : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const int loc = j * kThreads + threadIdx.x;
+                const int64_t p = base + loc;
+                const bool in = loc < window && p < F.g.N;
+                uint32_t w = fw[j];
+                if (F.K < 5) w &= (1u << (5 * F.K)) - 1u;
+                uint32_t plan = VARIANT == EPSM_VARIANT_MANIFOLD ? cp::manifold_plan(w) : cp::caustic_plan(w);
+                plan = in ? (plan | cp::kPlanInRange | ((w & 4u) ? cp::kPlanActive1 : 0u)) : 0u;
+                key[j] = cp::plan_m(plan);
+                if (loc < window) s_plan[loc] = plan;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const bool has = j * kThreads + (int) threadIdx.x < window;
+#pragma unroll
+            for (int q = 0; q < kKeys; ++q) {
+                const unsigned long long m = __ballot(has && key[j] == q);
+                if (key[j] == q) rank[j] = __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
+                if (lane == 0) s_cnt[(q * kPer + j) * kWaves + wv] = __popcll(m);
+            }
+        }
+        __syncthreads();
+        if (wv == 0) {
+            // exclusive scan in (m, j, wave) order: the whole window sorted by m, stable
+            int carry = 0;
+#pragma unroll
+            for (int q0 = 0; q0 < kEntries; q0 += 64) {
+                const int q = q0 + lane;
+                const int c = q < kEntries ? s_cnt[q] : 0;
+                int inc = c;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+                if (q < kEntries) {
+                    s_cnt[q] = carry + inc - c;
+                    if (q % kStride == 0) s_cls[q / kStride] = carry + inc - c;
+                }
+                carry += __shfl(inc, 63);
+            }
+            if (lane == 0) s_cls[kKeys] = window;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int loc = j * kThreads + threadIdx.x;
+            if (loc < window) s_perm[s_cnt[(key[j] * kPer + j) * kWaves + wv] + rank[j]] = (uint16_t) loc;
+        }
+        __syncthreads();
+        // ---- rounds: class q has n_q paths on c = max(q,1) lanes each, 64 / c paths per round
+        Rounds RS;
+        RS.perm = s_perm; RS.plan = s_plan;
+#pragma unroll
+        for (int q = 0; q <= kKeys; ++q) RS.cls[q] = __builtin_amdgcn_readfirstlane(s_cls[q]);
+        RS.rb[0] = 0;
+#pragma unroll
+        for (int q = 0; q < kKeys; ++q) {
+            const int c = q > 0 ? q : 1, ppr = 64 / c;
+            RS.rb[q + 1] = RS.rb[q] + (RS.cls[q + 1] - RS.cls[q] + ppr - 1) / ppr;
+        }
+#ifdef EPSM_CPKO_NOROUNDS                 // (knock-out builds, tools/build_cp_variant.sh: what a stage costs)
+        RS.rb[kKeys] = 0;
+#endif
+        // Software pipeline: the records of the wave's NEXT round are requested before this round's rows go into the
+        // queue / table, so the HBM round trip of one round runs under the LDS work of the other (measured apart they
+        // were 1.6 ms and 1.5 ms per 2^24-path slab, and their sum when a wave did one after the other).
+        const int n_rounds = RS.rb[kKeys];
+        LaneId L = RS.lane_of(wv, lane);
+        if (wv < n_rounds) fetch_issue<VARIANT, DMODE, PACKED>(X, F, L, base);
+#pragma unroll 1
+        for (int r = wv; r < n_rounds; r += kWaves) {
+            const int q = L.q, c = L.c, k = L.k;
+            const uint32_t plan = L.plan;
+            const bool ok = plan != 0u, first = k == 1;
+            const int64_t i = base + L.loc;                          // lanes without a path touch nothing (every load is guarded)
+            const Records<PACKED> R{F, s_ptrs, i};
+            const int nv = cp::plan_nv(plan);
+            const bool live = ok && q > 0;                           // this lane holds a constraint vertex
+            const bool has_next = live && k + 1 <= nv;
+            const bool d1 = ok && first && cp::plan_diffuse1(plan);
+            const bool act1 = (plan & cp::kPlanActive1) != 0;
+
+            // ---- geometry: own vertex, the two neighbours
+            cp::Own<float> own;
+            own.x = own.e1 = own.e2 = own.n = own.dn1 = own.dn2 = own.light = zero3<float>();
+            own.b0 = own.b1 = own.eta = 0.f;
+            cp::Nbr<float> prev, next;
+            prev.x = prev.e1 = prev.e2 = next.x = next.e1 = next.e2 = zero3<float>();
+            float nb0 = 0.f, nb1 = 0.f, fb0 = 0.f, fb1 = 0.f;        // barycentrics of vertex k+1; of vertex 1 (diffuse_grad[0])
+            uint32_t tid_own = kNoIndex, tid_next = kNoIndex, bid = kNoIndex, etri = kNoIndex;
+            V3<float> dhf = zero3<float>();
+            float eb0 = 0.f, eb1 = 0.f, ew = 0.f;
+            V2<float> dk = mk2<float>(0.f, 0.f);
+            V3<float> dp = zero3<float>();
+            U4 sh; sh.x = kNoIndex; sh.y = sh.z = sh.w = 0u;
+            const bool wN = VARIANT == EPSM_VARIANT_MANIFOLD && live && cp::plan_a(plan, k);
+            if (PACKED) {
+                if (live) {
+                    const Geo<float> g = geo_from(X.o[0], X.o[1], X.o[2], X.o[4].z, X.o[4].w);
+                    const Nrm<float> nr = nrm_from(X.o[2], X.o[3], X.o[4], X.o[4].z, X.o[4].w);
+                    own.x = g.x; own.e1 = g.e1; own.e2 = g.e2; own.b0 = g.b0; own.b1 = g.b1;
+                    own.n = nr.n; own.dn1 = nr.dn1; own.dn2 = nr.dn2;
+                    own.eta = X.o[5].x; own.light = mk3<float>(X.o[5].y, X.o[5].z, X.o[5].w);
+                    tid_own = X.o_tid;
+                    if (F.galpha) dhf = mk3<float>(X.dhf[0], X.dhf[1], X.dhf[2]);
+                    if (wN) { etri = __float_as_uint(X.o[6].x); eb0 = X.o[6].y; eb1 = X.o[6].z; ew = X.o[6].w; }      // (caustic: light_grad == 0)
+                    if (first) prev.x = mk3<float>(X.p[0].x, X.p[0].y, X.p[0].z);
+                    else { const Geo<float> gp = geo_from(X.p[0], X.p[1], X.p[2], X.p_b[0], X.p_b[1]); prev.x = gp.x; prev.e1 = gp.e1; prev.e2 = gp.e2; }
+                }
+                if (has_next) {
+                    const F4v nq2 = {X.n_z, 0.f, 0.f, 0.f};
+                    const Geo<float> gq = geo_from(X.n[0], X.n[1], nq2, X.n_b[0], X.n_b[1]);
+                    next.x = gq.x; next.e1 = gq.e1; next.e2 = gq.e2; nb0 = gq.b0; nb1 = gq.b1;
+                    tid_next = X.n_tid;
+                }
+                if (d1) { fb0 = X.o[4].z; fb1 = X.o[4].w; tid_own = X.o_tid; if (F.pk_shadow) sh = X.sh; }
+                if (ok && first) {       // epsm.py:250-272 in registers
+                    const V3<float> ro = mk3<float>(X.p[0].x, X.p[0].y, X.p[0].z), rd = mk3<float>(X.p[0].w, X.p[1].x, X.p[1].y),
+                                    rdx = mk3<float>(X.p[1].z, X.p[1].w, X.p[2].x), rdy = mk3<float>(X.p[2].y, X.p[2].z, X.p[2].w);
+                    V3<float> p0 = zero3<float>(), p1 = p0, p2 = p0;
+                    if (act1) { p0 = mk3<float>(X.o[0].x, X.o[0].y, X.o[0].z); p1 = mk3<float>(X.o[0].w, X.o[1].x, X.o[1].y); p2 = mk3<float>(X.o[1].z, X.o[1].w, X.o[2].x); }
+                    const Tangent t = tangent_from(ro, rd, rdx, rdy, X.gx, X.gy, p0, p1, p2, act1);
+                    dk = mk2<float>(t.db0, t.db1);
+                    dp = t.dp;
+                    gd_acc = gd_acc + t.gd;
+                }
+            } else {
+                if (live) {
+                    own = R.own(k);
+                    if (first) prev.x = R.cam();
+                    else { const Geo<float> g = R.geo(k - 1); prev.x = g.x; prev.e1 = g.e1; prev.e2 = g.e2; }
+                    tid_own = R.tri_id(k);
+                    if (wN) R.emit(k, etri, eb0, eb1, ew);
+                    if (F.galpha) R.aux(k, bid, dhf);
+                }
+                if (has_next) {
+                    const Geo<float> g = R.geo(k + 1);
+                    next.x = g.x; next.e1 = g.e1; next.e2 = g.e2; nb0 = g.b0; nb1 = g.b1;
+                    tid_next = R.tri_id(k + 1);
+                }
+                if (d1) {
+                    R.b0b1(1, fb0, fb1);
+                    tid_own = R.tri_id(1);
+                    if (s_ptrs.s[0].shadow) sh = load_u4(s_ptrs.s[0].shadow, i);
+                }
+                // the tangents of the path (lane k == 1): epsm.py:250-272 in registers, or the caller's arrays
+                if (DMODE == kTangentsInKernel) {
+                    if (ok && first) {
+                        const Tangent t = first_vertex_tangent(F.tin, i, s_ptrs.v[0].p0, s_ptrs.v[0].p1, s_ptrs.v[0].p2, act1);
+                        dk = mk2<float>(t.db0, t.db1);
+                        dp = t.dp;
+                        gd_acc = gd_acc + t.gd;
+                    }
+                } else {
+                    if (ok && (first || DMODE == kTangentsFullRows)) dk = load_d<float, DMODE == kTangentsFullRows>(F.g, i, k, dcols);
+                    if (ok && first) dp = load3(F.g.dldp, i);
+                }
+            }
+            // Addressing of the rows this lane will emit, requested BEFORE the arithmetic: under load every dependent global
+            // load is a multi-microsecond round trip for a wave that shares its SIMD with one other, so the chain is kept at
+            // two levels -- records (with the emitter / BSDF words of the same record), then the rows of the scene table
+            // they name -- instead of four (emitter record and its table row fetched where the gradient becomes known).
+            const U4 t_own = table_row(F.tab, tid_own), t_next = table_row(F.tab, tid_next);
+            const U4 er = table_row(F.tab, etri), t_sh = table_row(F.tab, sh.x);
+
+            V3<float> Gx = zero3<float>(), gn = Gx, gm = Gx, glight = Gx, gdiff = Gx;
+            bool emit_vertex = live;
+#ifdef EPSM_CPKO_NOSOLVE
+            gd_acc.x += own.x.x + own.n.y + own.light.z + own.eta + prev.x.x + prev.e1.y + next.x.z + next.e2.x + nb0 + dk.x + dp.y;
+            if (false) {
+#else
+            if (VARIANT == EPSM_VARIANT_MANIFOLD) {
+#endif
+                if (q > 0) {
+                    const bool wC = live && cp::plan_b(plan, k);
+                    const cp::MEval<float> e = cp::manifold_eval(own, prev, next, wN, has_next);
+                    cp::MFwd<float> f = cp::manifold_fwd(e, dk, true, cp::mfwd_zero<float>(), e.Aup, wN, has_next);
+#pragma unroll 1
+                    for (int s = 2; s <= c; ++s) {                   // forward recursion: lanes with k == s take their step
+                        cp::MFwd<float> pf;
+                        pf.z = up1(f.z); pf.Sinv = up1(f.Sinv); pf.zN = mk2<float>(0.f, 0.f);
+                        const M2<float> pAup = up1(e.Aup);
+                        const cp::MFwd<float> g = cp::manifold_fwd(e, dk, false, pf, pAup, wN, has_next);
+                        if (k == s) f = g;
+                    }
+                    cp::MBwd<float> mine; mine.GP = zero3<float>(); mine.W = 0;
+                    cp::MOut<float> o;
+                    o.Gx = o.gn = o.gm = o.glight = o.gdiff = zero3<float>();
+#pragma unroll 1
+                    for (int s = c; s >= 1; --s) {                   // backward recursion of the adjoint seeds
+                        cp::MBwd<float> nb;
+                        nb.GP = down1(mine.GP); nb.W = down1(mine.W);
+                        if (s == c) { nb.GP = zero3<float>(); nb.W = 0; }
+                        cp::MBwd<float> m2;
+                        const cp::MOut<float> o2 = cp::manifold_bwd(e, f, own, nb, wN, wC, has_next, m2);
+                        if (k == s) { o = o2; mine = m2; }
+                    }
+                    Gx = o.Gx; gn = o.gn; gm = o.gm; glight = o.glight; gdiff = o.gdiff;
+                }
+            } else {
+                if (q > 0) {
+                    const int idstar = cp::plan_idstar(plan);
+                    const cp::CEval<float> e = cp::caustic_eval(own, prev, next, first);
+                    cp::CFwd<float> f = cp::caustic_fwd(e, dk, true, cp::cfwd_zero<float>(), e.Aup);
+#pragma unroll 1
+                    for (int s = 2; s <= c; ++s) {
+                        cp::CFwd<float> pf = cp::cfwd_zero<float>();
+                        pf.v = up1(f.v); pf.r = up1(f.r);
+                        const M2<float> pAup = up1(e.Aup);
+                        const cp::CFwd<float> g = cp::caustic_fwd(e, dk, false, pf, pAup);
+                        if (k == s) f = g;
+                    }
+                    // a non-finite term at id* drops every parameter row of the path (nan_to_num, epsm.py:1076-1079)
+                    const unsigned long long bad = __ballot(live && k == idstar && !f.fin);
+                    const unsigned long long seg = ((1ull << c) - 1ull) << (lane - (k - 1));
+                    const bool poisoned = (bad & seg) != 0ull;
+                    const cp::COut<float> o = cp::caustic_finish(e, f, first, live && k <= idstar, live && k == idstar, live && cp::plan_b(plan, k));
+                    const V3<float> from_next = down1(o.gxp_prev);
+                    Gx = k < c ? o.Gx + from_next : o.Gx;
+                    gn = o.gn; gm = o.gm; gdiff = o.gdiff;
+                    emit_vertex = live && k <= idstar && !poisoned;
+                }
+            }
+            // ---- the next round's records, on their way while this round's rows are merged and inserted.  Every load issued
+            // so far must have LANDED first: the prefetch sits in branches the wave may skip, so behind it the compiler can only
+            // wait for "all loads" (s_waitcnt vmcnt(0)) -- a later first use of a table row would drain the prefetch with it.
+            if (PACKED) asm volatile("" :: "v"(t_own.x), "v"(t_own.y), "v"(t_own.z), "v"(t_own.w), "v"(t_next.x), "v"(t_next.y), "v"(t_next.z),
+                                     "v"(t_next.w), "v"(er.x), "v"(er.y), "v"(er.z), "v"(er.w), "v"(t_sh.x), "v"(t_sh.y), "v"(t_sh.z), "v"(t_sh.w));
+            const LaneId Ln = RS.lane_of(r + kWaves, lane);          // (past the last round: no lane has a path)
+#ifndef EPSM_CP_NOPIPE
+            fetch_issue<VARIANT, DMODE, PACKED>(X, F, Ln, base);
+#endif
+            // ---- emission
+#ifdef EPSM_CPKO_NOEMIT
+            gd_acc.x += Gx.x + gn.y + gm.x + glight.z + gdiff.x + dp.x + (float) (t_own.x + t_next.y + er.z + bid + t_sh.x) + dhf.x + eb0 + eb1 + ew + (emit_vertex ? 1.f : 0.f);
+            if (false) {
+#else
+            if (q > 0) {
+#endif
+                if (PACKED) bid = (t_own.w >> 8) - 1u;                // packed log: alpha slot + 1 in the table row
+                E.triangle(emit_vertex, Gx, gn, own, t_own);
+                E.light_alpha(emit_vertex, gm, glight, bid, dhf, er, eb0, eb1, ew);
+                E.diffuse(live, gdiff, nb0, nb1, t_next);
+            }
+#ifndef EPSM_CPKO_NOEMIT
+            // diffuse_grad[0] = dldp where the first hit is diffuse (epsm.py:791-792, 998-1000) + the occluder term (609-620)
+            if (__ballot(d1 && nz3(dp)) != 0ull) {
+                E.diffuse(d1, dp, fb0, fb1, t_own);
+                E.shadow(d1, dp, sh, t_sh);
+            }
+#endif
+#ifdef EPSM_CP_NOPIPE
+            fetch_issue<VARIANT, DMODE, PACKED>(X, F, Ln, base);
+#endif
+            L = Ln;
+        }
+        Q.drain(T);
+        // workgroup-uniform census once per window; a table that fills up in between sends the overflow straight to HBM
+        // (not after the workgroup's last window: the final flush follows at once)
+        if ((window == kWindow || (wi + 1 < windows_per_block && win + 1 < n_windows)) && T.crowded(6)) T.flush();
+    }
+    T.flush();
+    if (DMODE == kTangentsInKernel && F.grad_o_sum) {      // epsm.py:260-261: d/d ray.o = -sum grad_d, one atomic triple per workgroup
+        __shared__ float s_part[kWaves][3];
+        float sx = -gd_acc.x, sy = -gd_acc.y, sz = -gd_acc.z;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off, 64); sy += __shfl_down(sy, off, 64); sz += __shfl_down(sz, off, 64); }
+        if (lane == 0) { s_part[wv][0] = sx; s_part[wv][1] = sy; s_part[wv][2] = sz; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float tot = 0.f;
+            for (int w = 0; w < kWaves; ++w) tot += s_part[w][threadIdx.x];
+            atomicAdd((my_rep ? my_rep + 6 * F.V + F.B : F.grad_o_sum) + threadIdx.x, tot);
+        }
+    }
+}
+
+template <int VARIANT, int DMODE, bool PACKED>
+hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
+    FusedArgs F = F0;
+    // Window size: 1024 paths, fewer for a small wavefront (the reference's own backward sizes are 16 384 .. 524 288 paths)
+    // so that the ~512 workgroups the chip holds at a time all get one: a wave works through its rounds of a window one
+    // after the other, a few microseconds each, and that latency is the run time of a launch with fewer windows than
+    // workgroup slots.  Measured (ms, K = 2 / K = 4): 524 288 paths with windows of 128 / 256 / 512: 0.218 / 0.156 / 0.120;
+    // 16 384 paths: 0.034 / 0.046 / 0.061.  (EPSM_SMALL_WAVEFRONT=<paths> moves the switch to the small form: tests.)
+    int64_t small_limit = 1 << 20;
+    if (const char *e = getenv("EPSM_SMALL_WAVEFRONT")) small_limit = atoll(e);
+    const bool small = F.g.N <= small_limit;
+    int window = kWindow;
+    if (small) { window = 128; while (window < kWindow && F.g.N > 512 * (int64_t) window) window *= 2; }
+    const int64_t windows = (F.g.N + window - 1) / window;
+    const int64_t blocks = windows < EPSM_CP_BLOCKS ? windows : EPSM_CP_BLOCKS;
+    const int64_t per = (windows + blocks - 1) / blocks;
+    // small wavefronts: replicas of the gradient buffers (epsm_grad_scatter.hip, DESIGN.md section 5 "Small wavefronts")
+    F.rep = nullptr; F.replicas = 1; F.rep_stride = 0;
+    if (small) {
+        const int64_t stride = (6 * F.V + F.B + 3 + 63) / 64 * 64;        // floats; replicas start on 256-byte boundaries
+        int64_t R = blocks / 16;
+        if (R > 32) R = 32;
+        if (R * stride * 4 > (int64_t) kReplicaBudget) R = (int64_t) kReplicaBudget / (stride * 4);
+        const char *off = getenv("EPSM_NO_REPLICAS");
+        if (R >= 4 && !(off && off[0] == '1')) {
+            const hipError_t e = fused_workspace(s, (size_t) (R * stride * 4), &F.rep);
+            if (e != hipSuccess) return e;
+            if (F.rep) { F.replicas = (int) R; F.rep_stride = stride; }
+        }
+    }
+    // fixed-point rows hold |sum| < 2^31 at a resolution of 2^-32: fine for terms clamped to +-clip (0.1 in the reference),
+    // not for a caller who switched the clamp off
+    const bool float_rows = !(F.g.clip <= 1024.f);
+    if (float_rows)
+        hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, true>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
+    else
+        hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, false>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
+    if (F.rep) {
+        const int64_t n = 6 * F.V + F.B + 3;
+        hipLaunchKernelGGL(reduce_replicas_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, F.rep, F.replicas, F.rep_stride,
+                           F.V, F.B, F.gpos, F.gnrm, F.galpha, F.grad_o_sum);
+    }
+    return hipGetLastError();
+}
+template <int VARIANT, bool PACKED> hipError_t launch_d(int dmode, const FusedArgs &F, int dcols, hipStream_t s) {
+    switch (dmode) {
+        case kTangentsTwoColumns: return launch<VARIANT, kTangentsTwoColumns, PACKED>(F, dcols, s);
+        case kTangentsFullRows: return launch<VARIANT, kTangentsFullRows, PACKED>(F, dcols, s);
+        default: return launch<VARIANT, kTangentsInKernel, PACKED>(F, dcols, s);
+    }
+}
+
+}  // namespace
+
+namespace epsm {
+
+hipError_t launch_backward_cp(int variant, int dmode, bool packed, const FusedArgs &F, int dcols, hipStream_t s) {
+    if (packed) {
+        // the native log exists with the tangents computed in the kernel only (epsm_backward_pass_packed)
+        return variant == EPSM_VARIANT_MANIFOLD ? launch<EPSM_VARIANT_MANIFOLD, kTangentsInKernel, true>(F, dcols, s)
+                                                : launch<EPSM_VARIANT_MANIFOLD_CAUSTIC, kTangentsInKernel, true>(F, dcols, s);
+    }
+    return variant == EPSM_VARIANT_MANIFOLD ? launch_d<EPSM_VARIANT_MANIFOLD, false>(dmode, F, dcols, s)
+                                            : launch_d<EPSM_VARIANT_MANIFOLD_CAUSTIC, false>(dmode, F, dcols, s);
+}
+
+}  // namespace epsm

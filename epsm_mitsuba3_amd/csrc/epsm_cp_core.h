@@ -46,7 +46,8 @@ namespace cp {
 //               the first of which also carries the first-vertex tangent and diffuse_grad[0]
 //   bit  19     first logged vertex is diffuse
 //   bit  20     path index inside the wavefront (set by the caller)
-constexpr uint32_t kPlanInRange = 1u << 20;
+//   bit  21     first logged vertex is active (set by the caller: the first-vertex tangent needs it)
+constexpr uint32_t kPlanInRange = 1u << 20, kPlanActive1 = 1u << 21;
 EPSM_HD int plan_nv(uint32_t p) { return (int) ((p >> 10) & 7u); }
 EPSM_HD int plan_m(uint32_t p) { return (int) ((p >> 16) & 7u); }
 EPSM_HD int plan_idstar(uint32_t p) { return (int) ((p >> 13) & 7u); }

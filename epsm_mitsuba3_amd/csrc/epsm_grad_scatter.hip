@@ -14,10 +14,7 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "epsm_common.h"
-#include "epsm_path_core.h"
-#include "epsm_scatter_core.h"
-#include "epsm_tangent_core.h"
+#include "epsm_fused.h"
 #include "epsm_wave_scatter.h"
 
 using namespace epsm;
@@ -66,77 +63,6 @@ template <int K> struct Shape {
 #endif
 constexpr int64_t kSmallWavefront = EPSM_SMALL_WAVEFRONT;
 constexpr int kFusedBlocks = EPSM_FUSED_BLOCKS;             // 512 / 1024 / 8192 measured within 2 %
-
-struct FusedArgs {
-    GradArgs<float> g;
-    ScatterPtrs<float> s[kMaxVertices];
-    TriTable tab;                    // the scene's triangles: id -> [v0, v1, v2, mode]
-    float *gpos, *gnrm, *galpha;
-    int64_t V, B;
-    int P, K;
-    TangentIn tin;                   // epsm_backward_pass: the first-vertex tangent is computed in the kernel
-    float *grad_o_sum;
-    // small wavefronts: workgroup b adds to replica b % replicas of the four buffers (launch(), reduce_replicas_kernel)
-    float *rep;                      // replicas x rep_stride floats, each [pos 3V | nrm 3V | alpha B | o_sum 3]; null: none
-    int replicas;
-    int64_t rep_stride;
-    // epsm_backward_pass_packed: the native log (include/epsm.h, EpsmPackedLog) instead of the per-array records
-    const float *pk_rays;            // (N,12)  o, d, d_x, d_y
-    const uint32_t *pk_flags;        // (N)     5 bits per vertex
-    const float *pk_verts;           // (N,K,32) one 128-byte record per (path, vertex)
-    const uint32_t *pk_shadow;       // (N,4) or null
-};
-// where the tangents of a path come from
-enum { kTangentsTwoColumns = 0, kTangentsFullRows = 1, kTangentsInKernel = 2 };
-
-// The 85 array pointers of a K = 5 launch are 170 SGPRs: kept as kernel arguments the compiler hoists them
-// out of the persistent loop and spills ~240 of them into VGPR lanes (a v_readlane per use: ~10 % of the
-// kernel's VALU instructions).  The workgroup copies them to LDS once; the path code reads the few it
-// needs per vertex with ds_read_b64 into VGPR pairs that die with the loads they feed.
-struct PtrTable {
-    VertexPtrs<float> v[kMaxVertices];
-    ScatterPtrs<float> s[kMaxVertices];
-};
-// 16-byte global load of quad q of a packed vertex record
-typedef float F4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ F4v ldq(const float *rec, int q) {
-    return *(const __attribute__((address_space(1))) F4v *) (rec + 4 * q);
-}
-// EpsmPackedLog vertex record (32 words): p0 p1 p2 n0 n1 n2 | b0 b1 eta light(3) | etri eb0 eb1 ew | tri dhf(3)
-constexpr int kRecWords = 32;
-__device__ __forceinline__ Geo<float> geo_from(F4v q0, F4v q1, F4v q2, float b0, float b1) {
-    Geo<float> g;
-    const V3<float> p0 = mk3<float>(q0.x, q0.y, q0.z), p1 = mk3<float>(q0.w, q1.x, q1.y), p2 = mk3<float>(q1.z, q1.w, q2.x);
-    g.b0 = b0; g.b1 = b1;
-    g.x = p0 * b0 + p1 * b1 + p2 * (1.f - b0 - b1);
-    g.e1 = p0 - p2; g.e2 = p1 - p2;
-    return g;
-}
-__device__ __forceinline__ Nrm<float> nrm_from(F4v q2, F4v q3, F4v q4, float b0, float b1) {
-    Nrm<float> o;
-    const V3<float> n0 = mk3<float>(q2.y, q2.z, q2.w), n1 = mk3<float>(q3.x, q3.y, q3.z), n2 = mk3<float>(q3.w, q4.x, q4.y);
-    o.n = n0 * b0 + n1 * b1 + n2 * (1.f - b0 - b1);
-    o.dn1 = n0 - n2; o.dn2 = n1 - n2;
-    return o;
-}
-
-// epsm.py:250-272 on the packed log: rays = this path's 12 floats (o, d, d_x, d_y), rec1 = its first vertex record
-__device__ __forceinline__ Tangent first_vertex_tangent_packed(const TangentIn &A, int64_t i, const float *rays,
-                                                               const float *rec1, bool active) {
-    const int64_t pix = (A.path_offset + i) / A.spp;
-    const int64_t y = pix / A.res, x = pix % A.res;
-    const auto *g = gl(A.grad_img) + (y * A.img_width + x) * A.img_channels;
-    const float gx = g[3], gy = g[4];
-    const F4v r0 = ldq(rays, 0), r1 = ldq(rays, 1), r2 = ldq(rays, 2);
-    const V3<float> o = mk3<float>(r0.x, r0.y, r0.z), d = mk3<float>(r0.w, r1.x, r1.y), dx = mk3<float>(r1.z, r1.w, r2.x),
-                    dy = mk3<float>(r2.y, r2.z, r2.w);
-    V3<float> p0 = zero3<float>(), p1 = p0, p2 = p0;
-    if (active) {
-        const F4v q0 = ldq(rec1, 0), q1 = ldq(rec1, 1), q2 = ldq(rec1, 2);
-        p0 = mk3<float>(q0.x, q0.y, q0.z); p1 = mk3<float>(q0.w, q1.x, q1.y); p2 = mk3<float>(q1.z, q1.w, q2.x);
-    }
-    return tangent_from(o, d, dx, dy, gx, gy, p0, p1, p2, active);
-}
 
 template <bool FLAGS_IN_LDS, int DMODE, bool PACKED> struct LdsArgs {
     int64_t N;
@@ -206,10 +132,6 @@ template <bool FLAGS_IN_LDS, int DMODE, bool PACKED> struct LdsArgs {
 // 644-645) follows.  All 64 lanes call every method at the same program point (`ok` is
 // false for lanes past the end of the wavefront): rows of the hit triangle are merged
 // over runs of equal triangles before they reach LDS.
-// fewer lanes than this: the DPP sums (VALU, the kernel's bottleneck) cost more than the LDS atomics they save
-// (measured on the bathroom / specular / pool profiles: 4, 8, 16, 32 for the triangle rows)
-constexpr int kMinMergeLanes = 16, kMinMergeLanesAlpha = 4;
-
 template <typename Table, bool PACKED, int kQueueCap> struct ScatterOut {
     const FusedArgs &F;
     const PtrTable &P;
@@ -225,48 +147,6 @@ template <typename Table, bool PACKED, int kQueueCap> struct ScatterOut {
 #endif
         Q.reserve(T, ROWS);
         Q.template push_rows<ROWS>(valid, key, val);
-    }
-
-    // Lanes whose rows go to the SAME three parameter rows (the samples of one pixel at the first hit, the
-    // two triangles of an area light, one BSDF's alpha) are summed over the wave with DPP adds and the first
-    // of them alone carries the sum on: the LDS table then sees one row instead of up to 64 same-address
-    // atomics, which it executes one after the other.  Up to ROUNDS distinct targets per call; a round that
-    // would merge fewer than kMinMergeLanes lanes ends the search.
-    template <int ROWS, int ROUNDS>
-    __device__ __forceinline__ void merge_equal(bool &any, const uint32_t id[3], V3<float> vals[ROWS], int live_rows = ROWS) const {
-        constexpr int kMin = ROWS == 1 ? kMinMergeLanesAlpha : kMinMergeLanes;
-#ifdef EPSM_KO_NOMERGE
-        return;
-#endif
-        unsigned long long pending = __ballot(any);
-#pragma unroll 1
-        for (int round = 0; round < ROUNDS; ++round) {
-            if (__popcll(pending) < kMin) return;
-            const int leader = __ffsll((long long) pending) - 1;
-            const uint32_t l0 = (uint32_t) __builtin_amdgcn_readlane((int) id[0], leader),
-                           l1 = (uint32_t) __builtin_amdgcn_readlane((int) id[1], leader),
-                           l2 = (uint32_t) __builtin_amdgcn_readlane((int) id[2], leader);
-            const bool mine = any && id[0] == l0 && id[1] == l1 && id[2] == l2;
-            const unsigned long long mm = __ballot(mine);
-            pending &= ~mm;
-            if (__popcll(mm) < kMin) return;                             // incoherent wave: stop searching
-            const bool carrier = lane_id() == leader;
-            if (ROWS == 1) {
-                vals[0].x = merge_row1(vals[0].x, mine, carrier);        // alpha rows carry one component
-            } else {
-#pragma unroll
-                for (int j = 0; j + 2 < ROWS; j += 3) {
-                    if (j >= live_rows) break;                           // wave-uniform: rows nobody has
-                    Rows3 r = {{vals[j].x, vals[j].y, vals[j].z, vals[j + 1].x, vals[j + 1].y, vals[j + 1].z,
-                                vals[j + 2].x, vals[j + 2].y, vals[j + 2].z}};
-                    r = merge_rows3(r, mine, carrier);
-                    vals[j] = mk3<float>(r.v[0], r.v[1], r.v[2]);
-                    vals[j + 1] = mk3<float>(r.v[3], r.v[4], r.v[5]);
-                    vals[j + 2] = mk3<float>(r.v[6], r.v[7], r.v[8]);
-                }
-            }
-            if (mine && !carrier) any = false;
-        }
     }
 
     __device__ __forceinline__ const float *rec(int k) const { return F.pk_verts + (i * F.K + (k - 1)) * kRecWords; }
@@ -650,6 +530,10 @@ __global__ __launch_bounds__(256, Shape<K>::kWaves) void epsm_grad_scatter_kerne
     }
 }
 
+}  // namespace
+
+namespace epsm {
+
 // Sums the replicas of a small wavefront into the caller's buffers and leaves the workspace zero for the next launch.
 __global__ __launch_bounds__(256) void reduce_replicas_kernel(float *rep, int replicas, int64_t stride, int64_t V, int64_t B,
                                                               float *gpos, float *gnrm, float *galpha, float *go) {
@@ -673,8 +557,7 @@ struct Workspace { int dev; hipStream_t stream; float *p; size_t bytes; };
 static Workspace g_ws[16];
 static int g_ws_n = 0;
 static std::mutex g_ws_mutex;
-constexpr size_t kReplicaBudget = 48u << 20;
-static hipError_t workspace(hipStream_t s, size_t bytes, float **out) {
+hipError_t fused_workspace(hipStream_t s, size_t bytes, float **out) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -698,7 +581,7 @@ static hipError_t workspace(hipStream_t s, size_t bytes, float **out) {
     return hipSuccess;
 }
 
-static hipError_t release_workspaces() {
+hipError_t fused_release_workspaces() {
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     hipError_t first = hipSuccess;
     int here = 0;
@@ -713,6 +596,10 @@ static hipError_t release_workspaces() {
     (void) hipSetDevice(here);
     return first;
 }
+
+}  // namespace epsm
+
+namespace {
 
 template <int K, int VARIANT, int DMODE, bool PACKED = false>
 hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
@@ -737,7 +624,7 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
         if (R * stride * 4 > (int64_t) kReplicaBudget) R = (int64_t) kReplicaBudget / (stride * 4);
         const char *off = getenv("EPSM_NO_REPLICAS");
         if (R >= 4 && !(off && off[0] == '1')) {
-            const hipError_t e = workspace(s, (size_t) (R * stride * 4), &F.rep);
+            const hipError_t e = fused_workspace(s, (size_t) (R * stride * 4), &F.rep);
             if (e != hipSuccess) return e;
             if (F.rep) { F.replicas = (int) R; F.rep_stride = stride; }
         }
@@ -765,6 +652,13 @@ hipError_t launch_k(int K, const FusedArgs &F, int dcols, hipStream_t s) {
 }
 
 }  // namespace
+
+// Which form of the fused kernel runs: the constraint-parallel one (epsm_backward_cp.hip) unless EPSM_BACKWARD_FORM=path
+// asks for the one-lane-per-path kernel of this file (kept for A/B measurements; same sums).
+static bool use_cp() {
+    static const bool cp = [] { const char *e = getenv("EPSM_BACKWARD_FORM"); return !(e && strcmp(e, "path") == 0); }();
+    return cp;
+}
 
 // Shared by the two entry points: validates the records, fills FusedArgs.  Returns EPSM_OK or fails with `who` in the text.
 static int fill_args(FusedArgs &F, const char *who, int variant, int64_t N, int K, const float *cam,
@@ -810,7 +704,7 @@ static int fill_args(FusedArgs &F, const char *who, int variant, int64_t N, int 
 
 extern "C" int epsm_release_workspace(void) {
     epsm_host::err_buf()[0] = 0;
-    const hipError_t e = release_workspaces();
+    const hipError_t e = fused_release_workspaces();
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_release_workspace", e);
     return EPSM_OK;
 }
@@ -838,7 +732,9 @@ extern "C" int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
     const bool full_d = dcols > 2;
     hipStream_t s = (hipStream_t) stream;
     hipError_t e;
-    if (variant == EPSM_VARIANT_MANIFOLD)
+    if (use_cp())
+        e = launch_backward_cp(variant, full_d ? kTangentsFullRows : kTangentsTwoColumns, false, F, dcols, s);
+    else if (variant == EPSM_VARIANT_MANIFOLD)
         e = full_d ? launch_k<EPSM_VARIANT_MANIFOLD, kTangentsFullRows>(K, F, dcols, s)
                    : launch_k<EPSM_VARIANT_MANIFOLD, kTangentsTwoColumns>(K, F, dcols, s);
     else
@@ -869,7 +765,8 @@ extern "C" int epsm_backward_pass(int variant, int64_t N, int K, int64_t path_of
     F.tin = TangentIn{path_offset, spp, res, img_width, img_channels, ray_o, ray_d, ray_dx, ray_dy, grad_img};
     F.grad_o_sum = grad_o_sum;
     hipStream_t s = (hipStream_t) stream;
-    const hipError_t e = variant == EPSM_VARIANT_MANIFOLD ? launch_k<EPSM_VARIANT_MANIFOLD, kTangentsInKernel>(K, F, 2, s)
+    const hipError_t e = use_cp() ? launch_backward_cp(variant, kTangentsInKernel, false, F, 2, s)
+                       : variant == EPSM_VARIANT_MANIFOLD ? launch_k<EPSM_VARIANT_MANIFOLD, kTangentsInKernel>(K, F, 2, s)
                                                           : launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, kTangentsInKernel>(K, F, 2, s);
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_backward_pass", e);
     return EPSM_OK;
@@ -910,7 +807,8 @@ extern "C" int epsm_backward_pass_packed(int variant, int64_t N, int K, int64_t 
     F.tin = TangentIn{path_offset, spp, res, img_width, img_channels, nullptr, nullptr, nullptr, nullptr, grad_img};
     F.grad_o_sum = grad_o_sum;
     hipStream_t s = (hipStream_t) stream;
-    const hipError_t e = variant == EPSM_VARIANT_MANIFOLD ? launch_k<EPSM_VARIANT_MANIFOLD, kTangentsInKernel, true>(K, F, 2, s)
+    const hipError_t e = use_cp() ? launch_backward_cp(variant, kTangentsInKernel, true, F, 2, s)
+                       : variant == EPSM_VARIANT_MANIFOLD ? launch_k<EPSM_VARIANT_MANIFOLD, kTangentsInKernel, true>(K, F, 2, s)
                                                           : launch_k<EPSM_VARIANT_MANIFOLD_CAUSTIC, kTangentsInKernel, true>(K, F, 2, s);
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_backward_pass_packed", e);
     return EPSM_OK;

@@ -12,7 +12,7 @@
 //   * fused kernel: lanes with the same target (one pixel's samples on the first
 //     triangle, the couple of emitter triangles, a BSDF's alpha slot), adjacent
 //     or not, are summed with DPP adds in bounded leader rounds
-//     (ScatterOut::merge_equal, epsm_grad_scatter.hip).
+//     (merge_equal below; epsm_grad_scatter.hip, epsm_backward_cp.hip).
 // Device-only code.
 #pragma once
 
@@ -85,11 +85,15 @@ struct AccFixed64 {
     typedef long long T;
     static constexpr bool kBucketed = true;
     __device__ __forceinline__ static T to_fixed(float x) {
-        // x * 2^32 is exact in float (a power-of-two scale); clamped to the int64 range first, so the conversion is
-        // defined for every finite input (|x| < 2^31 - 2^7), then rounded to nearest: resolution 2^-32.
-        // NaN (a degenerate normal row) counts as 0, as a float row that is never flushed would.
-        const float s = fminf(fmaxf(x == x ? x : 0.f, -2147483520.f), 2147483520.f) * 4294967296.f;
-        return (T) __float2ll_rn(s);
+        // sign * trunc(|x| * 2^32), |x| saturated below 2^31: integer part and fraction converted separately (there is no
+        // float -> int64 instruction; the library conversion is ~20 VALU instructions per value, this is 8).  |x| - trunc(|x|)
+        // is exact in float, and so is its scaling by 2^32.  NaN (a degenerate normal row) counts as 0, as a float row
+        // that is never flushed would.  Truncation instead of rounding: < 2.4e-10 per term, towards zero.
+        const float a = fminf(fabsf(x), 2147483520.f);            // (fminf returns the non-NaN operand)
+        const unsigned hi = (unsigned) a;                          // v_cvt_u32_f32: truncates
+        const unsigned lo = (unsigned) ((a - (float) hi) * 4294967296.f);
+        const T mag = (T) (((unsigned long long) hi << 32) | lo);
+        return x < 0.f ? -mag : mag;
     }
     __device__ __forceinline__ static void add(T *p, float x) { atomicAdd((unsigned long long *) p, (unsigned long long) to_fixed(x)); }
     __device__ __forceinline__ static float get(T q) { return (float) ((double) q * 2.3283064365386963e-10); }
@@ -255,6 +259,52 @@ __device__ __attribute__((noinline)) float merge_row1(float v, bool mine, bool c
     return carrier ? tot : (mine ? 0.f : v);
 }
 
+// fewer lanes than this: the DPP sums (VALU, the kernel's bottleneck) cost more than the LDS atomics they save
+// (measured on the bathroom / specular / pool profiles: 4, 8, 16, 32 for the triangle rows)
+constexpr int kMinMergeLanes = 16, kMinMergeLanesAlpha = 4;
+
+// Lanes whose rows go to the SAME three parameter rows (the samples of one pixel at the first hit, the
+// two triangles of an area light, one BSDF's alpha) are summed over the wave with DPP adds and the first
+// of them alone carries the sum on: the LDS table then sees one row instead of up to 64 same-address
+// atomics, which it executes one after the other.  Up to ROUNDS distinct targets per call; a round that
+// would merge fewer than kMinMergeLanes lanes ends the search.
+template <int ROWS, int ROUNDS>
+__device__ __forceinline__ void merge_equal(bool &any, const uint32_t id[3], V3<float> vals[ROWS], int live_rows = ROWS) {
+    constexpr int kMin = ROWS == 1 ? kMinMergeLanesAlpha : kMinMergeLanes;
+#ifdef EPSM_KO_NOMERGE
+    return;
+#endif
+    unsigned long long pending = __ballot(any);
+#pragma unroll 1
+    for (int round = 0; round < ROUNDS; ++round) {
+        if (__popcll(pending) < kMin) return;
+        const int leader = __ffsll((long long) pending) - 1;
+        const uint32_t l0 = (uint32_t) __builtin_amdgcn_readlane((int) id[0], leader),
+                       l1 = (uint32_t) __builtin_amdgcn_readlane((int) id[1], leader),
+                       l2 = (uint32_t) __builtin_amdgcn_readlane((int) id[2], leader);
+        const bool mine = any && id[0] == l0 && id[1] == l1 && id[2] == l2;
+        const unsigned long long mm = __ballot(mine);
+        pending &= ~mm;
+        if (__popcll(mm) < kMin) return;                             // incoherent wave: stop searching
+        const bool carrier = lane_id() == leader;
+        if (ROWS == 1) {
+            vals[0].x = merge_row1(vals[0].x, mine, carrier);        // alpha rows carry one component
+        } else {
+#pragma unroll
+            for (int j = 0; j + 2 < ROWS; j += 3) {
+                if (j >= live_rows) break;                           // wave-uniform: rows nobody has
+                Rows3 r = {{vals[j].x, vals[j].y, vals[j].z, vals[j + 1].x, vals[j + 1].y, vals[j + 1].z,
+                            vals[j + 2].x, vals[j + 2].y, vals[j + 2].z}};
+                r = merge_rows3(r, mine, carrier);
+                vals[j] = mk3<float>(r.v[0], r.v[1], r.v[2]);
+                vals[j + 1] = mk3<float>(r.v[3], r.v[4], r.v[5]);
+                vals[j + 2] = mk3<float>(r.v[6], r.v[7], r.v[8]);
+            }
+        }
+        if (mine && !carrier) any = false;
+    }
+}
+
 // Direct insertion: LDS atomics merge equal keys natively (same-address lanes serialise
 // at LDS speed), which beats shuffle scans when runs are short.
 template <typename Table> __device__ __forceinline__ void scatter_triangle_direct(const Table &buf, uint32_t base, bool valid,
@@ -296,6 +346,9 @@ struct QItem { uint32_t key; float x, y, z; };
 // Inlined: as an out-of-line function (which kept the kernel at 54 KB of code) every call began with the callee's
 // s_waitcnt vmcnt(0), i.e. waited for the vertex records the path code had prefetched; with the larger queues there
 // are few enough call sites taken that inlining wins 1.5-4.5 % (config 2 4.60 -> 4.54 ms, V = 10^6 5.68 -> 5.44).
+// (Round 3: kU items per lane read together and their probes issued together -- the insertion is a chain of dependent
+// LDS round trips -- measured on the constraint-parallel kernel, headline slab, ms: kU = 1 2.89, 2 2.75, 4 3.02, 8 3.46
+// against 2.66 for the loop below: the drain is not waiting for its own latency.)
 template <typename Table>
 __device__ __forceinline__ void drain_queue(const QItem *q, int n, Table T) {
     // q is LDS: say so.  Through the generic pointer of this out-of-line function the read was a FLAT load, whose

@@ -314,6 +314,7 @@ int main(int argc, char **argv) {
     DeviceArray<float> out_p((size_t) P * N * 3), out_l((size_t) K * N * 3), out_d((size_t) K * N * 3);
     DeviceArray<float> pos_a(3 * V), nrm_a(3 * V), alpha_a(B), pos_b(3 * V), nrm_b(3 * V), alpha_b(B);
     DeviceArray<float> pos_c(3 * V), nrm_c(3 * V), alpha_c(B), grad_o_c(3);
+    DeviceArray<float> pos_lo(3 * V), nrm_lo(3 * V), alpha_lo(B), pos_hi(3 * V), nrm_hi(3 * V), alpha_hi(B);
 
     Timer t;
     // ---- first-vertex tangent (epsm.py:250-272)
@@ -331,6 +332,15 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 2; ++rep) {            // first round warms up (code objects, clocks)
         pos_a.zero(); nrm_a.zero(); alpha_a.zero(); pos_b.zero(); nrm_b.zero(); alpha_b.zero();
         pos_c.zero(); nrm_c.zero(); alpha_c.zero(); grad_o_c.zero();
+        pos_lo.zero(); nrm_lo.zero(); alpha_lo.zero(); pos_hi.zero(); nrm_hi.zero(); alpha_hi.zero();
+        // the two stages again with the outlier threshold (epsm.py:932-944) moved by -2 % / +2 %: how much of every sum
+        // hangs on components that sit on the threshold (the allowance of the comparison below)
+        for (int band = 0; band < 2; ++band) {
+            EPSM_CALL(epsm_manifold_grad(variant, N, K, d_cam.ptr, vrec.data(), dlduv.ptr, 2, 2, dldp.ptr, band ? 0.102f : 0.098f,
+                                         out_p.ptr, out_l.ptr, out_d.ptr, nullptr));
+            EPSM_CALL(epsm_scatter(variant, N, K, vrec.data(), srec.data(), table.ptr, T, out_p.ptr, out_l.ptr, out_d.ptr,
+                                   band ? pos_hi.ptr : pos_lo.ptr, band ? nrm_hi.ptr : nrm_lo.ptr, band ? alpha_hi.ptr : alpha_lo.ptr, V, B, nullptr));
+        }
         t.start();
         EPSM_CALL(epsm_manifold_grad(variant, N, K, d_cam.ptr, vrec.data(), dlduv.ptr, 2, 2, dldp.ptr, 0.1f,
                                      out_p.ptr, out_l.ptr, out_d.ptr, nullptr));
@@ -357,8 +367,27 @@ int main(int argc, char **argv) {
                              pc = pos_c.download(), nc = nrm_c.download(), ac = alpha_c.download(),
                              go = grad_o.download(), goc = grad_o_c.download();
     const double mp = max_abs(pa), mn = max_abs(na), ma = max_abs(aa);
-    const double ep = std::fmax(max_diff(pa, pb), max_diff(pa, pc)), en = std::fmax(max_diff(na, nb), max_diff(na, nc)),
-                 ea = std::fmax(max_diff(aa, ab), max_diff(aa, ac));
+    // fused and one launch run the same per-path arithmetic (epsm_cp_core.h): they differ by the order of the additions
+    const double ep = max_diff(pb, pc), en = max_diff(nb, nc), ea = max_diff(ab, ac);
+    // ... the dense calc_grad kernel runs the other restatement (epsm_path_core.h): same algebra, different rounding.
+    // Beyond the order of the additions the sums may part where a component sits on the outlier threshold (allowance: what
+    // the sum moves by when the threshold moves by +-2 %) and on ill-conditioned paths: beyond the allowance the MEAN
+    // difference within 2e-4 of the buffer's magnitude, every element within 1e-2 (tests/_util.py, two_routes_report).
+    auto routes = [](const std::vector<float> &two, const std::vector<float> &one, const std::vector<float> &lo, const std::vector<float> &hi,
+                     double m, double *mean, double *worst) {
+        double sum = 0; *worst = 0;
+        for (size_t i = 0; i < two.size(); ++i) {
+            const double allow = std::fabs((double) lo[i] - hi[i]), d = std::fabs((double) two[i] - one[i]);
+            const double excess = std::fmax(0.0, d - allow) / (m > 0 ? m : 1);
+            sum += excess;
+            *worst = std::fmax(*worst, excess);
+        }
+        *mean = two.empty() ? 0.0 : sum / two.size();
+    };
+    const std::vector<float> plo = pos_lo.download(), phi = pos_hi.download(), nlo = nrm_lo.download(), nhi = nrm_hi.download(),
+                             alo = alpha_lo.download(), ahi = alpha_hi.download();
+    double fp, wp, fn, wn, fa, wa;
+    routes(pa, pc, plo, phi, mp, &fp, &wp); routes(na, nc, nlo, nhi, mn, &fn, &wn); routes(aa, ac, alo, ahi, ma, &fa, &wa);
     // the stand-alone tangent call ran twice into grad_o (it accumulates), the one-launch pass once per round
     const double eo = max_diff(std::vector<float>{go[0] * 0.5f, go[1] * 0.5f, go[2] * 0.5f}, goc), mo = max_abs(goc);
     std::printf("epsm_host_driver: N=%lld K=%d variant=%d V=%lld (res %d @ %d spp)\n", (long long) N, K, variant, (long long) V, res, spp);
@@ -367,9 +396,12 @@ int main(int argc, char **argv) {
     std::printf("  scatter        %8.3f ms\n", ms_scatter);
     std::printf("  fused          %8.3f ms  %7.2f Gpaths/s   (two stages: %.3f ms)\n", ms_fused, N / ms_fused * 1e-6, ms_grad + ms_scatter);
     std::printf("  one launch     %8.3f ms  %7.2f Gpaths/s   (tangent + fused: %.3f ms)\n", ms_pass, N / ms_pass * 1e-6, ms_tangent + ms_fused);
-    std::printf("  fused / one launch vs two-stage: pos %.3g / %.3g  nrm %.3g / %.3g  alpha %.3g / %.3g  (max |diff| / max |value|)\n", ep, mp, en, mn, ea, ma);
+    std::printf("  fused vs one launch: pos %.3g / %.3g  nrm %.3g / %.3g  alpha %.3g / %.3g  (max |diff| / max |value|)\n", ep, mp, en, mn, ea, ma);
+    std::printf("  one launch vs two stages (threshold straddlers aside, / max |value|): mean |diff| pos %.3g nrm %.3g alpha %.3g; worst %.3g %.3g %.3g\n",
+                fp, fn, fa, wp, wn, wa);
     // (K = 1 has no continuing rows, hence no alpha gradient: only the position buffer must be non-zero)
     const bool ok = mp > 0 && max_abs(uv) > 0 && ep <= 2e-4 * mp && en <= 2e-4 * mn + 1e-30 && ea <= 2e-4 * ma + 1e-30 &&
+                    fp <= 2e-4 && fn <= 2e-4 && fa <= 2e-4 && wp <= 1e-2 && wn <= 1e-2 && wa <= 1e-2 &&
                     mo > 0 && eo <= 1e-3 * mo;
     std::printf("%s\n", ok ? "OK" : "MISMATCH");
     return ok ? 0 : 1;
