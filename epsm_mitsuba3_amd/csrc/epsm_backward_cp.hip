@@ -714,9 +714,9 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
             if (F.rep) { F.replicas = (int) R; F.rep_stride = stride; }
         }
     }
-    // fixed-point rows hold |sum| < 2^31 at a resolution of 2^-32: fine for terms clamped to +-clip (0.1 in the reference),
+    // fixed-point rows hold |sum| < 2^19 at a resolution of 2^-44: fine for terms clamped to +-clip (0.1 in the reference),
     // not for a caller who switched the clamp off
-    const bool float_rows = !(F.g.clip <= 1024.f);
+    const bool float_rows = !(F.g.clip <= 1.f);
     if (float_rows)
         hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, true>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
     else

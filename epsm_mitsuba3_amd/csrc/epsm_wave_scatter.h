@@ -69,12 +69,14 @@ __device__ __forceinline__ V3<float> seg_sum3(V3<float> v, int head) {
 constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
 constexpr int kMaxProbe = 8;
 
-// What a table row sums in.  float: 12 B of values per row, ds_add_f32.  Fixed64: 64-bit fixed point with 32 fractional
-// bits, 24 B per row, ds_add_u64 -- |sum| < 2^31 and a resolution of 2.3e-10 are ample for rows whose terms are clamped
-// to +-0.1 (epsm.py:932-944) and end up in float32 buffers, and the sum does not depend on the order of the additions.
-// The integer atomic is ~18x faster than the float one (rates below), but a row is 1.75x as large: the fixed-point
-// table pays where few rows suffice (manifold_caustic: -6 % on the pool profile with 1280 rows) and loses where the
-// window's distinct rows need the 2304 that only float rows fit (manifold: 4.9 against 4.5 ms on config 2).
+// What a table row sums in.  float: 12 B of values per row, ds_add_f32.  Fixed64: 64-bit fixed point with 44 fractional
+// bits, 24 B per row, ds_add_u64: a resolution of 5.7e-14 -- float32's own on terms down to 1e-6, the terms being clamped to
+// +-clip (0.1, epsm.py:932-944) and ending up in float32 buffers -- a range of +-2^19 for the sum of a row between two
+// flushes (a table lives for a few thousand paths), and a sum that does not depend on the order of the additions.
+// The LDS integer atomic is ~15x faster than the float one (rates below) and does not serialise as badly on one address,
+// but a row is 1.75x as large.  The fused kernels use fixed-point rows whenever the clamp is on (clip <= 1); a caller who
+// switched it off gets float rows (unbounded terms).  (Round 2 had 32 fractional bits: 2.3e-10, i.e. 2e-4 of a term of
+// 1e-6 -- visible in a per-path parity test with small tangents, tests/test_gpu_backward_per_path.py.)
 struct AccFloat {
     typedef float T;
     static constexpr bool kBucketed = false;         // see LdsTable::add
@@ -85,18 +87,18 @@ struct AccFixed64 {
     typedef long long T;
     static constexpr bool kBucketed = true;
     __device__ __forceinline__ static T to_fixed(float x) {
-        // sign * trunc(|x| * 2^32), |x| saturated below 2^31: integer part and fraction converted separately (there is no
-        // float -> int64 instruction; the library conversion is ~20 VALU instructions per value, this is 8).  |x| - trunc(|x|)
-        // is exact in float, and so is its scaling by 2^32.  NaN (a degenerate normal row) counts as 0, as a float row
-        // that is never flushed would.  Truncation instead of rounding: < 2.4e-10 per term, towards zero.
-        const float a = fminf(fabsf(x), 2147483520.f);            // (fminf returns the non-NaN operand)
+        // sign * trunc(|x| * 2^44), |x| saturated below 2^20: |x| * 2^12 is split into its integer part and its fraction,
+        // converted separately (there is no float -> int64 instruction; the library conversion is ~20 VALU instructions per
+        // value, this is 8).  a - trunc(a) is exact in float, and so is its scaling by 2^32.  NaN (a degenerate normal
+        // row) counts as 0, as a float row that is never flushed would.  Truncation instead of rounding: < 5.7e-14 per term.
+        const float a = fminf(fabsf(x) * 4096.f, 4294967040.f);   // (fminf returns the non-NaN operand)
         const unsigned hi = (unsigned) a;                          // v_cvt_u32_f32: truncates
         const unsigned lo = (unsigned) ((a - (float) hi) * 4294967296.f);
         const T mag = (T) (((unsigned long long) hi << 32) | lo);
         return x < 0.f ? -mag : mag;
     }
     __device__ __forceinline__ static void add(T *p, float x) { atomicAdd((unsigned long long *) p, (unsigned long long) to_fixed(x)); }
-    __device__ __forceinline__ static float get(T q) { return (float) ((double) q * 2.3283064365386963e-10); }
+    __device__ __forceinline__ static float get(T q) { return (float) ((double) q * 5.6843418860808015e-14); }      // 2^-44
 };
 
 template <int kRows, typename Acc = AccFloat>
@@ -143,6 +145,12 @@ struct LdsTable {
         return slot + kStep >= (uint32_t) kTableSize ? slot + kStep - (uint32_t) kTableSize : slot + kStep;
     }
     __device__ __forceinline__ void add_at(uint32_t slot, float x, float y, float z) const {
+        if (Acc::kBucketed) {
+            // integer rows: adding a zero costs an LDS operation, skipping it costs a branch (exec-mask bookkeeping) per
+            // component in a loop whose run time is the instructions it issues
+            Acc::add(&vals[3 * slot + 0], x); Acc::add(&vals[3 * slot + 1], y); Acc::add(&vals[3 * slot + 2], z);
+            return;
+        }
         if (x != 0.f) Acc::add(&vals[3 * slot + 0], x);
         if (y != 0.f) Acc::add(&vals[3 * slot + 1], y);
         if (z != 0.f) Acc::add(&vals[3 * slot + 2], z);
@@ -150,13 +158,15 @@ struct LdsTable {
     __device__ __forceinline__ void add(uint32_t key, float x, float y, float z) const {
         if (x == 0.f && y == 0.f && z == 0.f) return;
         uint32_t slot = home(key);
+        bool placed = false;
 #pragma unroll 1
         for (int probe = 0; probe < kMaxProbe; ++probe) {
             const uint32_t prev = atomicCAS(&keys[slot], kEmptyKey, key);
-            if (prev == kEmptyKey || prev == key) { add_at(slot, x, y, z); return; }
+            if (prev == kEmptyKey || prev == key) { placed = true; break; }
             slot = next(slot);
         }
-        global_add(key, x, y, z);          // crowded neighbourhood: go straight to HBM
+        if (placed) add_at(slot, x, y, z);
+        else global_add(key, x, y, z);          // crowded neighbourhood: go straight to HBM (out of line it cost 11 spilled registers: 2.55 -> 2.70 ms)
     }
     // all threads of the workgroup; barriers inside
     __device__ __forceinline__ void clear() const {
