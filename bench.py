@@ -24,10 +24,13 @@ time the reference-shaped pipelines.
 
 Prints ONE JSON line (rank 0).  ``value`` = paths/s over all ranks for the whole step;
 ``grad_image_ms`` = wall-clock of the step = one gradient image; ``roofline`` prices the
-dominant kernel (one slab's ``epsm_grad_scatter_kernel`` launch) against the 8 TB/s HBM
+dominant kernel (one slab's ``epsm_backward_cp_kernel`` launch) against the 8 TB/s HBM
 peak with the ALGORITHMIC bytes of SURVEY.md 8d (56 + 116 K per path in one launch,
 32 + 116 K fused, 32 + 200 K stand-alone) over its own average launch time, measured with
-HIP events on the launch stream around every launch of the timed region;
+HIP events on the launch stream around every launch of the timed region; next to it
+``live_algorithmic_bytes`` / ``frac_live`` (only the vertices a path's terms reach, from
+the flag words) and ``valu_floor_ms`` (the kernel's vector instructions at one per four
+clocks and SIMD, from the committed counter run), so that the line says which bound applies;
 ``cpu_baseline`` times oracle/ (the C restatement: tangent + calc_grad + scatter) on this
 box's host cores on a bounded sample of the same records.
 """
@@ -95,7 +98,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--real-scene", action="store_true",
-                    help="add the secondary leg that traces a real scene (128 k triangles) and runs the backward pass on its records")
+                    help="add the secondary leg that traces a real scene (128 k triangles) and runs the backward pass on its records "
+                         "(part of the default headline line; this flag adds it to the other configurations)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher + process group + one all-reduce of the parameter-gradient buffer only (gloo on a box "
                          "without GPU): what tests/test_bench_launcher.py runs")
@@ -299,6 +303,29 @@ def real_scene_leg(variant, res, spp, dev):
                     "tiles; outside the timed region"}
 
 
+def live_vertices(flags: torch.Tensor, K: int, variant: str) -> torch.Tensor:
+    """Per path, the number of logged vertices whose record the backward pass has to read: ``nv`` of cp::manifold_plan /
+    cp::caustic_plan (csrc/epsm_cp_core.h; the term masks of epsm.py:793-802, 852-855, 916-920 / 1172-1183) restated on
+    the flag words of the native log (5 bits per vertex: Diffuse, Null, active, active_em, ismesh), and at least the
+    first vertex where it is active (the first-vertex tangent reads its triangle)."""
+    f = flags.to(torch.int64)
+    bit = lambda k, b: ((f >> (5 * (k - 1))) & b) != 0 if 1 <= k <= K else torch.zeros_like(f, dtype=torch.bool)
+    valid = torch.ones_like(f, dtype=torch.bool)
+    hd = torch.zeros_like(f)
+    nv = torch.zeros_like(f)
+    for i in range(1, K + 1):
+        valid = valid & bit(i, 16)
+        hd = hd + bit(i, 1).to(torch.int64)
+        valid = valid & (hd < 2)
+        if variant == "manifold":
+            spec = valid & (hd == 0)
+            nv = torch.where(spec & bit(i, 4) & bit(i, 8), torch.full_like(nv, i), nv)
+            nv = torch.where(spec & bit(i + 1, 4) & bit(i + 1, 1), torch.full_like(nv, i + 1), nv)
+        else:
+            nv = torch.where(bit(1, 1) & valid & bit(i + 1, 4) & (bit(i + 1, 1) | bit(i + 1, 2)), torch.full_like(nv, i + 1), nv)
+    return torch.maximum(nv, bit(1, 4).to(torch.int64))
+
+
 def kernel_source_hash() -> str:
     """Fingerprint of the kernel sources: profiles/traffic.json entries carry the one they were measured on."""
     h = hashlib.sha256()
@@ -315,17 +342,17 @@ def lookup_traffic(kernel, paths, K, variant, profile):
     only for the kernel sources it was measured on."""
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.isfile(tfile):
-        return None, "no profiles/traffic.json"
+        return None, "no profiles/traffic.json", None
     src = kernel_source_hash()
     stale = False
     for rec in json.load(open(tfile)):
         if (rec.get("kernel") == kernel and rec.get("paths") == paths and rec.get("K") == K
                 and rec.get("variant") == variant and rec.get("profile") == profile):
             if rec.get("src_hash") == src:
-                return rec["hbm_bytes_per_launch"], rec.get("source")
+                return rec["hbm_bytes_per_launch"], rec.get("source"), rec
             stale = True
     return None, ("stale: the kernel sources changed since the PMC run in profiles/traffic.json" if stale
-                  else "no PMC run for this kernel / workload in profiles/traffic.json")
+                  else "no PMC run for this kernel / workload in profiles/traffic.json"), None
 
 
 def main():
@@ -408,6 +435,7 @@ def main():
     keep_per_path = (52 + 128 * K) if packed_log else (48 + K * 139)
     build_per_path = 48 + K * 200
     slabs, used0 = [], torch.cuda.memory_allocated(dev)
+    live0 = None
     for s in my_slabs:
         lo, hi = s * slab_paths, min((s + 1) * slab_paths, N_image)
         n_s = hi - lo
@@ -426,10 +454,13 @@ def main():
                                        n_paths_total=trace.n_paths_total)
         else:
             packed = (PackedRecords(trace.path_info, device=dev), PackedScatter(trace.scatter_info, device=dev, table=scene.triangle_table()))
+        if packed_log and not slabs:
+            live0 = int(live_vertices(packed.flags, K, variant).sum())   # slab 0: vertices its paths' terms reach
         slabs.append((trace, packed))
         torch.cuda.synchronize()
-    if not slabs:
+    if my_slabs and not slabs:
         raise SystemExit("bench.py: not even one slab fits into HBM")
+    # (a rank beyond the number of slabs -- --config 1, 2, 5 have one -- launches nothing and still enters the all-reduce)
     resident_bytes = torch.cuda.memory_allocated(dev) - used0
     n_my = len(my_slabs)
     P = num_param_grads(variant, K)
@@ -480,10 +511,16 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     rccl_ranks = 1
+    # this rank's own share of a step: its launches (events on the launch stream), without the wait for the slowest rank
+    own_ms = (sum(evs[0].elapsed_time(evs[-1]) for evs in launch_events) / args.steps) if launch_events else 0.0
+    rank_ms_min = rank_ms_max = own_ms
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         all_reduce_(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        lo = torch.tensor([own_ms], device=dev, dtype=torch.float64); hi = lo.clone()
+        all_reduce_(lo, op=dist.ReduceOp.MIN); all_reduce_(hi, op=dist.ReduceOp.MAX)
+        rank_ms_min, rank_ms_max = float(lo.item()), float(hi.item())
         probe = torch.ones(1, device=dev)
         all_reduce_(probe)                                       # the number of ranks RCCL actually summed over
         rccl_ranks = int(round(float(probe.item())))
@@ -494,7 +531,7 @@ def main():
     value = N_image * args.steps / elapsed
 
     names = ["tangent", "grad", "scatter"]
-    stage_ms = {n: sum(evs[i].elapsed_time(evs[i + 1]) for evs in launch_events) / len(launch_events)
+    stage_ms = {n: sum(evs[i].elapsed_time(evs[i + 1]) for evs in launch_events) / max(1, len(launch_events))
                 for i, n in enumerate(names)}
     stage_ms["allreduce"] = sum(a.elapsed_time(b) for a, b in step_events) / len(step_events)
 
@@ -528,7 +565,9 @@ def main():
         kernel_ms = stage_ms["grad"]
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         kname = ("epsm_backward_pass_packed" if packed_log else "epsm_backward_pass") if one_launch else ("epsm_grad_scatter_kernel" if fused else "epsm_grad_kernel")
-        traffic, traffic_src = lookup_traffic(kname, n_slab0, K, variant, profile)
+        traffic, traffic_src, traffic_rec = lookup_traffic(kname, n_slab0, K, variant, profile)
+        live_alg = (56 * n_slab0 + 116 * live0) if (one_launch and live0 is not None) else None
+        valu = (traffic_rec or {}).get("sq_insts_valu")
         distinct = len(slabs) == n_my
         result = {
             "metric": "manifold_paths_per_s", "value": value, "unit": "paths/s",
@@ -536,6 +575,8 @@ def main():
             "grad_image_ms": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks, "grad_abs_sum": grad_abs_sum,
+            "rank_launch_ms_per_step": {"min": rank_ms_min, "max": rank_ms_max,
+                                        "note": "each rank's own launches per step (HIP events), min / max over the ranks: load imbalance"},
             **({"rehearsal": f"{world} ranks SHARING GPU 0, collectives by gloo through the host: exercises the sharded path, "
                              "measures nothing"} if args.rehearse_one_gpu else {}),
             "config": {"workload": f"{label}: {profile}-like synthetic path records, {variant}, {res}x{res} @ {spp} spp = "
@@ -554,10 +595,18 @@ def main():
                              else "reference tensors: one (N,3) array per field",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("epsm_grad_scatter_kernel<tangents in kernel> (epsm_backward_pass: tangent + calc_grad + scatter)"
-                                    if one_launch else "epsm_grad_scatter_kernel (fused calc_grad + scatter)") if fused else "epsm_grad_kernel",
+                         "kernel": ("epsm_backward_cp_kernel<tangents in kernel> (epsm_backward_pass: tangent + calc_grad + scatter)"
+                                    if one_launch else "epsm_backward_cp_kernel (fused calc_grad + scatter)") if fused else "epsm_grad_kernel",
                          "kernel_ms": kernel_ms, "launches_timed": len(launch_events), "paths_per_launch": n_slab0,
                          "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_path": per_path,
+                         # SURVEY 8(d)'s figure counts all K vertices of every path; a path's terms stop at its first
+                         # diffuse / inactive vertex: what the kernel has to READ is this
+                         "live_algorithmic_bytes": live_alg,
+                         "frac_live": (live_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if live_alg else None,
+                         # the other bound: vector instructions of one launch (SQ_INSTS_VALU of the committed counter run) at
+                         # one per 4 clocks per SIMD (a wave alone on its SIMD; 1024 SIMDs, 2.4 GHz)
+                         "valu_insts_per_launch": valu,
+                         "valu_floor_ms": (valu / 1024 * 4 / 2.4e9 * 1e3) if valu else None,
                          "kernel_source_hash": kernel_source_hash()},
         }
         if not distinct:
@@ -575,7 +624,8 @@ def main():
             result["cpu_baseline"] = cpu_baseline(slabs[0][0], grad_in, variant, V, B, args.cpu_seconds)
         if world == 1 and args.config == 0 and not (args.soa or args.two_stage or args.separate_tangent or args.no_secondary):
             result["configs_1"] = secondary_config_leg(2, dev)          # BASELINE.json configs[1]: round 1's driver line
-        if args.real_scene and world == 1:
+        if world == 1 and (args.real_scene or (args.config == 0 and not (args.soa or args.two_stage or args.separate_tangent or args.no_secondary))):
+            # end to end on records the library's own tracer produces: trace + native log + backward pass
             del slabs, out
             torch.cuda.empty_cache()
             result["real_scene"] = real_scene_leg(variant, 512, 64, dev)

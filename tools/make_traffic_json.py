@@ -45,13 +45,15 @@ def main():
     ap.add_argument("--variant", default="manifold"); ap.add_argument("--profile", default="bathroom")
     ap.add_argument("--tag", default="r02")
     ap.add_argument("--packed", action="store_true"); ap.add_argument("--gather-calib", default=None)
+    ap.add_argument("--sq-dir", default=None, help="rocprofv3 --pmc run with SQ_INSTS_VALU: stored as sq_insts_valu (bench.py: valu_floor_ms)")
     a = ap.parse_args()
     import bench
-    needle = ", true, " if a.packed else "epsm_grad_scatter_kernel"        # <K, VARIANT, DMODE, PACKED, window>
-    fk, fv = pick({k: v for k, v in counters(a.fetch_dir, "FETCH_SIZE").items() if "epsm_grad_scatter_kernel" in k}, needle)
-    wk, wv = pick({k: v for k, v in counters(a.write_dir, "WRITE_SIZE").items() if "epsm_grad_scatter_kernel" in k}, needle)
+    kern = "epsm_backward_cp_kernel"                                        # <VARIANT, DMODE, PACKED, FLOAT_ROWS>
+    needle = ", true, " if a.packed else kern
+    fk, fv = pick({k: v for k, v in counters(a.fetch_dir, "FETCH_SIZE").items() if kern in k}, needle)
+    wk, wv = pick({k: v for k, v in counters(a.write_dir, "WRITE_SIZE").items() if kern in k}, needle)
     if not fv or not wv:
-        raise SystemExit("no FETCH_SIZE / WRITE_SIZE rows for epsm_grad_scatter_kernel")
+        raise SystemExit(f"no FETCH_SIZE / WRITE_SIZE rows for {kern}")
     fetch_kb, write_kb = sum(fv) / len(fv), sum(wv) / len(wv)          # rocprofv3 reports both in KB
     note = ""
     if a.calib_dir:
@@ -69,9 +71,17 @@ def main():
             fnote = (f"x {factor:.3f} (calibrated on tools/micro/gather128: {known / 1e9:.3f} GB read by per-lane 16-byte gathers of "
                      f"128-byte records, FETCH_SIZE reported {sum(gv) / len(gv) * 1024 / 1e9:.3f} GB)")
     total = int(factor * fetch_kb * 1024 + write_kb * 1024)
+    sq = {}
+    if a.sq_dir:
+        for name, key in (("SQ_INSTS_VALU", "sq_insts_valu"), ("SQ_INSTS_SALU", "sq_insts_salu"), ("SQ_WAIT_ANY", "sq_wait_any"),
+                          ("SQ_WAVE_CYCLES", "sq_wave_cycles")):
+            _, v = pick({k: x for k, x in counters(a.sq_dir, name).items() if kern in k}, needle)
+            if v:
+                sq[key] = sum(v) / len(v)
     entry = {"kernel": "epsm_backward_pass_packed" if a.packed else "epsm_backward_pass", "paths": a.paths, "K": a.K, "variant": a.variant, "profile": a.profile,
              "hbm_bytes_per_launch": total, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
              "dispatches": [len(fv), len(wv)], "src_hash": bench.kernel_source_hash(),
+             **sq,
              "source": f"profiles/{a.tag}_pmc_traffic.txt ({fk[:60]}...): FETCH_SIZE {fetch_kb:,.0f} KB {fnote} + "
                        f"WRITE_SIZE {write_kb:,.0f} KB (stores + float atomics, exact); separate rocprofv3 --pmc passes{note}"}
     path = os.path.join(ROOT, "profiles", "traffic.json")
