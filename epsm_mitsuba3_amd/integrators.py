@@ -108,7 +108,13 @@ class EPSMIntegrator:
         ignores them (epsm.py:142,145): the backward pass uses ``backward_sensor`` and
         ``backward_spp``.  Gradients are ACCUMULATED into ``params`` (as dr.backward does)."""
         if grad_in.shape[-1] == 3:
-            raise NotImplementedError("colour-only adjoint (epsm.py:230-234) is the PRB path, not the EPSM hot path")
+            # epsm.py:230-234: a 3-channel gradient image is the colour adjoint deltaL = grad_in of the PRB replay, on
+            # the sensor and sample count the caller names (the 5-channel branch alone ignores them, epsm.py:142-145).
+            # The manifold integrators move geometry through channels 3, 4 only (epsm.py:729-732 leaves the colour
+            # adjoint's propagation into geometry commented out): what a 3-channel image can reach are the colour
+            # parameters attached to the scene.
+            prb = PRBIntegrator({"max_depth": self.max_depth, "rr_depth": self.rr_depth})
+            return prb.render_backward(scene, params, grad_in, sensor=sensor, seed=seed, spp=spp)
         rank, world = _dist.world()
         # dr.backward ACCUMULATES into the gradients that are already there.  With more than one rank only THIS
         # call's contribution may be summed over the ranks: what `params` held on entry is already a sum over the
@@ -240,7 +246,9 @@ class PRBIntegrator:
         self.rr_depth = props.get("rr_depth", 5)
 
     def _depth(self) -> int:
-        return 1 << 20 if self.max_depth < 0 else int(self.max_depth)
+        """Depth of BOTH passes: ``epsm_trace_paths_color`` replays at most 6 bounces, and the image the adjoint is paired
+        with must come from the same estimator (render() went to the full max_depth, the replay to 6)."""
+        return 6 if self.max_depth < 0 else min(int(self.max_depth), 6)
 
     def to_string(self):
         return f"PRBIntegrator[max_depth = {self.max_depth}, rr_depth = {self.rr_depth}, reparam = False]"
@@ -256,7 +264,12 @@ class PRBIntegrator:
     def render_backward(self, scene, params: ParamGrads, grad_in: torch.Tensor, sensor=0, seed: int = 0, spp: int = 0) -> None:
         """Accumulates into ``params.color`` (one all-reduce of this call's contribution when there are several ranks)."""
         if not getattr(scene, "color_slots", None):
-            return                                  # nothing this phase can differentiate (geometry needs the warp field)
+            if getattr(scene, "has_attached_geometry", lambda: False)():
+                raise NotImplementedError(
+                    "prb / prb_reparam: geometry is attached but no colour parameter is -- the gradients of vertex positions "
+                    "through visibility need the warp field of ad/reparam.py, which this build does not have (DESIGN.md 6); "
+                    "keep the manifold integrator for geometric parameters")
+            return                                  # nothing attached that this phase differentiates
         si = min(sensor, len(scene.sensors) - 1)
         s = scene.sensors[si]
         spp = spp or s.spp
@@ -271,7 +284,7 @@ class PRBIntegrator:
         kept = []
         for t in _dist.my_tiles(len(tiles), rank, world):
             lo, hi = tiles[t]
-            film_pos, radiance, sums = scene.trace_color(si, seed, spp, min(self._depth(), 6), lo, hi)
+            film_pos, radiance, sums = scene.trace_color(si, seed, spp, self._depth(), lo, hi)
             rc = lib.epsm_film_splat(C.c_int64(hi - lo), C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()),
                                      s.width, s.height, s.rfilter, C.c_void_p(accum.data_ptr()), C.c_void_p(stream))
             assert rc == 0, "epsm_film_splat failed"

@@ -52,8 +52,8 @@ def run(method: str, exp: str, device="cuda", iterations=None, lr=None, log=prin
         method = method[:-7]
         integrator2 = load_dict({"type": "prb_reparam", "max_depth": tasks.max_depth})
         thres = getattr(tasks, "thres", 10000)
-        log(f"hybrid: switching to {integrator2} after {thres} iterations (colour adjoint only: geometry gradients of "
-            f"prb_reparam's warp field are not built)")
+        log(f"hybrid: phase 2 = {integrator2} after {thres} iterations (colour adjoint; geometric parameters keep the manifold "
+            f"integrator: prb_reparam's warp field is not built)")
     scene = tasks.load_scene(device)
     integrator = load_dict({"type": method, "max_depth": tasks.max_depth})
     sensor_id = 1 if method.startswith("manifold") else 0                      # optim.py:103-106
@@ -67,7 +67,12 @@ def run(method: str, exp: str, device="cuda", iterations=None, lr=None, log=prin
     rep = tasks.resolution // tasks.match_res
     for it in range(iterations or tasks.it):
         apply_transformation(scene, opt)                                        # optim.py:112
-        if it < thres:
+        # phase 2 differentiates colour parameters only (integrators.PRBIntegrator): an experiment whose attached parameters are
+        # geometric stays with the manifold integrator instead of silently stalling there
+        phase2 = it >= thres and bool(getattr(scene, "color_slots", None))
+        if it == thres and not phase2:
+            log(f"Iteration {it:02d}: hybrid switch skipped -- no colour parameter is attached, geometry stays on {integrator}")
+        if not phase2:
             integ, sid = integrator, sensor_id
         else:
             if it == thres:                                                     # optim.py:116-118: opt.reset(key)

@@ -536,6 +536,10 @@ class Scene:
         m.pos_attached, m.nrm_attached = positions, normals
         self._upload()
 
+    def has_attached_geometry(self) -> bool:
+        """Any mesh whose vertex positions / normals receive gradients?"""
+        return any(getattr(m, "pos_attached", False) or getattr(m, "nrm_attached", False) for m in self.meshes)
+
     def attach_alpha(self, bsdf_name: str) -> int:
         i = self.bsdf_names.index(bsdf_name)
         self.alpha_slots.setdefault(i, len(self.alpha_slots))
