@@ -31,18 +31,26 @@ matcher = "sliced_wasserstein"
 lr = 0.003                                                                # optim_human.py:57: 0.01 -- see the note below
 POSE_CLAMP = 0.1                                                          # optim_human.py:96
 
-# What the loop does here (tools/try_human.py, profiles/r02_e_human_loop.txt): from the zero pose the mean distance of the
-# vertices from the target's falls from 6.0 cm to 2.0 cm and the image MSE to 17 % within about 12 steps of 0.003 (four steps
-# of 0.01); it does NOT stay there.  With all 72 angles free most of them are weakly observed (twists about a limb's
-# axis, bends towards the camera: the first-hit term can only slide a visible point inside its triangle), Adam's
-# normalised step moves such an angle at full speed along whatever small consistent component its gradient has, and
-# after ~30 more steps the angles sit at the +-0.1 clamp with the image worse than at the start -- more slowly without the
-# occluder term (max_depth = 2).  It is not Adam: plain gradient steps do the same, with and without the occluder term, and
-# the matcher's own loss (Sinkhorn divergence of a 256-spp render from the target) rises with the image MSE after the
-# minimum.  (A candidate, not established: the first-hit term, si_follow.p * diffuse_grad[0], slides a visible point inside
-# its tilted triangle, which has a component along the view ray that nothing in the image restrains.)  At the target pose the seed-averaged gradient is
-# 8 % of the one at the zero pose, so the descent direction itself is sound.  exp/human_tube.py, which frees only the angles the view determines, converges and
-# stays.  The test therefore checks the descent (tests/test_gpu_optim.py), not a fixed point.
+# What the loop does here (tools/try_human.py, profiles/r02_e_human_loop.txt, profiles/r03_b_human_terms.txt): from the zero
+# pose the mean distance of the vertices from the target's falls from 6.0 cm to 2.0 cm and the image MSE to 17 % within about 12
+# steps of 0.003 (four steps of 0.01); it does NOT stay there: ~30 steps later most angles sit at the +-0.1 clamp with the image
+# worse than at the start.  It is not Adam (plain gradient steps do the same) and the matcher's own loss rises with the image MSE
+# after the minimum.  Round 3 took the gradient apart (tools/try_human_proj.py, tools/try_human_translate.py):
+#   * round 2's candidate -- the first-hit term slides a visible point INSIDE its tilted triangle, i.e. also along the view
+#     ray, 1/cos(tilt) times the screen-parallel motion the matcher asked for -- is NOT the cause: with that displacement
+#     projected onto the plane perpendicular to the view ray (an experiment; the reference's formula, epsm.py:250-272, keeps the
+#     component) the loop reaches the same minimum (2.1 cm) and drifts just the same (15 cm after 120 steps of 0.01, 22 cm without);
+#   * each term alone drifts: first-hit only 2.5 cm -> 17 cm, occluder (shadow) only never below 5.6 cm;
+#   * neither term has the wrong sign: with the SAME body translated by 5 cm as the target the mean step of the vertices has
+#     cosine 0.78 .. 1.0 with the offset for either term in every direction it can see (the shadow cannot lift the body: its
+#     displacements lie in the floor plane);
+#   * at the target pose the seed-averaged pose gradient is 8 % of the one at the zero pose, and at the zero pose its cosine
+#     with (pose - target) is 0.23: a descent direction, most of whose length is in angles the two views barely determine.
+# What remains is what the optimiser does with 72 angles of which a handful are observed: Adam's normalised step (0.01 per
+# iteration on a +-0.1 range, optim_human.py:57,96) moves an unobserved angle at full speed along whatever consistent sign its
+# small gradient has.  Whether the reference's own run behaves the same cannot be checked here (no Dr.Jit, no SMPL assets):
+# the formulas are its own, pinned term by term.  exp/human_tube.py, which frees only the angles the view
+# determines, converges and stays.  The test therefore checks the descent (tests/test_gpu_optim.py), not a fixed point.
 
 
 def target_pose() -> torch.Tensor:
