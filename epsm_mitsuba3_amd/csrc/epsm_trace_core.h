@@ -120,24 +120,13 @@ EPSM_HD bool moeller_trumbore(const Ray &r, F3 p0, F3 p1, F3 p2, float &t, float
     t = dot(e2, qvec) * inv_det;
     return u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t <= r.maxt;
 }
-// slab test; `tnear` is the entry distance (used to visit the nearer child first).  Per axis two subtractions, two
-// products, a min and a max; then max3 / min3 (v_max3_f32 / v_min3_f32) -- 23 instructions instead of the 33 of the
-// compare-and-swap form with its three scaled far planes (scaling the smallest far distance once is the same number:
-// rounding is monotonic).  `inv_d` is finite (trav_begin), so no 0 * inf turns up here.
-EPSM_HD bool hit_box(const float *lo, const float *hi, F3 o, F3 inv_d, float maxt, float &tnear) {
-    const float ax = (lo[0] - o.x) * inv_d.x, bx = (hi[0] - o.x) * inv_d.x;
-    const float ay = (lo[1] - o.y) * inv_d.y, by = (hi[1] - o.y) * inv_d.y;
-    const float az = (lo[2] - o.z) * inv_d.z, bz = (hi[2] - o.z) * inv_d.z;
-    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-    const float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f, maxt);
-    tnear = t0;
-    return t0 <= t1;
-}
+// (slab test of a box: per axis the two plane distances, a min and a max; then max3 / min3 -- in trav_round, four boxes
+// per node; `inv_d` is finite (trav_begin), so no 0 * inf turns up there; the far distance is widened by 2 ulp.)
 struct TriHit { bool hit; uint32_t tri; float t, u, v; };
 
 // Traversal stack of one path: entry k lives at base[k * stride] (LDS on the GPU: one column per thread,
 // conflict-free; a local array on the host).  Depth of the tree <= kBvhStack.
-constexpr int kBvhStack = 32;
+constexpr int kBvhStack = 48;          // a four-wide node pushes up to three references; depth <= 16
 constexpr int32_t kBvhNone = 0x7fffffff;
 // The first `cap` entries live at base (LDS); a stack that grows beyond them continues at ovf[(k - cap) * ovf_stride]
 // (global memory, rarely reached: the wavefront kernels keep only 16 entries per path in LDS to run 8 waves per SIMD).
@@ -156,15 +145,18 @@ struct BvhStack {
 #endif
 };
 
-// Ordered traversal of the two-wide BVH: one 64-byte node holds both children's boxes, of two inner children the
-// nearer is followed and the farther pushed.  While-while: a ROUND descends through inner nodes until the current
+// Ordered traversal of the FOUR-wide BVH (round 3; two-wide before): one 128-byte node holds the boxes of up to four
+// children, one component of all four per 16-byte quad; the hit children are sorted by entry distance (five
+// compare-exchanges), the nearest is followed and the others pushed farthest first.  Half the dependent node loads of the
+// two-wide tree for the same box arithmetic per level pair -- the traversal of incoherent rays waits for exactly those loads.
+// While-while: a ROUND descends through inner nodes until the current
 // reference is a leaf, then intersects that leaf's triangles -- the lanes of a wave run the (long) triangle code
 // together instead of each one in the middle of its own descent.  A reference is a node index (>= 0), a leaf
 // ~((first << 3) | count) (< 0) or kBvhNone.  The traversal is a resumable object so that the wavefront kernels can
 // give a lane whose ray is finished a new ray between two rounds.
 struct Traversal {
     Ray r;
-    F3 inv_d;
+    F3 inv_d, noid;               // 1 / d and -o / d: a slab plane's distance is one fma, (plane) * inv_d + noid
     int32_t cur, best_e;
     int sp;
     TriHit best;
@@ -175,6 +167,7 @@ EPSM_HD void trav_begin(Traversal &T, const EpsmScene &S, const Ray &r) {
     // finite reciprocals: a ray parallel to a slab sees its planes at +-1e18 x distance (or at 0 when it lies IN one,
     // which counts as inside) instead of +-inf / NaN
     T.inv_d = f3(fminf(fmaxf(1.f / r.d.x, -1e18f), 1e18f), fminf(fmaxf(1.f / r.d.y, -1e18f), 1e18f), fminf(fmaxf(1.f / r.d.z, -1e18f), 1e18f));
+    T.noid = f3(-r.o.x * T.inv_d.x, -r.o.y * T.inv_d.y, -r.o.z * T.inv_d.z);
     T.best_e = -1;
     T.cur = S.n_nodes > 0 ? 0 : kBvhNone;
     T.sp = 0;
@@ -184,15 +177,28 @@ template <bool ANY_HIT>
 EPSM_HD void trav_round(Traversal &T, const EpsmScene &S, const BvhStack &st) {
     while (T.cur >= 0 && T.cur != kBvhNone) {
         const EpsmBvhNode n = S.bvh[T.cur];
-        float t0, t1;
-        // both boxes always, the four outcomes by selects: the lanes of a wave take all of them anyway, and as
-        // branches each costs its mask bookkeeping and a jump (only the stack accesses stay conditional)
-        const bool b0 = hit_box(n.lo0, n.hi0, T.r.o, T.inv_d, T.r.maxt, t0), b1 = hit_box(n.lo1, n.hi1, T.r.o, T.inv_d, T.r.maxt, t1);
-        const bool h0 = b0 & (n.c0 != kBvhNone), h1 = b1 & (n.c1 != kBvhNone);
-        const bool first0 = t0 <= t1, both = h0 & h1;
-        const int32_t near = (h0 & (first0 | !h1)) ? n.c0 : n.c1, far = first0 ? n.c1 : n.c0;
-        if (both & (T.sp < kBvhStack)) st.put(T.sp++, (uint32_t) far);
-        if (h0 | h1) T.cur = near;
+        // slab test of the four boxes (an absent child's box is empty and its reference kBvhNone)
+        float t[4]; int32_t c[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float ax = fmaf(n.lox[s], T.inv_d.x, T.noid.x), bx = fmaf(n.hix[s], T.inv_d.x, T.noid.x);
+            const float ay = fmaf(n.loy[s], T.inv_d.y, T.noid.y), by = fmaf(n.hiy[s], T.inv_d.y, T.noid.y);
+            const float az = fmaf(n.loz[s], T.inv_d.z, T.noid.z), bz = fmaf(n.hiz[s], T.inv_d.z, T.noid.z);
+            const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+            const float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f, T.r.maxt);
+            const bool h = (t0 <= t1) & (n.c[s] != kBvhNone);
+            t[s] = h ? t0 : kInf;
+            c[s] = h ? n.c[s] : kBvhNone;
+        }
+        // sort by entry distance (selects, no branches: the lanes of a wave take every outcome anyway)
+#define EPSM_CX(i, j) { const bool sw = t[j] < t[i]; const float ta = sw ? t[j] : t[i], tb = sw ? t[i] : t[j]; \
+                        const int32_t ca = sw ? c[j] : c[i], cb = sw ? c[i] : c[j]; t[i] = ta; t[j] = tb; c[i] = ca; c[j] = cb; }
+        EPSM_CX(0, 1) EPSM_CX(2, 3) EPSM_CX(0, 2) EPSM_CX(1, 3) EPSM_CX(1, 2)
+#undef EPSM_CX
+        if (c[3] != kBvhNone && T.sp < kBvhStack) st.put(T.sp++, (uint32_t) c[3]);
+        if (c[2] != kBvhNone && T.sp < kBvhStack) st.put(T.sp++, (uint32_t) c[2]);
+        if (c[1] != kBvhNone && T.sp < kBvhStack) st.put(T.sp++, (uint32_t) c[1]);
+        if (c[0] != kBvhNone) T.cur = c[0];
         else T.cur = T.sp > 0 ? (int32_t) st.get(--T.sp) : kBvhNone;
     }
     if (T.cur == kBvhNone) return;

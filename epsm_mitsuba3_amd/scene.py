@@ -256,10 +256,12 @@ def _sah_split(cen: np.ndarray, lo: np.ndarray, hi: np.ndarray, bins: int = 16):
 
 
 def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE, sah_min: int = SAH_MIN):
-    """Binned-SAH BVH (16 bins per axis; nodes of <= ``sah_min`` triangles: median split), emitted as two-wide nodes (``EpsmBvhNode``: the boxes of both
-    children in one 64-byte record, leaf children embedded).  Returns a dict:
+    """Binned-SAH BVH (16 bins per axis; nodes of <= ``sah_min`` triangles: median split), built as a binary tree and
+    emitted as FOUR-wide nodes (``EpsmBvhNode``: the boxes of up to four children in one 128-byte record, one
+    component of all four per 16-byte quad, leaf children embedded).  Returns a dict:
 
-      nodes        (n,16) float32; columns 12..15 hold c0,c1 (child references) and n0,n1 as int32 bits
+      nodes        (n,32) float32; columns 0..23 lox loy loz hix hiy hiz (4 each), 24..27 the child references and
+                   28..31 the leaf counts as int32 bits
       order        (T,)   triangle ids in leaf order (``prim_index``)
       leaf_node / leaf_slot / leaf_tris   which (node, child slot) is a leaf and its triangles as rows of
                    leaf-ordered indices, padded to ``leaf_size`` by repetition          -> refit step 1
@@ -296,14 +298,43 @@ def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE, sah_
         tree.append([a, a + mid, -1, -1]); tree.append([a + mid, b, -1, -1])
         tdepth += [tdepth[ni] + 1, tdepth[ni] + 1]
         stack += [tree[ni][2], tree[ni][3]]
-    # wide nodes = the inner nodes of the binary tree (a single-leaf scene gets one node with an absent child)
-    inner = [i for i, t in enumerate(tree) if t[2] >= 0]
-    wide_of = {bi: wi for wi, bi in enumerate(inner)}
-    n = max(1, len(inner))
-    nodes = np.zeros((n, 16), dtype=np.float32)
+    # four-wide nodes: a wide node takes a binary inner node and, while it has fewer than four children and one of them
+    # is inner, replaces the inner child with the largest box by that child's two children
+    t_lo = np.zeros((len(tree), 3)); t_hi = np.zeros((len(tree), 3))
+    for bi in range(len(tree) - 1, -1, -1):          # children follow their parent in `tree`
+        a_, b_, l_, r_ = tree[bi]
+        if l_ < 0:
+            ids = order[a_:b_]
+            t_lo[bi], t_hi[bi] = lo_t[ids].min(axis=0), hi_t[ids].max(axis=0)
+        else:
+            t_lo[bi], t_hi[bi] = np.minimum(t_lo[l_], t_lo[r_]), np.maximum(t_hi[l_], t_hi[r_])
+
+    def half_area(bi):
+        e = t_hi[bi] - t_lo[bi]
+        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0]
+
+    wide_children: Dict[int, list] = {}
+    wide_order: List[int] = []
+    todo = [0] if tree[0][2] >= 0 else []
+    while todo:
+        bi = todo.pop(0)
+        kids = [tree[bi][2], tree[bi][3]]
+        while len(kids) < 4:
+            inner_kids = [k for k in kids if tree[k][2] >= 0]
+            if not inner_kids:
+                break
+            k = max(inner_kids, key=half_area)
+            i = kids.index(k)
+            kids[i:i + 1] = [tree[k][2], tree[k][3]]
+        wide_children[bi] = kids
+        wide_order.append(bi)
+        todo += [k for k in kids if tree[k][2] >= 0]
+    wide_of = {bi: wi for wi, bi in enumerate(wide_order)}
+    n = max(1, len(wide_order))
+    nodes = np.zeros((n, 32), dtype=np.float32)      # EpsmBvhNode: lox loy loz hix hiy hiz (4 each) | c[4] | n[4]
     inodes = nodes.view(np.int32)
-    nodes[:, 0:3] = nodes[:, 6:9] = np.inf; nodes[:, 3:6] = nodes[:, 9:12] = -np.inf
-    inodes[:, 12:14] = 0x7fffffff                  # absent child
+    nodes[:, 0:12] = np.inf; nodes[:, 12:24] = -np.inf
+    inodes[:, 24:28] = 0x7fffffff                  # absent child
     leaf_node, leaf_slot, leaf_tris = [], [], []
     depth = np.zeros(n, dtype=np.int64)
     per_level: Dict[int, list] = {}
@@ -311,21 +342,22 @@ def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE, sah_
     def put_child(wi, slot, bi):
         a, b, left, _ = tree[bi]
         if left < 0:
-            inodes[wi, 12 + slot], inodes[wi, 14 + slot] = ~((a << 3) | (b - a)), b - a     # leaf reference
+            inodes[wi, 24 + slot], inodes[wi, 28 + slot] = ~((a << 3) | (b - a)), b - a     # leaf reference
             leaf_node.append(wi); leaf_slot.append(slot)
             leaf_tris.append([a + min(j, b - a - 1) for j in range(leaf_size)])
         else:
             ci = wide_of[bi]
-            inodes[wi, 12 + slot], inodes[wi, 14 + slot] = ci, 0
+            inodes[wi, 24 + slot], inodes[wi, 28 + slot] = ci, 0
             depth[ci] = depth[wi] + 1
             per_level.setdefault(int(depth[wi]), []).append((wi, slot, ci))
 
-    if not inner:
+    if not wide_order:
         put_child(0, 0, 0)
-    for bi in inner:                               # parents precede children in `tree`, hence in `inner`
-        put_child(wide_of[bi], 0, tree[bi][2]); put_child(wide_of[bi], 1, tree[bi][3])
-    if int(depth.max(initial=0)) + 1 > 31:
-        raise ValueError("BVH deeper than the traversal stack (kBvhStack)")
+    for bi in wide_order:                          # breadth first: parents precede their children
+        for slot, k in enumerate(wide_children[bi]):
+            put_child(wide_of[bi], slot, k)
+    if int(depth.max(initial=0)) + 1 > 16:
+        raise ValueError("BVH deeper than the traversal stack (kBvhStack = 3 pushes x 16 levels)")
     levels = [np.asarray(per_level[d], dtype=np.int64).reshape(-1, 3) for d in sorted(per_level, reverse=True)]
     return {"nodes": nodes, "order": order.astype(np.int64),
             "leaf_node": np.asarray(leaf_node, np.int64), "leaf_slot": np.asarray(leaf_slot, np.int64),
@@ -339,18 +371,18 @@ class DeviceBvh:
 
     def __init__(self, plan: dict, device):
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-        self.nodes = t(plan["nodes"])                              # (n,16) float32
+        self.nodes = t(plan["nodes"])                              # (n,32) float32
         self.order = t(plan["order"])
         self.prim_index = self.order.to(torch.int32)
         self.leaf_node, self.leaf_slot, self.leaf_tris = t(plan["leaf_node"]), t(plan["leaf_slot"]), t(plan["leaf_tris"])
         self.levels = [(t(l[:, 0]), t(l[:, 1]), t(l[:, 2])) for l in plan["levels"]]
-        self._cols = torch.arange(3, device=device)
+        self._cols = torch.arange(3, device=device) * 4            # component k of slot s sits in column 4 k + s (lo) / 12 + 4 k + s (hi)
         self.tri_verts = None
 
     def _write(self, node, slot, lo, hi):
-        c = (slot * 6).unsqueeze(1) + self._cols
+        c = slot.unsqueeze(1) + self._cols
         self.nodes[node.unsqueeze(1), c] = lo
-        self.nodes[node.unsqueeze(1), c + 3] = hi
+        self.nodes[node.unsqueeze(1), c + 12] = hi
 
     def refit(self, positions: torch.Tensor, tri: torch.Tensor):
         """positions (V,3) f32, tri (T,3) int -> tri_verts (T,9) in leaf order and fresh boxes."""
@@ -364,8 +396,8 @@ class DeviceBvh:
             lo, hi = g.amin(dim=(1, 2)), g.amax(dim=(1, 2))
             self._write(self.leaf_node, self.leaf_slot, lo - 1e-6 * (1 + lo.abs()), hi + 1e-6 * (1 + hi.abs()))
         for node, slot, child in self.levels:
-            cb = self.nodes[child]
-            self._write(node, slot, torch.minimum(cb[:, 0:3], cb[:, 6:9]), torch.maximum(cb[:, 3:6], cb[:, 9:12]))
+            cb = self.nodes[child]                                 # union of the child's (up to) four boxes; absent: +-inf
+            self._write(node, slot, cb[:, 0:12].reshape(-1, 3, 4).amin(dim=2), cb[:, 12:24].reshape(-1, 3, 4).amax(dim=2))
 
 
 # ---------------------------------------------------------------------------- scene

@@ -92,13 +92,13 @@ typedef struct EpsmEmitter {
     uint32_t pad;
 } EpsmEmitter;
 
-typedef struct EpsmBvhNode {         /* 64 bytes: one load brings the boxes of BOTH children */
-    float lo0[3], hi0[3];            /* child 0 */
-    float lo1[3], hi1[3];            /* child 1 */
-    int32_t c0, c1;                  /* child reference: >= 0 node index; < 0 leaf ~((first << 3) | count) with `first`
+typedef struct EpsmBvhNode {         /* 128 bytes: the boxes of up to FOUR children, one component of all four per 16-byte quad */
+    float lox[4], loy[4], loz[4];    /* lower corners (absent child: +inf) */
+    float hix[4], hiy[4], hiz[4];    /* upper corners (absent child: -inf) */
+    int32_t c[4];                    /* child reference: >= 0 node index; < 0 leaf ~((first << 3) | count) with `first`
                                         the leaf's first triangle in tri_verts / prim_index and count <= 7;
                                         0x7fffffff = absent */
-    int32_t n0, n1;                  /* build-side copy of the leaf counts (0 = inner); not read by the traversal */
+    int32_t n[4];                    /* build-side copy of the leaf counts (0 = inner); not read by the traversal */
 } EpsmBvhNode;
 
 typedef struct EpsmSensor {
@@ -118,7 +118,7 @@ typedef struct EpsmScene {           /* host struct holding DEVICE pointers */
     const EpsmBsdf *bsdfs;           int32_t n_bsdfs;
     const EpsmEmitter *emitters;     int32_t n_emitters;
     const float *emitter_cdf;        /* concatenated normalised area CDFs of the emitting meshes */
-    const EpsmBvhNode *bvh;          int32_t n_nodes;   /* node 0 is the root; depth <= 31 */
+    const EpsmBvhNode *bvh;          int32_t n_nodes;   /* node 0 is the root; depth <= 16 (four-wide) */
     const uint32_t *prim_index;      /* leaf entries: BVH order -> triangle id (triangles stay mesh-contiguous) */
     const float *tri_verts;          /* (T,9) p0,p1,p2 of the triangles in BVH (leaf) order */
     int64_t n_vertices, n_triangles;

@@ -84,7 +84,7 @@ def test_trace_structs_match_header_sizes():
         open(os.path.join(td, "t.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(td, "t"), os.path.join(td, "t.c")], check=True)
         sizes = [int(x) for x in subprocess.run([os.path.join(td, "t")], capture_output=True, text=True, check=True).stdout.split()]
-    mine = [C.sizeof(S.EpsmMesh), C.sizeof(S.EpsmBsdf), C.sizeof(S.EpsmEmitter), 64, C.sizeof(S.EpsmSensor),
+    mine = [C.sizeof(S.EpsmMesh), C.sizeof(S.EpsmBsdf), C.sizeof(S.EpsmEmitter), 128, C.sizeof(S.EpsmSensor),
             C.sizeof(S.EpsmSceneC), C.sizeof(S.EpsmRecordOut)]
     assert sizes == mine, (sizes, mine)
 

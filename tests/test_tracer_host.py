@@ -269,8 +269,8 @@ def test_vertex_update_refits_the_bvh_and_recomputes_normals():
     moved = scene(v0.numpy().astype(np.float64))
     nodes_before = moved.bvh.nodes.clone()
     moved.set_vertex_positions("tube", v1)
-    assert not torch.equal(moved.bvh.nodes[:, :12], nodes_before[:, :12])                  # boxes changed,
-    assert torch.equal(moved.bvh.nodes[:, 12:].view(torch.int32), nodes_before[:, 12:].view(torch.int32))   # topology kept
+    assert not torch.equal(moved.bvh.nodes[:, :24], nodes_before[:, :24])                  # boxes changed,
+    assert torch.equal(moved.bvh.nodes[:, 24:].view(torch.int32), nodes_before[:, 24:].view(torch.int32))   # topology kept
     fresh = scene(v1.numpy().astype(np.float64))
     lo, hi = fresh.mesh_slices["tube"]
     assert torch.allclose(moved.positions, fresh.positions, atol=1e-6)
