@@ -14,10 +14,16 @@ namespace {
 // four waves per SIMD: 128 registers and 56 B/lane of scratch instead of 151 registers and three waves:
 // -11 % / -17 % at 128 k / 512 k triangles (five waves, 96 registers + 184 B of scratch: +5 % / -2 %)
 __global__ __launch_bounds__(128, 4) void epsm_trace_kernel(TraceArgs A) {
-    __shared__ uint32_t s_stack[kBvhStack * 128];        // traversal stacks: one LDS column per path (16 KB)
+    // traversal stacks: one LDS column of 32 entries per path (16 KB: four waves per SIMD); the four-wide tree may push
+    // 3 x 16 references: the rare entries beyond 32 go to a private array (scratch)
+    constexpr int kLds = 32;
+    __shared__ uint32_t s_stack[kLds * 128];
+    uint32_t deep[kBvhStack - kLds];
     const int64_t i = (int64_t) blockIdx.x * 128 + threadIdx.x;
     if (i >= A.N) return;
-    trace_one_path(A, i, BvhStack{s_stack + threadIdx.x, 128});
+    BvhStack st{s_stack + threadIdx.x, 128};
+    st.cap = kLds; st.ovf = deep; st.ovf_stride = 1;
+    trace_one_path(A, i, st);
 }
 
 // ---- the wavefront form (epsm_trace_wavefront.h): queues of live paths, three small kernels per bounce ----

@@ -4,4 +4,3 @@ run() { python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary $
 import sys,json
 d=json.loads(sys.stdin.read()); print('[$1 $2]', 'kernel %.4f ms'%d['stages_ms']['grad'], 'step %.4f ms'%d['ms_per_step'], 'frac %.3f'%d['roofline']['frac'])"; }
 for k in "$@"; do for p in "--config 5" "--config 1"; do EPSM_LIB_NAME=libepsm_$k.so run "$k" "$p"; done; done
-EPSM_BACKWARD_FORM=path run "path-form" "--config 5"; EPSM_BACKWARD_FORM=path run "path-form" "--config 1"
