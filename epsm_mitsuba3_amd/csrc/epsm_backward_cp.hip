@@ -154,6 +154,8 @@ template <typename Table> struct Emitter {
             for (int j = 0; j < ROWS; ++j) T.add(key[j], val[j].x, val[j].y, val[j].z);
         }
 #else
+        // (Dense pushes -- 16 / 32 / 48 or more lanes holding rows -- straight into the table, the others through the queue:
+        // 2.71 / 2.62 / 2.60 ms against 2.49: a lane's rows are then inserted one after the other.)
         Q.reserve(T, ROWS);
         Q.template push_rows<ROWS>(valid, key, val);
 #endif

@@ -44,6 +44,7 @@ POSE_CLAMP = 0.1                                                          # opti
 #   * neither term has the wrong sign: with the SAME body translated by 5 cm as the target the mean step of the vertices has
 #     cosine 0.78 .. 1.0 with the offset for either term in every direction it can see (the shadow cannot lift the body: its
 #     displacements lie in the floor plane);
+#   * it is not the matcher chasing Monte-Carlo noise: with the primal image at 1024 spp the history is the same;
 #   * at the target pose the seed-averaged pose gradient is 8 % of the one at the zero pose, and at the zero pose its cosine
 #     with (pose - target) is 0.23: a descent direction, most of whose length is in angles the two views barely determine.
 # What remains is what the optimiser does with 72 angles of which a handful are observed: Adam's normalised step (0.01 per
