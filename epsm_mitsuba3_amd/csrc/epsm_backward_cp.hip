@@ -348,15 +348,25 @@ __device__ __forceinline__ void fetch_issue(Fetch &X, const FusedArgs &F, const 
 
 // kWindow: the largest window (paths a workgroup plans, sorts and works through at a time); `window` <= kWindow, a multiple
 // of 64, is what this launch uses -- a small wavefront is cut into smaller windows so that every CU gets some (launch()).
-constexpr int kWindow = 1024;
-template <int VARIANT, int DMODE, bool PACKED, bool FLOAT_ROWS>
+// Large wavefronts take windows of 2048 paths: every class of paths ends in a partly filled round, six of the 23 rounds of
+// a 1024-path window of the bathroom profile and six of 42 at 2048 -- headline slab 2.48 -> 2.28 ms, config 2 2.82 -> 2.56,
+// pool slab 3.54 -> 3.31 (3072: 2.39 / 2.82 / 3.62 and 4096: 2.12 / 2.78 / 3.46 -- the 6 bytes of LDS per path are taken from
+// the table; with ONE partly filled round per window -- paths on 8 / 4 / 2 / 1 lanes, widest first, classes mixed inside a
+// round -- 2.56: the mixed rounds run the longest chain's recursion for everybody).  Small wavefronts keep <= 1024.
+#ifndef EPSM_CP_WINDOW
+#define EPSM_CP_WINDOW 2048
+#endif
+template <int VARIANT, int DMODE, bool PACKED, bool FLOAT_ROWS, int kWindow>
 __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel(FusedArgs F, int dcols, int64_t windows_per_block, int window) {
     // float rows where the window's distinct rows need the larger table (epsm_wave_scatter.h, AccFixed64)
     // Rows of the accumulator table: 64-bit fixed point (epsm_wave_scatter.h, AccFixed64: the LDS integer atomic inserts an
     // order of magnitude faster than ds_add_f32, and same-address lanes do not serialise as badly) unless the caller disabled
     // the outlier clamp -- then the terms are unbounded and the sums stay in float.
     constexpr bool kFloatRows = FLOAT_ROWS;
-    typedef LdsTable<kFloatRows ? EPSM_CP_ROWS_FLOAT : EPSM_CP_ROWS_FIXED, typename std::conditional<kFloatRows, AccFloat, AccFixed64>::type> Table;
+    // (a window costs 6 bytes of LDS per path: the larger one leaves 224 fixed-point / 384 float rows fewer)
+    constexpr int kRowsFixed = kWindow > 1024 ? EPSM_CP_ROWS_FIXED - 224 * ((kWindow - 1024) / 1024) : EPSM_CP_ROWS_FIXED;
+    constexpr int kRowsFloat = kWindow > 1024 ? EPSM_CP_ROWS_FLOAT - 384 * ((kWindow - 1024) / 1024) : EPSM_CP_ROWS_FLOAT;
+    typedef LdsTable<kFloatRows ? kRowsFloat : kRowsFixed, typename std::conditional<kFloatRows, AccFloat, AccFixed64>::type> Table;
     constexpr int kTableSize = Table::kTableSize;
     __shared__ uint32_t s_keys[kTableSize];
     __shared__ typename Table::Val s_vals[kTableSize * 3];
@@ -698,8 +708,9 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
     int64_t small_limit = 1 << 20;
     if (const char *e = getenv("EPSM_SMALL_WAVEFRONT")) small_limit = atoll(e);
     const bool small = F.g.N <= small_limit;
-    int window = kWindow;
-    if (small) { window = 128; while (window < kWindow && F.g.N > 512 * (int64_t) window) window *= 2; }
+    constexpr int kLarge = EPSM_CP_WINDOW, kSmall = 1024;
+    int window = kLarge;
+    if (small) { window = 128; while (window < kSmall && F.g.N > 512 * (int64_t) window) window *= 2; }
     const int64_t windows = (F.g.N + window - 1) / window;
     const int64_t blocks = windows < EPSM_CP_BLOCKS ? windows : EPSM_CP_BLOCKS;
     const int64_t per = (windows + blocks - 1) / blocks;
@@ -720,10 +731,14 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
     // fixed-point rows hold |sum| < 2^19 at a resolution of 2^-44: fine for terms clamped to +-clip (0.1 in the reference),
     // not for a caller who switched the clamp off
     const bool float_rows = !(F.g.clip <= 1.f);
-    if (float_rows)
-        hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, true>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
-    else
-        hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, false>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
+    // (the small form's instantiation plans at most 1024 paths per window: the planning loops are unrolled over kWindow / 256)
+    if (float_rows) {
+        if (small) hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, true, kSmall>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
+        else hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, true, kLarge>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
+    } else {
+        if (small) hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, false, kSmall>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
+        else hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, false, kLarge>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
+    }
     if (F.rep) {
         const int64_t n = 6 * F.V + F.B + 3;
         hipLaunchKernelGGL(reduce_replicas_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, F.rep, F.replicas, F.rep_stride,
