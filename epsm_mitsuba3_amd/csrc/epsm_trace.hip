@@ -262,8 +262,10 @@ static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene
         return bad("bad N / spp / max_depth / rr_depth / path_offset");
     if (K_log < 0 || K_log > EPSM_MAX_VERTICES || K_log > (max_depth < 6 ? max_depth : 6))
         return bad("K_log must be <= min(max_depth, 5)");
-    if (path_offset + N > (int64_t) sensor->width * sensor->height * spp || path_offset + N > 0xFFFFFFFFLL)
-        return bad("path range exceeds width*height*spp (or 2^32, common.py:468-475)");
+    if (sensor->border < 0 || sensor->border > 8) return bad("bad sensor border");
+    if (path_offset + N > (int64_t) (sensor->width + 2 * sensor->border) * (sensor->height + 2 * sensor->border) * spp ||
+        path_offset + N > 0xFFFFFFFFLL)
+        return bad("path range exceeds (width + 2 border) * (height + 2 border) * spp (or 2^32, common.py:468-475)");
     const bool packed = (flags & EPSM_TRACE_PACKED_LOG) != 0;
     if (!ray_o || (!packed && (!ray_d || !ray_dx || !ray_dy)) || (K_log > 0 && !recs)) return bad("NULL output");
     if (packed && ((((uintptr_t) ray_o) & 15) || (K_log > 0 && (!recs[0].packed || !recs[0].pflags || (((uintptr_t) recs[0].packed) & 15)))))

@@ -601,7 +601,8 @@ struct PrimaryRay { Ray ray; F3 dx, dy; float px, py; };
 EPSM_HD PrimaryRay sample_primary_ray(const EpsmSensor &C, int64_t wavefront_index, int spp, Pcg32 &rng) {
     // common.py:320-335: idx // spp -> pixel, pos = pixel + next_2d()
     const int64_t pix = wavefront_index / spp;
-    const int py = (int) (pix / C.width), px = (int) (pix - (int64_t) py * C.width);
+    const int fw = C.width + 2 * C.border;                                // film_size += 2 * border_size (common.py:314-315)
+    const int py0 = (int) (pix / fw), px = (int) (pix - (int64_t) py0 * fw) - C.border, py = py0 - C.border;
     const float jx = rng.next_1d(), jy = rng.next_1d();
     PrimaryRay o;
     o.px = px + jx; o.py = py + jy;
@@ -776,8 +777,13 @@ EPSM_HD int path_max_depth(const TraceArgs &A) { return A.max_depth < 6 ? A.max_
 //   vis.occluder(A, i, si, es, active_em)     the occluder record of the first vertex (epsm.py:609-620)
 // so that the one-launch tracer answers them on the spot (InlineVis) and the wavefront tracer
 // (epsm_trace_wavefront.h) queues them for its shadow-ray stage.
-template <class Vis>
-EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState &s, const TriHit &th, Vis &vis) {
+// `obs.vertex(...)` sees what the bounce computed before the state moves on (the reparameterised backward pass,
+// epsm_trace_reparam.h, replays paths through this very function); the default observer is empty.
+struct NoObserver {
+    EPSM_HD void vertex(const SurfHit &, const EpsmBsdf &, uint32_t, F3, F3, const EmitterSample &, bool, float, const BsdfSample &, bool) {}
+};
+template <class Vis, class Obs>
+EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState &s, const TriHit &th, Vis &vis, Obs &obs) {
     const EpsmScene &S = A.S;
     const SurfHit si = surface_interaction(S, s.ray, th);                 // epsm.py:556-558
     EpsmBsdf bsdf;
@@ -802,11 +808,12 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
     const EmitterSample es = sample_emitter_direction(S, si, e1, e2, active_em, vis, false);
     active_em = active_em && es.pdf != 0.f;                               // :590
     F3 Lr_dir = zero3<float>();
+    float mis_em = 0.f;
     if (active_em) {
         const F3 wo = to_local(si, es.d);
         F3 bval; float bpdf;
         bsdf_eval_pdf(bsdf, si.wi, wo, bval, bpdf);
-        const float mis_em = es.delta ? 1.f : mis_weight(es.pdf, bpdf);
+        mis_em = es.delta ? 1.f : mis_weight(es.pdf, bpdf);
         Lr_dir = mul3(mul3(s.beta, bval), es.weight) * mis_em;            // :605
         // The visibility ray of scene.cpp:270-275, AFTER the BSDF value is known: an occluded sample only zeroes
         // ds.weight, i.e. Lr_dir and the logged emitter weight -- when they are zero already (emitter below the
@@ -858,6 +865,7 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
         }
         if (here >= 0 && bs.valid) s.cnt += 1u << (8 * here);              // the sampled direction carries one more factor rho_j
     }
+    obs.vertex(si, bsdf, flags, Le, Lr_dir, es, active_em, mis_em, bs, s.active);
     // ---- update (epsm.py:658-683)
     if (s.active) vis.direct(s.L, Le, Lr_dir);
     const F3 wo_world = to_world(si, bs.wo);
@@ -876,6 +884,11 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
     active_next = active_next && (!rr_active || rr_continue);
     if (si.valid && s.active) s.depth += 1;                               // :734
     s.active = s.active && active_next;                                   // :735
+}
+template <class Vis>
+EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState &s, const TriHit &th, Vis &vis) {
+    NoObserver obs;
+    path_bounce(A, i, iteration, s, th, vis, obs);
 }
 EPSM_HD void path_end(const TraceArgs &A, int64_t i, const PathState &s) {
     st3(A.radiance, i, s.L);

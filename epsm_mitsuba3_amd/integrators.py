@@ -225,6 +225,45 @@ def film_adjoint(film_pos: torch.Tensor, grad_img: torch.Tensor, weight_img: tor
     return (gw * (wy[:, :, None] * wx[:, None, :])[..., None]).sum(dim=(1, 2))
 
 
+def film_adjoint_reparam(film_pos: torch.Tensor, radiance: torch.Tensor, grad_img: torch.Tensor, accum: torch.Tensor):
+    """Adjoint of the gaussian splat + weight division w.r.t. a sample's radiance, its FILM POSITION and the determinant
+    of the reparameterisation that multiplies both its value and its weight (common.py:880-920):
+        image[p] = sum_i w_ip L_i det_i / sum_i w_ip det_i,   w_ip = f(p - pos_i)
+    ``accum (H,W,4)``: the film [r,g,b,w] of the primal pass.  Returns ``dL (n,3)`` and ``adj (n,3)`` =
+    [d loss / d pos.x, d loss / d pos.y, d loss / d det] at det = 1."""
+    H, W = accum.shape[:2]
+    Wp = accum[..., 3]
+    ok = (Wp > 0)[..., None]
+    inv = torch.where(ok, 1.0 / Wp.clamp_min(1e-30)[..., None], torch.zeros_like(accum[..., :1]))
+    g = grad_img[..., :3] * inv                                     # grad / W_p
+    gi = (g * (accum[..., :3] * inv)).sum(-1)                       # (grad . image) / W_p
+    px, py = film_pos[:, 0], film_pos[:, 1]
+    X, Y = torch.floor(px).long(), torch.floor(py).long()
+    radius, alpha = 2.0, -1.0 / (2.0 * 0.5 * 0.5)
+    bias = math.exp(alpha * radius * radius)
+    off = torch.arange(-2, 3, device=film_pos.device)
+    xs, ys = X[:, None] + off[None, :], Y[:, None] + off[None, :]
+    dx, dy = (xs.float() + 0.5) - px[:, None], (ys.float() + 0.5) - py[:, None]
+
+    def weights(d_, inside):
+        e = torch.exp(alpha * d_ * d_)
+        w = (e - bias).clamp_min(0)
+        live = (d_.abs() <= radius) & inside & (w > 0)
+        w = torch.where(live, w, torch.zeros_like(w))
+        dw = torch.where(live, -2.0 * alpha * d_ * e, torch.zeros_like(w))      # d w / d pos  (d_ = pixel centre - pos)
+        return w, dw
+    wx, dwx = weights(dx, (xs >= 0) & (xs < W))
+    wy, dwy = weights(dy, (ys >= 0) & (ys < H))
+    yi, xi = ys.clamp(0, H - 1)[:, :, None], xs.clamp(0, W - 1)[:, None, :]
+    gw = g[yi, xi]                                                   # (n,5,5,3)
+    A = (gw * radiance[:, None, None, :]).sum(-1) - gi[yi, xi]       # (n,5,5): grad_p . (L_i - image_p) / W_p
+    w2 = wy[:, :, None] * wx[:, None, :]
+    dL = (gw * w2[..., None]).sum(dim=(1, 2))
+    adj = torch.stack([(A * (wy[:, :, None] * dwx[:, None, :])).sum(dim=(1, 2)),
+                       (A * (dwy[:, :, None] * wx[:, None, :])).sum(dim=(1, 2)), (A * w2).sum(dim=(1, 2))], dim=1)
+    return dL.contiguous(), adj.contiguous()
+
+
 class PRBIntegrator:
     """Second phase of the reference's ``*_hybrid`` scheme (EPSM/optim.py:87-94, 113-119 switch to ``prb_reparam`` after
     ``thres`` iterations): a 3-channel image and the COLOUR adjoint -- ``render_backward`` takes ``grad_in (H,W,3)``
@@ -263,7 +302,12 @@ class PRBIntegrator:
 
     def render_backward(self, scene, params: ParamGrads, grad_in: torch.Tensor, sensor=0, seed: int = 0, spp: int = 0) -> None:
         """Accumulates into ``params.color`` (one all-reduce of this call's contribution when there are several ranks)."""
+        self._color_backward(scene, params, grad_in, sensor, seed, spp)
+
+    def _color_backward(self, scene, params: ParamGrads, grad_in: torch.Tensor, sensor=0, seed: int = 0, spp: int = 0) -> None:
         if not getattr(scene, "color_slots", None):
+            if self.reparam:
+                return
             if getattr(scene, "has_attached_geometry", lambda: False)():
                 raise NotImplementedError(
                     "prb / prb_reparam: geometry is attached but no colour parameter is -- the gradients of vertex positions "
@@ -273,7 +317,7 @@ class PRBIntegrator:
         si = min(sensor, len(scene.sensors) - 1)
         s = scene.sensors[si]
         spp = spp or s.spp
-        n_total = s.width * s.height * spp
+        n_total = s.wavefront_size(spp)
         rank, world = _dist.world()
         import ctypes as C
         from . import _lib
@@ -303,6 +347,81 @@ class PRBIntegrator:
         params.color += contrib
 
 
+class PRBReparamIntegrator(PRBIntegrator):
+    """``prb_reparam`` (src/python/python/ad/integrators/prb_reparam.py): path replay with detached sampling PLUS the
+    reparameterisation of Bangaru et al. that makes visibility differentiable -- ``render_backward`` accumulates
+    d sum(image * grad_in) / d vertex positions (and vertex normals) of the attached meshes into ``params.pos`` /
+    ``params.nrm`` through silhouettes, shadow boundaries and shading, and the colour adjoint of ``PRBIntegrator`` into
+    ``params.color``.  Properties as in prb_reparam.py:226-250: ``reparam_max_depth`` (default: max_depth),
+    ``reparam_rays`` (16; at most 64 here), ``reparam_kappa`` (1e5), ``reparam_exp`` (3.0).  ``reparam_antithetic`` is not
+    implemented (the reference's default is False).  The pass replays the estimator of ``Scene.render_primal`` under the
+    same seed (csrc/epsm_trace_reparam.h); a box reconstruction filter is refused as in common.py:379-388."""
+    reparam = True
+
+    def __init__(self, props: Optional[dict] = None):
+        super().__init__(props)
+        props = dict(props or {})
+        self.reparam_max_depth = props.get("reparam_max_depth", self._depth())
+        self.reparam_rays = int(props.get("reparam_rays", 16))
+        self.reparam_kappa = float(props.get("reparam_kappa", 1e5))
+        self.reparam_exp = float(props.get("reparam_exp", 3.0))
+        if props.get("reparam_antithetic", False):
+            raise NotImplementedError("prb_reparam: reparam_antithetic is not implemented")
+        if not 1 <= self.reparam_rays <= 64:
+            raise ValueError("prb_reparam: 1 <= reparam_rays <= 64")
+
+    def to_string(self):
+        return (f"PRBReparamIntegrator[max_depth = {self.max_depth}, rr_depth = {self.rr_depth}, reparam_max_depth = "
+                f"{self.reparam_max_depth}, reparam_rays = {self.reparam_rays}]")
+
+    __repr__ = to_string
+
+    def render_backward(self, scene, params: ParamGrads, grad_in: torch.Tensor, sensor=0, seed: int = 0, spp: int = 0) -> None:
+        self._color_backward(scene, params, grad_in, sensor, seed, spp)
+        if not scene.has_attached_geometry():
+            return
+        si = min(sensor, len(scene.sensors) - 1)
+        s = scene.sensors[si]
+        if s.rfilter == 0:
+            raise Exception("ADIntegrator detected the potential for image-space motion due to differentiable shape or camera "
+                            "pose parameters. This is, however, incompatible with the box reconstruction filter that is "
+                            "currently used. Please specify a smooth reconstruction filter in your scene description (e.g. "
+                            "'gaussian', which is actually the default)")          # common.py:379-388
+        spp = spp or s.spp
+        n_total = s.wavefront_size(spp)
+        rank, world = _dist.world()
+        import ctypes as C
+        from . import _lib
+        lib = scene._backend if scene._backend is not None else _lib.lib()
+        stream = torch.cuda.current_stream(scene.device).cuda_stream if scene.device.type == "cuda" else None
+        # pass 1 (common.py:872-882): the primal estimate of every sample and the film they make
+        accum = torch.zeros((s.height, s.width, 4), device=scene.device, dtype=torch.float32)
+        tiles = _dist.tile_ranges(n_total, scene.tile_paths)
+        mine = list(_dist.my_tiles(len(tiles), rank, world))
+        kept = {}
+        for t in mine:
+            lo, hi = tiles[t]
+            tr = scene._trace(si, seed, spp, self._depth(), 0, lo, hi)
+            rc = lib.epsm_film_splat(C.c_int64(hi - lo), C.c_void_p(tr.film_pos.data_ptr()), C.c_void_p(tr.radiance.data_ptr()),
+                                     s.width, s.height, s.rfilter, C.c_void_p(accum.data_ptr()), C.c_void_p(stream))
+            assert rc == 0, "epsm_film_splat failed"
+            kept[t] = (tr.film_pos, tr.radiance.contiguous())
+        if world > 1:
+            _dist.allreduce_param_grads(accum)
+        # pass 2 (common.py:944-955): adjoint radiance, adjoint film position / determinant, the reparameterised replay
+        g = grad_in.to(scene.device, torch.float32)[: s.height, : s.width, :3]
+        out = params.scratch() if world > 1 else params
+        for t in mine:
+            lo, hi = tiles[t]
+            film_pos, radiance = kept.pop(t)
+            dL, adj = film_adjoint_reparam(film_pos, radiance, g, accum)
+            scene.trace_reparam(si, seed, spp, self._depth(), lo, hi, radiance, dL, adj, out.pos, out.nrm,
+                                int(self.reparam_max_depth), self.reparam_rays, self.reparam_kappa, self.reparam_exp)
+        if world > 1:
+            _dist.allreduce_param_grads(out.flat)
+            params.flat += out.flat
+
+
 # -- plugin registry (mi.register_integrator / mi.load_dict) -------------------
 _REGISTRY: Dict[str, Callable[[dict], EPSMIntegrator]] = {}
 
@@ -322,4 +441,4 @@ def load_dict(d: dict) -> EPSMIntegrator:
 register_integrator("manifold", lambda props: ManifoldIntegrator(props))                  # epsm.py:948
 register_integrator("manifold_caustic", lambda props: ManifoldCausticIntegrator(props))   # epsm.py:1202
 register_integrator("prb", lambda props: PRBIntegrator(props))
-register_integrator("prb_reparam", lambda props: PRBIntegrator(props))    # EPSM/optim.py:89-92 asks for this name; colour adjoint only
+register_integrator("prb_reparam", lambda props: PRBReparamIntegrator(props))    # EPSM/optim.py:89-92 asks for this name

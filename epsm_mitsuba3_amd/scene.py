@@ -65,7 +65,7 @@ class EpsmEmitter(C.Structure):
 class EpsmSensor(C.Structure):
     _fields_ = [("to_world", C.c_float * 12), ("sample_to_camera", C.c_float * 16), ("dx", C.c_float * 3),
                 ("dy", C.c_float * 3), ("near_clip", C.c_float), ("far_clip", C.c_float),
-                ("width", C.c_int32), ("height", C.c_int32)]
+                ("width", C.c_int32), ("height", C.c_int32), ("border", C.c_int32), ("pad", C.c_int32)]
 
 
 class EpsmSceneC(C.Structure):
@@ -423,13 +423,22 @@ class Sensor:
         self.width, self.height = int(film.get("width", 768)), int(film.get("height", 576))
         rf = film.get("rfilter", {"type": "gaussian"})
         self.rfilter = {"box": 0, "gaussian": 1}[rf.get("type", "gaussian")]
+        # film.sample_border (hdrfilm): samples are also generated in a border of rfilter.border_size() pixels around the
+        # film (ceil(radius - 1/2): 2 for the gaussian of radius 2, 0 for the box) so that what enters or leaves the
+        # viewport is accounted for (common.py:309-336, 390-399); the sensors the reparameterised integrator renders with set it
+        self.sample_border = bool(film.get("sample_border", False))
+        self.border = 2 if (self.sample_border and self.rfilter == 1) else 0
         self.spp = int(sampler.get("sample_count", 4))
         self.fov = float(d.get("fov", 45.0))
         self.near, self.far = float(d.get("near_clip", 1e-2)), float(d.get("far_clip", 1e4))
         self.to_world = np.asarray(d.get("to_world", np.eye(4)), dtype=np.float64)
 
+    def wavefront_size(self, spp: int) -> int:
+        """Paths of one pass: every pixel of the film (and of its sample border) spp times."""
+        return (self.width + 2 * self.border) * (self.height + 2 * self.border) * int(spp)
+
     def c_struct(self) -> EpsmSensor:
-        key = (self.width, self.height, self.fov, self.near, self.far, self.to_world.tobytes())
+        key = (self.width, self.height, self.fov, self.near, self.far, self.to_world.tobytes(), self.border)
         if getattr(self, "_c_key", None) == key:
             return self._c_struct
         s = EpsmSensor()
@@ -441,6 +450,7 @@ class Sensor:
         s.dx[:] = (_xform_point(s2c, [1.0 / self.width, 0, 0]) - p0).astype(np.float32).tolist()    # perspective.cpp:178-182
         s.dy[:] = (_xform_point(s2c, [0, 1.0 / self.height, 0]) - p0).astype(np.float32).tolist()
         s.near_clip, s.far_clip, s.width, s.height = self.near, self.far, self.width, self.height
+        s.border, s.pad = self.border, 0
         self._c_key, self._c_struct = key, s
         return s
 
@@ -667,6 +677,10 @@ class Scene:
         lo, hi = self.mesh_slices[mesh_name]
         return self.positions[lo:hi]
 
+    def vertex_normals(self, mesh_name: str) -> torch.Tensor:
+        lo, hi = self.mesh_slices[mesh_name]
+        return self.normals[lo:hi]
+
     def param_grads(self) -> ParamGrads:
         return ParamGrads(self.V, len(self.alpha_slots), device=self.device, mesh_slices=self.mesh_slices,
                           n_colors=len(self.color_slots))
@@ -774,6 +788,31 @@ class Scene:
             _lib.check(rc, "epsm_trace_paths_color") if self._backend is None else (_ for _ in ()).throw(RuntimeError(f"host tracer rc={rc}"))
         return film_pos, radiance, sums
 
+    def trace_reparam(self, sensor_index: int, seed: int, spp: int, max_depth: int, lo: int, hi: int, radiance, adj_radiance,
+                      adj_film, grad_pos, grad_nrm, reparam_max_depth: int, reparam_rays: int, kappa: float, exponent: float):
+        """``epsm_trace_paths_reparam``: the reparameterised backward pass of paths [lo, hi) -- accumulates d loss / d vertex
+        positions (and normals) into ``grad_pos`` / ``grad_nrm`` (V,3) given, per path, the radiance of the primal pass under
+        the same seed, its adjoint and the adjoint of the film position + determinant (integrators.film_adjoint_reparam)."""
+        dev = self.device
+        if dev.type != "cuda" and self._backend is None:
+            raise _lib.EpsmError("the tracer runs on the GPU only (no CPU fallback)")
+        lib = self._backend if self._backend is not None else _lib.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+        n = hi - lo
+        for t_, w in ((radiance, 3), (adj_radiance, 3), (adj_film, 3)):
+            assert t_.is_contiguous() and t_.dtype == torch.float32 and tuple(t_.shape) == (n, w) and t_.device == dev
+        for t_ in (grad_pos, grad_nrm):
+            assert t_.is_contiguous() and t_.dtype == torch.float32 and tuple(t_.shape) == (self.V, 3) and t_.device == dev
+        cs = self.sensors[sensor_index].c_struct()
+        fn = lib.epsm_trace_paths_reparam
+        fn.restype = C.c_int
+        rc = fn(C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
+                C.c_int64(lo), C.c_int64(n), C.c_void_p(radiance.data_ptr()), C.c_void_p(adj_radiance.data_ptr()),
+                C.c_void_p(adj_film.data_ptr()), int(reparam_max_depth), int(reparam_rays), C.c_float(kappa), C.c_float(exponent),
+                C.c_void_p(grad_pos.data_ptr()), C.c_void_p(grad_nrm.data_ptr()), C.c_void_p(stream))
+        if rc != 0:
+            _lib.check(rc, "epsm_trace_paths_reparam") if self._backend is None else (_ for _ in ()).throw(RuntimeError(f"host tracer rc={rc}"))
+
     def _trace_packed(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int):
         """The same trace with the vertex log in the NATIVE layout of the backward kernel (EPSM_TRACE_PACKED_LOG,
         include/epsm.h EpsmPackedLog): the PathTrace carries ``log`` (a PackedLog) instead of per-field arrays."""
@@ -813,7 +852,7 @@ class Scene:
         if rc != 0:
             _lib.check(rc, "epsm_trace_paths") if self._backend is None else (_ for _ in ()).throw(RuntimeError(f"host tracer rc={rc}"))
         tr = PathTrace(res=sensor.width, spp=spp, ray_o=rays[:, 0:3], ray_d=rays[:, 3:6], ray_dx=rays[:, 6:9], ray_dy=rays[:, 9:12],
-                       path_info=None, scatter_info=None, path_offset=lo, n_paths_total=sensor.width * sensor.height * spp)
+                       path_info=None, scatter_info=None, path_offset=lo, n_paths_total=sensor.wavefront_size(spp))
         tr.film_pos, tr.radiance, tr.valid = film_pos, radiance, valid
         tr.log = PackedLog(rays, flags, verts, shadow, self.tri_table, K)
         return tr
@@ -883,7 +922,7 @@ class Scene:
             _lib.check(rc, "epsm_trace_paths") if self._backend is None else (_ for _ in ()).throw(RuntimeError(f"host tracer rc={rc}"))
         tr = PathTrace(res=sensor.width, spp=spp, ray_o=ray[0], ray_d=ray[1], ray_dx=ray[2], ray_dy=ray[3],
                        path_info=info, scatter_info=sinfo, path_offset=lo,
-                       n_paths_total=sensor.width * sensor.height * spp)
+                       n_paths_total=sensor.wavefront_size(spp))
         tr.film_pos, tr.radiance, tr.valid = film_pos, radiance, valid
         return tr
 
@@ -900,9 +939,12 @@ class Scene:
         s = self.sensors[si]
         if s.width != s.height:
             raise ValueError("the EPSM backward pass assumes a square film (epsm.py:239)")
+        if s.border:
+            raise ValueError("the EPSM backward pass maps path -> pixel without a sample border (epsm.py:239-246: its sensors "
+                             "set sample_border = False); sample_border is for the sensor prb_reparam renders with")
         max_depth = 6 if max_depth < 0 else min(int(max_depth), 6)       # -1 = no limit; the path loop stops at 6 (epsm.py:549)
         K = min(max_log_depth, max_depth, 5)
-        n_total = s.width * s.height * spp
+        n_total = s.wavefront_size(spp)
         tile = self.tile_paths
         if self.use_wavefront():       # as large as the sharding allows: every rank still gets a tile, none larger than 2^24 paths
             per_rank = -(-n_total // max(1, world_size))
@@ -926,7 +968,7 @@ class Scene:
         si = min(sensor, len(self.sensors) - 1)
         s = self.sensors[si]
         spp = spp or s.spp
-        n_total = s.width * s.height * spp
+        n_total = s.wavefront_size(spp)
         accum = torch.zeros((s.height, s.width, 4), device=self.device, dtype=torch.float32)
         lib = self._backend if self._backend is not None else _lib.lib()
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None

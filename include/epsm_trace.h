@@ -107,6 +107,10 @@ typedef struct EpsmSensor {
     float dx[3], dy[3];              /* position differentials on the near plane, perspective.cpp:178-182 */
     float near_clip, far_clip;
     int32_t width, height;
+    int32_t border;                  /* film.sample_border: samples are also generated for `border` pixels around the film
+                                        (rfilter.border_size(): 2 for the gaussian, 0 for the box), common.py:309-336; the
+                                        wavefront is then (width + 2 border) (height + 2 border) spp paths */
+    int32_t pad;
 } EpsmSensor;
 
 typedef struct EpsmScene {           /* host struct holding DEVICE pointers */
@@ -194,6 +198,28 @@ int epsm_trace_paths_color(const EpsmScene *scene, const EpsmSensor *sensor,
                            int64_t path_offset, int64_t N,
                            float *film_pos, float *radiance, uint8_t *valid,
                            float *color_sum, int n_color, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * epsm_trace_paths_reparam -- the second pass of RBIntegrator.render_backward for `prb_reparam`
+ *   (src/python/python/ad/integrators/common.py:944-955, prb_reparam.py:277-607, ad/reparam.py:10-333): paths
+ *   [path_offset, path_offset + N) are replayed under the primal pass's seed and the gradient of
+ *   sum(image * grad_in) w.r.t. the VERTEX POSITIONS (and vertex normals) of the meshes flagged EPSM_MESH_POS_ATTACHED
+ *   (EPSM_MESH_NRM_ATTACHED) is ACCUMULATED into grad_pos / grad_nrm -- through shading, and through visibility by the
+ *   warp field of Bangaru et al. (auxiliary rays, harmonic weights, divergence).
+ *     radiance      (N,3) L of every path from the primal pass (epsm_trace_paths with the same seed / spp / depth)
+ *     adj_radiance  (N,3) d loss / d L               } the adjoint of splat + weight division, which the caller owns
+ *     adj_film      (N,3) d loss / d film position (x, y in pixels) and d loss / d det of the primary ray's
+ *                         reparameterisation (common.py:405-418, 888-903)
+ *     reparam_max_depth, reparam_rays (<= 64), kappa, exponent   prb_reparam.py:226-250
+ *     grad_pos, grad_nrm   (V,3) f32 device buffers, float atomics; grad_nrm may be NULL
+ *   One-launch form (a lane replays its path and traces its auxiliary rays itself).
+ * ------------------------------------------------------------------------- */
+int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor *sensor,
+                             uint32_t seed, int spp, int max_depth, int rr_depth,
+                             int64_t path_offset, int64_t N,
+                             const float *radiance, const float *adj_radiance, const float *adj_film,
+                             int reparam_max_depth, int reparam_rays, float kappa, float exponent,
+                             float *grad_pos, float *grad_nrm, void *stream);
 
 /* epsm_film_splat -- ImageBlock::put + weight division (film.develop): accumulates
  * radiance with the reconstruction filter into accum (height,width,4) [r,g,b,w] (atomics);

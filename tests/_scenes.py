@@ -18,7 +18,7 @@ def host_tracer():
     if _lib is None:
         src = os.path.join(_DIR, "trace_host.cpp")
         csrc = os.path.join(_DIR, "..", "..", "epsm_mitsuba3_amd", "csrc")
-        hdrs = [os.path.join(csrc, h) for h in ("epsm_trace_core.h", "epsm_trace_wavefront.h")]
+        hdrs = [os.path.join(csrc, h) for h in ("epsm_trace_core.h", "epsm_trace_wavefront.h", "epsm_trace_reparam.h")]
         from epsm_mitsuba3_amd._lib import build_lock
         with build_lock(_DIR):
             if (not os.path.isfile(_SO)) or any(os.path.getmtime(p) > os.path.getmtime(_SO) for p in [src] + hdrs):
@@ -44,10 +44,10 @@ def quad(z=0.0, half=1.0, up=True):
     return v, f
 
 
-def sensor(origin, target, up=(0, 1, 0), fov=40, res=16, spp=4, rfilter="box", near=0.01, far=100.0):
+def sensor(origin, target, up=(0, 1, 0), fov=40, res=16, spp=4, rfilter="box", near=0.01, far=100.0, sample_border=False):
     return {"type": "perspective", "fov": fov, "near_clip": near, "far_clip": far,
             "to_world": S.look_at(origin, target, up),
-            "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": rfilter}},
+            "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": rfilter}, "sample_border": sample_border},
             "sampler": {"type": "independent", "sample_count": spp}}
 
 

@@ -5,6 +5,7 @@
 #include <string.h>
 #include "../../epsm_mitsuba3_amd/csrc/epsm_trace_core.h"
 #include "../../epsm_mitsuba3_amd/csrc/epsm_trace_wavefront.h"
+#include "../../epsm_mitsuba3_amd/csrc/epsm_trace_reparam.h"
 
 using namespace epsm;
 
@@ -45,6 +46,53 @@ extern "C" int epsm_trace_paths_color(const EpsmScene *scene, const EpsmSensor *
         uint32_t stack[kBvhStack];
         trace_one_path(A, i, BvhStack{stack, 1});
     }
+    return 0;
+}
+
+extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor *sensor, uint32_t seed, int spp, int max_depth,
+                                        int rr_depth, int64_t path_offset, int64_t N, const float *radiance,
+                                        const float *adj_radiance, const float *adj_film, int reparam_max_depth, int reparam_rays,
+                                        float kappa, float exponent, float *grad_pos, float *grad_nrm, void *) {
+    if (reparam_rays < 1 || reparam_rays > rp::kMaxAux) return -22;
+    rp::ReparamArgs R;
+    memset(&R, 0, sizeof(R));
+    R.A.S = *scene; R.A.C = *sensor;
+    R.A.seed = seed; R.A.spp = spp; R.A.max_depth = max_depth; R.A.rr_depth = rr_depth; R.A.K_log = 0;
+    R.A.path_offset = path_offset; R.A.N = N;
+    R.cfg.max_depth = reparam_max_depth; R.cfg.rays = reparam_rays; R.cfg.kappa = kappa; R.cfg.exponent = exponent;
+    R.radiance = radiance; R.adj_radiance = adj_radiance; R.adj_film = adj_film;
+    R.G.pos = grad_pos; R.G.nrm = grad_nrm;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < N; ++i) {
+        uint32_t stack[kBvhStack];
+        rp::Warp W;
+        rp::reparam_one_path(R, i, BvhStack{stack, 1}, W);
+    }
+    return 0;
+}
+
+// Test probe: the warp field's value and divergence at one ray when only the ray ORIGIN moves with velocity `odot`
+// (forward mode of reparam.py:155-221): out = [V_theta (3), div V_theta, Z].
+extern "C" int epsm_debug_warp(const EpsmScene *scene, const float *o, const float *d, const float *odot, int rays, float kappa,
+                               float exponent, uint32_t seed, float *out) {
+    rp::ReparamCfg cfg; cfg.max_depth = 8; cfg.rays = rays; cfg.kappa = kappa; cfg.exponent = exponent;
+    Pcg32 rng = seed_sampler(seed, 0);
+    uint32_t stack[kBvhStack];
+    rp::Warp W;
+    rp::warp_collect(*scene, cfg, rng, ld3(o), ld3(d), BvhStack{stack, 1}, W);
+    double V[3] = {0, 0, 0}, dl = 0;
+    const F3 od = ld3(odot);
+    for (int i = 0; i < W.n; ++i) {
+        const rp::Aux &A = W.a[i];
+        if (A.tri == kNoIndex) continue;
+        const F3 dv = (od - A.v * dot(A.v, od)) * (-A.inv_dist);
+        V[0] += A.w * dv.x; V[1] += A.w * dv.y; V[2] += A.w * dv.z;
+        dl += dot(A.dw, dv);
+    }
+    const double Z = W.Z > 1e-8f ? W.Z : 1e-8;
+    out[0] = (float) (V[0] / Z); out[1] = (float) (V[1] / Z); out[2] = (float) (V[2] / Z);
+    out[3] = (float) ((dl - (out[0] * W.dZ.x + out[1] * W.dZ.y + out[2] * W.dZ.z)) / Z);
+    out[4] = W.Z;
     return 0;
 }
 
