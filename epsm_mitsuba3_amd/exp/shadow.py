@@ -32,10 +32,10 @@ def _disc(z, radius, n=24):
     return v, f
 
 
-def _sensor(res, spp_):
+def _sensor(res, spp_, sample_border=False):
     return {"type": "perspective", "fov": 50, "near_clip": 0.01, "far_clip": 100.0,
             "to_world": look_at([0.0, -3.2, 3.0], [0.0, 0.0, 0.0], [0, 0, 1]),
-            "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": "gaussian"}},
+            "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": "gaussian"}, "sample_border": sample_border},
             "sampler": {"type": "independent", "sample_count": spp_}}
 
 
@@ -44,7 +44,8 @@ def load_scene(device="cuda", shift=(0.0, 0.0, 0.0)):
     ov, of = _disc(1.0, 0.45)
     ov = ov + np.asarray(shift)
     lv, lf = _quad(4.0, 0.04)
-    d = {"type": "scene", "sensor0": _sensor(resolution, spp), "sensor1": _sensor(resolution, spp),
+    # sensor 0 (primal / prb_reparam) samples the film's border, the manifold integrators' sensors do not (exp/shadow.py:38,128,147)
+    d = {"type": "scene", "sensor0": _sensor(resolution, spp, True), "sensor1": _sensor(resolution, spp),
          "sensor2": _sensor(match_res, 8),
          "floor": {"type": "mesh", "vertices": fv, "faces": ff, "face_normals": True,
                    "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}},

@@ -7,10 +7,9 @@ back to the film size (optim.py:130-135) -> ``render_backward`` -> chain rule in
 -> NaN scrub (optim.py:143-154) -> Adam step (torch, as the reference's optim_human.py does).
 ``*_hybrid`` (optim.py:87-94, 113-119): after ``tasks.thres`` iterations the optimiser state is reset and the loop
 switches to the ``prb_reparam`` integrator on sensor 0 with the L2 image loss of optim.py:137-141
-(``grad_in = 2 (img - ref) / len(img)``, 3 channels).  That integrator's backward pass here is the COLOUR adjoint
-only (integrators.PRBIntegrator: diffuse reflectances / emitter radiances attached with Scene.attach_color /
-attach_radiance); the reparameterised visibility gradients of vertex positions are not built, so geometric
-parameters stop moving in the second phase -- the loop says so.
+(``grad_in = 2 (img - ref) / len(img)``, 3 channels): integrators.PRBReparamIntegrator -- vertex positions / normals
+through the warp field (csrc/epsm_trace_reparam.h), colour parameters (Scene.attach_color / attach_radiance) through the
+colour adjoint.  ``METHOD = prb_reparam`` runs that integrator from the first iteration.
 """
 from __future__ import annotations
 
@@ -52,8 +51,7 @@ def run(method: str, exp: str, device="cuda", iterations=None, lr=None, log=prin
         method = method[:-7]
         integrator2 = load_dict({"type": "prb_reparam", "max_depth": tasks.max_depth})
         thres = getattr(tasks, "thres", 10000)
-        log(f"hybrid: phase 2 = {integrator2} after {thres} iterations (colour adjoint; geometric parameters keep the manifold "
-            f"integrator: prb_reparam's warp field is not built)")
+        log(f"hybrid: phase 2 = {integrator2} after {thres} iterations")
     scene = tasks.load_scene(device)
     integrator = load_dict({"type": method, "max_depth": tasks.max_depth})
     sensor_id = 1 if method.startswith("manifold") else 0                      # optim.py:103-106
@@ -67,11 +65,7 @@ def run(method: str, exp: str, device="cuda", iterations=None, lr=None, log=prin
     rep = tasks.resolution // tasks.match_res
     for it in range(iterations or tasks.it):
         apply_transformation(scene, opt)                                        # optim.py:112
-        # phase 2 differentiates colour parameters only (integrators.PRBIntegrator): an experiment whose attached parameters are
-        # geometric stays with the manifold integrator instead of silently stalling there
-        phase2 = it >= thres and bool(getattr(scene, "color_slots", None))
-        if it == thres and not phase2:
-            log(f"Iteration {it:02d}: hybrid switch skipped -- no colour parameter is attached, geometry stays on {integrator}")
+        phase2 = it >= thres
         if not phase2:
             integ, sid = integrator, sensor_id
         else:

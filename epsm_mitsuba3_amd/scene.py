@@ -800,9 +800,9 @@ class Scene:
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
         n = hi - lo
         for t_, w in ((radiance, 3), (adj_radiance, 3), (adj_film, 3)):
-            assert t_.is_contiguous() and t_.dtype == torch.float32 and tuple(t_.shape) == (n, w) and t_.device == dev
+            assert t_.is_contiguous() and t_.dtype == torch.float32 and tuple(t_.shape) == (n, w) and t_.device.type == dev.type
         for t_ in (grad_pos, grad_nrm):
-            assert t_.is_contiguous() and t_.dtype == torch.float32 and tuple(t_.shape) == (self.V, 3) and t_.device == dev
+            assert t_.is_contiguous() and t_.dtype == torch.float32 and tuple(t_.shape) == (self.V, 3) and t_.device.type == dev.type
         cs = self.sensors[sensor_index].c_struct()
         fn = lib.epsm_trace_paths_reparam
         fn.restype = C.c_int

@@ -30,6 +30,6 @@ def test_hybrid_switches_integrators_after_thres_iterations():
     from epsm_mitsuba3_amd.optim import run
     lines = []
     hist, opt = run("manifold_hybrid", "albedo", iterations=40, lr=0.03, log=lines.append)
-    assert "phase 2 = PRBIntegrator" in lines[0]
+    assert "phase 2 = PRBReparamIntegrator" in lines[0]
     assert abs(hist[3] - hist[0]) < 1e-6                      # the manifold phase has no colour gradient
     assert min(hist[-8:]) < 0.5 * hist[0], hist

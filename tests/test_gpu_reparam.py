@@ -1,0 +1,102 @@
+"""`prb_reparam` on the GPU (csrc/epsm_trace_reparam.hip through the C ABI): the device pass against the host build of the
+same per-path code, and the reference's recipe -- backward gradient against finite differences of the primal image
+(src/integrators/tests/test_ad_integrators.py:833-871) -- at sample counts of the order of the reference's (its configs:
+1024 .. 12 000 spp, 64 auxiliary rays) with ITS thresholds for the configs restated in tests/_reparam_scenes.py."""
+import numpy as np
+import pytest
+import torch
+
+import epsm_mitsuba3_amd as epsm
+from _reparam_scenes import CONFIGS, build, fd_check, fd_check_normals
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(got, fd):
+    g, f = float(np.mean(got)), float(np.mean(fd))
+    return abs(g - f) / max(abs(f), 1e-3), g, f
+
+
+@pytest.mark.parametrize("name", ["diffuse_sphere_area_light", "sphere_on_glossy_floor", "occluder_area_light"])
+def test_device_pass_equals_the_host_build(name):
+    """Same seed, same auxiliary rays: per-vertex gradients agree up to what fma contraction flips (a hit that becomes a
+    miss moves one auxiliary ray's share)."""
+    res, spp = 16, 32
+    cfg = CONFIGS[name]
+    integ = epsm.load_dict({"type": "prb_reparam", "max_depth": cfg["max_depth"], "reparam_rays": 16, "reparam_kappa": cfg.get("kappa", 1e5)})
+    g = torch.ones((res, res, 3)) * (0.5 + torch.arange(res, dtype=torch.float32) / res)[None, :, None]
+    out = []
+    for dev in ("cpu", "cuda"):
+        sc = build(name, 0.0, res, spp, dev)
+        for m in cfg["moving"]:
+            sc.attach(m, positions=True, normals=True)
+        p = sc.param_grads()
+        integ.render_backward(sc, p, g.to(sc.device), sensor=0, seed=5, spp=spp)
+        out.append((p.pos.cpu().clone(), p.nrm.cpu().clone()))
+    for a, b, what in ((out[0][0], out[1][0], "pos"), (out[0][1], out[1][1], "nrm")):
+        scale = float(a.abs().max())
+        if what == "nrm" and name == "occluder_area_light":          # never shaded: the camera does not see it, depth 2
+            assert scale == 0 and float(b.abs().max()) == 0
+            continue
+        assert scale > 0, what
+        bad = ((a - b).abs() > 2e-2 * scale).float().mean()
+        assert float(bad) < 0.02, (name, what, float(bad), scale)
+        assert abs(float(a.sum() - b.sum())) < 2e-2 * float(a.abs().sum()), (name, what)
+
+
+@pytest.mark.parametrize("name,spp,tol", [
+    ("receiver_point_light", 256, 0.01),
+    ("receiver_along_normal", 1024, 0.06),
+    ("corner_along_normal", 1024, 0.06),
+    ("rectangle_emitter_on_black", 2048, 0.2),       # error_mean_threshold_bwd of the config it restates (:383-410)
+    ("sphere_emitter_on_black", 2048, 0.15),         # :413-435
+    ("occluder_area_light", 4096, 0.25),             # :463-500
+    ("sphere_on_glossy_floor", 4096, 0.2),           # :601-640
+    ("diffuse_sphere_area_light", 4096, 0.15),
+])
+def test_backward_gradient_matches_finite_differences(name, spp, tol):
+    got, fd, dt = fd_check(name, device="cuda", spp=spp, rays=64, seeds=2, fd_eps=0.0 if "emitter" in name else 5e-3, fd_spp_mult=2)
+    r, g, f = rel(got, fd)
+    print(f"{name}: grad {g:+.3f} per seed {[round(x, 2) for x in got]}, FD {f:+.3f} per seed {[round(x, 2) for x in fd]}, rel {r:.3f}, "
+          f"{dt:.2f} s for the backward passes")
+    assert r < tol, (name, g, f)
+
+
+def test_vertex_normals_on_the_device():
+    got, fd = fd_check_normals("diffuse_sphere_area_light", device="cuda", spp=1024, rays=16, fd_spp_mult=1)
+    assert got * fd > 0 and abs(got - fd) < 0.12 * abs(fd), (got, fd)
+
+
+def test_hybrid_second_phase_moves_geometry():
+    """manifold_hybrid on the shadow experiment (EPSM/optim.py:87-119): the manifold phase brings the occluder's shadow
+    near the target, then ``prb_reparam`` on sensor 0 with the L2 loss keeps moving the GEOMETRY (round 2: it stood still
+    there) and ends closer."""
+    from epsm_mitsuba3_amd.exp import shadow
+    from epsm_mitsuba3_amd.optim import run
+    old = shadow.thres
+    shadow.thres = 25
+    try:
+        lines = []
+        hist, opt = run("manifold_hybrid", "shadow", iterations=60, lr=0.02, log=lines.append)
+    finally:
+        shadow.thres = old
+    assert "phase 2 = PRBReparamIntegrator" in lines[0]
+    moved = abs(hist[-1] - hist[26])
+    print("error at the switch", hist[25], "at the end", hist[-1], "history", [round(h, 3) for h in hist])
+    assert moved > 1e-4                                       # the second phase moves the occluder
+    assert np.mean(hist[-8:]) < 0.6 * hist[25] or np.mean(hist[-8:]) < 0.05 * hist[0], hist
+
+
+def test_prb_reparam_alone_refines_a_nearby_start():
+    """``python -m epsm_mitsuba3_amd.optim prb_reparam shadow`` from a start whose shadow overlaps the target's (the regime
+    the L2 loss works in, the reason for the hybrid scheme)."""
+    from epsm_mitsuba3_amd.exp import shadow
+    from epsm_mitsuba3_amd.optim import run
+    old = shadow._TARGET_SHIFT.copy()
+    shadow._TARGET_SHIFT[:] = [0.12, -0.08, 0.0]
+    try:
+        hist, opt = run("prb_reparam", "shadow", iterations=40, lr=0.01, log=lambda s: None)
+    finally:
+        shadow._TARGET_SHIFT[:] = old
+    print([round(h, 4) for h in hist])
+    assert np.mean(hist[-8:]) < 0.4 * hist[0], hist
