@@ -172,3 +172,52 @@ def test_two_rank_primal_render_matches_single_process():
     assert float(single.max()) > 0
     assert torch.equal(got[0][1], got[1][1])
     assert torch.allclose(got[0][1], single, rtol=1e-5, atol=1e-6)
+
+
+def _reparam_single(tile_paths):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import epsm_mitsuba3_amd as epsm
+    from _reparam_scenes import build
+    sc = build("diffuse_sphere_area_light", 0.0, 12, 8, "cpu")
+    sc.tile_paths = tile_paths                            # 16 * 16 * 8 = 2048 paths (12 + 2 * 2 border pixels a side)
+    sc.attach("sphere", positions=True, normals=True)
+    integ = epsm.load_dict({"type": "prb_reparam", "max_depth": 3, "reparam_rays": 8})
+    params = sc.param_grads()
+    g = torch.ones((12, 12, 3)) * (0.5 + torch.arange(12, dtype=torch.float32) / 12)[None, :, None]
+    integ.render_backward(sc, params, g, sensor=0, seed=3, spp=8)
+    once = params.flat.clone()
+    integ.render_backward(sc, params, g, sensor=0, seed=3, spp=8)
+    return once, params.flat.clone()
+
+
+def _reparam_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    edist.init_from_env("gloo")
+    once, twice = _reparam_single(512)
+    q.put((rank, once, twice))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_prb_reparam_matches_single_process():
+    """The reparameterised backward pass shards its tiles like the others: the film of the primal pass is all-reduced
+    before the adjoints are formed, each rank replays its own tiles, ONE all-reduce sums the geometry gradients, and a
+    second accumulating call adds one more copy."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reparam_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    single, single2 = _reparam_single(512)
+    m = float(single.abs().max())
+    assert m > 0
+    for rank, once, twice in got:
+        assert torch.allclose(once, single, rtol=1e-4, atol=1e-5 * m)
+        assert torch.allclose(twice, 2 * single, rtol=1e-4, atol=2e-5 * m)
