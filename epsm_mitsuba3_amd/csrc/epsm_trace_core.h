@@ -173,10 +173,18 @@ EPSM_HD void trav_begin(Traversal &T, const EpsmScene &S, const Ray &r) {
     T.sp = 0;
 }
 EPSM_HD bool trav_done(const Traversal &T) { return T.cur == kBvhNone; }
+#if defined(EPSM_TRAV_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+// host harness only (tools/count_traversal.py): nodes fetched / triangles tested / rays, by ray kind (0 closest hit, 1 any hit)
+extern "C" { extern long long g_trav_nodes[2], g_trav_tris[2], g_trav_rays[2]; }
+#define EPSM_STAT(x) x
+#else
+#define EPSM_STAT(x)
+#endif
 template <bool ANY_HIT>
 EPSM_HD void trav_round(Traversal &T, const EpsmScene &S, const BvhStack &st) {
     while (T.cur >= 0 && T.cur != kBvhNone) {
         const EpsmBvhNode n = S.bvh[T.cur];
+        EPSM_STAT(__atomic_fetch_add(&g_trav_nodes[ANY_HIT], 1, __ATOMIC_RELAXED);)
         // slab test of the four boxes (an absent child's box is empty and its reference kBvhNone)
         float t[4]; int32_t c[4];
 #pragma unroll
@@ -207,6 +215,7 @@ EPSM_HD void trav_round(Traversal &T, const EpsmScene &S, const BvhStack &st) {
     for (int32_t e = first; e < first + count; ++e) {
         const float *q = S.tri_verts + 9 * (int64_t) e;
         float t, u, v;
+        EPSM_STAT(__atomic_fetch_add(&g_trav_tris[ANY_HIT], 1, __ATOMIC_RELAXED);)
         if (moeller_trumbore(T.r, ld3(q), ld3(q + 3), ld3(q + 6), t, u, v)) {
             T.best.hit = true; T.best_e = e; T.best.t = t; T.best.u = u; T.best.v = v;
             T.r.maxt = t;
@@ -225,6 +234,7 @@ template <bool ANY_HIT>
 EPSM_HD TriHit intersect(const EpsmScene &S, Ray r, const BvhStack &st) {
     Traversal T;
     trav_begin(T, S, r);
+    EPSM_STAT(__atomic_fetch_add(&g_trav_rays[ANY_HIT], 1, __ATOMIC_RELAXED);)
     while (!trav_done(T)) trav_round<ANY_HIT>(T, S, st);
     return trav_result(T, S);
 }
