@@ -14,13 +14,21 @@ namespace {
 // One lane = one path, replayed with all its auxiliary rays.  The three vertex records, the warp's auxiliary-ray table
 // (2.8 KB) and the dual numbers live in scratch: this pass is bound by its 16..64 closest-hit traversals per warp, not by
 // the bookkeeping around them.  64-thread workgroups: paths of neighbouring samples, whose auxiliary rays stay together.
-__global__ __launch_bounds__(64) void epsm_reparam_kernel(rp::ReparamArgs R) {
+// Waves per SIMD (4.26 M paths, 128 k triangles, 16 rays, ms per render_backward): 1 (256 + 256 registers, 5.4 KB of
+// scratch) 181, 2: 127, 3: 108, 4 (128 registers, 6.7 KB) 100, 5: 103; 128-thread workgroups at 2: 137 against 127.
+#ifndef EPSM_RP_THREADS
+#define EPSM_RP_THREADS 64
+#endif
+#ifndef EPSM_RP_OCC
+#define EPSM_RP_OCC 4
+#endif
+__global__ __launch_bounds__(EPSM_RP_THREADS, EPSM_RP_OCC) void epsm_reparam_kernel(rp::ReparamArgs R) {
     constexpr int kLds = 32;
-    __shared__ uint32_t s_stack[kLds * 64];
+    __shared__ uint32_t s_stack[kLds * EPSM_RP_THREADS];
     uint32_t deep[kBvhStack - kLds];
-    const int64_t i = (int64_t) blockIdx.x * 64 + threadIdx.x;
+    const int64_t i = (int64_t) blockIdx.x * EPSM_RP_THREADS + threadIdx.x;
     if (i >= R.A.N) return;
-    BvhStack st{s_stack + threadIdx.x, 64};
+    BvhStack st{s_stack + threadIdx.x, EPSM_RP_THREADS};
     st.cap = kLds; st.ovf = deep; st.ovf_stride = 1;
     rp::Warp W;
     rp::reparam_one_path(R, i, st, W);
@@ -58,7 +66,7 @@ extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor
     R.cfg.max_depth = reparam_max_depth; R.cfg.rays = reparam_rays; R.cfg.kappa = kappa; R.cfg.exponent = exponent;
     R.radiance = radiance; R.adj_radiance = adj_radiance; R.adj_film = adj_film;
     R.G.pos = grad_pos; R.G.nrm = grad_nrm;
-    hipLaunchKernelGGL(epsm_reparam_kernel, dim3((unsigned) ((N + 63) / 64)), dim3(64), 0, (hipStream_t) stream, R);
+    hipLaunchKernelGGL(epsm_reparam_kernel, dim3((unsigned) ((N + EPSM_RP_THREADS - 1) / EPSM_RP_THREADS)), dim3(EPSM_RP_THREADS), 0, (hipStream_t) stream, R);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_trace_paths_reparam", e);
     return EPSM_OK;

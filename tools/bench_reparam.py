@@ -28,6 +28,15 @@ def once():
     integ.render_backward(scene, params, g, sensor=0, seed=1, spp=spp)
 
 
+# run-to-run: the same call twice into fresh buffers (float atomics: the order of the additions differs)
+pa, pb = scene.param_grads(), scene.param_grads()
+integ.render_backward(scene, pa, g, sensor=0, seed=1, spp=spp)
+integ.render_backward(scene, pb, g, sensor=0, seed=1, spp=spp)
+sa = torch.stack([pa.mesh_pos(f"s{i}").sum(0) for i in range(0, 100, 10)])
+sb = torch.stack([pb.mesh_pos(f"s{i}").sum(0) for i in range(0, 100, 10)])
+print(f"two runs: per-vertex max |a - b| / max |a| = {float((pa.pos - pb.pos).abs().max() / pa.pos.abs().max()):.2e}; per-mesh translation "
+      f"gradients max |a - b| / max |a| = {float((sa - sb).abs().max() / sa.abs().max()):.2e}; max |per-vertex| {float(pa.pos.abs().max()):.3e}, "
+      f"max |per-mesh sum| {float(sa.abs().max()):.3e}")
 once(); once()
 ts = []
 for _ in range(3):
