@@ -258,6 +258,34 @@ def secondary_config_leg(index, dev):
             "note": "secondary figure, outside the timed region"}
 
 
+def hybrid_phase2_leg(res, spp, rays, dev):
+    """Secondary figure, outside the timed region: the hybrid scheme's second phase (EPSM/optim.py:113-119) on the same
+    traced scene -- prb_reparam's render_backward (primal replay, film adjoints, the reparameterised pass with its
+    auxiliary rays: csrc/epsm_trace_reparam.hip), wall-clock, median of 3."""
+    import epsm_mitsuba3_amd as epsm
+    from epsm_mitsuba3_amd.exp import clutter
+    from epsm_mitsuba3_amd.scene import Scene
+    d = clutter.scene_dict(100, res, spp)
+    d["sensor0"]["film"]["sample_border"] = True                       # as the reference's sensor 0 (exp/shadow.py:38)
+    scene = Scene.from_dict(d, device=dev)
+    for i in range(0, 100, 10):
+        scene.attach(f"s{i}", positions=True, normals=True)
+    integ = epsm.load_dict({"type": "prb_reparam", "max_depth": 3, "reparam_rays": rays})
+    params = scene.param_grads()
+    g = torch.Generator(device=dev).manual_seed(3)
+    grad_in = torch.randn((res, res, 3), generator=g, device=dev) * 1e-2
+    fn = lambda: integ.render_backward(scene, params, grad_in, sensor=0, seed=1, spp=spp)
+    fn(); out = []
+    for _ in range(3):
+        torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize()
+        out.append((time.perf_counter() - t) * 1e3)
+    ms = sorted(out)[1]
+    n = scene.sensors[0].wavefront_size(spp)
+    return {"scene": f"exp/clutter.py, {scene.T} triangles, every tenth sphere attached", "integrator": "prb_reparam", "paths": n,
+            "max_depth": 3, "reparam_rays": rays, "render_backward_ms": ms, "paths_per_s": n / (ms * 1e-3),
+            "note": "gradients of vertex positions / normals through visibility (warp field); secondary figure, outside the timed region"}
+
+
 def real_scene_leg(variant, res, spp, dev):
     """Secondary figure, outside the timed region: gradient image of a TRACED scene (epsm_mitsuba3_amd/exp/clutter.py,
     the stand-in for the bathroom asset the reference does not ship): render_backward = native tracer with vertex log
@@ -629,6 +657,8 @@ def main():
             del slabs, out
             torch.cuda.empty_cache()
             result["real_scene"] = real_scene_leg(variant, 512, 64, dev)
+            torch.cuda.empty_cache()
+            result["hybrid_phase2"] = hybrid_phase2_leg(256, 16, 16, dev)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -44,6 +44,11 @@ CONFIGS = {
     "emitter_in_view": dict(max_depth=2, moving=["light"], fd_eps=1e-3),
     # TranslateSphereEmitterOnBlackConfig (:413-435)
     "sphere_emitter_on_black": dict(max_depth=2, moving=["light"], fd_eps=1e-3),
+    # ScaleSphereEmitterOnBlackConfig (:438-460): vertex positions * (1 + theta)
+    "scale_sphere_emitter_on_black": dict(max_depth=3, moving=["light"], fd_eps=1e-3, motion="scale"),
+    # TranslateSelfShadowAreaLightConfig (:551-596): a plane and an upright rectangle on it move TOGETHER under a point
+    # light; max_depth 3 (its dim constant emitter is left out: not in this tracer's plugin set)
+    "self_shadow_point_light": dict(max_depth=3, moving=["plane", "occluder"], fd_eps=1e-3),
     # TranslateOccluderAreaLightConfig (:463-500): a small sphere between a small bright light and a diffuse plane
     "occluder_area_light": dict(max_depth=2, moving=["occluder"], fd_eps=2e-4, kappa=5e5),
     # a diffuse sphere in front of a lit diffuse wall, lit by an area light: silhouette + shading + shadow
@@ -63,6 +68,8 @@ def build(name, theta=0.0, res=32, spp=64, device="cpu", theta_n=0.0):
     """``theta``: translation of the moving meshes; ``theta_n``: their vertex normals become n + theta_n * NRM_DIR (not
     renormalised: the interpolation normalises, mesh.cpp:795-797)."""
     off = theta * np.asarray(CONFIGS[name].get("dir", (1.0, 0.0, 0.0)), float)
+    if CONFIGS[name].get("motion") == "scale":
+        off = 0.0
     cam = sensor([0, 0, 4], [0, 0, 0], up=(0, 1, 0), fov=28.8415, res=res, spp=spp, rfilter="gaussian", sample_border=True)   # mi default fov; film as in test_ad_integrators.py:60-70
     d = {"type": "scene", "cam": cam}
     white = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}
@@ -78,6 +85,18 @@ def build(name, theta=0.0, res=32, spp=64, device="cpu", theta_n=0.0):
         v, n, f = sphere(1.0, (1.25, 0, 0))
         d["light"] = {"type": "mesh", "vertices": v + off, "normals": n, "faces": f,
                       "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}}
+    elif name == "scale_sphere_emitter_on_black":
+        v, n, f = sphere(1.0, (0, 0, 0))
+        d["light"] = {"type": "mesh", "vertices": v * (1.0 + theta), "normals": n, "faces": f,
+                      "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}}
+    elif name == "self_shadow_point_light":
+        v, f = rect(1.0)
+        d["plane"] = {"type": "mesh", "vertices": v + off, "faces": f, "face_normals": True, "bsdf": white}
+        v, f = rect(1.0, (-1.0, 0, 0.5), "+x")
+        v = (v - np.array([-1.0, 0, 0.5])) * np.array([1.0, 1.0, 0.5]) + np.array([-1.0, 0, 0.5])     # 2 x 1, standing on the plane
+        d["occluder"] = {"type": "mesh", "vertices": v + off, "faces": f, "face_normals": True,
+                         "bsdf": {"type": "twosided", "bsdf": white}}
+        d["light"] = {"type": "point", "position": [-4.0, 0.0, 6.0], "intensity": {"type": "rgb", "value": [50.0, 0.0, 0.0]}}
     elif name == "occluder_area_light":
         v, f = rect(1.0)
         d["plane"] = {"type": "mesh", "vertices": v, "faces": f, "face_normals": True, "bsdf": white}
@@ -188,7 +207,10 @@ def fd_check(name, device="cpu", spp=128, seeds=1, rays=32, weights="ramp", fd_s
     for seed in range(seeds):
         params = sc.param_grads()
         integ.render_backward(sc, params, g, sensor=0, seed=seed, spp=spp)
-        got.append(sum(float((params.mesh_pos(m) @ u).sum()) for m in cfg["moving"]))
+        if cfg.get("motion") == "scale":      # p(theta) = p (1 + theta)
+            got.append(sum(float((params.mesh_pos(m) * sc.vertex_positions(m)).sum()) for m in cfg["moving"]))
+        else:
+            got.append(sum(float((params.mesh_pos(m) @ u).sum()) for m in cfg["moving"]))
     dt = time.time() - t0
     h = fd_eps or cfg.get("fd_eps", 1e-3)
     fd = []

@@ -45,6 +45,8 @@ def test_device_pass_equals_the_host_build(name):
 
 
 @pytest.mark.parametrize("name,spp,tol", [
+    ("scale_sphere_emitter_on_black", 2048, 0.1),    # :438-460
+    ("self_shadow_point_light", 4096, 0.35),         # :551-596 (all-ones weights, as there: the ramp's answer is ~0)
     ("receiver_point_light", 256, 0.01),
     ("receiver_along_normal", 1024, 0.06),
     ("corner_along_normal", 1024, 0.06),
@@ -55,7 +57,8 @@ def test_device_pass_equals_the_host_build(name):
     ("diffuse_sphere_area_light", 4096, 0.15),
 ])
 def test_backward_gradient_matches_finite_differences(name, spp, tol):
-    got, fd, dt = fd_check(name, device="cuda", spp=spp, rays=64, seeds=2, fd_eps=0.0 if "emitter" in name else 5e-3, fd_spp_mult=2)
+    got, fd, dt = fd_check(name, device="cuda", spp=spp, rays=64, seeds=2, fd_eps=0.0 if "emitter" in name else 5e-3, fd_spp_mult=2,
+                           weights="ones" if name == "self_shadow_point_light" else "ramp")
     r, g, f = rel(got, fd)
     print(f"{name}: grad {g:+.3f} per seed {[round(x, 2) for x in got]}, FD {f:+.3f} per seed {[round(x, 2) for x in fd]}, rel {r:.3f}, "
           f"{dt:.2f} s for the backward passes")

@@ -83,6 +83,7 @@ def test_emitter_moving_inside_the_image_matches_the_closed_form():
     ("corner_along_normal", 32, 128, 0.08),          # + the neighbours' BSDFs (`extra`, prb_reparam.py:515-542)
     ("rectangle_emitter_on_black", 32, 128, 0.15),   # the reference's thresholds for these two: 0.2 and 0.15
     ("sphere_emitter_on_black", 32, 128, 0.15),
+    ("scale_sphere_emitter_on_black", 32, 128, 0.1),  # :438-460, its threshold
 ])
 def test_smooth_and_silhouette_configs_match_finite_differences(name, rays, spp, tol):
     r, g, f = rel(*fd_check(name, spp=spp, rays=rays, seeds=1, fd_spp_mult=4)[:2])
