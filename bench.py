@@ -32,7 +32,11 @@ HIP events on the launch stream around every launch of the timed region; next to
 the flag words) and ``valu_floor_ms`` (the kernel's vector instructions at one per four
 clocks and SIMD, from the committed counter run), so that the line says which bound applies;
 ``cpu_baseline`` times oracle/ (the C restatement: tangent + calc_grad + scatter) on this
-box's host cores on a bounded sample of the same records.
+box's host cores on a bounded sample of the same records.  Secondary keys, all outside the
+timed region (default run only): ``configs_1`` (BASELINE.json configs[1]), ``real_scene``
+(render_backward on records the library's own tracer produces: trace + native log + backward
+pass) and ``hybrid_phase2`` (prb_reparam's render_backward on the same traced scene: the
+reparameterised pass of the hybrid scheme's second phase).
 """
 from __future__ import annotations
 

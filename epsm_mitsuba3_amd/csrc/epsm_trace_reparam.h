@@ -262,7 +262,9 @@ EPSM_HD void warp_collect(const EpsmScene &S, const ReparamCfg &cfg, Pcg32 &rng,
 // accumulation into the gradient buffers
 // ---------------------------------------------------------------------------
 EPSM_HD void acc_add(float *p, float v) {
-    if (v == 0.f) return;
+    // (a degenerate contribution -- a grazing ray's 1 / 0, a zero-length normal -- is dropped here instead of poisoning the
+    // row for good; the reference scrubs NaN from the final parameter gradients, EPSM/optim.py:143-154)
+    if (v == 0.f || !(fabsf(v) <= 3.0e38f)) return;
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicAdd(p, v);
 #else
