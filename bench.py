@@ -229,7 +229,12 @@ def cpu_baseline(trace, grad_in, variant, V, B, target_s):
     return {"value": n1 / dt1, "unit": "paths/s", "cores": int(cores), "kind": "port",
             "sample": f"tangent + calc_grad + scatter (epsm.py:238-297) on the first {n1} paths of slab 0 of the same "
                       f"workload, oracle/epsm_oracle.c (fp32) + oracle/epsm_oracle_aux.c (fp64), OpenMP on {int(cores)} "
-                      f"threads, {dt1:.2f} s"}
+                      f"threads, {dt1:.2f} s",
+            # the only number from the reference's OWN code (it cannot travel to the GPU box): BASELINE.md section 2
+            "reference_code": {"value": 4.8e4, "unit": "paths/s", "cores": 8,
+                               "what": "the reference's calc_grad (torch, CPU) imported in place at survey time, manifold, "
+                                       "N = 262 144, K = 5, 8 threads of the build container (BASELINE.md section 2): calc_grad "
+                                       "only, not measured in this run"}}
 
 
 def secondary_config_leg(index, dev):
