@@ -11,8 +11,8 @@ gradients arrive through ``si_follow.p * diffuse_grad[0]`` (the figure itself, e
 term (its shadow, epsm.py:609-620).  The backward sensor is 256 x 256 at 8 spp = 524 288 paths, BASELINE.json's configs[4].
 At that matching resolution the 5-D clouds have 65 536 points: as dense torch the Sinkhorn matcher is four 17 GB cost
 matrices and 6.7 s per call; on ``epsm_sinkhorn_softmin`` (csrc/epsm_matcher.hip, what ``Matcher`` uses on a GPU) it is
-0.21 s and no matrix (`matcher = "Sinkhorn"`), and brings the vertices to 53 % of their initial distance.  The default
-here is the reference's own sort-based ``match_sliced_wasserstein`` (utils/matcher.py:76-180): 0.1 s per call, 34 %.
+0.21 s and no matrix.  ``matcher = "Sinkhorn"`` is the reference's choice for this experiment (optim_human.py:105) and,
+since round 3, the default here: see the note below on what the sort-based ``match_sliced_wasserstein`` does to this loop.
 
 exp/human_tube.py keeps round 1's three-bone tube (large bends, coarse image)."""
 import numpy as np
@@ -21,37 +21,33 @@ import torch
 from ..scene import Scene, look_at
 from .body_model import SMPL
 
-it = 25                                                                   # exp/human.py:6-11: 1000, 64, 512, 1200, 3, 256
+it = 200                                                                  # exp/human.py:6-11: 1000, 64, 512, 1200, 3, 256
 spp = 64
 resolution = 512
-thres = 1200
+thres = 1200                                                              # (> it: the reference's hybrid never switches here)
 max_depth = 3
 match_res = 256
-matcher = "sliced_wasserstein"
-lr = 0.003                                                                # optim_human.py:57: 0.01 -- see the note below
+matcher = "Sinkhorn"                                                      # optim_human.py:105 match_Sinkhorn
+lr = 0.01                                                                 # optim_human.py:57
 POSE_CLAMP = 0.1                                                          # optim_human.py:96
 
-# What the loop does here (tools/try_human.py, profiles/r02_e_human_loop.txt, profiles/r03_b_human_terms.txt): from the zero
-# pose the mean distance of the vertices from the target's falls from 6.0 cm to 2.0 cm and the image MSE to 17 % within about 12
-# steps of 0.003 (four steps of 0.01); it does NOT stay there: ~30 steps later most angles sit at the +-0.1 clamp with the image
-# worse than at the start.  It is not Adam (plain gradient steps do the same) and the matcher's own loss rises with the image MSE
-# after the minimum.  Round 3 took the gradient apart (tools/try_human_proj.py, tools/try_human_translate.py):
-#   * round 2's candidate -- the first-hit term slides a visible point INSIDE its tilted triangle, i.e. also along the view
-#     ray, 1/cos(tilt) times the screen-parallel motion the matcher asked for -- is NOT the cause: with that displacement
-#     projected onto the plane perpendicular to the view ray (an experiment; the reference's formula, epsm.py:250-272, keeps the
-#     component) the loop reaches the same minimum (2.1 cm) and drifts just the same (15 cm after 120 steps of 0.01, 22 cm without);
-#   * each term alone drifts: first-hit only 2.5 cm -> 17 cm, occluder (shadow) only never below 5.6 cm;
-#   * neither term has the wrong sign: with the SAME body translated by 5 cm as the target the mean step of the vertices has
-#     cosine 0.78 .. 1.0 with the offset for either term in every direction it can see (the shadow cannot lift the body: its
-#     displacements lie in the floor plane);
-#   * it is not the matcher chasing Monte-Carlo noise: with the primal image at 1024 spp the history is the same;
-#   * at the target pose the seed-averaged pose gradient is 8 % of the one at the zero pose, and at the zero pose its cosine
-#     with (pose - target) is 0.23: a descent direction, most of whose length is in angles the two views barely determine.
-# What remains is what the optimiser does with 72 angles of which a handful are observed: Adam's normalised step (0.01 per
-# iteration on a +-0.1 range, optim_human.py:57,96) moves an unobserved angle at full speed along whatever consistent sign its
-# small gradient has.  Whether the reference's own run behaves the same cannot be checked here (no Dr.Jit, no SMPL assets):
-# the formulas are its own, pinned term by term.  exp/human_tube.py, which frees only the angles the view
-# determines, converges and stays.  The test therefore checks the descent (tests/test_gpu_optim.py), not a fixed point.
+# What the loop does (profiles/r03_f_human_field.txt; tools/try_human_{bias,target,jacobian}.py), mean distance of the vertices
+# from the target's, 6.0 cm at the zero pose:
+#   * at the reference's settings (Adam 0.01, match_Sinkhorn, clamp): 6.0 -> 2.6 cm by iteration 30, then 3.5 cm (58 %) and
+#     STAYS there for 200 iterations; the image MSE falls to 23 % and stays; 49 of the 72 angles end at the clamp.  The field's
+#     fixed point is not the target pose: the same with a noise-free, unrounded or per-iteration re-rendered target.
+#   * rounds 1-2 ran it with the sort-based matcher (0.1 s instead of 0.25 s per call) and saw it run away to 21 cm after a
+#     minimum of 2 cm at iteration ~5.  Not Adam, not noise, not a term (rounds 2-3 excluded those): the Jacobian of the field
+#     the optimiser follows, J = d(pose gradient)/d(pose) at the target pose, is 68 % antisymmetric with eigenvalues of its
+#     symmetric part down to -13.5 (of +51) -- root rotation against the spine's, directions the image barely sees -- where a
+#     gradient field has a symmetric positive semi-definite one.  With match_Sinkhorn: 23 % antisymmetric, eigenvalues >= -1.1.
+#     The geometric half is not the cause: render_backward is linear in the matcher's field (the seed-mean of the pose gradient
+#     at the target pose IS the image of the matcher's mean field; with that removed it vanishes into the noise).
+#   * the problem itself is well posed: prb_reparam (true gradients of the L2 image loss, csrc/epsm_trace_reparam.h) from the
+#     same start brings the vertices to 0.6 cm (10 %) and the image MSE to 1 %, 9 angles at the clamp -- which is what the
+#     hybrid scheme is for: `manifold_hybrid` with the switch inside the run (thres = 40) ends there too
+#     (tests/test_gpu_optim.py).  Whether the reference's own run shows the 58 % plateau cannot be checked here (no Dr.Jit, no
+#     SMPL assets, geomloss not installable): the formulas are its own, pinned term by term.
 
 
 def target_pose() -> torch.Tensor:

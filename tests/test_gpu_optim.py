@@ -42,18 +42,38 @@ def test_tube_pose_is_recovered_through_per_vertex_gradients():
     assert min(hist[-15:]) < 0.35 * hist[0], hist
 
 
-def test_body_pose_descends_through_the_skinning_module():
+def test_body_pose_converges_and_stays_at_the_reference_settings():
     """Config 5 as the reference runs it (optim_human.py): 72 pose angles -> exp/body_model.py (SMPL's function, 6 890
     vertices, 7 829 in the atlas) -> renderer; backward sensor 256 x 256 @ 8 spp = 524 288 paths; per-vertex gradients
-    chained with sum(verts * grad).backward(); pose clamped to +-0.1.  From the zero pose the loop brings the vertices
-    to within 45 % of their initial mean distance from the target's (2.0 of 6.0 cm measured); see exp/human.py on
-    what happens when it is left running."""
+    chained with sum(verts * grad).backward(); Adam lr 0.01, match_Sinkhorn, pose clamped to +-0.1; 200 iterations.  The
+    assertion is on the END of the history, not on its minimum: 6.0 -> 3.5 cm and staying (measured last-20
+    mean 0.58 of the start; exp/human.py on why not closer)."""
+    import numpy as np
     from epsm_mitsuba3_amd.optim import run
     from epsm_mitsuba3_amd.exp import human
+    assert (human.matcher, human.lr, human.it) == ("Sinkhorn", 0.01, 200)
     hist, opt = run("manifold", "human", log=lambda s: None)
     assert len(hist) == human.it + 1 and 0.05 < hist[0] < 0.07
-    assert min(hist) < 0.45 * hist[0], hist
+    print("last-20 mean / start", np.mean(hist[-20:]) / hist[0], "max of last 60 / start", max(hist[-60:]) / hist[0], "best", min(hist) / hist[0])
+    assert np.mean(hist[-20:]) < 0.68 * hist[0] and max(hist[-60:]) < 0.75 * hist[0], hist[::10]
     assert float(opt["pose"].detach().abs().max()) <= human.POSE_CLAMP + human.lr * 1.5
+
+
+def test_body_pose_is_recovered_by_the_hybrid_scheme():
+    """`manifold_hybrid` with the switch inside the run: 40 manifold iterations, then prb_reparam's gradients of the L2
+    image loss through the same skinning module (EPSM/optim_human.py:66-74, 100-114): ends below 20 % of the initial vertex
+    distance and stays (measured 10 %)."""
+    import numpy as np
+    from epsm_mitsuba3_amd.optim import run
+    from epsm_mitsuba3_amd.exp import human
+    old = human.thres, human.spp
+    human.thres, human.spp = 40, 16
+    try:
+        hist, opt = run("manifold_hybrid", "human", iterations=140, log=lambda s: None)
+    finally:
+        human.thres, human.spp = old
+    print("at the switch", hist[40] / hist[0], "last-20 mean / start", np.mean(hist[-20:]) / hist[0])
+    assert np.mean(hist[-20:]) < 0.2 * hist[0] and max(hist[-20:]) < 0.25 * hist[0], hist[::10]
 
 
 def test_objects_seen_in_a_mirror_are_moved_onto_their_targets():
