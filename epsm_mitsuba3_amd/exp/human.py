@@ -21,7 +21,7 @@ import torch
 from ..scene import Scene, look_at
 from .body_model import SMPL
 
-it = 200                                                                  # exp/human.py:6-11: 1000, 64, 512, 1200, 3, 256
+it = 1000                                                                 # exp/human.py:6-11: 1000, 64, 512, 1200, 3, 256
 spp = 64
 resolution = 512
 thres = 1200                                                              # (> it: the reference's hybrid never switches here)

@@ -222,6 +222,44 @@ def test_small_wavefront_forms_agree(kind, profile, K, res, spp, V, monkeypatch)
     print(kind, profile, assert_two_routes_agree(ref, bufs["two stages"], bufs["lo"], bufs["hi"]))
 
 
+@pytest.mark.parametrize("kind,profile", [("manifold", "bathroom"), ("manifold_caustic", "pool")])
+def test_tiny_terms_and_a_disabled_clamp_sum_alike_in_both_window_forms(kind, profile, monkeypatch):
+    """the accumulating kernel's LDS rows are 64-bit fixed point (44 fractional bits) while the clamp bounds the
+    terms, float rows when the caller disables it (clip <= 0).  (a) A gradient image scaled to 1e-8 -- terms around 1e-11,
+    as from a mean-normalised loss -- gives the sums of the float route (the reference-shaped two stages) in the small-
+    wavefront form AND in the large one; (b) with the clamp off (float rows) the two forms agree with each other."""
+    import epsm_mitsuba3_amd as epsm
+    dev = torch.device("cuda", 0)
+    res, spp, K, V, B = 128, 16, 4, 5000, 4
+    scene = epsm.SyntheticScene(res=res, n_vertices=K, n_scene_vertices=V, n_bsdfs=B, profile=profile, device=dev, tile_paths=res * res * spp)
+    g = torch.Generator().manual_seed(6)
+    base = (torch.randn((res, res, 5), generator=g) * 1e-3).to(dev)
+    for what, scale, clip in (("tiny terms", 1e-5, 0.1), ("clamp off", 1.0, 0.0)):
+        bufs = {}
+        for name, env, fused in (("small form", {}, "pass"), ("large form", {"EPSM_SMALL_WAVEFRONT": "0"}, "pass"), ("two stages", {}, False)):
+            monkeypatch.delenv("EPSM_SMALL_WAVEFRONT", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            integ = epsm.load_dict({"type": kind, "max_depth": 8, "fused": fused, "outlier_clip": clip})
+            integ.backward_spp = spp
+            params = epsm.ParamGrads(V, B, device=dev)
+            integ.render_backward(scene, params, base * scale, seed=2)
+            torch.cuda.synchronize()
+            bufs[name] = params.flat.double().cpu()
+        ref = bufs["two stages"]
+        m = float(ref.abs().max())
+        assert m > 0 and torch.isfinite(ref).all(), what
+        print(what, kind, "max |sum| of the two stages", m)
+        for name in ("small form", "large form") if what == "tiny terms" else ():   # (unclamped, ill-conditioned paths dominate the two restatements' difference)
+            d = (bufs[name] - ref).abs()
+            # the two restatements of the per-path arithmetic part on ill-conditioned paths (test_small_wavefront_forms_agree);
+            # what must NOT appear is a quantisation floor or a saturated row: mean difference and the bulk of the elements
+            assert float(d.mean()) <= 2e-4 * m and float((d > 1e-2 * m).double().mean()) < 1e-3, (what, name, float(d.mean()) / m, float(d.max()) / m)
+        ms = float(bufs["small form"].abs().max())
+        assert torch.isfinite(bufs["small form"]).all() and torch.isfinite(bufs["large form"]).all(), what
+        assert float((bufs["small form"] - bufs["large form"]).abs().max()) <= 2e-4 * ms, what     # same arithmetic: order of the additions only
+
+
 def _permute_info(info, perm):
     out = []
     for rec in info:
