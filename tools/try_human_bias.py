@@ -55,11 +55,11 @@ rms = lambda t: float(t.pow(2).mean().sqrt())
 print(f"# {mname}, render {spp} spp vs target {gt_spp} spp, {S} seeds, AT the target pose")
 print(f"image: mean render - target (LDR, resized) {float((torch.stack(lows).mean(0) - gt_low).mean()):+.5f}, rms per-seed difference "
       f"{rms(torch.stack(lows) - gt_low[None]):.5f}")
-print(f"displacement field (channels 0,1): rms of one seed {rms(D[..., :2]):.4e}, rms of the MEAN over seeds {rms(M[..., :2]):.4e} "
-      f"(pure noise would give {rms(D[..., :2]) / S ** 0.5:.4e})")
+print(f"displacement field (channels 3,4 = x,y of the 5-D points r,g,b,x,y: matcher.py:51-63): rms of one seed {rms(D[..., 3:5]):.4e}, rms of the MEAN over seeds {rms(M[..., 3:5]):.4e} "
+      f"(pure noise would give {rms(D[..., 3:5]) / S ** 0.5:.4e})")
 body = (gt_low - gt_low[0, 0]).abs().sum(-1) > 0.05               # crude: pixels that differ from the corner's floor colour
 print(f"   of the mean field's energy, on pixels that differ from the floor colour ({float(body.float().mean()):.2f} of the image): "
-      f"{float(M[..., :2][body].pow(2).sum() / M[..., :2].pow(2).sum()):.2f}")
+      f"{float(M[..., 3:5][body].pow(2).sum() / M[..., 3:5].pow(2).sum()):.2f}")
 g_full = torch.stack([pose_grad(D[s], s) for s in range(S)])
 g_debiased = torch.stack([pose_grad(D[s] - M, s) for s in range(S)])
 g_mean_only = torch.stack([pose_grad(M, s) for s in range(S)])
