@@ -95,6 +95,21 @@ extern "C" int epsm_debug_warp(const EpsmScene *scene, const float *o, const flo
     out[4] = W.Z;
     return 0;
 }
+// Test probe: the hand-written ADJOINT of the same warp (same seed -> same auxiliary rays): d loss / d ray.o for given
+// d loss / d direction and d loss / d divergence.  No mesh need be attached: grad_pos may be null-sized.
+extern "C" int epsm_debug_warp_adjoint(const EpsmScene *scene, const float *o, const float *d, const float *g_dir, float g_div, int rays,
+                                       float kappa, float exponent, uint32_t seed, float *grad_pos, float *out) {
+    rp::ReparamCfg cfg; cfg.max_depth = 8; cfg.rays = rays; cfg.kappa = kappa; cfg.exponent = exponent;
+    Pcg32 rng = seed_sampler(seed, 0);
+    uint32_t stack[kBvhStack];
+    rp::Warp W;
+    rp::warp_collect(*scene, cfg, rng, ld3(o), ld3(d), BvhStack{stack, 1}, W);
+    rp::GradOut G; G.pos = grad_pos; G.nrm = nullptr;
+    F3 g_o, g_d;
+    rp::warp_backward(*scene, G, W, ld3(g_dir), g_div, g_o, g_d);
+    out[0] = g_o.x; out[1] = g_o.y; out[2] = g_o.z; out[3] = g_d.x; out[4] = g_d.y; out[5] = g_d.z;
+    return 0;
+}
 
 // The wavefront form, stage by stage as the device launches them (serial loops in place of the kernels; the queues
 // are appended in path order here, on the device in the order the waves arrive -- per-path results do not depend on it).

@@ -153,3 +153,72 @@ def test_sample_border_widens_the_wavefront_not_the_image():
     # the manifold integrators' sensors have no border (epsm.py:239-246 maps path -> pixel without one)
     with pytest.raises(ValueError, match="sample border"):
         next(iter(sc.iter_traces(0, 0, 4, 3)))
+
+
+def test_film_adjoint_against_autograd_of_the_splat():
+    """integrators.film_adjoint_reparam = the adjoint of `image[p] = sum_i w_ip L_i det_i / sum_i w_ip det_i` (gaussian of
+    stddev 0.5, radius 2, minus its value at the radius: src/rfilters/gaussian.cpp; common.py:888-903) w.r.t. every sample's
+    radiance, film position and determinant: against torch autograd of that expression written densely."""
+    from epsm_mitsuba3_amd.integrators import film_adjoint_reparam
+    torch.manual_seed(3)
+    H = W = 9
+    n = 300
+    pos = (torch.rand(n, 2, dtype=torch.float64) * (W + 3) - 1.5).requires_grad_(True)      # some samples in the border, some outside
+    L = (torch.rand(n, 3, dtype=torch.float64) * 2).requires_grad_(True)
+    det = torch.ones(n, dtype=torch.float64, requires_grad=True)
+    grad_img = torch.randn(H, W, 3, dtype=torch.float64)
+    radius, alpha = 2.0, -1.0 / (2.0 * 0.5 * 0.5)
+    bias = math.exp(alpha * radius * radius)
+    cx = torch.arange(W, dtype=torch.float64) + 0.5
+    cy = torch.arange(H, dtype=torch.float64) + 0.5
+
+    def w1(c, p):
+        d = c[None, :] - p[:, None]
+        return torch.where(d.abs() <= radius, (torch.exp(alpha * d * d) - bias).clamp_min(0), torch.zeros_like(d))
+    wx, wy = w1(cx, pos[:, 0]), w1(cy, pos[:, 1])                      # (n,W), (n,H)
+    w = wy[:, :, None] * wx[:, None, :] * det[:, None, None]          # (n,H,W)
+    num = (w[..., None] * L[:, None, None, :]).sum(0)
+    den = w.sum(0)
+    image = num / den.clamp_min(1e-30)[..., None]
+    (image * grad_img).sum().backward()
+    accum = torch.cat([num, den[..., None]], -1).detach().float()
+    dL, adj = film_adjoint_reparam(pos.detach().float(), L.detach().float(), grad_img.float(), accum)
+    assert torch.allclose(dL.double(), L.grad, rtol=2e-4, atol=2e-5 * float(L.grad.abs().max()))
+    want = torch.cat([pos.grad, det.grad[:, None]], 1)
+    assert torch.allclose(adj.double(), want, rtol=2e-3, atol=2e-4 * float(want.abs().max())), float((adj.double() - want).abs().max())
+
+
+def test_warp_adjoint_is_the_transpose_of_its_forward_mode():
+    """<g, J u> = <J^T g, u>: the forward mode of one warp (origin moving with velocity u: V_theta, div V_theta,
+    reparam.py:155-221) against the hand-written adjoint (reparam.py:269-333 in closed form, warp_backward) on the SAME
+    auxiliary rays, and the same identity for a rigid translation of the mesh the rays hit (every hit point moves by u, the
+    origin stays: the adjoint's vertex rows summed)."""
+    v, f = rect(1.5, (0, 0, 2.0))
+    d = {"type": "scene", "cam": sensor([0, 0, 4], [0, 0, 0], res=8),
+         "wall": {"type": "mesh", "vertices": v, "faces": f[:, ::-1], "face_normals": True,
+                  "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}}}
+    sc = on_host(S.Scene.from_dict(d, device="cpu"))
+    sc.attach("wall", positions=True)
+    lib = host_tracer()
+    rng = np.random.default_rng(0)
+    o = np.array([0.2, -0.1, 0.0], np.float32)
+    for trial in range(6):
+        w = np.array([rng.normal() * 0.3, rng.normal() * 0.3, 1.0], np.float32); w /= np.linalg.norm(w)
+        if trial >= 4:                                          # towards the rectangle's edge: some auxiliary rays miss
+            w = np.array([1.5 - 0.2, 0.3, 2.0], np.float32) - o; w[0] += 0.003 * (trial - 4); w /= np.linalg.norm(w)
+        u = rng.normal(size=3).astype(np.float32)
+        g_dir = rng.normal(size=3).astype(np.float32); g_dir -= w * (w @ g_dir)
+        g_div = np.float32(rng.normal())
+        fwd = (C.c_float * 5)()
+        adj = (C.c_float * 6)()
+        gp = np.zeros((sc.V, 3), np.float32)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        kappa = 1e3 if trial >= 4 else 1e4
+        lib.epsm_debug_warp(C.byref(sc.c_scene), ptr(o), ptr(w), ptr(u), 32, C.c_float(kappa), C.c_float(3.0), C.c_uint32(trial), fwd)
+        lib.epsm_debug_warp_adjoint(C.byref(sc.c_scene), ptr(o), ptr(w), ptr(g_dir), C.c_float(g_div), 32, C.c_float(kappa), C.c_float(3.0),
+                                    C.c_uint32(trial), ptr(gp), adj)
+        lhs = float(g_dir @ np.array(fwd[:3]) + g_div * fwd[3])
+        rhs = float(np.array(adj[:3]) @ u)
+        assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), 1e-3), (trial, lhs, rhs)
+        # the mesh translated by u with the origin fixed moves every hit point as the origin moved by -u
+        assert abs(float(gp.sum(0) @ u) + rhs) <= 2e-3 * max(abs(rhs), 1e-3), (trial, float(gp.sum(0) @ u), rhs)
