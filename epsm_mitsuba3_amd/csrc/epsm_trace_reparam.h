@@ -181,7 +181,7 @@ struct Warp {
 struct ReparamCfg { int max_depth, rays; float kappa, exponent; };
 
 // Boundary term of a hit (mesh.cpp:832-887; rectangle.cpp:320-321 for the tessellated rectangles)
-EPSM_HD float boundary_test(const EpsmScene &S, const TriHit &th, F3 ray_o, F3 ray_d) {
+EPSM_HD float boundary_test(const EpsmScene &S, const TriHit &th, F3 ray_d) {
     const uint32_t mi = S.tri_mesh[th.tri];
     const EpsmMesh m = S.meshes[mi];
     const float u = th.u, v = th.v, w = 1.f - u - v;
@@ -244,7 +244,7 @@ EPSM_HD void warp_collect(const EpsmScene &S, const ReparamCfg &cfg, Pcg32 &rng,
             const float dist = sqrtf(dot(r, r));
             if (dist > 0.f) {
                 A.tri = th.tri; A.b1 = th.u; A.b2 = th.v; A.inv_dist = 1.f / dist; A.v = r * A.inv_dist;
-                B = boundary_test(S, th, o, ar.d);
+                B = boundary_test(S, th, ar.d);
             }
         }
         const float inv_vmf = 1.f / (sy_ * expf(-2.f * kappa) + (1.f - sy_));            // reparam.py:111
