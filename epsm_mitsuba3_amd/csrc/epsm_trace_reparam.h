@@ -15,6 +15,9 @@
 // gradient buffers and (b) to the hand-derived adjoint of the warp field (reparam.py:269-327), which distributes them over
 // the triangles its auxiliary rays hit (`FollowShape`: si.p = sum b_j p_j with the b_j detached) and over the ray origin.
 // Sampling is detached as in the reference (pdfs, MIS weights, emitter samples are constants).
+// Where a warp is traced is a policy (`Sink`): on the spot, one auxiliary ray after the other (InlineSink: the host build,
+// the test probes), or left as a request for a second launch that gives every auxiliary ray its own lane (QueueSink:
+// epsm_trace_reparam.hip).  Every auxiliary ray has its own random stream, so both trace the same rays.
 //
 // PARITY UNPINNED by the reference (no Dr.Jit here): pinned by the reference's OWN recipe for this integrator
 // (src/integrators/tests/test_ad_integrators.py:833-871: backward gradient against finite differences of the primal
@@ -216,45 +219,55 @@ EPSM_HD float boundary_test(const EpsmScene &S, const TriHit &th, F3 ray_d) {
     return dp * dp;
 }
 
+// Which warp of which path: the n-th reparameterize_ray call of path `widx` under the reparameterisation's own seed
+// (common.py:1196-1203: 0xffffffff ^ seed).  Every auxiliary ray draws from its OWN stream, keyed by (seed, path, call,
+// ray), so that the rays of a warp can be traced by different lanes (the device's second stage) or one after the other
+// (the host build) with the same numbers.
+struct WarpId { uint32_t key, widx; int n; };
+EPSM_HD Aux aux_ray(const EpsmScene &S, const ReparamCfg &cfg, const WarpId &id, int r, F3 o, F3 d, F3 fs, F3 ft, const BvhStack &st) {
+    Pcg32 rng = seed_sampler(id.key ^ (0x9E3779B9u * (uint32_t) (id.n * 64 + r + 1)), id.widx);
+    const float kappa = cfg.kappa;
+    const float sx = rng.next_1d(), sy_ = rng.next_1d();
+    // warp.h:559-566 square_to_von_mises_fisher (1 - cos^2 formed without the cancellation of fp32)
+    const float sy = fmaxf(1.f - sy_, 1e-6f);
+    const float e = logf(sy + (1.f - sy) * expf(-2.f * kappa)) / kappa;             // cos_theta - 1 <= 0
+    const float cos_theta = 1.f + e, sin_theta = safe_sqrt(-e * (2.f + e));
+    const float phi = 2.f * kPi * sx;
+    const F3 ol = f3(cosf(phi) * sin_theta, sinf(phi) * sin_theta, cos_theta);
+    Ray ar; ar.o = o; ar.d = fs * ol.x + ft * ol.y + d * ol.z; ar.maxt = kInf;
+    const TriHit th = intersect<false>(S, ar, st);
+    Aux A;
+    float B = 1.f;                                                         // reparam.py:104
+    A.tri = kNoIndex; A.b1 = A.b2 = 0.f; A.inv_dist = 0.f; A.v = d;
+    if (th.hit) {
+        const uint32_t *iv = S.tri + 3 * (int64_t) th.tri;
+        const F3 p = ld3(S.positions + 3 * (int64_t) iv[0]) * (1.f - th.u - th.v) + ld3(S.positions + 3 * (int64_t) iv[1]) * th.u +
+                     ld3(S.positions + 3 * (int64_t) iv[2]) * th.v;
+        const F3 r3 = p - o;
+        const float dist = sqrtf(dot(r3, r3));
+        if (dist > 0.f) {
+            A.tri = th.tri; A.b1 = th.u; A.b2 = th.v; A.inv_dist = 1.f / dist; A.v = r3 * A.inv_dist;
+            B = boundary_test(S, th, ar.d);
+        }
+    }
+    const float inv_vmf = 1.f / (sy_ * expf(-2.f * kappa) + (1.f - sy_));                // reparam.py:111
+    const float w_denom = inv_vmf - 1.f + B;
+    const float w_denom_rcp = w_denom > 1e-4f ? 1.f / w_denom : 0.f;
+    const float w = powf(w_denom_rcp, cfg.exponent) * inv_vmf;
+    const float tmp1 = fminf(fmaxf(inv_vmf * w * w_denom_rcp * kappa * cfg.exponent, -1e10f), 1e10f);
+    A.w = w;
+    A.dw = (fs * ol.x + ft * ol.y) * tmp1;
+    return A;
+}
 // One call of reparameterize_ray's sampling loops (reparam.py:249-267 and 300-328 trace the same rays: kept instead of
-// traced twice).  `rng` is the reparameterisation's own stream (common.py:1196-1203).
-EPSM_HD void warp_collect(const EpsmScene &S, const ReparamCfg &cfg, Pcg32 &rng, F3 o, F3 d, const BvhStack &st, Warp &W) {
+// traced twice).
+EPSM_HD void warp_collect(const EpsmScene &S, const ReparamCfg &cfg, const WarpId &id, F3 o, F3 d, const BvhStack &st, Warp &W) {
     W.n = cfg.rays; W.Z = 0.f; W.dZ = zero3<float>(); W.o = o; W.d = d;
     F3 fs, ft;
     coordinate_system(d, fs, ft);                                          // Frame3f(ray.d)
-    const float kappa = cfg.kappa;
     for (int it = 0; it < cfg.rays; ++it) {
-        const float sx = rng.next_1d(), sy_ = rng.next_1d();
-        // warp.h:559-566 square_to_von_mises_fisher (1 - cos^2 formed without the cancellation of fp32)
-        const float sy = fmaxf(1.f - sy_, 1e-6f);
-        const float e = logf(sy + (1.f - sy) * expf(-2.f * kappa)) / kappa;         // cos_theta - 1 <= 0
-        const float cos_theta = 1.f + e, sin_theta = safe_sqrt(-e * (2.f + e));
-        const float phi = 2.f * kPi * sx;
-        const F3 ol = f3(cosf(phi) * sin_theta, sinf(phi) * sin_theta, cos_theta);
-        Ray ar; ar.o = o; ar.d = fs * ol.x + ft * ol.y + d * ol.z; ar.maxt = kInf;
-        const TriHit th = intersect<false>(S, ar, st);
-        Aux &A = W.a[it];
-        float B = 1.f;                                                     // reparam.py:104
-        A.tri = kNoIndex; A.b1 = A.b2 = 0.f; A.inv_dist = 0.f; A.v = d;
-        if (th.hit) {
-            const uint32_t *iv = S.tri + 3 * (int64_t) th.tri;
-            const F3 p = ld3(S.positions + 3 * (int64_t) iv[0]) * (1.f - th.u - th.v) + ld3(S.positions + 3 * (int64_t) iv[1]) * th.u +
-                         ld3(S.positions + 3 * (int64_t) iv[2]) * th.v;
-            const F3 r = p - o;
-            const float dist = sqrtf(dot(r, r));
-            if (dist > 0.f) {
-                A.tri = th.tri; A.b1 = th.u; A.b2 = th.v; A.inv_dist = 1.f / dist; A.v = r * A.inv_dist;
-                B = boundary_test(S, th, ar.d);
-            }
-        }
-        const float inv_vmf = 1.f / (sy_ * expf(-2.f * kappa) + (1.f - sy_));            // reparam.py:111
-        const float w_denom = inv_vmf - 1.f + B;
-        const float w_denom_rcp = w_denom > 1e-4f ? 1.f / w_denom : 0.f;
-        const float w = powf(w_denom_rcp, cfg.exponent) * inv_vmf;
-        const float tmp1 = fminf(fmaxf(inv_vmf * w * w_denom_rcp * kappa * cfg.exponent, -1e10f), 1e10f);
-        A.w = w;
-        A.dw = (fs * ol.x + ft * ol.y) * tmp1;
-        W.Z += w; W.dZ = W.dZ + A.dw;
+        W.a[it] = aux_ray(S, cfg, id, it, o, d, fs, ft, st);
+        W.Z += W.a[it].w; W.dZ = W.dZ + W.a[it].dw;
     }
 }
 
@@ -471,10 +484,41 @@ EPSM_HD F3 film_to_direction(const EpsmSensor &C, const PrimaryRay &pr, float gx
     return c0 * gq.x + c1 * gq.y + c2 * gq.z;
 }
 
-// The differential step of one vertex (prb_reparam.py:341-589).  `primary`: the warp of the camera ray collected by
-// the caller for the first vertex (shared with the film's reparameterisation), null otherwise.
-EPSM_HD void differential(const ReparamArgs &R, Pcg32 &rng, const BvhStack &st, const Vertex *prev, const Vertex &cur,
-                          const Vertex *next, F3 dL, Warp &W, F3 *primary_g_dir) {
+// What happens to a warp once its ray and the adjoints of its direction / divergence are known.
+//   o, d            the ray; g_dir, g_div: d loss / d direction, d loss / d divergence of its reparameterisation
+//   ftri, fb1, fb2  the triangle + barycentrics its ORIGIN is glued to (kNoIndex: the camera)
+//   em_inv_dist     emitter rays: 1 / |ds.p - o| -- their direction normalize(ds.p - o) follows the origin; else 0
+// InlineSink: traced and back-propagated on the spot (the host build, and epsm_debug_*).
+struct InlineSink {
+    const EpsmScene &S; const ReparamCfg &cfg; const GradOut &G; const BvhStack &st; Warp &W; WarpId id;
+    EPSM_HD void warp(F3 o, F3 d, F3 g_dir, float g_div, uint32_t ftri, float fb1, float fb2, float em_inv_dist) {
+        warp_collect(S, cfg, id, o, d, st, W);
+        id.n += 1;
+        F3 g_o, g_d;
+        warp_backward(S, G, W, g_dir, g_div, g_o, g_d);
+        if (em_inv_dist != 0.f) g_o = g_o - (g_d - d * dot(d, g_d)) * em_inv_dist;
+        if (ftri != kNoIndex) add_follow_point(S, G, ftri, fb1, fb2, g_o);
+    }
+};
+// QueueSink: the request is written for the second stage (epsm_trace_reparam.hip), the n-th of path i at req[n * N + i].
+struct alignas(16) WarpReq { float o[3], gdiv, d[3], em_inv_dist, gdir[3], fb1; uint32_t ftri; float fb2, pad0, pad1; };
+constexpr int kMaxReq = 1 + 2 * 6;           // the camera ray + two warps per vertex (epsm.py:549: at most six vertices)
+struct QueueSink {
+    WarpReq *req; int64_t N, i; int n;
+    EPSM_HD void warp(F3 o, F3 d, F3 g_dir, float g_div, uint32_t ftri, float fb1, float fb2, float em_inv_dist) {
+        if (n >= kMaxReq) return;
+        WarpReq q;
+        q.o[0] = o.x; q.o[1] = o.y; q.o[2] = o.z; q.gdiv = g_div; q.d[0] = d.x; q.d[1] = d.y; q.d[2] = d.z; q.em_inv_dist = em_inv_dist;
+        q.gdir[0] = g_dir.x; q.gdir[1] = g_dir.y; q.gdir[2] = g_dir.z; q.fb1 = fb1; q.ftri = ftri; q.fb2 = fb2; q.pad0 = q.pad1 = 0.f;
+        req[(int64_t) n * N + i] = q;
+        n += 1;
+    }
+};
+
+// The differential step of one vertex (prb_reparam.py:341-589).  The camera ray's direction adjoint goes back to the
+// caller (`primary_g_dir`): its warp also serves the film's reparameterisation.
+template <class Sink>
+EPSM_HD void differential(const ReparamArgs &R, Sink &sink, const Vertex *prev, const Vertex &cur, const Vertex *next, F3 dL, F3 *primary_g_dir) {
     const EpsmScene &S = R.A.S;
     const SurfHit &c = cur.si;
     const bool first = prev == nullptr;
@@ -501,37 +545,27 @@ EPSM_HD void differential(const ReparamArgs &R, Pcg32 &rng, const BvhStack &st, 
         add_vertex(R.G.nrm, c.vi[0], f3(g[15], g[16], g[17])); add_vertex(R.G.nrm, c.vi[1], f3(g[18], g[19], g[20]));
         add_vertex(R.G.nrm, c.vi[2], f3(g[21], g[22], g[23]));
     }
-    // ---- the ray into this vertex (prb_reparam.py:341-358): d', det (det = 1 for the camera ray: the film carries it)
+    // ---- the ray into this vertex (prb_reparam.py:341-358): d', det (det = 1 for the camera ray: the film carries it);
+    //      its origin follows the previous shape (si_prev.spawn_ray: offset_p along the detached normal)
     const F3 g_dir = f3(g[0], g[1], g[2]);
-    if (first) {
-        *primary_g_dir = g_dir;                                            // joins the film's term in the caller's warp
-    } else if (cur.depth < R.cfg.max_depth) {
-        const float g_det = dot(dL, cur.L_in);                             // (Le + Lr_dir + Lr_ind) has the value L_in
-        warp_collect(S, R.cfg, rng, cur.ray.o, cur.ray.d, st, W);
-        F3 g_o, g_d;
-        warp_backward(S, R.G, W, g_dir, g_det, g_o, g_d);
-        // the origin follows the previous shape (si_prev.spawn_ray: offset_p along the detached normal)
-        add_follow_point(S, R.G, prev->th.tri, prev->th.u, prev->th.v, g_o);
-    }
-    // ---- the emitter ray (prb_reparam.py:394-411)
+    if (first) *primary_g_dir = g_dir;
+    else if (cur.depth < R.cfg.max_depth)
+        sink.warp(cur.ray.o, cur.ray.d, g_dir, dot(dL, cur.L_in) /* (Le + Lr_dir + Lr_ind) has the value L_in */, prev->th.tri, prev->th.u, prev->th.v, 0.f);
+    // ---- the emitter ray (prb_reparam.py:394-411): em_ray.d = normalize(ds.p - o) with o glued to this triangle
+    //      (si_cur_follow.spawn_ray_to)
     if (cur.active_em && cur.depth + 1 < R.cfg.max_depth && (cur.Lr_dir.x != 0.f || cur.Lr_dir.y != 0.f || cur.Lr_dir.z != 0.f)) {
         float dist;
         const Ray er = spawn_ray_to(c, cur.es.p, dist);
-        warp_collect(S, R.cfg, rng, er.o, er.d, st, W);
-        F3 g_o, g_d;
-        warp_backward(S, R.G, W, f3(g[3], g[4], g[5]), dot(dL, cur.Lr_dir), g_o, g_d);
-        // em_ray.d = normalize(ds.p - o) with o glued to this triangle (si_cur_follow.spawn_ray_to)
-        g_o = g_o - (g_d - er.d * dot(er.d, g_d)) * (1.f / dist);
-        add_follow_point(S, R.G, cur.th.tri, cur.th.u, cur.th.v, g_o);
+        sink.warp(er.o, er.d, f3(g[3], g[4], g[5]), dot(dL, cur.Lr_dir), cur.th.tri, cur.th.u, cur.th.v, 1.f / dist);
     }
 }
 
 // One path of RBIntegrator.render_backward's second pass (common.py:944-955).
-EPSM_HD void reparam_one_path(const ReparamArgs &R, int64_t i, const BvhStack &st, Warp &W) {
+template <class Sink>
+EPSM_HD void reparam_one_path(const ReparamArgs &R, int64_t i, const BvhStack &st, Sink &sink) {
     const TraceArgs &A = R.A;
     const int64_t widx = A.path_offset + i;
     PathState s = path_begin(A, i, false);
-    Pcg32 rng = seed_sampler(0xffffffffu ^ A.seed, (uint32_t) widx);     // common.py:1196-1203
     const F3 dL = ld3(R.adj_radiance + 3 * i);
     // ---- the camera ray: one warp serves sample_rays (film position + det, common.py:405-418) and the first vertex
     PrimaryRay pr;
@@ -565,19 +599,14 @@ EPSM_HD void reparam_one_path(const ReparamArgs &R, int64_t i, const BvhStack &s
         const Vertex &cur = v[(j - 1) % 3];
         if (!cur.valid) continue;                                          // (a dead or escaped path: every term is zero)
         const Vertex *prev = j >= 2 ? &v[(j - 2) % 3] : nullptr;
-        differential(R, rng, st, prev, cur, &nx, dL, W, &g_first);
+        differential(R, sink, prev, cur, &nx, dL, &g_first);
         if (j == 1 && R.cfg.max_depth > 0) {
-            warp_collect(A.S, R.cfg, rng, pr.ray.o, pr.ray.d, st, W);
-            F3 g_o, g_d;
-            warp_backward(A.S, R.G, W, g_film + g_first, g_det_film, g_o, g_d);
+            sink.warp(pr.ray.o, pr.ray.d, g_film + g_first, g_det_film, kNoIndex, 0.f, 0.f, 0.f);
             primary_done = true;
         }
     }
-    if (!primary_done && R.cfg.max_depth > 0) {                            // the camera ray hit nothing: the film's term alone
-        warp_collect(A.S, R.cfg, rng, pr.ray.o, pr.ray.d, st, W);
-        F3 g_o, g_d;
-        warp_backward(A.S, R.G, W, g_film, g_det_film, g_o, g_d);
-    }
+    if (!primary_done && R.cfg.max_depth > 0)                              // the camera ray hit nothing: the film's term alone
+        sink.warp(pr.ray.o, pr.ray.d, g_film, g_det_film, kNoIndex, 0.f, 0.f, 0.f);
 }
 
 }  // namespace rp

@@ -11,18 +11,16 @@ using epsm_host::fail;
 
 namespace {
 
-// One lane = one path, replayed with all its auxiliary rays.  The three vertex records, the warp's auxiliary-ray table
-// (2.8 KB) and the dual numbers live in scratch: this pass is bound by its 16..64 closest-hit traversals per warp, not by
-// the bookkeeping around them.  64-thread workgroups: paths of neighbouring samples, whose auxiliary rays stay together.
-// Waves per SIMD (4.26 M paths, 128 k triangles, 16 rays, ms per render_backward): 1 (256 + 256 registers, 5.4 KB of
-// scratch) 181, 2: 127, 3: 108, 4 (128 registers, 6.7 KB) 100, 5: 103; 128-thread workgroups at 2: 137 against 127.
 #ifndef EPSM_RP_THREADS
 #define EPSM_RP_THREADS 64
 #endif
 #ifndef EPSM_RP_OCC
 #define EPSM_RP_OCC 4
 #endif
-__global__ __launch_bounds__(EPSM_RP_THREADS, EPSM_RP_OCC) void epsm_reparam_kernel(rp::ReparamArgs R) {
+// Stage 1: one lane = one path, replayed; every vertex differentiated (dual numbers, scratch: three vertex records);
+// its warps are left as requests.  (First version, auxiliary rays traced by the same lane: 182 ms per render_backward
+// at 4.26 M paths / 128 k triangles / 16 rays with one wave per SIMD, 99 ms with four.)
+__global__ __launch_bounds__(EPSM_RP_THREADS, EPSM_RP_OCC) void epsm_reparam_path_kernel(rp::ReparamArgs R, rp::WarpReq *req, int *count) {
     constexpr int kLds = 32;
     __shared__ uint32_t s_stack[kLds * EPSM_RP_THREADS];
     uint32_t deep[kBvhStack - kLds];
@@ -30,18 +28,100 @@ __global__ __launch_bounds__(EPSM_RP_THREADS, EPSM_RP_OCC) void epsm_reparam_ker
     if (i >= R.A.N) return;
     BvhStack st{s_stack + threadIdx.x, EPSM_RP_THREADS};
     st.cap = kLds; st.ovf = deep; st.ovf_stride = 1;
-    rp::Warp W;
-    rp::reparam_one_path(R, i, st, W);
+    rp::QueueSink sink{req, R.A.N, i, 0};
+    rp::reparam_one_path(R, i, st, sink);
+    count[i] = sink.n;
 }
 
+// Stage 2: one lane = one auxiliary ray.  Group g of G lanes (G = 16, 32 or 64 >= reparam_rays) serves request
+// n = g / N of path i = g % N: neighbouring groups hold the same call of neighbouring paths -- rays that start next to each
+// other and point the same way.  Z, dZ and the origin's adjoint are reduced over the group with xor shuffles.
+template <int G>
+__global__ __launch_bounds__(256) void epsm_reparam_warp_kernel(rp::ReparamArgs R, const rp::WarpReq *req, const int *count, int n_max) {
+    constexpr int kLds = 32;
+    __shared__ uint32_t s_stack[kLds * 256];
+    uint32_t deep[kBvhStack - kLds];
+    const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x, g = t / G;
+    const int r = (int) (t % G);
+    const int64_t N = R.A.N;
+    if (g >= (int64_t) n_max * N) return;
+    const int n = (int) (g / N);
+    const int64_t i = g - (int64_t) n * N;
+    if (n >= count[i]) return;                                             // (the whole group)
+    BvhStack st{s_stack + threadIdx.x, 256};
+    st.cap = kLds; st.ovf = deep; st.ovf_stride = 1;
+    const rp::WarpReq q = req[(int64_t) n * N + i];
+    const F3 o = f3(q.o[0], q.o[1], q.o[2]), d = f3(q.d[0], q.d[1], q.d[2]), g_dir = f3(q.gdir[0], q.gdir[1], q.gdir[2]);
+    F3 fs, ft;
+    coordinate_system(d, fs, ft);
+    rp::Aux A;
+    A.w = 0.f; A.dw = zero3<float>(); A.v = d; A.tri = kNoIndex; A.b1 = A.b2 = A.inv_dist = 0.f;
+    const bool mine = r < R.cfg.rays;
+    if (mine) A = rp::aux_ray(R.A.S, R.cfg, rp::WarpId{0xffffffffu ^ R.A.seed, (uint32_t) (R.A.path_offset + i), n}, r, o, d, fs, ft, st);
+    float Z = A.w; F3 dZ = A.dw;
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) { Z += __shfl_xor(Z, m); dZ.x += __shfl_xor(dZ.x, m); dZ.y += __shfl_xor(dZ.y, m); dZ.z += __shfl_xor(dZ.z, m); }
+    // the adjoint of reparam.py:269-327 at V = 0 (warp_backward, one auxiliary ray per lane)
+    Z = fmaxf(Z, 1e-8f);
+    const float iZ = 1.f / Z;
+    const F3 g_V = (g_dir - d * dot(d, g_dir)) * iZ - dZ * (q.gdiv * iZ * iZ);
+    const F3 g_v = mine ? g_V * A.w + A.dw * (q.gdiv * iZ) : zero3<float>();
+    F3 g_o = zero3<float>(), g_d = zero3<float>(), g_p = zero3<float>();
+    uint32_t pending = 0xFFFFFFFFu;                                        // the triangle this lane still owes its share to
+    if (mine) {
+        if (A.tri == kNoIndex) g_d = g_v;
+        else {
+            g_p = (g_v - A.v * dot(A.v, g_v)) * A.inv_dist;
+            g_o = -g_p;
+            if (R.A.S.meshes[R.A.S.tri_mesh[A.tri]].flags & EPSM_MESH_POS_ATTACHED) pending = A.tri;
+        }
+    }
+    // The rays of a warp mostly hit the same one or two triangles: their shares are summed over the group first, triangle
+    // by triangle, and added by one lane.  (One float atomic per ray loses the small ones: a vertex's sum over 10^7 rays
+    // is 10^5 times a single share, which then falls under half an ulp of it -- 2 % of a four-vertex wall's gradient at
+    // 256 spp.)
+    for (int round = 0; round < G; ++round) {
+        uint32_t t = pending;
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1) { const uint32_t u = (uint32_t) __shfl_xor((int) t, m); t = u < t ? u : t; }
+        if (t == 0xFFFFFFFFu) break;                                       // (uniform over the group)
+        const bool sel = pending == t;
+        const float b1 = sel ? A.b1 : 0.f, b2 = sel ? A.b2 : 0.f, b0 = sel ? 1.f - A.b1 - A.b2 : 0.f;
+        float acc[9] = {g_p.x * b0, g_p.y * b0, g_p.z * b0, g_p.x * b1, g_p.y * b1, g_p.z * b1, g_p.x * b2, g_p.y * b2, g_p.z * b2};
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] += __shfl_xor(acc[k], m);
+        if (r == 0) {
+            const uint32_t *iv = R.A.S.tri + 3 * (int64_t) t;
+            rp::add_vertex(R.G.pos, iv[0], f3(acc[0], acc[1], acc[2])); rp::add_vertex(R.G.pos, iv[1], f3(acc[3], acc[4], acc[5]));
+            rp::add_vertex(R.G.pos, iv[2], f3(acc[6], acc[7], acc[8]));
+        }
+        if (sel) pending = 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) {
+        g_o.x += __shfl_xor(g_o.x, m); g_o.y += __shfl_xor(g_o.y, m); g_o.z += __shfl_xor(g_o.z, m);
+        g_d.x += __shfl_xor(g_d.x, m); g_d.y += __shfl_xor(g_d.y, m); g_d.z += __shfl_xor(g_d.z, m);
+    }
+    if (r == 0 && q.ftri != kNoIndex) {
+        if (q.em_inv_dist != 0.f) g_o = g_o - (g_d - d * dot(d, g_d)) * q.em_inv_dist;
+        rp::add_follow_point(R.A.S, R.G, q.ftri, q.fb1, q.fb2, g_o);
+    }
+}
+
+size_t req_bytes(int64_t N) { return ((size_t) N * rp::kMaxReq * sizeof(rp::WarpReq) + 255) & ~(size_t) 255; }
+
 }  // namespace
+
+extern "C" size_t epsm_trace_reparam_workspace_bytes(int64_t N) { return N > 0 ? req_bytes(N) + (size_t) N * sizeof(int) : 0; }
 
 extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor *sensor,
                                         uint32_t seed, int spp, int max_depth, int rr_depth,
                                         int64_t path_offset, int64_t N,
                                         const float *radiance, const float *adj_radiance, const float *adj_film,
                                         int reparam_max_depth, int reparam_rays, float kappa, float exponent,
-                                        float *grad_pos, float *grad_nrm, void *stream) {
+                                        float *grad_pos, float *grad_nrm, void *workspace, size_t workspace_bytes, void *stream) {
     epsm_host::err_buf()[0] = 0;
     auto bad = [&](const char *what) { char msg[200]; snprintf(msg, sizeof(msg), "epsm_trace_paths_reparam: %s", what); return fail(EPSM_EINVAL, msg); };
     if (!scene || !sensor) return bad("NULL scene / sensor");
@@ -52,6 +132,8 @@ extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor
         path_offset + N > 0xFFFFFFFFLL)
         return bad("path range exceeds (width + 2 border) * (height + 2 border) * spp (or 2^32)");
     if (!radiance || !adj_radiance || !adj_film || !grad_pos) return bad("NULL per-path input or grad_pos");
+    if (!workspace || (((uintptr_t) workspace) & 15) || workspace_bytes < epsm_trace_reparam_workspace_bytes(N))
+        return bad("workspace: 16-byte aligned, >= epsm_trace_reparam_workspace_bytes(N)");
     if (reparam_rays < 1 || reparam_rays > rp::kMaxAux || reparam_max_depth < 0 || !(kappa > 0.f) || !(exponent > 0.f))
         return bad("need 1 <= reparam_rays <= 64, reparam_max_depth >= 0, kappa > 0, exponent > 0");
     if (scene->n_triangles <= 0 || !scene->positions || !scene->normals || !scene->tri || !scene->tri_mesh || !scene->meshes ||
@@ -66,8 +148,25 @@ extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor
     R.cfg.max_depth = reparam_max_depth; R.cfg.rays = reparam_rays; R.cfg.kappa = kappa; R.cfg.exponent = exponent;
     R.radiance = radiance; R.adj_radiance = adj_radiance; R.adj_film = adj_film;
     R.G.pos = grad_pos; R.G.nrm = grad_nrm;
-    hipLaunchKernelGGL(epsm_reparam_kernel, dim3((unsigned) ((N + EPSM_RP_THREADS - 1) / EPSM_RP_THREADS)), dim3(EPSM_RP_THREADS), 0, (hipStream_t) stream, R);
-    const hipError_t e = hipGetLastError();
+    rp::WarpReq *req = (rp::WarpReq *) workspace;
+    int *count = (int *) ((char *) workspace + req_bytes(N));
+    hipLaunchKernelGGL(epsm_reparam_path_kernel, dim3((unsigned) ((N + EPSM_RP_THREADS - 1) / EPSM_RP_THREADS)), dim3(EPSM_RP_THREADS), 0,
+                       (hipStream_t) stream, R, req, count);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_trace_paths_reparam", e);
+    if (reparam_max_depth > 0) {
+        // the n-th requests of all paths, n = 0 .. n_max - 1: the camera ray + two warps per vertex the depths allow
+        const int depth = max_depth < 6 ? max_depth : 6;
+        const int n_max = 1 + 2 * depth < rp::kMaxReq ? 1 + 2 * depth : rp::kMaxReq;
+        const int G = reparam_rays <= 16 ? 16 : reparam_rays <= 32 ? 32 : 64;
+        const int64_t threads = (int64_t) n_max * N * G;
+        const dim3 grid((unsigned) ((threads + 255) / 256));
+        if ((threads + 255) / 256 > 0x7fffffffLL) return bad("too many auxiliary rays for one launch: use smaller tiles");
+        if (G == 16) hipLaunchKernelGGL(epsm_reparam_warp_kernel<16>, grid, dim3(256), 0, (hipStream_t) stream, R, req, count, n_max);
+        else if (G == 32) hipLaunchKernelGGL(epsm_reparam_warp_kernel<32>, grid, dim3(256), 0, (hipStream_t) stream, R, req, count, n_max);
+        else hipLaunchKernelGGL(epsm_reparam_warp_kernel<64>, grid, dim3(256), 0, (hipStream_t) stream, R, req, count, n_max);
+        e = hipGetLastError();
+        if (e != hipSuccess) return epsm_host::hip_fail("epsm_trace_paths_reparam", e);
+    }
     return EPSM_OK;
 }

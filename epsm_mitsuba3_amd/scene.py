@@ -804,12 +804,19 @@ class Scene:
         for t_ in (grad_pos, grad_nrm):
             assert t_.is_contiguous() and t_.dtype == torch.float32 and tuple(t_.shape) == (self.V, 3) and t_.device.type == dev.type
         cs = self.sensors[sensor_index].c_struct()
+        wsb = lib.epsm_trace_reparam_workspace_bytes
+        wsb.restype, wsb.argtypes = C.c_size_t, [C.c_int64]
+        need = int(wsb(C.c_int64(n)))
+        ws = getattr(self, "_reparam_ws", None)
+        if ws is None or ws.numel() < max(need, 16) or ws.device != radiance.device:
+            ws = self._reparam_ws = torch.empty(max(need, 16), device=radiance.device, dtype=torch.uint8)
         fn = lib.epsm_trace_paths_reparam
         fn.restype = C.c_int
         rc = fn(C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
                 C.c_int64(lo), C.c_int64(n), C.c_void_p(radiance.data_ptr()), C.c_void_p(adj_radiance.data_ptr()),
                 C.c_void_p(adj_film.data_ptr()), int(reparam_max_depth), int(reparam_rays), C.c_float(kappa), C.c_float(exponent),
-                C.c_void_p(grad_pos.data_ptr()), C.c_void_p(grad_nrm.data_ptr()), C.c_void_p(stream))
+                C.c_void_p(grad_pos.data_ptr()), C.c_void_p(grad_nrm.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()),
+                C.c_void_p(stream))
         if rc != 0:
             _lib.check(rc, "epsm_trace_paths_reparam") if self._backend is None else (_ for _ in ()).throw(RuntimeError(f"host tracer rc={rc}"))
 

@@ -52,7 +52,7 @@ extern "C" int epsm_trace_paths_color(const EpsmScene *scene, const EpsmSensor *
 extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor *sensor, uint32_t seed, int spp, int max_depth,
                                         int rr_depth, int64_t path_offset, int64_t N, const float *radiance,
                                         const float *adj_radiance, const float *adj_film, int reparam_max_depth, int reparam_rays,
-                                        float kappa, float exponent, float *grad_pos, float *grad_nrm, void *) {
+                                        float kappa, float exponent, float *grad_pos, float *grad_nrm, void *, size_t, void *) {
     if (reparam_rays < 1 || reparam_rays > rp::kMaxAux) return -22;
     rp::ReparamArgs R;
     memset(&R, 0, sizeof(R));
@@ -66,20 +66,22 @@ extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor
     for (int64_t i = 0; i < N; ++i) {
         uint32_t stack[kBvhStack];
         rp::Warp W;
-        rp::reparam_one_path(R, i, BvhStack{stack, 1}, W);
+        const BvhStack st{stack, 1};
+        rp::InlineSink sink{R.A.S, R.cfg, R.G, st, W, rp::WarpId{0xffffffffu ^ seed, (uint32_t) (path_offset + i), 0}};
+        rp::reparam_one_path(R, i, st, sink);
     }
     return 0;
 }
+extern "C" size_t epsm_trace_reparam_workspace_bytes(int64_t) { return 0; }
 
 // Test probe: the warp field's value and divergence at one ray when only the ray ORIGIN moves with velocity `odot`
 // (forward mode of reparam.py:155-221): out = [V_theta (3), div V_theta, Z].
 extern "C" int epsm_debug_warp(const EpsmScene *scene, const float *o, const float *d, const float *odot, int rays, float kappa,
                                float exponent, uint32_t seed, float *out) {
     rp::ReparamCfg cfg; cfg.max_depth = 8; cfg.rays = rays; cfg.kappa = kappa; cfg.exponent = exponent;
-    Pcg32 rng = seed_sampler(seed, 0);
     uint32_t stack[kBvhStack];
     rp::Warp W;
-    rp::warp_collect(*scene, cfg, rng, ld3(o), ld3(d), BvhStack{stack, 1}, W);
+    rp::warp_collect(*scene, cfg, rp::WarpId{seed, 0u, 0}, ld3(o), ld3(d), BvhStack{stack, 1}, W);
     double V[3] = {0, 0, 0}, dl = 0;
     const F3 od = ld3(odot);
     for (int i = 0; i < W.n; ++i) {
@@ -100,10 +102,9 @@ extern "C" int epsm_debug_warp(const EpsmScene *scene, const float *o, const flo
 extern "C" int epsm_debug_warp_adjoint(const EpsmScene *scene, const float *o, const float *d, const float *g_dir, float g_div, int rays,
                                        float kappa, float exponent, uint32_t seed, float *grad_pos, float *out) {
     rp::ReparamCfg cfg; cfg.max_depth = 8; cfg.rays = rays; cfg.kappa = kappa; cfg.exponent = exponent;
-    Pcg32 rng = seed_sampler(seed, 0);
     uint32_t stack[kBvhStack];
     rp::Warp W;
-    rp::warp_collect(*scene, cfg, rng, ld3(o), ld3(d), BvhStack{stack, 1}, W);
+    rp::warp_collect(*scene, cfg, rp::WarpId{seed, 0u, 0}, ld3(o), ld3(d), BvhStack{stack, 1}, W);
     rp::GradOut G; G.pos = grad_pos; G.nrm = nullptr;
     F3 g_o, g_d;
     rp::warp_backward(*scene, G, W, ld3(g_dir), g_div, g_o, g_d);
