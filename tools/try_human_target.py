@@ -29,6 +29,8 @@ lr = float(sys.argv[2]) if len(sys.argv) > 2 else 0.01
 modes = sys.argv[3:] or ["ref", "fresh"]
 mname = "match_" + os.environ.get("HUMAN_MATCHER", tasks.matcher)
 prb_spp = int(os.environ.get("HUMAN_PRB_SPP", 16))
+if os.environ.get("HUMAN_SPP"):                      # samples per pixel of the render the matcher sees (the reference: 64)
+    tasks.spp = int(os.environ["HUMAN_SPP"])
 
 
 def ldr(img, quant):
