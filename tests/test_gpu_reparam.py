@@ -17,13 +17,15 @@ def rel(got, fd):
     return abs(g - f) / max(abs(f), 1e-3), g, f
 
 
-@pytest.mark.parametrize("name", ["diffuse_sphere_area_light", "sphere_on_glossy_floor", "occluder_area_light"])
-def test_device_pass_equals_the_host_build(name):
-    """Same seed, same auxiliary rays: per-vertex gradients agree up to what fma contraction flips (a hit that becomes a
-    miss moves one auxiliary ray's share)."""
+@pytest.mark.parametrize("name,rays", [("diffuse_sphere_area_light", 16), ("sphere_on_glossy_floor", 16), ("occluder_area_light", 16),
+                                       ("diffuse_sphere_area_light", 24), ("diffuse_sphere_area_light", 5), ("sphere_on_glossy_floor", 64)])
+def test_device_pass_equals_the_host_build(name, rays):
+    """Same seed, same auxiliary rays (every ray has its own stream): the device's two stages -- requests, then one lane per
+    auxiliary ray in groups of 16 / 32 / 64, partly filled for 5 and 24 rays -- against the host build's inline warps; per-vertex
+    gradients agree up to what fma contraction flips (a hit that becomes a miss moves one auxiliary ray's share)."""
     res, spp = 16, 32
     cfg = CONFIGS[name]
-    integ = epsm.load_dict({"type": "prb_reparam", "max_depth": cfg["max_depth"], "reparam_rays": 16, "reparam_kappa": cfg.get("kappa", 1e5)})
+    integ = epsm.load_dict({"type": "prb_reparam", "max_depth": cfg["max_depth"], "reparam_rays": rays, "reparam_kappa": cfg.get("kappa", 1e5)})
     g = torch.ones((res, res, 3)) * (0.5 + torch.arange(res, dtype=torch.float32) / res)[None, :, None]
     out = []
     for dev in ("cpu", "cuda"):
