@@ -101,6 +101,10 @@ def _declare(lib):
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.epsm_release_workspace.restype = C.c_int
     lib.epsm_release_workspace.argtypes = []
+    lib.epsm_set_option.restype = C.c_int
+    lib.epsm_set_option.argtypes = [C.c_int, C.c_int64]
+    lib.epsm_get_option.restype = C.c_int64
+    lib.epsm_get_option.argtypes = [C.c_int]
     declare_tracer(lib)
     return lib
 
@@ -143,3 +147,26 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = lib().epsm_last_error().decode("utf-8", "replace")
         raise EpsmError(f"{what} failed with code {rc}: {msg}")
+
+
+OPT_SMALL_WAVEFRONT_PATHS, OPT_REPLICAS = 0, 1       # include/epsm.h EPSM_OPT_*
+
+
+class options:
+    """``with options(small_wavefront_paths=0, replicas=False): ...`` -- launch options of the fused entry points
+    (include/epsm.h, epsm_set_option) for the duration of a block; the previous values come back on exit."""
+
+    def __init__(self, small_wavefront_paths=None, replicas=None):
+        self.want = {OPT_SMALL_WAVEFRONT_PATHS: small_wavefront_paths, OPT_REPLICAS: None if replicas is None else int(bool(replicas))}
+
+    def __enter__(self):
+        self.saved = {k: lib().epsm_get_option(k) for k, v in self.want.items() if v is not None}
+        for k, v in self.want.items():
+            if v is not None:
+                check(lib().epsm_set_option(k, int(v)), "epsm_set_option")
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            lib().epsm_set_option(k, v)
+        return False

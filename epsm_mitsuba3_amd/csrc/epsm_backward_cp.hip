@@ -704,10 +704,8 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
     // so that the ~512 workgroups the chip holds at a time all get one: a wave works through its rounds of a window one
     // after the other, a few microseconds each, and that latency is the run time of a launch with fewer windows than
     // workgroup slots.  Measured (ms, K = 2 / K = 4): 524 288 paths with windows of 128 / 256 / 512: 0.218 / 0.156 / 0.120;
-    // 16 384 paths: 0.034 / 0.046 / 0.061.  (EPSM_SMALL_WAVEFRONT=<paths> moves the switch to the small form: tests.)
-    int64_t small_limit = 1 << 20;
-    if (const char *e = getenv("EPSM_SMALL_WAVEFRONT")) small_limit = atoll(e);
-    const bool small = F.g.N <= small_limit;
+    // 16 384 paths: 0.034 / 0.046 / 0.061.  (epsm_set_option(EPSM_OPT_SMALL_WAVEFRONT_PATHS) moves the switch: tests.)
+    const bool small = F.g.N <= fused_option(EPSM_OPT_SMALL_WAVEFRONT_PATHS);
     constexpr int kLarge = EPSM_CP_WINDOW, kSmall = 1024;
     int window = kLarge;
     if (small) { window = 128; while (window < kSmall && F.g.N > 512 * (int64_t) window) window *= 2; }
@@ -721,8 +719,7 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
         int64_t R = blocks / 16;
         if (R > 32) R = 32;
         if (R * stride * 4 > (int64_t) kReplicaBudget) R = (int64_t) kReplicaBudget / (stride * 4);
-        const char *off = getenv("EPSM_NO_REPLICAS");
-        if (R >= 4 && !(off && off[0] == '1')) {
+        if (R >= 4 && fused_option(EPSM_OPT_REPLICAS) != 0) {
             const hipError_t e = fused_workspace(s, (size_t) (R * stride * 4), &F.rep);
             if (e != hipSuccess) return e;
             if (F.rep) { F.replicas = (int) R; F.rep_stride = stride; }

@@ -89,6 +89,9 @@ hipError_t fused_release_workspaces();
 __global__ void reduce_replicas_kernel(float *rep, int replicas, int64_t stride, int64_t V, int64_t B,
                                        float *gpos, float *gnrm, float *galpha, float *go);
 
+// ---- launch options (include/epsm.h, epsm_set_option): process-wide, initialised from the environment when the library loads
+int64_t fused_option(int option);
+
 // ---- the constraint-parallel form (epsm_backward_cp.hip).  dmode: kTangents*; packed: the native log.
 hipError_t launch_backward_cp(int variant, int dmode, bool packed, const FusedArgs &F, int dcols, hipStream_t s);
 

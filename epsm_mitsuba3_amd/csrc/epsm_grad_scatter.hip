@@ -4,6 +4,7 @@
 // kernel.  The kernel behind all three is csrc/epsm_backward_cp.hip (one lane per (path, constraint vertex), round 3); round
 // 2's one-lane-per-path fused kernel, which lived here, is gone (profiles/r03_a_knockouts.txt holds the last A/B numbers).
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <stdio.h>
 #include <string.h>
@@ -123,6 +124,31 @@ static int fill_args(FusedArgs &F, const char *who, int variant, int64_t N, int 
     F.P = epsm_num_param_grads(variant, K);
     F.K = K;
     return EPSM_OK;
+}
+
+// ---- launch options: two process-wide integers, set from the environment by a static initialiser (never by an entry point)
+namespace {
+std::atomic<int64_t> g_options[2];
+struct OptionsInit {
+    OptionsInit() {
+        const char *e = getenv("EPSM_SMALL_WAVEFRONT");
+        g_options[EPSM_OPT_SMALL_WAVEFRONT_PATHS] = e ? atoll(e) : (int64_t) 1 << 20;
+        const char *off = getenv("EPSM_NO_REPLICAS");
+        g_options[EPSM_OPT_REPLICAS] = (off && off[0] == '1') ? 0 : 1;
+    }
+} g_options_init;
+}  // namespace
+namespace epsm {
+int64_t fused_option(int option) { return g_options[option].load(std::memory_order_relaxed); }
+}
+extern "C" int epsm_set_option(int option, int64_t value) {
+    epsm_host::err_buf()[0] = 0;
+    if (option < 0 || option > EPSM_OPT_REPLICAS || value < 0) return fail(EPSM_EINVAL, "epsm_set_option: unknown option or negative value");
+    g_options[option].store(value, std::memory_order_relaxed);
+    return EPSM_OK;
+}
+extern "C" int64_t epsm_get_option(int option) {
+    return (option < 0 || option > EPSM_OPT_REPLICAS) ? -1 : g_options[option].load(std::memory_order_relaxed);
 }
 
 extern "C" int epsm_release_workspace(void) {

@@ -89,10 +89,14 @@ struct AccFixed64 {
     __device__ __forceinline__ static T to_fixed(float x) {
         // sign * trunc(|x| * 2^44), |x| saturated below 2^20: |x| * 2^12 is split into its integer part and its fraction,
         // converted separately (there is no float -> int64 instruction; the library conversion is ~20 VALU instructions per
-        // value, this is 8).  a - trunc(a) is exact in float, and so is its scaling by 2^32.  NaN (a degenerate normal
-        // row) counts as 0, as a float row that is never flushed would.  Truncation instead of rounding: < 5.7e-14 per term.
-        const float a = fminf(fabsf(x) * 4096.f, 4294967040.f);   // (fminf returns the non-NaN operand)
-        const unsigned hi = (unsigned) a;                          // v_cvt_u32_f32: truncates
+        // value, this is 10).  a - trunc(a) is exact in float, and so is its scaling by 2^32.  Truncation instead of
+        // rounding: < 5.7e-14 per term.  A NON-FINITE term (a zero-length interpolated normal: il = inf, sh = NaN; an unbounded
+        // emitter weight) adds NOTHING -- the reference's buffers would hold NaN there and its optimiser loop scrubs that to 0
+        // (EPSM/optim.py:143-154); a finite one beyond the range saturates at 2^19 - 2^-5, below the sign bit.  (The kernel
+        // runs with IEEE mode on: v_min_f32(NaN, c) returns c, so a bare fminf would turn NaN into the largest magnitude.)
+        const float ax = fabsf(x) * 4096.f;
+        const float a = ax < __builtin_inff() ? fminf(ax, 2147483520.f) : 0.f;     // NaN and inf fail the compare
+        const unsigned hi = (unsigned) a;                          // v_cvt_u32_f32: truncates; hi < 2^31
         const unsigned lo = (unsigned) ((a - (float) hi) * 4294967296.f);
         const T mag = (T) (((unsigned long long) hi << 32) | lo);
         return x < 0.f ? -mag : mag;

@@ -30,6 +30,33 @@ from .tangent_scatter import (backward_pass, backward_pass_packed, first_vertex_
                               scatter)
 
 
+def sample_tea_32(v0: int, v1: int, rounds: int = 4):
+    """drjit's ``sample_tea_32`` on two 32-bit integers (the Tiny Encryption Algorithm, 4 rounds by default) -- what the
+    sampler seeds its streams with (src/render/sampler.cpp:115-134) and what ``mi.render`` derives the differential
+    seed from (src/python/python/util.py:505-508)."""
+    v0 &= 0xFFFFFFFF; v1 &= 0xFFFFFFFF
+    s = 0
+    for _ in range(rounds):
+        s = (s + 0x9E3779B9) & 0xFFFFFFFF
+        v0 = (v0 + ((((v1 << 4) + 0xA341316C) ^ (v1 + s) ^ ((v1 >> 5) + 0xC8013EA4)) & 0xFFFFFFFF)) & 0xFFFFFFFF
+        v1 = (v1 + ((((v0 << 4) + 0xAD90777D) ^ (v0 + s) ^ ((v0 >> 5) + 0x7E95761E)) & 0xFFFFFFFF)) & 0xFFFFFFFF
+    return v0, v1
+
+
+def render_seeds(seed: int, seed_grad: int = 0):
+    """(seed, seed_grad) of one ``mi.render`` call, src/python/python/util.py:505-513: the differential pass gets its OWN
+    seed -- ``sample_tea_32(seed, 1)[0]`` unless the caller names one -- because ``grad_in`` is a function of the primal
+    image: replaying the very samples whose noise it carries correlates the two factors of the estimator and biases the
+    gradient (E[grad] picks up a variance-gradient term).  An explicit ``seed_grad == seed`` is refused with the
+    reference's message."""
+    if seed_grad == 0:
+        seed_grad = sample_tea_32(seed, 1)[0]
+    elif seed_grad == seed:
+        raise Exception('The primal and differential seed should be different '
+                        'to ensure unbiased gradient computation!')
+    return seed, seed_grad
+
+
 @dataclass
 class PathTrace:
     """What one logging trace of the backward sensor yields (epsm.py:166-181, 547, 648-654)
@@ -271,9 +298,10 @@ class PRBIntegrator:
     to the scene (``Scene.attach_color``: diffuse reflectances, ``Scene.attach_radiance``: emitters) into
     ``params.color``.  Path replay with detached sampling as in prb.py: one pass of ``epsm_trace_paths_color`` under the
     primal pass's seed returns, per path, the radiance and its derivative sums; the film's adjoint turns ``grad_in``
-    into the adjoint radiance of every sample.  What ``prb_reparam`` adds on top -- the warp field that makes
-    visibility differentiable, i.e. gradients of vertex positions through silhouettes (ad/reparam.py) -- is NOT
-    implemented: ``reparam`` is False and geometry receives nothing in this phase."""
+    into the adjoint radiance of every sample.  This class is ``prb`` (prb.py): colour parameters only, ``reparam`` is
+    False and geometry receives nothing.  What ``prb_reparam`` adds on top -- the warp field that makes visibility
+    differentiable, i.e. gradients of vertex positions and normals through shading, silhouettes and shadow boundaries
+    (ad/reparam.py) -- is the subclass ``PRBReparamIntegrator`` below (csrc/epsm_trace_reparam.h)."""
     reparam = False
 
     def __init__(self, props: Optional[dict] = None):

@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from . import load_dict
+from .integrators import render_seeds
 from .matcher import Matcher
 
 
@@ -72,7 +73,8 @@ def run(method: str, exp: str, device="cuda", iterations=None, lr=None, log=prin
             if it == thres:                                                     # optim.py:116-118: opt.reset(key)
                 optimizer = torch.optim.Adam(list(opt.values()), lr=lr)
             integ, sid = integrator2, 0
-        img = integ.render(scene, sensor=sid, seed=it, spp=tasks.spp)           # (H,W,5) or (H,W,3)
+        seed, seed_grad = render_seeds(it)                                      # util.py:505-513: de-correlated passes
+        img = integ.render(scene, sensor=sid, seed=seed, spp=tasks.spp)         # (H,W,5) or (H,W,3)
         params = scene.param_grads() if params.flat.numel() != scene.param_grads().flat.numel() else params
         params.zero_()
         if img.shape[-1] == 5:                                                  # optim.py:130-136
@@ -82,7 +84,7 @@ def run(method: str, exp: str, device="cuda", iterations=None, lr=None, log=prin
         else:                                                                   # optim.py:137-141: L2 against the reference
             ref = gt if tuple(gt.shape[:2]) == tuple(img.shape[:2]) else resize(gt, img.shape[0])
             grad = 2.0 * (img - ref[..., :3]) / img.shape[0]
-        integ.render_backward(scene, params, grad, sensor=sid, seed=it, spp=tasks.spp)   # dr.backward(img*grad) / dr.backward(loss)
+        integ.render_backward(scene, params, grad, sensor=sid, seed=seed_grad, spp=tasks.spp)   # dr.backward(img*grad) / dr.backward(loss)
         backward(opt, params)
         for p in opt.values():                                                  # optim.py:143-154
             if p.grad is not None:

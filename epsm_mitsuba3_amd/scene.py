@@ -255,6 +255,10 @@ def _sah_split(cen: np.ndarray, lo: np.ndarray, hi: np.ndarray, bins: int = 16):
     return best[1]
 
 
+kMaxWideDepth = 16                      # four-wide levels the traversal stack holds (csrc/epsm_trace_core.h: kBvhStack = 3 x 16)
+kMaxBinaryHeight = 2 * kMaxWideDepth    # binary height the collapse folds into them
+
+
 def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE, sah_min: int = SAH_MIN):
     """Binned-SAH BVH (16 bins per axis; nodes of <= ``sah_min`` triangles: median split), built as a binary tree and
     emitted as FOUR-wide nodes (``EpsmBvhNode``: the boxes of up to four children in one 128-byte record, one
@@ -284,7 +288,10 @@ def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE, sah_
         ids = order[a:b]
         c = cen[ids]
         mid = None
-        if b - a > sah_min and tdepth[ni] < 20:    # deep SAH chains fall back to halving: depth stays <= kBvhStack
+        # A SAH plane may peel off a few triangles per level (mixed triangle scales: a teapot in a stadium); halving cannot.
+        # SAH is used while the subtree can still be finished by halving inside kMaxBinaryHeight levels, which is what the
+        # four-wide collapse below can always fold into the traversal's 16 wide levels.
+        if b - a > sah_min and tdepth[ni] + 1 + int(np.ceil(np.log2(b - a))) <= kMaxBinaryHeight:
             split = _sah_split(c, lo_t[ids], hi_t[ids])
             if split is not None:
                 left_mask = split
@@ -299,7 +306,10 @@ def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE, sah_
         tdepth += [tdepth[ni] + 1, tdepth[ni] + 1]
         stack += [tree[ni][2], tree[ni][3]]
     # four-wide nodes: a wide node takes a binary inner node and, while it has fewer than four children and one of them
-    # is inner, replaces the inner child with the largest box by that child's two children
+    # is inner, replaces the inner child with the largest box by that child's two children -- unless a child's subtree is
+    # too TALL for the wide levels left below this node: then the tallest child is opened instead.  (Opening the tallest
+    # child twice takes two binary levels off every chain, so a subtree of binary height h fits into ceil(h / 2) wide
+    # levels whatever its shape; a wide node at depth d may therefore keep children of height <= 2 (kMaxWideDepth - 1 - d).)
     t_lo = np.zeros((len(tree), 3)); t_hi = np.zeros((len(tree), 3))
     for bi in range(len(tree) - 1, -1, -1):          # children follow their parent in `tree`
         a_, b_, l_, r_ = tree[bi]
@@ -309,26 +319,33 @@ def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE, sah_
         else:
             t_lo[bi], t_hi[bi] = np.minimum(t_lo[l_], t_lo[r_]), np.maximum(t_hi[l_], t_hi[r_])
 
+    t_height = np.zeros(len(tree), dtype=np.int64)   # leaves 0
+    for bi in range(len(tree) - 1, -1, -1):
+        if tree[bi][2] >= 0:
+            t_height[bi] = 1 + max(t_height[tree[bi][2]], t_height[tree[bi][3]])
+
     def half_area(bi):
         e = t_hi[bi] - t_lo[bi]
         return e[0] * e[1] + e[1] * e[2] + e[2] * e[0]
 
     wide_children: Dict[int, list] = {}
     wide_order: List[int] = []
-    todo = [0] if tree[0][2] >= 0 else []
+    todo = [(0, 0)] if tree[0][2] >= 0 else []
     while todo:
-        bi = todo.pop(0)
+        bi, wd = todo.pop(0)
+        allowed = 2 * (kMaxWideDepth - 1 - wd)       # tallest subtree a child of this wide node may root
         kids = [tree[bi][2], tree[bi][3]]
         while len(kids) < 4:
             inner_kids = [k for k in kids if tree[k][2] >= 0]
             if not inner_kids:
                 break
-            k = max(inner_kids, key=half_area)
+            too_tall = [k for k in inner_kids if t_height[k] > allowed]
+            k = max(too_tall, key=lambda q: t_height[q]) if too_tall else max(inner_kids, key=half_area)
             i = kids.index(k)
             kids[i:i + 1] = [tree[k][2], tree[k][3]]
         wide_children[bi] = kids
         wide_order.append(bi)
-        todo += [k for k in kids if tree[k][2] >= 0]
+        todo += [(k, wd + 1) for k in kids if tree[k][2] >= 0]
     wide_of = {bi: wi for wi, bi in enumerate(wide_order)}
     n = max(1, len(wide_order))
     nodes = np.zeros((n, 32), dtype=np.float32)      # EpsmBvhNode: lox loy loz hix hiy hiz (4 each) | c[4] | n[4]
@@ -356,7 +373,7 @@ def build_bvh(pos: np.ndarray, tri: np.ndarray, leaf_size: int = LEAF_SIZE, sah_
     for bi in wide_order:                          # breadth first: parents precede their children
         for slot, k in enumerate(wide_children[bi]):
             put_child(wide_of[bi], slot, k)
-    if int(depth.max(initial=0)) + 1 > 16:
+    if int(depth.max(initial=0)) + 1 > kMaxWideDepth:      # (cannot happen: both bounds above hold by construction)
         raise ValueError("BVH deeper than the traversal stack (kBvhStack = 3 pushes x 16 levels)")
     levels = [np.asarray(per_level[d], dtype=np.int64).reshape(-1, 3) for d in sorted(per_level, reverse=True)]
     return {"nodes": nodes, "order": order.astype(np.int64),

@@ -286,9 +286,22 @@ int epsm_backward_pass_packed(int variant, int64_t N, int K, int64_t path_offset
  * a stream calls hipMalloc (do it outside a stream capture); results are complete when the stream reaches the end of the
  * call's work, as before; launches on ONE stream from several host threads must be serialised by the caller, as any use
  * of a stream.  epsm_release_workspace frees every workspace (call it when no launch is in flight; they come back on
- * demand).  EPSM_NO_REPLICAS=1 in the environment turns the replicas off.
+ * demand).
  * There is no reference counterpart: Dr.Jit's scatter_reduce goes straight to global atomics. */
 int epsm_release_workspace(void);
+
+/* Launch options of the three fused entry points (process-wide; a launch reads them when it is issued).  Their initial values
+ * come from the environment ONCE, when the library is loaded -- no entry point calls getenv.
+ *   EPSM_OPT_SMALL_WAVEFRONT_PATHS  wavefronts of up to this many paths take the small form (windows of 128 .. 1024 paths,
+ *                                   replicas); larger ones walk windows of 2048 paths.  Default 2^20; EPSM_SMALL_WAVEFRONT=<paths>.
+ *   EPSM_OPT_REPLICAS               1: small wavefronts accumulate into replicas (above); 0: straight into the caller's
+ *                                   buffers.  Default 1; EPSM_NO_REPLICAS=1 sets 0.
+ * Results are the same sums either way (the parity tests run both forms at every size).
+ * epsm_set_option returns EPSM_OK or -EINVAL (unknown option, negative value); epsm_get_option returns -1 for an unknown option. */
+#define EPSM_OPT_SMALL_WAVEFRONT_PATHS 0
+#define EPSM_OPT_REPLICAS 1
+int epsm_set_option(int option, int64_t value);
+int64_t epsm_get_option(int option);
 
 /* The Sinkhorn matcher's inner operation (outer loop).  EPSM/utils/matcher.py:51-63 calls
  * geomloss.SamplesLoss("sinkhorn", p=2, blur=0.01, scaling=0.9) on two 5-D point clouds (r,g,b,x,y); geomloss's online

@@ -21,9 +21,10 @@ def oracle_lib():
 
 
 @pytest.fixture(params=["windows of 256", "windows of 1024"])
-def window_form(request, monkeypatch):
+def window_form(request):
     """The accumulating kernel has two window forms (csrc/epsm_backward_cp.hip, launch): wavefronts of up to 2^20 paths are
     cut into windows of 128 .. 1024 paths and flushed into replicas, larger ones walk windows of 2048 paths.  The parity
     tests, whose sizes are all on the small side, run both (the ids keep the sizes of the round they were written in)."""
-    monkeypatch.setenv("EPSM_SMALL_WAVEFRONT", str(1 << 20) if request.param == "windows of 256" else "0")
-    return request.param
+    from epsm_mitsuba3_amd import _lib
+    with _lib.options(small_wavefront_paths=(1 << 20) if request.param == "windows of 256" else 0):
+        yield request.param

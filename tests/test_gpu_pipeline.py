@@ -34,10 +34,10 @@ def test_render_backward_matches_oracle_pipeline(kind, profile, fused):
                                    (params.alpha, ga, allow[2], "alpha"), (params.cam_origin, go, 0.0, "cam")):
         m = float(ref.abs().max())
         assert m > 0, name
-        # end-to-end fp32 chain + atomic order: 1 % of the buffer's magnitude, plus the weight of the per-path
-        # components within 2 % of the outlier threshold (fp32 and fp64 may zero different ones) and of
-        # the ill-conditioned paths on which the fp32 oracle itself leaves the fp64 one
-        assert bool(((mine.cpu().double() - ref).abs() <= 1e-2 * m + slack).all()), name
+        # end-to-end fp32 chain + atomic order: 2e-3 of the buffer's magnitude (as test_fused_matches_the_oracle_at_every_
+        # coherence below), plus the weight of the per-path components within 2 % of the outlier threshold (fp32 and fp64
+        # may zero different ones) and of the ill-conditioned paths on which the fp32 oracle itself leaves the fp64 one
+        assert bool(((mine.cpu().double() - ref).abs() <= 2e-3 * m + slack).all()), (name, float(((mine.cpu().double() - ref).abs() - slack).max()) / m)
         if name in ("pos", "nrm"):
             assert float(slack.sum() / ref.abs().sum()) < 0.1, name      # the allowance is the exception, not the rule
     # accumulation: a second backward doubles the gradients (dr.backward accumulates)
@@ -176,7 +176,7 @@ def test_fused_equals_two_stage_at_scale(kind, profile, res, spp, V):
 
 @pytest.mark.parametrize("kind,profile,K,res,spp,V", [("manifold", "bathroom", 2, 256, 8, 7829), ("manifold_caustic", "pool", 4, 64, 32, 500),
                                                       ("manifold", "mixed", 5, 128, 16, 100000)])
-def test_small_wavefront_forms_agree(kind, profile, K, res, spp, V, monkeypatch):
+def test_small_wavefront_forms_agree(kind, profile, K, res, spp, V):
     """2^17 .. 2^19 paths (the reference's own backward sizes): the three routes a small wavefront can take -- small
     windows flushed into the library's replicas and summed by the reduction kernel, the same without replicas, and
     the windows of 1024 paths of the large wavefronts -- and the reference's two stages accumulate the same sums, camera
@@ -189,27 +189,25 @@ def test_small_wavefront_forms_agree(kind, profile, K, res, spp, V, monkeypatch)
     g = torch.Generator().manual_seed(5)
     grad_in = (torch.randn((res, res, 5), generator=g) * 1e-3).to(dev)
     bufs = {}
-    for name, env, fused in (("replicas", {}, "pass"), ("replicas again", {}, "pass"), ("direct", {"EPSM_NO_REPLICAS": "1"}, "pass"),
-                             ("windows of 1024", {"EPSM_SMALL_WAVEFRONT": "0"}, "pass"), ("two stages", {}, False),
-                             ("lo", {}, False), ("hi", {}, False)):
-        for k in ("EPSM_NO_REPLICAS", "EPSM_SMALL_WAVEFRONT"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        integ = epsm.load_dict({"type": kind, "max_depth": 8, "fused": fused,
-                                "outlier_clip": {"lo": 0.098, "hi": 0.102}.get(name, 0.1)})
-        integ.backward_spp = spp
-        params = epsm.ParamGrads(V, B, device=dev)
-        integ.render_backward(scene, params, grad_in, seed=1)
-        torch.cuda.synchronize()
-        bufs[name] = params.flat.double().cpu()
-        if name == "replicas again":               # the workspace can be given back and comes back on demand
-            from epsm_mitsuba3_amd import _lib
-            assert _lib.lib().epsm_release_workspace() == 0
-            params.zero_()
+    from epsm_mitsuba3_amd import _lib
+    default = dict(small_wavefront_paths=1 << 20, replicas=True)          # (include/epsm.h, epsm_set_option)
+    for name, opts, fused in (("replicas", {}, "pass"), ("replicas again", {}, "pass"), ("direct", {"replicas": False}, "pass"),
+                              ("windows of 1024", {"small_wavefront_paths": 0}, "pass"), ("two stages", {}, False),
+                              ("lo", {}, False), ("hi", {}, False)):
+        with _lib.options(**{**default, **opts}):
+            integ = epsm.load_dict({"type": kind, "max_depth": 8, "fused": fused,
+                                    "outlier_clip": {"lo": 0.098, "hi": 0.102}.get(name, 0.1)})
+            integ.backward_spp = spp
+            params = epsm.ParamGrads(V, B, device=dev)
             integ.render_backward(scene, params, grad_in, seed=1)
             torch.cuda.synchronize()
-            bufs["replicas after a release"] = params.flat.double().cpu()
+            bufs[name] = params.flat.double().cpu()
+            if name == "replicas again":               # the workspace can be given back and comes back on demand
+                assert _lib.lib().epsm_release_workspace() == 0
+                params.zero_()
+                integ.render_backward(scene, params, grad_in, seed=1)
+                torch.cuda.synchronize()
+                bufs["replicas after a release"] = params.flat.double().cpu()
     from _util import assert_two_routes_agree
     ref = bufs["replicas"]
     m = float(ref.abs().max())
@@ -223,7 +221,7 @@ def test_small_wavefront_forms_agree(kind, profile, K, res, spp, V, monkeypatch)
 
 
 @pytest.mark.parametrize("kind,profile", [("manifold", "bathroom"), ("manifold_caustic", "pool")])
-def test_tiny_terms_and_a_disabled_clamp_sum_alike_in_both_window_forms(kind, profile, monkeypatch):
+def test_tiny_terms_and_a_disabled_clamp_sum_alike_in_both_window_forms(kind, profile):
     """the accumulating kernel's LDS rows are 64-bit fixed point (44 fractional bits) while the clamp bounds the
     terms, float rows when the caller disables it (clip <= 0).  (a) A gradient image scaled to 1e-8 -- terms around 1e-11,
     as from a mean-normalised loss -- gives the sums of the float route (the reference-shaped two stages) in the small-
@@ -236,16 +234,15 @@ def test_tiny_terms_and_a_disabled_clamp_sum_alike_in_both_window_forms(kind, pr
     base = (torch.randn((res, res, 5), generator=g) * 1e-3).to(dev)
     for what, scale, clip in (("tiny terms", 1e-5, 0.1), ("clamp off", 1.0, 0.0)):
         bufs = {}
-        for name, env, fused in (("small form", {}, "pass"), ("large form", {"EPSM_SMALL_WAVEFRONT": "0"}, "pass"), ("two stages", {}, False)):
-            monkeypatch.delenv("EPSM_SMALL_WAVEFRONT", raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            integ = epsm.load_dict({"type": kind, "max_depth": 8, "fused": fused, "outlier_clip": clip})
-            integ.backward_spp = spp
-            params = epsm.ParamGrads(V, B, device=dev)
-            integ.render_backward(scene, params, base * scale, seed=2)
-            torch.cuda.synchronize()
-            bufs[name] = params.flat.double().cpu()
+        from epsm_mitsuba3_amd import _lib
+        for name, limit, fused in (("small form", 1 << 20, "pass"), ("large form", 0, "pass"), ("two stages", 1 << 20, False)):
+            with _lib.options(small_wavefront_paths=limit):
+                integ = epsm.load_dict({"type": kind, "max_depth": 8, "fused": fused, "outlier_clip": clip})
+                integ.backward_spp = spp
+                params = epsm.ParamGrads(V, B, device=dev)
+                integ.render_backward(scene, params, base * scale, seed=2)
+                torch.cuda.synchronize()
+                bufs[name] = params.flat.double().cpu()
         ref = bufs["two stages"]
         m = float(ref.abs().max())
         assert m > 0 and torch.isfinite(ref).all(), what
