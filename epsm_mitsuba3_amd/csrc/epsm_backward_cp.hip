@@ -56,6 +56,7 @@ template <typename T> __device__ __forceinline__ T down1(T v) { return __shfl_do
 __device__ __forceinline__ V2<float> up1(V2<float> v) { return mk2<float>(up1(v.x), up1(v.y)); }
 __device__ __forceinline__ M2<float> up1(M2<float> m) { M2<float> o; o.a = up1(m.a); o.b = up1(m.b); o.c = up1(m.c); o.d = up1(m.d); return o; }
 __device__ __forceinline__ V3<float> down1(V3<float> v) { return mk3<float>(down1(v.x), down1(v.y), down1(v.z)); }
+__device__ __forceinline__ V3<float> up1(V3<float> v) { return mk3<float>(up1(v.x), up1(v.y), up1(v.z)); }
 
 // ---- record access: the native packed log or the reference's per-field arrays
 template <bool PACKED> struct Records {
@@ -140,7 +141,29 @@ template <bool PACKED> struct Records {
 };
 
 // ---- emission: the rows of one vertex into the wave queue (clamp / NaN rule of calc_grad per (N,3) component first,
-// then the linear map of epsm_scatter_core.h: epsm.py:559-562, 622-627, 644-645).  All 64 lanes call every method.
+// then the linear map of epsm_scatter_core.h: epsm.py:559-562, 622-627, 644-645).
+//
+// Two steps, so that few registers live across the prefetch of the next round's records (which sits between them):
+//   rows_of()   everything that needs the vertex's geometry, its gradients and its table rows is folded into the SEEDS of
+//               the row groups -- the position rows themselves (with the flat-normal part and diffuse_grad[0] added), the
+//               projected normal gradient, the emitter gradient times its weight, the alpha scalar, the end-point and occluder
+//               gradients -- plus the weights and keys they will be spread with: ~45 registers;
+//   emit()      one group of three rows after the other is formed in ONE reused V3 vals[3], merged over the wave (DPP) and
+//               pushed: positions, normals, emitter, alpha, end point, occluder.  All 64 lanes call both.
+struct RowSeeds {
+    V3<float> P[3];                  // position rows of the hit triangle: fin(b_j Gx) (+ flat-normal part) + b_j fin(dldp) where the first hit is diffuse
+    V3<float> pg;                    // normal rows: pg b_j
+    float b0, b1;
+    uint32_t k0, k1, k2;             // rows of the hit triangle
+    V3<float> gl; float eb0, eb1;    // emitter rows: gl eb_j
+    uint32_t e0, e1, e2;
+    float a; uint32_t akey;          // alpha row
+    V3<float> gd; float nb0, nb1;    // end-point rows (diffuse_grad of the next vertex): gd nb_j
+    uint32_t n0, n1, n2;
+    V3<float> gs; float c0, c1;      // occluder rows: gs c_j
+    uint32_t s0, s1, s2;
+    bool pos_v, nrm_v, e_v, a_v, d_v, s_v;
+};
 template <typename Table> struct Emitter {
     const FusedArgs &F;
     const Table &T;
@@ -148,17 +171,8 @@ template <typename Table> struct Emitter {
 
     template <int ROWS>
     __device__ __forceinline__ void push(bool valid, const uint32_t key[ROWS], const V3<float> val[ROWS]) const {
-#ifdef EPSM_CP_DIRECT                       // (A/B: rows straight into the table, no wave queue)
-        if (valid) {
-#pragma unroll
-            for (int j = 0; j < ROWS; ++j) T.add(key[j], val[j].x, val[j].y, val[j].z);
-        }
-#else
-        // (Dense pushes -- 16 / 32 / 48 or more lanes holding rows -- straight into the table, the others through the queue:
-        // 2.71 / 2.62 / 2.60 ms against 2.49: a lane's rows are then inserted one after the other.)
         Q.reserve(T, ROWS);
         Q.template push_rows<ROWS>(valid, key, val);
-#endif
     }
     __device__ __forceinline__ V3<float> fin(V3<float> g) const {
         return mk3<float>(finalize(g.x, F.g.clip), finalize(g.y, F.g.clip), finalize(g.z, F.g.clip));
@@ -166,89 +180,93 @@ template <typename Table> struct Emitter {
     __device__ __forceinline__ static bool tri_ok(const U4 &t, int64_t V) {
         return t.x < (uint64_t) V && t.y < (uint64_t) V && t.z < (uint64_t) V;
     }
-    // rows of the hit triangle t: d/dp_j = b_j Gx (+ the flat-normal part of d/dn), d/dn_j; `on`: this lane has a vertex to emit
-    __device__ __forceinline__ void triangle(bool on, V3<float> Gx, V3<float> gn, const cp::Own<float> &c, const U4 &t) const {
-        const float b0 = c.b0, b1 = c.b1, b2 = 1.f - b0 - b1;
-        V3<float> pos[3] = {fin(Gx * b0), fin(Gx * b1), fin(Gx * b2)};       // si.p_j * path_grad[5it+j]
-        V3<float> nrm[3] = {zero3<float>(), zero3<float>(), zero3<float>()};
+    // `on`: this lane has a vertex whose parameter rows exist; `live`: it has a constraint (its end-point rows exist);
+    // `d1`: it carries diffuse_grad[0] = dldp of a path whose first hit is diffuse (epsm.py:791-792, 998-1000) and the
+    // occluder term (609-620).  n, e1, e2, b0, b1: geometry of the lane's vertex (b0, b1 also for a d1 lane without constraint).
+    __device__ __forceinline__ RowSeeds rows_of(bool on, bool live, bool d1, V3<float> Gx, V3<float> gn, V3<float> gm, V3<float> glight,
+                                                V3<float> gdiff, V3<float> dp, V3<float> n, V3<float> e1, V3<float> e2, float b0, float b1,
+                                                float nb0, float nb1, uint32_t bid, V3<float> dhf, float eb0, float eb1, float ew,
+                                                const U4 &t, const U4 &tn, const U4 &er, const U4 &sh, const U4 &ts) const {
+        RowSeeds S;
+        const float b2 = 1.f - b0 - b1;
+        const V3<float> z = zero3<float>();
+        const bool idx_ok = tri_ok(t, F.V), pos_ok = idx_ok && (t.w & kModePos);
+        S.b0 = b0; S.b1 = b1; S.k0 = t.x; S.k1 = t.y; S.k2 = t.z;
+        // si.p_j * path_grad[5it+j]
+        S.P[0] = on ? fin(Gx * b0) : z; S.P[1] = on ? fin(Gx * b1) : z; S.P[2] = on ? fin(Gx * b2) : z;
+        S.pg = z; S.nrm_v = false;
         gn = fin(gn);
-        const bool idx_ok = on && tri_ok(t, F.V);
-        const bool pos_v = idx_ok && (t.w & kModePos);
-        bool nrm_v = false;
-        if (idx_ok && nz3(gn)) {                                              // si_follow.sh_frame.n * path_grad[5it+3]
+        if (on && idx_ok && nz3(gn)) {                                        // si_follow.sh_frame.n * path_grad[5it+3]
             const float sgn = (t.w & kModeFlip) ? -1.f : 1.f;
             if (t.w & kModeVertexNormals) {
                 if (t.w & kModeNrm) {
-                    // logged normals are post-flip: c.n = sum_j b_j n'_j; sh = normalize(c.n)   (mesh.cpp:784-790, 820-827)
-                    const float il = rsqrt_(dot(c.n, c.n));
-                    const V3<float> sh = c.n * il;
-                    const V3<float> pg = (gn - sh * dot(sh, gn)) * (il * sgn);
-                    nrm[0] = pg * b0; nrm[1] = pg * b1; nrm[2] = pg * b2;
-                    nrm_v = true;
+                    // logged normals are post-flip: n = sum_j b_j n'_j; sh = normalize(n)   (mesh.cpp:784-790, 820-827)
+                    const float il = rsqrt_(dot(n, n));
+                    const V3<float> sh_ = n * il;
+                    S.pg = (gn - sh_ * dot(sh_, gn)) * (il * sgn);
+                    S.nrm_v = nz3(S.pg);
                 }
-            } else if (pos_v) {
+            } else if (pos_ok) {
                 // flat: sh = sgn normalize(cross(p1-p0, p2-p0)) with p1-p0 = e2-e1, p2-p0 = -e1   (mesh.cpp:729, 811)
-                const V3<float> d0 = c.e2 - c.e1, d1 = -c.e1;
-                const V3<float> cr = cross(d0, d1);
+                const V3<float> d0 = e2 - e1, d1_ = -e1;
+                const V3<float> cr = cross(d0, d1_);
                 const float il = rsqrt_(dot(cr, cr));
                 const V3<float> ch = cr * il;
                 const V3<float> cb = (gn - ch * dot(ch, gn)) * (il * sgn);
-                const V3<float> d0b = cross(d1, cb), d1b = cross(cb, d0);
-                pos[1] = pos[1] + d0b; pos[2] = pos[2] + d1b; pos[0] = pos[0] - (d0b + d1b);
+                const V3<float> d0b = cross(d1_, cb), d1b = cross(cb, d0);
+                S.P[1] = S.P[1] + d0b; S.P[2] = S.P[2] + d1b; S.P[0] = S.P[0] - (d0b + d1b);
             }
         }
-        const uint32_t V32 = (uint32_t) F.V;
-        const V3<float> z = zero3<float>();
-        V3<float> vals[6] = {pos_v ? pos[0] : z, pos_v ? pos[1] : z, pos_v ? pos[2] : z,
-                             nrm_v ? nrm[0] : z, nrm_v ? nrm[1] : z, nrm_v ? nrm[2] : z};
-        bool any = (pos_v && (nz3(pos[0]) || nz3(pos[1]) || nz3(pos[2]))) || nrm_v;
-        const uint32_t tri[3] = {t.x, t.y, t.z};
-        const bool some_nrm = __ballot(nrm_v) != 0ull;
-        merge_equal<6, 2>(any, tri, vals, some_nrm ? 6 : 3);
-        push<3>(any, tri, vals);
-        if (some_nrm) {
-            const uint32_t nk[3] = {V32 + tri[0], V32 + tri[1], V32 + tri[2]};
-            push<3>(any && (nz3(vals[3]) || nz3(vals[4]) || nz3(vals[5])), nk, vals + 3);     // (the carrier of a merge holds the others' rows)
-        }
-    }
-    // bsdf_sample.hf * path_grad[5it+4]  and  si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627, 645)
-    __device__ __forceinline__ void light_alpha(bool on, V3<float> gm, V3<float> glight, uint32_t bid, V3<float> dhf,
-                                                const U4 &er, float eb0, float eb1, float ew) const {
+        const V3<float> dpf = d1 ? fin(dp) : z;                                // si_follow.p * diffuse_grad[0], detached barycentrics (561-562)
+        if (d1) { S.P[0] = S.P[0] + dpf * b0; S.P[1] = S.P[1] + dpf * b1; S.P[2] = S.P[2] + dpf * b2; }
+        S.pos_v = pos_ok && (nz3(S.P[0]) || nz3(S.P[1]) || nz3(S.P[2]));
+        // bsdf_sample.hf * path_grad[5it+4]  and  si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627, 645)
         gm = fin(gm);
+        S.a_v = on && nz3(gm) && bid < (uint64_t) F.B;
+        S.a = S.a_v ? dot(gm, dhf) : 0.f;
+        S.akey = 2u * (uint32_t) F.V + bid;
         glight = fin(glight);
-        const bool a_ok = on && nz3(gm) && bid < (uint64_t) F.B;
-        const bool e_ok = on && nz3(glight) && tri_ok(er, F.V) && (er.w & kModePos);
-        const V3<float> gl = e_ok ? glight * ew : zero3<float>();
-        const uint32_t keys[4] = {e_ok ? er.x : 0u, e_ok ? er.y : 0u, e_ok ? er.z : 0u, a_ok ? 2u * (uint32_t) F.V + bid : 0u};
-        V3<float> vals[4] = {gl * eb0, gl * eb1, gl * (1.f - eb0 - eb1), mk3<float>(a_ok ? dot(gm, dhf) : 0.f, 0.f, 0.f)};
-        bool e_any = e_ok, a_any = a_ok;
-        merge_equal<3, 2>(e_any, keys, vals);                       // area lights are a handful of triangles
-        const uint32_t aid[3] = {keys[3], 0u, 0u};
-        merge_equal<1, 4>(a_any, aid, vals + 3);                    // a handful of materials
-        if (__ballot(a_any || e_any) != 0ull) push<4>(a_any || e_any, keys, vals);
+        S.e_v = on && nz3(glight) && tri_ok(er, F.V) && (er.w & kModePos);
+        S.gl = S.e_v ? glight * ew : z; S.eb0 = eb0; S.eb1 = eb1; S.e0 = er.x; S.e1 = er.y; S.e2 = er.z;
+        // si_follow.p * diffuse_grad[it] with detached barycentrics (epsm.py:561-562): rows of the NEXT vertex's triangle
+        gdiff = fin(gdiff);
+        S.d_v = live && nz3(gdiff) && tri_ok(tn, F.V) && (tn.w & kModePos);
+        S.gd = S.d_v ? gdiff : z; S.nb0 = nb0; S.nb1 = nb1; S.n0 = tn.x; S.n1 = tn.y; S.n2 = tn.z;
+        // occluder of the first vertex's emitter sample: si_direct.p * diffuse_grad[0] * dis (epsm.py:609-620);
+        // sh = [stri, sb0, sb1, dis] (EpsmScatterRecord.shadow), ts = the occluder triangle's row of the scene table
+        const float dis = bits_to_float(sh.w);
+        S.s_v = d1 && nz3(dpf) && tri_ok(ts, F.V) && (ts.w & kModePos) && dis != 0.f;
+        S.gs = S.s_v ? dpf * dis : z; S.c0 = bits_to_float(sh.y); S.c1 = bits_to_float(sh.z); S.s0 = ts.x; S.s1 = ts.y; S.s2 = ts.z;
+        return S;
     }
-    // si_follow.p * diffuse_grad[it] with detached barycentrics (epsm.py:561-562): rows of triangle t, weights b_j
-    __device__ __forceinline__ void diffuse(bool on, V3<float> g, float b0, float b1, const U4 &t) const {
-        g = fin(g);
-        bool pos_v = on && nz3(g) && tri_ok(t, F.V) && (t.w & kModePos);
-        if (__ballot(pos_v) == 0ull) return;
-        V3<float> pos[3] = {g * b0, g * b1, g * (1.f - b0 - b1)};
-        const uint32_t tri[3] = {t.x, t.y, t.z};
-        merge_equal<3, 2>(pos_v, tri, pos);
-        push<3>(pos_v, tri, pos);
-    }
-    // occluder of the first vertex's emitter sample: si_direct.p * diffuse_grad[0] * dis (epsm.py:609-620);
-    // a = [stri, sb0, sb1, dis] (EpsmScatterRecord.shadow), row = the occluder triangle's row of the scene table
-    __device__ __forceinline__ void shadow(bool on, V3<float> g, const U4 &a, const U4 &row) const {
-        g = fin(g);
-        const float c0 = bits_to_float(a.y), c1 = bits_to_float(a.z), dis = bits_to_float(a.w);
-        bool v = on && nz3(g) && tri_ok(row, F.V) && (row.w & kModePos) && dis != 0.f;
+    // three rows g w_j on keys (a, b, c)
+    __device__ __forceinline__ void group(bool v, V3<float> g, float w0, float w1, uint32_t a, uint32_t b, uint32_t c) const {
         if (__ballot(v) == 0ull) return;
-        const V3<float> gd = g * dis;
-        V3<float> val[3] = {gd * c0, gd * c1, gd * (1.f - c0 - c1)};
-        const uint32_t si[3] = {row.x, row.y, row.z};
-        merge_equal<3, 2>(v, si, val);
-        push<3>(v, si, val);
+        V3<float> vals[3] = {g * w0, g * w1, g * (1.f - w0 - w1)};
+        const uint32_t keys[3] = {a, b, c};
+        merge_equal<3, 2>(v, keys, vals);
+        push<3>(v, keys, vals);
+    }
+    __device__ __forceinline__ void emit(const RowSeeds &S) const {
+        if (__ballot(S.pos_v) != 0ull) {
+            bool v = S.pos_v;
+            V3<float> vals[3] = {S.P[0], S.P[1], S.P[2]};
+            const uint32_t keys[3] = {S.k0, S.k1, S.k2};
+            merge_equal<3, 2>(v, keys, vals);
+            push<3>(v, keys, vals);
+        }
+        const uint32_t V32 = (uint32_t) F.V;
+        group(S.nrm_v, S.pg, S.b0, S.b1, V32 + S.k0, V32 + S.k1, V32 + S.k2);
+        group(S.e_v, S.gl, S.eb0, S.eb1, S.e0, S.e1, S.e2);                  // area lights are a handful of triangles
+        if (__ballot(S.a_v) != 0ull) {                                        // a handful of materials
+            bool v = S.a_v;
+            V3<float> val[1] = {mk3<float>(S.a, 0.f, 0.f)};
+            const uint32_t aid[3] = {S.akey, 0u, 0u};
+            merge_equal<1, 4>(v, aid, val);
+            push<1>(v, aid, val);
+        }
+        group(S.d_v, S.gd, S.nb0, S.nb1, S.n0, S.n1, S.n2);
+        group(S.s_v, S.gs, S.c0, S.c1, S.s0, S.s1, S.s2);
     }
 };
 
@@ -279,13 +297,16 @@ struct Rounds {
 
 // ---- the first-level global loads of a round (native log), held in registers from their issue -- one round ahead, before
 // the previous round's emission -- to their use.  o: the lane's own record (words 24..27 emitter sample, 28 triangle id,
-// 29..31 d hf / d alpha); p: the first lane of a path holds its rays here (12 words), the others quads 0, 1, 2, 4 of
-// record k-1; n: quads 0, 1, 2, 4 of record k+1 and its triangle id; the image gradient of the path's pixel.
+// 29..31 d hf / d alpha); p: the FIRST lane of a path holds its rays here (12 words); n: the LAST lane of a path whose chain
+// ends on a vertex without a lane of its own (the diffuse end point: k + 1 = nv > m) holds quads 0, 1, word 8, words 18, 19
+// and the triangle id of record k + 1; the image gradient of the path's pixel.  The geometry of vertices k - 1 and k + 1 that
+// DO have a lane comes from that lane (one shuffle per word once the records have landed) instead of being read again:
+// round 3 re-read 2 x (2 quads + 4 words) per lane.
 struct Fetch {
     F4v o[7];                        // own record, quads 0..6
     uint32_t o_tid; float dhf[3];    // own record, word 28 and words 29..31
-    F4v p[3]; float p_b[2];          // first lane: the rays.  Others, of record k-1: quads 0, 1, word 8 (p[2].x), words 18, 19
-    F4v n[2]; float n_z, n_b[2];     // record k+1: quads 0, 1, word 8, words 18, 19 ...
+    F4v p[3];                        // first lane: the rays
+    F4v n[2]; float n_z, n_b[2];     // last lane, record k+1: quads 0, 1, word 8, words 18, 19 ...
     uint32_t n_tid;                  // ... and its triangle id
     float gx, gy;
     U4 sh;                           // the first vertex's occluder record (max_depth <= 3 logs)
@@ -296,14 +317,6 @@ typedef float F2v __attribute__((ext_vector_type(2)));
 typedef float F3v __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ F2v ld2(const float *p) { return *(const __attribute__((address_space(1))) F2v *) p; }
 __device__ __forceinline__ F3v ld3(const float *p) { return *(const __attribute__((address_space(1))) F3v *) p; }
-// x / d and x % d for 0 <= x < 2^24, d >= 1 (float reciprocal + one correction step each way)
-__device__ __forceinline__ void divmod24(uint32_t x, uint32_t d, float rcp_d, uint32_t &qo, uint32_t &ro) {
-    uint32_t q = (uint32_t) ((float) x * rcp_d);
-    int32_t r = (int32_t) x - (int32_t) (q * d);
-    if (r < 0) { --q; r += (int32_t) d; }
-    if (r >= (int32_t) d) { ++q; r -= (int32_t) d; }
-    qo = q; ro = (uint32_t) r;
-}
 template <int VARIANT, int DMODE, bool PACKED>
 __device__ __forceinline__ void fetch_issue(Fetch &X, const FusedArgs &F, const LaneId &L, int64_t base) {
     if (!PACKED) return;             // per-field arrays: loaded where they are used (the reference's layout is not the fast path)
@@ -311,7 +324,7 @@ __device__ __forceinline__ void fetch_issue(Fetch &X, const FusedArgs &F, const 
     const bool ok = L.plan != 0u;
     const int64_t i = base + L.loc;
     const bool first = k == 1, live = ok && L.q > 0;
-    const bool has_next = live && k + 1 <= cp::plan_nv(L.plan);
+    const bool end_next = live && k == L.c && k + 1 <= cp::plan_nv(L.plan);      // vertex k+1 exists and has no lane
     const bool d1 = ok && first && cp::plan_diffuse1(L.plan);
     const float *rec = F.pk_verts + (i * F.K + (k - 1)) * kRecWords;
     if (live) {
@@ -333,12 +346,8 @@ __device__ __forceinline__ void fetch_issue(Fetch &X, const FusedArgs &F, const 
         const F2v g = ld2(F.tin.grad_img + (y * F.tin.img_width + x) * F.tin.img_channels + 3);
         X.gx = g.x; X.gy = g.y;
         if (d1 && F.pk_shadow) X.sh = load_u4(F.pk_shadow, i);
-    } else if (live) {
-        const float *pr = rec - kRecWords;
-        X.p[0] = ldq(pr, 0); X.p[1] = ldq(pr, 1); X.p[2].x = lds_(pr, 8);
-        const F2v b = ld2(pr + 18); X.p_b[0] = b.x; X.p_b[1] = b.y;
     }
-    if (has_next) {
+    if (end_next) {
         const float *nx = rec + kRecWords;
         X.n[0] = ldq(nx, 0); X.n[1] = ldq(nx, 1); X.n_z = lds_(nx, 8);
         const F2v b = ld2(nx + 18); X.n_b[0] = b.x; X.n_b[1] = b.y;
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
         for (int t = 0; t < 7; ++t) X.o[t] = z4;
         X.p[0] = X.p[1] = X.p[2] = X.n[0] = X.n[1] = z4;
         X.o_tid = X.n_tid = kNoIndex;
-        X.dhf[0] = X.dhf[1] = X.dhf[2] = X.p_b[0] = X.p_b[1] = X.n_z = X.n_b[0] = X.n_b[1] = X.gx = X.gy = 0.f;
+        X.dhf[0] = X.dhf[1] = X.dhf[2] = X.n_z = X.n_b[0] = X.n_b[1] = X.gx = X.gy = 0.f;
         X.sh.x = kNoIndex; X.sh.y = X.sh.z = X.sh.w = 0u;
     }
     T.clear();                                                       // ends with a barrier: the table of pointers is visible too
@@ -501,13 +510,13 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             const bool d1 = ok && first && cp::plan_diffuse1(plan);
             const bool act1 = (plan & cp::kPlanActive1) != 0;
 
-            // ---- geometry: own vertex, the two neighbours
+            // ---- geometry: own vertex; the two neighbours from the lanes that hold them (or from the words fetched for that)
             cp::Own<float> own;
             own.x = own.e1 = own.e2 = own.n = own.dn1 = own.dn2 = own.light = zero3<float>();
             own.b0 = own.b1 = own.eta = 0.f;
             cp::Nbr<float> prev, next;
             prev.x = prev.e1 = prev.e2 = next.x = next.e1 = next.e2 = zero3<float>();
-            float nb0 = 0.f, nb1 = 0.f, fb0 = 0.f, fb1 = 0.f;        // barycentrics of vertex k+1; of vertex 1 (diffuse_grad[0])
+            float nb0 = 0.f, nb1 = 0.f;                              // barycentrics of vertex k+1
             uint32_t tid_own = kNoIndex, tid_next = kNoIndex, bid = kNoIndex, etri = kNoIndex;
             V3<float> dhf = zero3<float>();
             float eb0 = 0.f, eb1 = 0.f, ew = 0.f;
@@ -525,16 +534,23 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     tid_own = X.o_tid;
                     if (F.galpha) dhf = mk3<float>(X.dhf[0], X.dhf[1], X.dhf[2]);
                     if (wN) { etri = __float_as_uint(X.o[6].x); eb0 = X.o[6].y; eb1 = X.o[6].z; ew = X.o[6].w; }      // (caustic: light_grad == 0)
-                    if (first) prev.x = mk3<float>(X.p[0].x, X.p[0].y, X.p[0].z);
-                    else { const Geo<float> gp = geo_from(X.p[0], X.p[1], X.p[2], X.p_b[0], X.p_b[1]); prev.x = gp.x; prev.e1 = gp.e1; prev.e2 = gp.e2; }
                 }
-                if (has_next) {
+                if (c > 1) {                                         // wave-uniform: paths on several lanes exchange their vertices
+                    const V3<float> ux = up1(own.x), ue1 = up1(own.e1), ue2 = up1(own.e2);
+                    const V3<float> dx = down1(own.x), de1 = down1(own.e1), de2 = down1(own.e2);
+                    const float db0 = down1(own.b0), db1 = down1(own.b1);
+                    const uint32_t dt = down1(tid_own);
+                    if (live && !first) { prev.x = ux; prev.e1 = ue1; prev.e2 = ue2; }
+                    if (has_next && k < c) { next.x = dx; next.e1 = de1; next.e2 = de2; nb0 = db0; nb1 = db1; tid_next = dt; }
+                }
+                if (live && first) prev.x = mk3<float>(X.p[0].x, X.p[0].y, X.p[0].z);
+                if (has_next && k == c) {
                     const F4v nq2 = {X.n_z, 0.f, 0.f, 0.f};
                     const Geo<float> gq = geo_from(X.n[0], X.n[1], nq2, X.n_b[0], X.n_b[1]);
                     next.x = gq.x; next.e1 = gq.e1; next.e2 = gq.e2; nb0 = gq.b0; nb1 = gq.b1;
                     tid_next = X.n_tid;
                 }
-                if (d1) { fb0 = X.o[4].z; fb1 = X.o[4].w; tid_own = X.o_tid; if (F.pk_shadow) sh = X.sh; }
+                if (d1) { own.b0 = X.o[4].z; own.b1 = X.o[4].w; tid_own = X.o_tid; if (F.pk_shadow) sh = X.sh; }
                 if (ok && first) {       // epsm.py:250-272 in registers
                     const V3<float> ro = mk3<float>(X.p[0].x, X.p[0].y, X.p[0].z), rd = mk3<float>(X.p[0].w, X.p[1].x, X.p[1].y),
                                     rdx = mk3<float>(X.p[1].z, X.p[1].w, X.p[2].x), rdy = mk3<float>(X.p[2].y, X.p[2].z, X.p[2].w);
@@ -560,7 +576,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     tid_next = R.tri_id(k + 1);
                 }
                 if (d1) {
-                    R.b0b1(1, fb0, fb1);
+                    R.b0b1(1, own.b0, own.b1);
                     tid_own = R.tri_id(1);
                     if (s_ptrs.s[0].shadow) sh = load_u4(s_ptrs.s[0].shadow, i);
                 }
@@ -578,12 +594,16 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                 }
             }
             // Addressing of the rows this lane will emit, requested BEFORE the arithmetic: under load every dependent global
-            // load is a multi-microsecond round trip for a wave that shares its SIMD with one other, so the chain is kept at
-            // two levels -- records (with the emitter / BSDF words of the same record), then the rows of the scene table
-            // they name -- instead of four (emitter record and its table row fetched where the gradient becomes known).
-            // (Requested after the arithmetic instead -- 16 registers fewer across it, their latency exposed: 2.49 -> 2.55 ms.)
+            // load is a multi-microsecond round trip, so the chain is kept at two levels -- records (with the emitter / BSDF
+            // words of the same record), then the rows of the scene table they name.
             const U4 t_own = table_row(F.tab, tid_own), t_next = table_row(F.tab, tid_next);
             const U4 er = table_row(F.tab, etri), t_sh = table_row(F.tab, sh.x);
+
+            // what the second pass needs of the geometry: positions only (epsm_cp_core.h, Pts)
+            cp::Pts<float> pts;
+            pts.x = own.x; pts.n = own.n; pts.light = own.light; pts.eta = own.eta; pts.xp = prev.x; pts.xn = next.x;
+            // the flat-normal rows need the triangle's edges, the normal rows its interpolated normal (rows_of)
+            const V3<float> keep_e1 = own.e1, keep_e2 = own.e2;
 
             V3<float> Gx = zero3<float>(), gn = Gx, gm = Gx, glight = Gx, gdiff = Gx;
             bool emit_vertex = live;
@@ -595,7 +615,8 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
 #endif
                 if (q > 0) {
                     const bool wC = live && cp::plan_b(plan, k);
-                    const cp::MEval<float> e = cp::manifold_eval(own, prev, next, wN, has_next);
+                    // pass 1: the 2x2 blocks of the lane's constraint(s)
+                    const cp::MBlocks<float> e = cp::manifold_blocks(own, prev, next, wN, has_next);
                     cp::MFwd<float> f = cp::manifold_fwd(e, dk, true, cp::mfwd_zero<float>(), e.Aup, wN, has_next);
 #pragma unroll 1
                     for (int s = 2; s <= c; ++s) {                   // forward recursion: lanes with k == s take their step
@@ -605,24 +626,28 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                         const cp::MFwd<float> g = cp::manifold_fwd(e, dk, false, pf, pAup, wN, has_next);
                         if (k == s) f = g;
                     }
-                    cp::MBwd<float> mine; mine.GP = zero3<float>(); mine.W = 0;
-                    cp::MOut<float> o;
-                    o.Gx = o.gn = o.gm = o.glight = o.gdiff = zero3<float>();
+                    cp::MBwd<float> mine; mine.q = mk2<float>(0.f, 0.f); mine.W = 0;
+                    cp::MSeeds<float> sd;
+                    sd.sN = sd.sC = mk2<float>(0.f, 0.f); sd.useN = sd.useC = sd.fC = false;
 #pragma unroll 1
-                    for (int s = c; s >= 1; --s) {                   // backward recursion of the adjoint seeds
+                    for (int s = c; s >= 1; --s) {                   // backward recursion of the adjoint seeds, on the blocks alone
                         cp::MBwd<float> nb;
-                        nb.GP = down1(mine.GP); nb.W = down1(mine.W);
-                        if (s == c) { nb.GP = zero3<float>(); nb.W = 0; }
+                        nb.q = mk2<float>(down1(mine.q.x), down1(mine.q.y)); nb.W = down1(mine.W);
+                        if (s == c) { nb.q = mk2<float>(0.f, 0.f); nb.W = 0; }
                         cp::MBwd<float> m2;
-                        const cp::MOut<float> o2 = cp::manifold_bwd(e, f, own, nb, wN, wC, has_next, m2);
-                        if (k == s) { o = o2; mine = m2; }
+                        const cp::MSeeds<float> s2 = cp::manifold_bwd(e, f, nb, wN, wC, has_next, m2);
+                        if (k == s) { sd = s2; mine = m2; }
                     }
-                    Gx = o.Gx; gn = o.gn; gm = o.gm; glight = o.glight; gdiff = o.gdiff;
+                    // pass 2: the constraint(s) swept once more with the final seeds
+                    const cp::MOut<float> o = cp::manifold_contract(pts, sd, has_next);
+                    const V3<float> from_next = down1(o.GP);         // d/dx_k through constraint k+1
+                    Gx = k < c ? o.Gx - from_next : o.Gx;
+                    gn = o.gn; gm = o.gm; glight = o.glight; gdiff = o.gdiff;
                 }
             } else {
                 if (q > 0) {
                     const int idstar = cp::plan_idstar(plan);
-                    const cp::CEval<float> e = cp::caustic_eval(own, prev, next, first);
+                    const cp::CBlocks<float> e = cp::caustic_blocks(own, prev, next, first);
                     cp::CFwd<float> f = cp::caustic_fwd(e, dk, true, cp::cfwd_zero<float>(), e.Aup);
 #pragma unroll 1
                     for (int s = 2; s <= c; ++s) {
@@ -636,40 +661,34 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     const unsigned long long bad = __ballot(live && k == idstar && !f.fin);
                     const unsigned long long seg = ((1ull << c) - 1ull) << (lane - (k - 1));
                     const bool poisoned = (bad & seg) != 0ull;
-                    const cp::COut<float> o = cp::caustic_finish(e, f, first, live && k <= idstar, live && k == idstar, live && cp::plan_b(plan, k));
+                    const cp::COut<float> o = cp::caustic_finish(pts, f, first, live && k <= idstar, live && k == idstar, live && cp::plan_b(plan, k));
                     const V3<float> from_next = down1(o.gxp_prev);
                     Gx = k < c ? o.Gx + from_next : o.Gx;
                     gn = o.gn; gm = o.gm; gdiff = o.gdiff;
                     emit_vertex = live && k <= idstar && !poisoned;
                 }
             }
+            // ---- the seeds of this lane's rows (the table rows have landed by now)
+            if (PACKED) bid = (t_own.w >> 8) - 1u;                    // packed log: alpha slot + 1 in the table row
+#ifdef EPSM_CPKO_NOEMIT
+            gd_acc.x += Gx.x + gn.y + gm.x + glight.z + gdiff.x + dp.x + (float) (t_own.x + t_next.y + er.z + bid + t_sh.x) + dhf.x + eb0 + eb1 + ew + (emit_vertex ? 1.f : 0.f);
+#else
+            const RowSeeds S = E.rows_of(emit_vertex && q > 0, live, d1, Gx, gn, gm, glight, gdiff, dp, pts.n, keep_e1, keep_e2, own.b0, own.b1,
+                                         nb0, nb1, bid, dhf, eb0, eb1, ew, t_own, t_next, er, sh, t_sh);
+#endif
             // ---- the next round's records, on their way while this round's rows are merged and inserted.  Every load issued
-            // so far must have LANDED first: the prefetch sits in branches the wave may skip, so behind it the compiler can only
-            // wait for "all loads" (s_waitcnt vmcnt(0)) -- a later first use of a table row would drain the prefetch with it.
-            if (PACKED) asm volatile("" :: "v"(t_own.x), "v"(t_own.y), "v"(t_own.z), "v"(t_own.w), "v"(t_next.x), "v"(t_next.y), "v"(t_next.z),
-                                     "v"(t_next.w), "v"(er.x), "v"(er.y), "v"(er.z), "v"(er.w), "v"(t_sh.x), "v"(t_sh.y), "v"(t_sh.z), "v"(t_sh.w));
+            // so far has LANDED (rows_of read the table rows): the prefetch sits in branches the wave may skip, so behind it the
+            // compiler can only wait for "all loads" (s_waitcnt vmcnt(0)) -- a later first use of an earlier load would drain the
+            // prefetch with it.
             const LaneId Ln = RS.lane_of(r + kWaves, lane);          // (past the last round: no lane has a path)
+            __builtin_amdgcn_sched_barrier(0);                       // nothing of rows_of may sink below the prefetch (its first use would wait for ALL loads)
 #ifndef EPSM_CP_NOPIPE
             fetch_issue<VARIANT, DMODE, PACKED>(X, F, Ln, base);
 #endif
+            __builtin_amdgcn_sched_barrier(0);
             // ---- emission
-#ifdef EPSM_CPKO_NOEMIT
-            gd_acc.x += Gx.x + gn.y + gm.x + glight.z + gdiff.x + dp.x + (float) (t_own.x + t_next.y + er.z + bid + t_sh.x) + dhf.x + eb0 + eb1 + ew + (emit_vertex ? 1.f : 0.f);
-            if (false) {
-#else
-            if (q > 0) {
-#endif
-                if (PACKED) bid = (t_own.w >> 8) - 1u;                // packed log: alpha slot + 1 in the table row
-                E.triangle(emit_vertex, Gx, gn, own, t_own);
-                E.light_alpha(emit_vertex, gm, glight, bid, dhf, er, eb0, eb1, ew);
-                E.diffuse(live, gdiff, nb0, nb1, t_next);
-            }
 #ifndef EPSM_CPKO_NOEMIT
-            // diffuse_grad[0] = dldp where the first hit is diffuse (epsm.py:791-792, 998-1000) + the occluder term (609-620)
-            if (__ballot(d1 && nz3(dp)) != 0ull) {
-                E.diffuse(d1, dp, fb0, fb1, t_own);
-                E.shadow(d1, dp, sh, t_sh);
-            }
+            E.emit(S);
 #endif
 #ifdef EPSM_CP_NOPIPE
             fetch_issue<VARIANT, DMODE, PACKED>(X, F, Ln, base);

@@ -4,18 +4,18 @@
 // a forward and a backward pass (130 of the 256 VGPRs of the fused kernel), every half-vector constraint is evaluated
 // twice and its frame three times.  Here the unit of work is ONE CONSTRAINT VERTEX of one path:
 //
-//   eval      lane (path, k) loads vertex k and the positions / edges of its two neighbours, evaluates the projected
-//             half-vector constraint(s) of vertex k ONCE and keeps their unit-seed reverse sweeps -- the 2 x 12 Jacobian
-//             of C_k w.r.t. (x_{k-1}, x_k, x_{k+1}, n_k) -- in registers, together with the 2x2 blocks of `cur`
-//             (epsm.py:771, 826-833, 889-900) they contract to;
+//   blocks    lane (path, k) loads vertex k and the positions / edges of its two neighbours, evaluates the projected
+//             half-vector constraint(s) of vertex k with unit seeds and keeps the 2x2 blocks of `cur` (epsm.py:771,
+//             826-833, 889-900) they contract to -- 20 numbers; the 2 x 12 Jacobians themselves are dropped;
 //   recursion the block recursions of epsm_path_core.h (manifold: block LU forward, adjoint seeds backward;
-//             manifold_caustic: one forward recursion) run ACROSS the lanes of a path: step s is taken by the lanes
-//             with k == s, which receive ten-odd numbers from lane k-1 (k+1);
-//   finish    every output of vertex k is a linear combination of the lane's own unit sweeps with the seeds the
-//             recursion produced -- nothing is re-evaluated -- plus d/dx_k through constraint k+1, handed down by
-//             the neighbouring lane.
+//             manifold_caustic: one forward recursion) run ACROSS the lanes of a path on the blocks alone: step s is
+//             taken by the lanes with k == s, which receive ten-odd numbers from lane k-1 (two from k+1);
+//   contract  the lane's constraint(s) swept once more, SEEDED with the 2-vectors the recursion produced: every output
+//             of vertex k at once, plus d/dx_k through constraint k+1, handed down by the neighbouring lane.
+// (Round 3 kept the unit-seed Jacobians of both versions across the recursions -- 36 registers -- so that nothing was
+// evaluated twice; the second sweep costs ~80 multiply-adds per version and is what lets three waves share a SIMD.)
 //
-// Per-lane state no longer grows with the chain length, chains of different lengths keep all lanes busy, and the
+// Per-lane state does not grow with the chain length, chains of different lengths keep all lanes busy, and the
 // vertex loops are real loops (the per-vertex arrays that forced compile-time unrolling are gone).
 //
 // What is computed is what epsm_path_core.h computes -- ManifoldIntegrator.calc_grad (epsm.py:745-946) and
@@ -186,31 +186,66 @@ template <typename R> EPSM_HD M2<R> blk_own(const Jac<R> &j, const Own<R> &o) {
     return madd2(block2(c0, c1, o.e1, o.e2), block2(j.gn[0], j.gn[1], o.dn1, o.dn2));
 }
 
+// ----------------------------------------------------------------------------
+// seeded reverse sweeps: s . J for a 2-vector s, without the unit-seed rows (s . gxp, s . gxn, s . gn of the Jac above)
+// ----------------------------------------------------------------------------
+template <typename R> struct Swp { V3<R> p, n, g; };      // d/dx_{k-1}, d/dx_{k+1}, d/dn_k;  d/dx_k = -(p + n)
+template <typename R> EPSM_HD Swp<R> zero_swp() { Swp<R> w; w.p = w.n = w.g = zero3<R>(); return w; }
+template <typename R> EPSM_HD V3<R> frame_grad_seeded(const Frm<R> &f, V3<R> w, R cx, V2<R> s) {
+    const R x = f.nn.x, q = f.nn.y * w.y + f.nn.z * w.z, xi = x * f.isg, qi = q * f.isg;
+    const V3<R> G0 = mk3<R>(R(0), (w.z - cx * f.tz) * f.isg, (cx * f.ty - w.y) * f.isg);
+    const V3<R> G1 = mk3<R>(-qi, w.x * f.tz + xi * (qi * f.tz - w.y), -w.x * f.ty - xi * (w.z + qi * f.ty));
+    const V3<R> G = G0 * s.x + G1 * s.y;
+    return (G - f.nn * dot(f.nn, G)) * f.inv_n;
+}
+template <typename R> EPSM_HD Swp<R> halfvec_seeded(const Frm<R> &f, const Dir<R> &wi, const Dir<R> &wo, R eta, V2<R> s) {
+    Swp<R> o;
+    const V3<R> u = madd(wi.w, wo.w, eta);
+    const R inv_u = rsqrt_(dot(u, u));
+    const V3<R> uh = u * inv_u;
+    const R cx = f.ty * uh.y + f.tz * uh.z, cy = dot(f.bt, uh);
+    const V3<R> P = (mk3<R>(R(0), f.ty, f.tz) * s.x + f.bt * s.y - uh * (cx * s.x + cy * s.y)) * inv_u;      // s . dC/du
+    o.p = (P - wi.w * dot(wi.w, P)) * wi.inv;
+    o.n = (P - wo.w * dot(wo.w, P)) * (eta * wo.inv);
+    o.g = frame_grad_seeded(f, uh, cx, s);
+    return o;
+}
+template <typename R> EPSM_HD Swp<R> wo2_seeded(const Frm<R> &f, const Dir<R> &wo, V2<R> s) {      // p == 0
+    Swp<R> o;
+    const R cx = f.ty * wo.w.y + f.tz * wo.w.z, cy = dot(f.bt, wo.w);
+    o.p = zero3<R>();
+    o.n = (mk3<R>(R(0), f.ty, f.tz) * s.x + f.bt * s.y - wo.w * (cx * s.x + cy * s.y)) * wo.inv;
+    o.g = frame_grad_seeded(f, wo.w, cx, s);
+    return o;
+}
+
+// What a lane keeps of its vertex between the two passes: positions only (directions and the frame are rebuilt: five
+// v_rsq_f32 and ~70 multiply-adds against 23 registers held across the recursions).
+template <typename R> struct Pts { V3<R> x, n, light, xp, xn; R eta; };      // x_k, n_k, emitter sample, x_{k-1}, x_{k+1}
+
 // ============================================================================
 // "manifold"
 // ============================================================================
-template <typename R> struct MEval {
-    Jac<R> jn, jc;                       // light-sampling / continuing version
-    M2<R> AkkN, AkmN, AkkC, AkmC, Aup;   // A_{k,k}, A_{k,k-1} of both versions; A^C_{k,k+1}
-};
+// Pass 1: the 2x2 blocks of `cur` the lane's constraint(s) contribute (epsm.py:826-833, 889-900) -- the unit-seed sweeps they
+// are contracted from are NOT kept (round 3 kept both versions' 2 x 12 Jacobians, 36 registers, across the recursions).
+template <typename R> struct MBlocks { M2<R> AkkN, AkmN, AkkC, AkmC, Aup; };   // A_{k,k}, A_{k,k-1} of both versions; A^C_{k,k+1}
 // lane (path, k): wN = plan_a(k), has_next = k + 1 <= nv
-template <typename R> EPSM_HD MEval<R> manifold_eval(const Own<R> &o, const Nbr<R> &prev, const Nbr<R> &next, bool wN, bool has_next) {
-    MEval<R> e;
+template <typename R> EPSM_HD MBlocks<R> manifold_blocks(const Own<R> &o, const Nbr<R> &prev, const Nbr<R> &next, bool wN, bool has_next) {
+    MBlocks<R> e;
     const M2<R> z{R(0), R(0), R(0), R(0)};
-    e.jn = zero_jac<R>(); e.jc = e.jn;
     e.AkkN = e.AkmN = e.AkkC = e.AkmC = e.Aup = z;
     const Frm<R> f = make_frm(o.n);
     const Dir<R> wi = make_dir(o.x, prev.x);
     if (wN) {
-        e.jn = halfvec_jac(f, wi, make_dir(o.x, o.light), o.eta);
-        e.AkkN = blk_own(e.jn, o);
-        e.AkmN = blk(e.jn.gxp, prev.e1, prev.e2);
+        const Jac<R> j = halfvec_jac(f, wi, make_dir(o.x, o.light), o.eta);
+        e.AkkN = blk_own(j, o);
+        e.AkmN = blk(j.gxp, prev.e1, prev.e2);
     }
     if (has_next) {
-        e.jc = halfvec_jac(f, wi, make_dir(o.x, next.x), o.eta);
-        e.AkkC = blk_own(e.jc, o);
-        e.AkmC = blk(e.jc.gxp, prev.e1, prev.e2);
-        e.Aup = blk(e.jc.gxn, next.e1, next.e2);
+        const Jac<R> j = halfvec_jac(f, wi, make_dir(o.x, next.x), o.eta);
+        e.AkkC = blk_own(j, o);
+        e.AkmC = blk(j.gxp, prev.e1, prev.e2);
+        e.Aup = blk(j.gxn, next.e1, next.e2);
     }
     return e;
 }
@@ -226,7 +261,7 @@ template <typename R> EPSM_HD MFwd<R> mfwd_zero() {
 // forward step of lane k (block LU of the continuing rows; pass 1 of manifold_path).  `pf`, `pAup`: z, Sinv and
 // A^C_{k-1,k} of lane k-1 (ignored for k == 1).  Computed in RecType (float64, see epsm_path_core.h), kept in R.
 template <typename R>
-EPSM_HD MFwd<R> manifold_fwd(const MEval<R> &e, V2<R> dk, bool first, const MFwd<R> &pf, const M2<R> &pAup, bool wN, bool has_next) {
+EPSM_HD MFwd<R> manifold_fwd(const MBlocks<R> &e, V2<R> dk, bool first, const MFwd<R> &pf, const M2<R> &pAup, bool wN, bool has_next) {
     typedef typename RecType<R>::type Q;
     MFwd<R> o = mfwd_zero<R>();
     V2<Q> rhs = cvv<Q>(dk);
@@ -250,65 +285,73 @@ EPSM_HD MFwd<R> manifold_fwd(const MEval<R> &e, V2<R> dk, bool first, const MFwd
     }
     return o;
 }
-// what lane k hands to lane k-1 in the backward recursion
-template <typename R> struct MBwd { V3<R> GP; int W; };       // d/dx_{k-1} through constraint k; live terms of depth >= k
-// results of lane k
-template <typename R> struct MOut { V3<R> Gx, gn, gm, glight, gdiff; };
+// What lane k hands to lane k-1 in the backward recursion: q = (GP . e1, GP . e2) of vertex k-1, GP = d/dx_{k-1} through
+// constraint k with the lane's final seeds -- which is sN A^N_{k,k-1} + sC A^C_{k,k-1}, so the recursion runs on the blocks
+// alone -- and the number W of live terms of depth >= k.
+template <typename R> struct MBwd { V2<R> q; int W; };
+// the adjoint seeds of lane k: y_k summed over the depths and sub-paths that reach it
+template <typename R> struct MSeeds { V2<R> sN, sC; bool useN, useC, fC; };
 // backward step of lane k (pass 2 of manifold_path): `nb` comes from lane k+1 (zero for the last lane)
 template <typename R>
-EPSM_HD MOut<R> manifold_bwd(const MEval<R> &e, const MFwd<R> &f, const Own<R> &o, const MBwd<R> &nb, bool wN, bool wC, bool has_next,
-                             MBwd<R> &mine) {
+EPSM_HD MSeeds<R> manifold_bwd(const MBlocks<R> &e, const MFwd<R> &f, const MBwd<R> &nb, bool wN, bool wC, bool has_next, MBwd<R> &mine) {
     typedef typename RecType<R>::type Q;
-    MOut<R> out;
+    MSeeds<R> s;
     // carry = W z_k - (GP . [e1 e2]_k) Sinv_k : the sum over deeper terms of their y_k
     V2<Q> carry = mk2<Q>(Q(0), Q(0));
-    if (nb.W > 0) {
-        const V2<Q> q = mk2<Q>(Q(dot(nb.GP, o.e1)), Q(dot(nb.GP, o.e2)));
-        carry = cvv<Q>(f.z) * Q(nb.W) - vmul(q, cvm<Q>(f.Sinv));
-    }
+    if (nb.W > 0) carry = cvv<Q>(f.z) * Q(nb.W) - vmul(cvv<Q>(nb.q), cvm<Q>(f.Sinv));
     const bool fN = wN && finite2(f.zN);
-    const bool fC = wC && finite2(f.z);
-    const V2<R> sN = fN ? f.zN : mk2<R>(R(0), R(0));
+    s.fC = wC && finite2(f.z);
+    s.sN = fN ? f.zN : mk2<R>(R(0), R(0));
     V2<Q> sCq = carry;
-    if (fC) sCq = sCq + cvv<Q>(f.z);
-    const V2<R> sC = cvv<R>(sCq);
-    const bool useN = sN.x != R(0) || sN.y != R(0);
-    const bool useC = has_next && (sC.x != R(0) || sC.y != R(0));
+    if (s.fC) sCq = sCq + cvv<Q>(f.z);
+    s.sC = cvv<R>(sCq);
+    s.useN = s.sN.x != R(0) || s.sN.y != R(0);
+    s.useC = has_next && (s.sC.x != R(0) || s.sC.y != R(0));
+    V2<Q> q = mk2<Q>(Q(0), Q(0));
+    if (s.useN) q = q + vmul(cvv<Q>(s.sN), cvm<Q>(e.AkmN));
+    if (s.useC) q = q + vmul(sCq, cvm<Q>(e.AkmC));
+    mine.q = cvv<R>(q);
+    mine.W = nb.W + (fN ? 1 : 0) + (s.fC ? 1 : 0);
+    return s;
+}
+// results of lane k.  Gx lacks d/dx_k through constraint k+1: the caller subtracts GP of lane k+1.
+template <typename R> struct MOut { V3<R> Gx, gn, gm, glight, gdiff, GP; };
+// Pass 2: both versions swept once more, seeded with the lane's final seeds.
+template <typename R> EPSM_HD MOut<R> manifold_contract(const Pts<R> &p, const MSeeds<R> &s, bool has_next) {
+    MOut<R> out;
     const V3<R> z3 = zero3<R>();
-    const V3<R> a_p = useN ? lin(e.jn.gxp, sN) : z3, a_n = useN ? lin(e.jn.gxn, sN) : z3, a_g = useN ? lin(e.jn.gn, sN) : z3;
-    const V3<R> c_p = useC ? lin(e.jc.gxp, sC) : z3, c_n = useC ? lin(e.jc.gxn, sC) : z3, c_g = useC ? lin(e.jc.gn, sC) : z3;
-    // -(a.gxc + c.gxc + GP) with gxc = -(gxp + gxn)
-    out.Gx = (a_p + a_n) + (c_p + c_n) - nb.GP;
-    out.gn = -(a_g + c_g);
-    out.gm = has_next ? mk3<R>(sC.x, sC.y, R(0)) : z3;        // dC/dm = -I on continuing rows (epsm.py:883)
-    out.glight = -a_n;
-    out.gdiff = fC ? -c_n : z3;                               // carry == 0 whenever fC (a diffuse x_{k+1} ends the chain)
-    mine.GP = a_p + c_p;
-    mine.W = nb.W + (fN ? 1 : 0) + (fC ? 1 : 0);
+    Swp<R> a = zero_swp<R>(), c = a;
+    if (s.useN || s.useC) {
+        const Frm<R> f = make_frm(p.n);
+        const Dir<R> wi = make_dir(p.x, p.xp);
+        if (s.useN) a = halfvec_seeded(f, wi, make_dir(p.x, p.light), p.eta, s.sN);
+        if (s.useC) c = halfvec_seeded(f, wi, make_dir(p.x, p.xn), p.eta, s.sC);
+    }
+    out.Gx = (a.p + a.n) + (c.p + c.n);                       // -(a.gxc + c.gxc) with gxc = -(gxp + gxn)
+    out.gn = -(a.g + c.g);
+    out.gm = has_next ? mk3<R>(s.sC.x, s.sC.y, R(0)) : z3;    // dC/dm = -I on continuing rows (epsm.py:883)
+    out.glight = -a.n;
+    out.gdiff = s.fC ? -c.n : z3;                             // carry == 0 whenever fC (a diffuse x_{k+1} ends the chain)
+    out.GP = a.p + c.p;
     return out;
 }
 
 // ============================================================================
 // "manifold_caustic"
 // ============================================================================
-template <typename R> struct CEval {
-    Jac<R> jc, jw;                  // half-vector constraint of vertex k (k >= 2), pseudo-constraint wo2 of depth k
-    M2<R> Akk, Akm, Aup, Wk;
-};
-template <typename R> EPSM_HD CEval<R> caustic_eval(const Own<R> &o, const Nbr<R> &prev, const Nbr<R> &next, bool first) {
-    CEval<R> e;
+template <typename R> struct CBlocks { M2<R> Akk, Akm, Aup, Wk; };      // half-vector constraint of vertex k (k >= 2); pseudo-constraint wo2 of depth k
+template <typename R> EPSM_HD CBlocks<R> caustic_blocks(const Own<R> &o, const Nbr<R> &prev, const Nbr<R> &next, bool first) {
+    CBlocks<R> e;
     const M2<R> z{R(0), R(0), R(0), R(0)};
     const Frm<R> f = make_frm(o.n);
     const Dir<R> wo = make_dir(o.x, next.x);
-    e.jw = wo2_jac(f, wo);
-    e.Wk = blk_own(e.jw, o);
-    e.jc = zero_jac<R>();
+    e.Wk = blk_own(wo2_jac(f, wo), o);
     e.Akk = e.Akm = e.Aup = z;
     if (!first) {
-        e.jc = halfvec_jac(f, make_dir(o.x, prev.x), wo, o.eta);
-        e.Akm = blk(e.jc.gxp, prev.e1, prev.e2);
-        e.Akk = blk_own(e.jc, o);
-        e.Aup = blk(e.jc.gxn, next.e1, next.e2);
+        const Jac<R> j = halfvec_jac(f, make_dir(o.x, prev.x), wo, o.eta);
+        e.Akm = blk(j.gxp, prev.e1, prev.e2);
+        e.Akk = blk_own(j, o);
+        e.Aup = blk(j.gxn, next.e1, next.e2);
     }
     return e;
 }
@@ -321,7 +364,7 @@ template <typename R> EPSM_HD CFwd<R> cfwd_zero() {
     return f;
 }
 template <typename R>
-EPSM_HD CFwd<R> caustic_fwd(const CEval<R> &e, V2<R> dk, bool first, const CFwd<R> &pf, const M2<R> &pAup) {
+EPSM_HD CFwd<R> caustic_fwd(const CBlocks<R> &e, V2<R> dk, bool first, const CFwd<R> &pf, const M2<R> &pAup) {
     CFwd<R> o;
     o.v = mk2<R>(R(0), R(0));
     V2<R> rk = dk;
@@ -335,32 +378,32 @@ EPSM_HD CFwd<R> caustic_fwd(const CEval<R> &e, V2<R> dk, bool first, const CFwd<
     return o;
 }
 template <typename R> struct COut { V3<R> Gx, gn, gm, gdiff, gxp_prev; };
-// lane k once the recursion has reached it; `inP` = k <= id*, `star` = k == id*, wD = plan_b(k).
+// lane k once the recursion has reached it (pass 2: seeded sweeps); `inP` = k <= id*, `star` = k == id*, wD = plan_b(k).
 // gxp_prev: -(d/dx_{k-1}) through constraint k, to be ADDED to Gx of lane k-1.
-template <typename R> EPSM_HD COut<R> caustic_finish(const CEval<R> &e, const CFwd<R> &f, bool first, bool inP, bool star, bool wD) {
+template <typename R> EPSM_HD COut<R> caustic_finish(const Pts<R> &p, const CFwd<R> &f, bool first, bool inP, bool star, bool wD) {
     COut<R> o;
     const V3<R> z3 = zero3<R>();
     o.Gx = o.gn = o.gm = o.gdiff = o.gxp_prev = z3;
-    const V3<R> cs_p = lin(e.jc.gxp, f.v), cs_n = lin(e.jc.gxn, f.v), cs_g = lin(e.jc.gn, f.v);
-    const V3<R> ws_n = lin(e.jw.gxn, f.u), ws_g = lin(e.jw.gn, f.u);
+    const Frm<R> fr = make_frm(p.n);
+    const Dir<R> wo = make_dir(p.x, p.xn);
+    Swp<R> cs = zero_swp<R>();
+    if (!first) cs = halfvec_seeded(fr, make_dir(p.x, p.xp), wo, p.eta, f.v);
     if (inP) {
-        o.Gx = cs_p + cs_n;                       // -cs.gxc
-        o.gn = -cs_g;
+        o.Gx = cs.p + cs.n;                       // -cs.gxc
+        o.gn = -cs.g;
         if (!first) o.gm = mk3<R>(f.v.x, f.v.y, R(0));
-        o.gxp_prev = -cs_p;
+        o.gxp_prev = -cs.p;
         if (star) {
-            o.Gx = o.Gx + ws_n;                   // -ws.gxc, gxc = -gxn
-            o.gn = o.gn - ws_g;
+            const Swp<R> ws = wo2_seeded(fr, wo, f.u);
+            o.Gx = o.Gx + ws.n;                   // -ws.gxc, gxc = -gxn
+            o.gn = o.gn - ws.g;
         }
     }
     if (wD && f.fin) {
         // epsm.py:1139-1157: row block id (gxn, plus the stale wo2[0] gradient on its second row) and the pseudo rows
-        if (!first) {
-            const V3<R> wx = e.jw.gxn[0] * (f.u.x + f.v.y) + e.jw.gxn[1] * f.u.y;
-            o.gdiff = -(wx + cs_n);
-        } else {
-            o.gdiff = -ws_n;
-        }
+        const V2<R> sw = first ? f.u : mk2<R>(f.u.x + f.v.y, f.u.y);
+        const Swp<R> wx = wo2_seeded(fr, wo, sw);
+        o.gdiff = first ? -wx.n : -(wx.n + cs.n);
     }
     return o;
 }

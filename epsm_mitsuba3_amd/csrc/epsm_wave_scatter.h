@@ -80,9 +80,10 @@ constexpr int kMaxProbe = 8;
 struct AccFloat {
     typedef float T;
     static constexpr bool kBucketed = false;         // see LdsTable::add
-    __device__ __forceinline__ static void add(T *p, float x) { atomicAdd(p, x); }
+    __device__ __forceinline__ static void add(T *p, float x) { if (fabsf(x) < __builtin_inff()) atomicAdd(p, x); }   // non-finite terms add nothing (AccFixed64::to_fixed)
     __device__ __forceinline__ static float get(T q) { return q; }
 };
+__device__ __forceinline__ bool adds_something(float x) { return x != 0.f && fabsf(x) < __builtin_inff(); }   // neither 0 nor NaN / inf
 struct AccFixed64 {
     typedef long long T;
     static constexpr bool kBucketed = true;
@@ -119,10 +120,10 @@ struct LdsTable {
         float *p;
         if (key < V) p = gpos + 3 * (int64_t) key;
         else if (key < 2u * V) p = gnrm + 3 * (int64_t) (key - V);
-        else { if (x != 0.f) atomicAdd(galpha + (key - 2u * V), x); return; }
-        if (x != 0.f) atomicAdd(p + 0, x);
-        if (y != 0.f) atomicAdd(p + 1, y);
-        if (z != 0.f) atomicAdd(p + 2, z);
+        else { if (adds_something(x)) atomicAdd(galpha + (key - 2u * V), x); return; }
+        if (adds_something(x)) atomicAdd(p + 0, x);
+        if (adds_something(y)) atomicAdd(p + 1, y);
+        if (adds_something(z)) atomicAdd(p + 2, z);
     }
     // LDS atomic rates on MI355X (tools/micro/lds_atomics.hip; lane-ops per clock and CU, scattered rows / 16 hot rows):
     // ds_add_f32 0.33 / 0.42, read + ds_cmpst float-add loop 3.3 / 0.47, ds_add_u64 6.1 / 3.4, ds_add_u32 11.4 / 4.3,

@@ -55,32 +55,48 @@ template <typename R> static V2<R> d_of(const HostArgs<R> &A, int k, int64_t i) 
 }
 template <typename R> static void put(R *base, int64_t slot, const HostArgs<R> &A, int64_t i, V3<R> g) { store3(base, slot, A.N, i, g, A.clip); }
 
+template <typename R> static cp::Pts<R> pts_of(const cp::Own<R> &o, const cp::Nbr<R> &prev, const cp::Nbr<R> &next) {
+    cp::Pts<R> p;
+    p.x = o.x; p.n = o.n; p.light = o.light; p.eta = o.eta; p.xp = prev.x; p.xn = next.x;
+    return p;
+}
+
 template <typename R> static void manifold_one(const HostArgs<R> &A, int64_t i) {
     const uint32_t plan = cp::manifold_plan(flag_word(A, i));
     const int nv = cp::plan_nv(plan), m = cp::plan_m(plan);
     if (cp::plan_diffuse1(plan)) put(A.od, 0, A, i, load3(A.dldp, i));
     cp::Own<R> own[kMaxVertices + 1];
-    cp::MEval<R> ev[kMaxVertices + 1];
+    cp::Pts<R> pts[kMaxVertices + 1];
+    cp::MBlocks<R> ev[kMaxVertices + 1];
     cp::MFwd<R> fw[kMaxVertices + 2];
-    for (int k = 1; k <= m; ++k) {
+    cp::MOut<R> out[kMaxVertices + 2];
+    for (int k = 1; k <= m; ++k) {                        // pass 1: the blocks
         const bool has_next = k + 1 <= nv;
         own[k] = own_of(A, k, i);
         cp::Nbr<R> next; next.x = next.e1 = next.e2 = zero3<R>();
         if (has_next) next = nbr_of(A, k + 1, i);
-        ev[k] = cp::manifold_eval(own[k], nbr_of(A, k - 1, i), next, cp::plan_a(plan, k), has_next);
+        const cp::Nbr<R> prev = nbr_of(A, k - 1, i);
+        ev[k] = cp::manifold_blocks(own[k], prev, next, cp::plan_a(plan, k), has_next);
+        pts[k] = pts_of(own[k], prev, next);
     }
     fw[0] = cp::mfwd_zero<R>();
     for (int k = 1; k <= m; ++k)
         fw[k] = cp::manifold_fwd(ev[k], d_of(A, k, i), k == 1, fw[k - 1], k > 1 ? ev[k - 1].Aup : ev[k].Aup, cp::plan_a(plan, k), k + 1 <= nv);
-    cp::MBwd<R> nb; nb.GP = zero3<R>(); nb.W = 0;
-    for (int k = m; k >= 1; --k) {
+    cp::MBwd<R> nb; nb.q = mk2<R>(R(0), R(0)); nb.W = 0;
+    for (int k = m; k >= 1; --k) {                        // backward recursion on the blocks, then pass 2: the seeded sweeps
         cp::MBwd<R> mine;
-        const cp::MOut<R> o = cp::manifold_bwd(ev[k], fw[k], own[k], nb, cp::plan_a(plan, k), cp::plan_b(plan, k), k + 1 <= nv, mine);
+        const cp::MSeeds<R> sd = cp::manifold_bwd(ev[k], fw[k], nb, cp::plan_a(plan, k), cp::plan_b(plan, k), k + 1 <= nv, mine);
         nb = mine;
+        out[k] = cp::manifold_contract(pts[k], sd, k + 1 <= nv);
+    }
+    out[m + 1].GP = zero3<R>();
+    for (int k = 1; k <= m; ++k) {
+        const cp::MOut<R> &o = out[k];
+        const V3<R> Gx = o.Gx - out[k + 1].GP;           // d/dx_k through constraint k+1 (the lane exchange of the kernel)
         const R b0 = own[k].b0, b1 = own[k].b1;
-        put(A.op, 5 * (k - 1) + 0, A, i, o.Gx * b0);
-        put(A.op, 5 * (k - 1) + 1, A, i, o.Gx * b1);
-        put(A.op, 5 * (k - 1) + 2, A, i, o.Gx * (R(1) - b0 - b1));
+        put(A.op, 5 * (k - 1) + 0, A, i, Gx * b0);
+        put(A.op, 5 * (k - 1) + 1, A, i, Gx * b1);
+        put(A.op, 5 * (k - 1) + 2, A, i, Gx * (R(1) - b0 - b1));
         put(A.op, 5 * (k - 1) + 3, A, i, o.gn);
         put(A.op, 5 * (k - 1) + 4, A, i, o.gm);
         put(A.ol, k - 1, A, i, o.glight);
@@ -93,19 +109,22 @@ template <typename R> static void caustic_one(const HostArgs<R> &A, int64_t i) {
     const int m = cp::plan_m(plan), idstar = cp::plan_idstar(plan);
     if (cp::plan_diffuse1(plan)) put(A.od, 0, A, i, load3(A.dldp, i));
     cp::Own<R> own[kMaxVertices + 1];
-    cp::CEval<R> ev[kMaxVertices + 1];
+    cp::Pts<R> pts[kMaxVertices + 1];
+    cp::CBlocks<R> ev[kMaxVertices + 1];
     cp::CFwd<R> fw[kMaxVertices + 2];
     cp::COut<R> out[kMaxVertices + 2];
     for (int k = 1; k <= m; ++k) {
         own[k] = own_of(A, k, i);
-        ev[k] = cp::caustic_eval(own[k], nbr_of(A, k - 1, i), nbr_of(A, k + 1, i), k == 1);
+        const cp::Nbr<R> prev = nbr_of(A, k - 1, i), next = nbr_of(A, k + 1, i);
+        ev[k] = cp::caustic_blocks(own[k], prev, next, k == 1);
+        pts[k] = pts_of(own[k], prev, next);
     }
     fw[0] = cp::cfwd_zero<R>();
     bool poisoned = false;
     for (int k = 1; k <= m; ++k) {
         fw[k] = cp::caustic_fwd(ev[k], d_of(A, k, i), k == 1, fw[k - 1], k > 1 ? ev[k - 1].Aup : ev[k].Aup);
         if (k == idstar && !fw[k].fin) poisoned = true;
-        out[k] = cp::caustic_finish(ev[k], fw[k], k == 1, k <= idstar, k == idstar, cp::plan_b(plan, k));
+        out[k] = cp::caustic_finish(pts[k], fw[k], k == 1, k <= idstar, k == idstar, cp::plan_b(plan, k));
     }
     out[m + 1].gxp_prev = zero3<R>();
     for (int k = 1; k <= m; ++k) {

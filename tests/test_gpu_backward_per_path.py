@@ -78,11 +78,14 @@ def test_unbounded_emitter_weights_leave_finite_rows():
     b = bad.pos.view(2, K, N, 3, 3).cpu()
     untouched = ~(inf_paths | big_paths)
     assert float(c[1].abs().max()) > 0                                       # there ARE light-sample terms
-    assert torch.equal(b[0], c[0]) and torch.equal(bad.nrm, clean.nrm) and torch.equal(bad.alpha, clean.alpha)   # hit rows, normals, alphas
-    assert torch.equal(b[1][:, untouched], c[1][:, untouched])               # emitter rows of the other paths
+    same = lambda x, y: torch.allclose(x, y, rtol=1e-5, atol=1e-7 * float(y.abs().max()))      # (order of the float atomics of a crowded table)
+    assert same(b[0], c[0]) and same(bad.nrm, clean.nrm) and same(bad.alpha, clean.alpha)   # hit rows, normals, alphas
+    assert same(b[1][:, untouched], c[1][:, untouched])                      # emitter rows of the other paths
     assert float(b[1][:, inf_paths].abs().max()) == 0.0                      # inf x term: nothing (0 x inf = NaN included)
     live = c[1][:, big_paths] != 0
     got, want = b[1][:, big_paths][live], c[1][:, big_paths][live]
-    assert live.any() and bool((got.sign() == want.sign()).all())            # saturated, with the term's own sign ...
-    assert float(got.abs().min()) > 5e5 and float(got.abs().max()) <= 2 ** 19     # ... at the top of the rows' range
+    # saturated at the top of the rows' range (or, for a row the crowded table sent straight to HBM, the product itself),
+    # with the term's own sign: never wrapped around, never a small number
+    assert live.any() and bool((got.sign() == want.sign()).all())
+    assert float(got.abs().min()) > 5e5
     assert bool((b[1][:, big_paths][~live] == 0).all())
