@@ -28,14 +28,14 @@ dominant kernel (one slab's ``epsm_backward_cp_kernel`` launch) against the 8 TB
 peak with the ALGORITHMIC bytes of SURVEY.md 8d (56 + 116 K per path in one launch,
 32 + 116 K fused, 32 + 200 K stand-alone) over its own average launch time, measured with
 HIP events on the launch stream around every launch of the timed region; next to it
-``live_algorithmic_bytes`` / ``frac_live`` (only the vertices a path's terms reach, from
+``frac_survey`` (SURVEY 8d's 32 + 116 K), ``live_algorithmic_bytes`` / ``frac_live`` (only the vertices a path's terms reach, from
 the flag words) and ``valu_floor_ms`` (the kernel's vector instructions at one per four
 clocks and SIMD, from the committed counter run), so that the line says which bound applies;
 ``cpu_baseline`` times oracle/ (the C restatement: tangent + calc_grad + scatter) on this
 box's host cores on a bounded sample of the same records.  Secondary keys, all outside the
 timed region (default run only): ``configs_1`` (BASELINE.json configs[1]), ``real_scene``
 (render_backward on records the library's own tracer produces: trace + native log + backward
-pass) and ``hybrid_phase2`` (prb_reparam's render_backward on the same traced scene: the
+pass; its rate is repeated at top level as ``end_to_end_paths_per_s``) and ``hybrid_phase2`` (prb_reparam's render_backward on the same traced scene: the
 reparameterised pass of the hybrid scheme's second phase).
 """
 from __future__ import annotations
@@ -631,7 +631,11 @@ def main():
             "record_layout": "packed: one 128-byte record per (path, vertex) + rays (N,12) + flag word" if packed_log
                              else "reference tensors: one (N,3) array per field",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # SURVEY.md 8(d)'s own figure for a fused pass, 32 + 116 K B/path (cam + dlduv + dldp = 32 instead of the
+                         # rays + image gradient = 56 this launch reads because it computes the tangent itself)
+                         "frac_survey": ((32 + 116 * K) * n_slab0 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fused else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("epsm_backward_cp_kernel<tangents in kernel> (epsm_backward_pass: tangent + calc_grad + scatter)"
                                     if one_launch else "epsm_backward_cp_kernel (fused calc_grad + scatter)") if fused else "epsm_grad_kernel",
                          "kernel_ms": kernel_ms, "launches_timed": len(launch_events), "paths_per_launch": n_slab0,
@@ -666,6 +670,11 @@ def main():
             del slabs, out
             torch.cuda.empty_cache()
             result["real_scene"] = real_scene_leg(variant, 512, 64, dev)
+            # `value` counts the backward pass on RESIDENT synthetic records; with the library's own tracer producing them the
+            # whole gradient image runs at this rate (first screen of the line, not a nested key)
+            result["end_to_end_paths_per_s"] = result["real_scene"]["paths_per_s"]
+            result["end_to_end_note"] = ("render_backward on TRACED records (real_scene: trace + native log + backward pass); "
+                                         "`value` is the backward pass alone on resident synthetic records")
             torch.cuda.empty_cache()
             result["hybrid_phase2"] = hybrid_phase2_leg(256, 16, 16, dev)
     if world > 1:

@@ -27,20 +27,30 @@ namespace {
 #ifndef EPSM_CP_THREADS
 #define EPSM_CP_THREADS 256
 #endif
+// Shape (round 4): workgroups of four waves, THREE of them per CU = three waves per SIMD.  That takes <= 168 registers (the
+// kernel has 168, no scratch access inside the round loop: csrc/build/asm, tools/cp_regs.sh) and <= 53 248 bytes of LDS per
+// workgroup -- a CU hands out 159 744 bytes (2 x 79 872 fitted in round 3, 3 x 53 872 does not, 3 x 53 120 does): the wave
+// queues went from 384 to 192 items (one push of three rows from every lane), the table from 1504 to 960 fixed-point rows.
+// (384-thread workgroups, two per CU: the second one is never co-resident -- 1485 waves in flight of 3072, 3.40 ms; 768
+// threads, one per CU: 2.53 ms -- twelve waves meet at every barrier of a window; 192 threads, four per CU: 2.83 ms.)
 #ifndef EPSM_CP_OCC
-#define EPSM_CP_OCC 2                   // waves per SIMD the register budget is set for
+#define EPSM_CP_OCC 3                   // waves per SIMD the register budget is set for
 #endif
 #ifndef EPSM_CP_ROWS_FLOAT
-#define EPSM_CP_ROWS_FLOAT 3072
+#define EPSM_CP_ROWS_FLOAT 2064
 #endif
 #ifndef EPSM_CP_ROWS_FIXED
-#define EPSM_CP_ROWS_FIXED 1728
+#define EPSM_CP_ROWS_FIXED 1184
 #endif
 #ifndef EPSM_CP_QUEUE
-#define EPSM_CP_QUEUE 384               // >= 4 rows x 64 lanes, the largest push
+#define EPSM_CP_QUEUE 192               // >= 3 rows x 64 lanes, the largest push
 #endif
+// One window per workgroup: the hardware's dispatcher balances the windows over the 768 resident workgroups better than
+// contiguous ranges per persistent workgroup did (headline slab, ms: 768 workgroups 2.22, 1536 2.32, 2048 -- round 3's
+// choice at 512 resident ones -- 2.14, 3072 2.16, 4096 2.12, 8192 = one window each 2.07); the table is flushed about once
+// per window anyway.  A launch of more windows than this walks several per workgroup.
 #ifndef EPSM_CP_BLOCKS
-#define EPSM_CP_BLOCKS 2048
+#define EPSM_CP_BLOCKS (1 << 20)
 #endif
 constexpr int kThreads = EPSM_CP_THREADS, kWaves = kThreads / 64, kQueueCap = EPSM_CP_QUEUE;
 constexpr int kKeys = 6;                // m = 0..5
@@ -141,29 +151,11 @@ template <bool PACKED> struct Records {
 };
 
 // ---- emission: the rows of one vertex into the wave queue (clamp / NaN rule of calc_grad per (N,3) component first,
-// then the linear map of epsm_scatter_core.h: epsm.py:559-562, 622-627, 644-645).
-//
-// Two steps, so that few registers live across the prefetch of the next round's records (which sits between them):
-//   rows_of()   everything that needs the vertex's geometry, its gradients and its table rows is folded into the SEEDS of
-//               the row groups -- the position rows themselves (with the flat-normal part and diffuse_grad[0] added), the
-//               projected normal gradient, the emitter gradient times its weight, the alpha scalar, the end-point and occluder
-//               gradients -- plus the weights and keys they will be spread with: ~45 registers;
-//   emit()      one group of three rows after the other is formed in ONE reused V3 vals[3], merged over the wave (DPP) and
-//               pushed: positions, normals, emitter, alpha, end point, occluder.  All 64 lanes call both.
-struct RowSeeds {
-    V3<float> P[3];                  // position rows of the hit triangle: fin(b_j Gx) (+ flat-normal part) + b_j fin(dldp) where the first hit is diffuse
-    V3<float> pg;                    // normal rows: pg b_j
-    float b0, b1;
-    uint32_t k0, k1, k2;             // rows of the hit triangle
-    V3<float> gl; float eb0, eb1;    // emitter rows: gl eb_j
-    uint32_t e0, e1, e2;
-    float a; uint32_t akey;          // alpha row
-    V3<float> gd; float nb0, nb1;    // end-point rows (diffuse_grad of the next vertex): gd nb_j
-    uint32_t n0, n1, n2;
-    V3<float> gs; float c0, c1;      // occluder rows: gs c_j
-    uint32_t s0, s1, s2;
-    bool pos_v, nrm_v, e_v, a_v, d_v, s_v;
-};
+// then the linear map of epsm_scatter_core.h: epsm.py:559-562, 622-627, 644-645).  One GROUP of three rows after the other
+// is formed in one reused V3 vals[3], merged over the wave (DPP) and pushed -- positions (with the flat-normal part and
+// diffuse_grad[0] folded in), normals, emitter, alpha, end point, occluder -- so that what a group needed is dead before
+// the next one starts (round 3 held pos[3], nrm[3], vals[6] and the emitter / alpha rows together: part of what pinned the
+// kernel at 256 registers).  All 64 lanes call it.
 template <typename Table> struct Emitter {
     const FusedArgs &F;
     const Table &T;
@@ -180,33 +172,35 @@ template <typename Table> struct Emitter {
     __device__ __forceinline__ static bool tri_ok(const U4 &t, int64_t V) {
         return t.x < (uint64_t) V && t.y < (uint64_t) V && t.z < (uint64_t) V;
     }
+    // three rows on keys (a, b, c), merged over the wave and queued
+    __device__ __forceinline__ void rows3(bool v, V3<float> vals[3], uint32_t a, uint32_t b, uint32_t c) const {
+        const uint32_t keys[3] = {a, b, c};
+        merge_equal<3, 2>(v, keys, vals);
+        push<3>(v, keys, vals);
+    }
+    // three rows g w_j
+    __device__ __forceinline__ void group(bool v, V3<float> g, float w0, float w1, uint32_t a, uint32_t b, uint32_t c) const {
+        if (__ballot(v) == 0ull) return;
+        V3<float> vals[3] = {g * w0, g * w1, g * (1.f - w0 - w1)};
+        rows3(v, vals, a, b, c);
+    }
     // `on`: this lane has a vertex whose parameter rows exist; `live`: it has a constraint (its end-point rows exist);
     // `d1`: it carries diffuse_grad[0] = dldp of a path whose first hit is diffuse (epsm.py:791-792, 998-1000) and the
     // occluder term (609-620).  n, e1, e2, b0, b1: geometry of the lane's vertex (b0, b1 also for a d1 lane without constraint).
-    __device__ __forceinline__ RowSeeds rows_of(bool on, bool live, bool d1, V3<float> Gx, V3<float> gn, V3<float> gm, V3<float> glight,
-                                                V3<float> gdiff, V3<float> dp, V3<float> n, V3<float> e1, V3<float> e2, float b0, float b1,
-                                                float nb0, float nb1, uint32_t bid, V3<float> dhf, float eb0, float eb1, float ew,
-                                                const U4 &t, const U4 &tn, const U4 &er, const U4 &sh, const U4 &ts) const {
-        RowSeeds S;
-        const float b2 = 1.f - b0 - b1;
+    __device__ __forceinline__ void vertex(bool on, bool live, bool d1, V3<float> Gx, V3<float> gn, V3<float> gm, V3<float> glight,
+                                           V3<float> gdiff, V3<float> dp, V3<float> n, V3<float> e1, V3<float> e2, float b0, float b1,
+                                           float nb0, float nb1, uint32_t bid, V3<float> dhf, float eb0, float eb1, float ew,
+                                           const U4 &t, const U4 &tn, const U4 &er, const U4 &sh, const U4 &ts) const {
         const V3<float> z = zero3<float>();
         const bool idx_ok = tri_ok(t, F.V), pos_ok = idx_ok && (t.w & kModePos);
-        S.b0 = b0; S.b1 = b1; S.k0 = t.x; S.k1 = t.y; S.k2 = t.z;
-        // si.p_j * path_grad[5it+j]
-        S.P[0] = on ? fin(Gx * b0) : z; S.P[1] = on ? fin(Gx * b1) : z; S.P[2] = on ? fin(Gx * b2) : z;
-        S.pg = z; S.nrm_v = false;
         gn = fin(gn);
-        if (on && idx_ok && nz3(gn)) {                                        // si_follow.sh_frame.n * path_grad[5it+3]
-            const float sgn = (t.w & kModeFlip) ? -1.f : 1.f;
-            if (t.w & kModeVertexNormals) {
-                if (t.w & kModeNrm) {
-                    // logged normals are post-flip: n = sum_j b_j n'_j; sh = normalize(n)   (mesh.cpp:784-790, 820-827)
-                    const float il = rsqrt_(dot(n, n));
-                    const V3<float> sh_ = n * il;
-                    S.pg = (gn - sh_ * dot(sh_, gn)) * (il * sgn);
-                    S.nrm_v = nz3(S.pg);
-                }
-            } else if (pos_ok) {
+        const bool gn_on = on && idx_ok && nz3(gn);
+        const float sgn = (t.w & kModeFlip) ? -1.f : 1.f;
+        const V3<float> dpf = d1 ? fin(dp) : z;                               // diffuse_grad[0]
+        {   // ---- position rows of the hit triangle: si.p_j * path_grad[5it+j]  +  si_follow.p * diffuse_grad[0] (561-562)
+            const float b2 = 1.f - b0 - b1;
+            V3<float> P[3] = {on ? fin(Gx * b0) : z, on ? fin(Gx * b1) : z, on ? fin(Gx * b2) : z};
+            if (gn_on && !(t.w & kModeVertexNormals) && pos_ok) {
                 // flat: sh = sgn normalize(cross(p1-p0, p2-p0)) with p1-p0 = e2-e1, p2-p0 = -e1   (mesh.cpp:729, 811)
                 const V3<float> d0 = e2 - e1, d1_ = -e1;
                 const V3<float> cr = cross(d0, d1_);
@@ -214,59 +208,49 @@ template <typename Table> struct Emitter {
                 const V3<float> ch = cr * il;
                 const V3<float> cb = (gn - ch * dot(ch, gn)) * (il * sgn);
                 const V3<float> d0b = cross(d1_, cb), d1b = cross(cb, d0);
-                S.P[1] = S.P[1] + d0b; S.P[2] = S.P[2] + d1b; S.P[0] = S.P[0] - (d0b + d1b);
+                P[1] = P[1] + d0b; P[2] = P[2] + d1b; P[0] = P[0] - (d0b + d1b);
+            }
+            if (d1) { P[0] = P[0] + dpf * b0; P[1] = P[1] + dpf * b1; P[2] = P[2] + dpf * b2; }
+            const bool v = pos_ok && (nz3(P[0]) || nz3(P[1]) || nz3(P[2]));
+            if (__ballot(v) != 0ull) rows3(v, P, t.x, t.y, t.z);
+        }
+        {   // ---- normal rows: si_follow.sh_frame.n * path_grad[5it+3]; logged normals are post-flip: n = sum_j b_j n'_j,
+            // sh = normalize(n)   (mesh.cpp:784-790, 820-827)
+            V3<float> pg = z;
+            if (gn_on && (t.w & kModeVertexNormals) && (t.w & kModeNrm)) {
+                const float il = rsqrt_(dot(n, n));
+                const V3<float> sh_ = n * il;
+                pg = (gn - sh_ * dot(sh_, gn)) * (il * sgn);
+            }
+            const uint32_t V32 = (uint32_t) F.V;
+            group(nz3(pg), pg, b0, b1, V32 + t.x, V32 + t.y, V32 + t.z);
+        }
+        {   // ---- emitter rows: si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627); area lights are a handful of triangles
+            glight = fin(glight);
+            const bool v = on && nz3(glight) && tri_ok(er, F.V) && (er.w & kModePos);
+            group(v, glight * ew, eb0, eb1, er.x, er.y, er.z);
+        }
+        {   // ---- alpha row: bsdf_sample.hf * path_grad[5it+4]  (epsm.py:645); a handful of materials
+            gm = fin(gm);
+            bool v = on && nz3(gm) && bid < (uint64_t) F.B;
+            if (__ballot(v) != 0ull) {
+                V3<float> val[1] = {mk3<float>(v ? dot(gm, dhf) : 0.f, 0.f, 0.f)};
+                const uint32_t aid[3] = {2u * (uint32_t) F.V + bid, 0u, 0u};
+                merge_equal<1, 4>(v, aid, val);
+                push<1>(v, aid, val);
             }
         }
-        const V3<float> dpf = d1 ? fin(dp) : z;                                // si_follow.p * diffuse_grad[0], detached barycentrics (561-562)
-        if (d1) { S.P[0] = S.P[0] + dpf * b0; S.P[1] = S.P[1] + dpf * b1; S.P[2] = S.P[2] + dpf * b2; }
-        S.pos_v = pos_ok && (nz3(S.P[0]) || nz3(S.P[1]) || nz3(S.P[2]));
-        // bsdf_sample.hf * path_grad[5it+4]  and  si_direct.p * light_grad[it] * sum(Lr_dir)  (epsm.py:622-627, 645)
-        gm = fin(gm);
-        S.a_v = on && nz3(gm) && bid < (uint64_t) F.B;
-        S.a = S.a_v ? dot(gm, dhf) : 0.f;
-        S.akey = 2u * (uint32_t) F.V + bid;
-        glight = fin(glight);
-        S.e_v = on && nz3(glight) && tri_ok(er, F.V) && (er.w & kModePos);
-        S.gl = S.e_v ? glight * ew : z; S.eb0 = eb0; S.eb1 = eb1; S.e0 = er.x; S.e1 = er.y; S.e2 = er.z;
-        // si_follow.p * diffuse_grad[it] with detached barycentrics (epsm.py:561-562): rows of the NEXT vertex's triangle
-        gdiff = fin(gdiff);
-        S.d_v = live && nz3(gdiff) && tri_ok(tn, F.V) && (tn.w & kModePos);
-        S.gd = S.d_v ? gdiff : z; S.nb0 = nb0; S.nb1 = nb1; S.n0 = tn.x; S.n1 = tn.y; S.n2 = tn.z;
-        // occluder of the first vertex's emitter sample: si_direct.p * diffuse_grad[0] * dis (epsm.py:609-620);
-        // sh = [stri, sb0, sb1, dis] (EpsmScatterRecord.shadow), ts = the occluder triangle's row of the scene table
-        const float dis = bits_to_float(sh.w);
-        S.s_v = d1 && nz3(dpf) && tri_ok(ts, F.V) && (ts.w & kModePos) && dis != 0.f;
-        S.gs = S.s_v ? dpf * dis : z; S.c0 = bits_to_float(sh.y); S.c1 = bits_to_float(sh.z); S.s0 = ts.x; S.s1 = ts.y; S.s2 = ts.z;
-        return S;
-    }
-    // three rows g w_j on keys (a, b, c)
-    __device__ __forceinline__ void group(bool v, V3<float> g, float w0, float w1, uint32_t a, uint32_t b, uint32_t c) const {
-        if (__ballot(v) == 0ull) return;
-        V3<float> vals[3] = {g * w0, g * w1, g * (1.f - w0 - w1)};
-        const uint32_t keys[3] = {a, b, c};
-        merge_equal<3, 2>(v, keys, vals);
-        push<3>(v, keys, vals);
-    }
-    __device__ __forceinline__ void emit(const RowSeeds &S) const {
-        if (__ballot(S.pos_v) != 0ull) {
-            bool v = S.pos_v;
-            V3<float> vals[3] = {S.P[0], S.P[1], S.P[2]};
-            const uint32_t keys[3] = {S.k0, S.k1, S.k2};
-            merge_equal<3, 2>(v, keys, vals);
-            push<3>(v, keys, vals);
+        {   // ---- end-point rows: si_follow.p * diffuse_grad[it] with detached barycentrics (epsm.py:561-562), the NEXT vertex's triangle
+            gdiff = fin(gdiff);
+            const bool v = live && nz3(gdiff) && tri_ok(tn, F.V) && (tn.w & kModePos);
+            group(v, gdiff, nb0, nb1, tn.x, tn.y, tn.z);
         }
-        const uint32_t V32 = (uint32_t) F.V;
-        group(S.nrm_v, S.pg, S.b0, S.b1, V32 + S.k0, V32 + S.k1, V32 + S.k2);
-        group(S.e_v, S.gl, S.eb0, S.eb1, S.e0, S.e1, S.e2);                  // area lights are a handful of triangles
-        if (__ballot(S.a_v) != 0ull) {                                        // a handful of materials
-            bool v = S.a_v;
-            V3<float> val[1] = {mk3<float>(S.a, 0.f, 0.f)};
-            const uint32_t aid[3] = {S.akey, 0u, 0u};
-            merge_equal<1, 4>(v, aid, val);
-            push<1>(v, aid, val);
+        {   // ---- occluder of the first vertex's emitter sample: si_direct.p * diffuse_grad[0] * dis (epsm.py:609-620);
+            // sh = [stri, sb0, sb1, dis] (EpsmScatterRecord.shadow), ts = the occluder triangle's row of the scene table
+            const float dis = bits_to_float(sh.w);
+            const bool v = d1 && nz3(dpf) && tri_ok(ts, F.V) && (ts.w & kModePos) && dis != 0.f;
+            group(v, dpf * dis, bits_to_float(sh.y), bits_to_float(sh.z), ts.x, ts.y, ts.z);
         }
-        group(S.d_v, S.gd, S.nb0, S.nb1, S.n0, S.n1, S.n2);
-        group(S.s_v, S.gs, S.c0, S.c1, S.s0, S.s1, S.s2);
     }
 };
 
@@ -287,7 +271,7 @@ struct Rounds {
         const int c = q > 0 ? q : 1, ppr = 64 / c;
         const int j = div_small(lane, c), k = lane - j * c + 1;
         const int idx = (r - rb_q) * ppr + j;
-        const bool lane_on = r < rb[kKeys] && j < ppr && idx < n_q;
+        const bool lane_on = r >= 0 && r < rb[kKeys] && j < ppr && idx < n_q;      // (r < 0: past the last round handed out)
         const int loc = lane_on ? (int) perm[cls_q + idx] : 0;
         L.q = q; L.c = c; L.k = k; L.loc = loc;
         L.plan = lane_on ? plan[loc] : 0u;               // (paths beyond the end of the wavefront have plan 0)
@@ -295,63 +279,99 @@ struct Rounds {
     }
 };
 
-// ---- the first-level global loads of a round (native log), held in registers from their issue -- one round ahead, before
-// the previous round's emission -- to their use.  o: the lane's own record (words 24..27 emitter sample, 28 triangle id,
-// 29..31 d hf / d alpha); p: the FIRST lane of a path holds its rays here (12 words); n: the LAST lane of a path whose chain
-// ends on a vertex without a lane of its own (the diffuse end point: k + 1 = nv > m) holds quads 0, 1, word 8, words 18, 19
-// and the triangle id of record k + 1; the image gradient of the path's pixel.  The geometry of vertices k - 1 and k + 1 that
-// DO have a lane comes from that lane (one shuffle per word once the records have landed) instead of being read again:
-// round 3 re-read 2 x (2 quads + 4 words) per lane.
-struct Fetch {
-    F4v o[7];                        // own record, quads 0..6
-    uint32_t o_tid; float dhf[3];    // own record, word 28 and words 29..31
-    F4v p[3];                        // first lane: the rays
-    F4v n[2]; float n_z, n_b[2];     // last lane, record k+1: quads 0, 1, word 8, words 18, 19 ...
-    uint32_t n_tid;                  // ... and its triangle id
+// ---- what a round reads of the native log, in three steps (round 4; round 3 prefetched all of it -- 62 registers -- one round
+// ahead and held it across the whole emission, which pinned the kernel at 256 registers = two waves per SIMD):
+//   touch   ONE word per cache line the NEXT round will read, issued between this round's solve and its emission: the lines
+//           travel from HBM to L2 while the rows are merged and inserted (4 registers, nobody reads them);
+//   geo     at the start of a round: the lane's own record, quads 0..5; the FIRST lane of a path its rays (12 words) and the
+//           image gradient of its pixel; the LAST lane of a path whose chain ends on a vertex without a lane of its own (the
+//           diffuse end point: k + 1 = nv > m) quads 0, 1, word 8 and words 18, 19 of record k + 1.  L2 hits, consumed at
+//           once.  The geometry of vertices k - 1 and k + 1 that DO have a lane comes from that lane (one shuffle per word)
+//           instead of being read again: round 3 re-read 2 x (2 quads + 4 words) per lane;
+//   addr    after the recursions: the words only the EMISSION needs -- emitter sample (quad 6), triangle id and d hf / d alpha
+//           (quad 7), triangle id and barycentrics of the end point, the occluder record -- from lines the geo step has just
+//           pulled into the vector cache; they and the rows of the scene table they name (requested after the second sweep)
+//           are NOT live across the recursions, where the 2x2 blocks in float64 need the registers.
+// A record is one 128-byte line; the 48 bytes of a path's rays may straddle two.
+struct Touch { float own, ray0, ray1, nxt; };
+struct GeoFetch {                    // (named fields, no arrays: the struct has to end up in registers, not in scratch memory)
+    F4v o0, o1, o2, o3, o4, o5;      // own record, quads 0..5
+    F4v p0, p1, p2;                  // first lane: the rays
+    F4v n0, n1; float n_z, n_b0, n_b1;   // last lane, record k+1: quads 0, 1, word 8, words 18, 19
     float gx, gy;
-    U4 sh;                           // the first vertex's occluder record (max_depth <= 3 logs)
+};
+struct AddrFetch {
+    F4v q6;                          // emitter sample [etri, eb0, eb1, eweight]
+    F4v q7;                          // [triangle id, d hf / d alpha]
+    float b0, b1;                    // a path without a constraint whose first hit is diffuse: its barycentrics ...
+    U4 sh;                           // ... and the first vertex's occluder record (max_depth <= 3 logs)
+    float n_b0, n_b1; uint32_t n_tid;    // last lane: barycentrics and triangle id of the end point
 };
 // (Only words that are USED are loaded: a register of a pending load's destination that nobody reads is free for the
-// register allocator, and the hardware's write to it then has to be waited for -- s_waitcnt in the middle of the emission.)
+// register allocator, and the hardware's write to it then has to be waited for.)
 typedef float F2v __attribute__((ext_vector_type(2)));
 typedef float F3v __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ F2v ld2(const float *p) { return *(const __attribute__((address_space(1))) F2v *) p; }
-__device__ __forceinline__ F3v ld3(const float *p) { return *(const __attribute__((address_space(1))) F3v *) p; }
-template <int VARIANT, int DMODE, bool PACKED>
-__device__ __forceinline__ void fetch_issue(Fetch &X, const FusedArgs &F, const LaneId &L, int64_t base) {
-    if (!PACKED) return;             // per-field arrays: loaded where they are used (the reference's layout is not the fast path)
-    const int k = L.k;
-    const bool ok = L.plan != 0u;
-    const int64_t i = base + L.loc;
-    const bool first = k == 1, live = ok && L.q > 0;
-    const bool end_next = live && k == L.c && k + 1 <= cp::plan_nv(L.plan);      // vertex k+1 exists and has no lane
-    const bool d1 = ok && first && cp::plan_diffuse1(L.plan);
-    const float *rec = F.pk_verts + (i * F.K + (k - 1)) * kRecWords;
-    if (live) {
-#pragma unroll
-        for (int t = 0; t < 6; ++t) X.o[t] = ldq(rec, t);
-        X.o_tid = __float_as_uint(lds_(rec, 28));
-        if (F.galpha) { const F3v d = ld3(rec + 29); X.dhf[0] = d.x; X.dhf[1] = d.y; X.dhf[2] = d.z; }
-        if (VARIANT == EPSM_VARIANT_MANIFOLD && cp::plan_a(L.plan, k)) X.o[6] = ldq(rec, 6);
-    } else if (ok) {                 // a path without a constraint: its tangent and diffuse_grad[0] only
-        if (L.plan & cp::kPlanActive1) { X.o[0] = ldq(rec, 0); X.o[1] = ldq(rec, 1); X.o[2] = ldq(rec, 2); }
-        if (d1) { X.o[4] = ldq(rec, 4); X.o_tid = __float_as_uint(lds_(rec, 28)); }
+struct LaneRole { bool ok, first, live, end_next, d1, act1; int64_t i; const float *rec; };
+__device__ __forceinline__ LaneRole role_of(const FusedArgs &F, const LaneId &L, int64_t base) {
+    LaneRole R;
+    R.ok = L.plan != 0u;
+    R.first = L.k == 1;
+    R.live = R.ok && L.q > 0;
+    R.end_next = R.live && L.k == L.c && L.k + 1 <= cp::plan_nv(L.plan);      // vertex k+1 exists and has no lane
+    R.d1 = R.ok && R.first && cp::plan_diffuse1(L.plan);
+    R.act1 = (L.plan & cp::kPlanActive1) != 0;
+    R.i = base + L.loc;
+    R.rec = F.pk_verts + (R.i * F.K + (L.k - 1)) * kRecWords;
+    return R;
+}
+__device__ __forceinline__ void touch_issue(Touch &C, const FusedArgs &F, const LaneId &L, int64_t base) {
+    const LaneRole R = role_of(F, L, base);
+    if (R.live || (R.ok && (R.act1 || R.d1))) C.own = lds_(R.rec, 0);
+    if (R.ok && R.first) { const float *rays = F.pk_rays + 12 * R.i; C.ray0 = lds_(rays, 0); C.ray1 = lds_(rays, 11); }
+    if (R.end_next) C.nxt = lds_(R.rec + kRecWords, 0);
+}
+// pixel of path i: (path_offset + i) / spp, row-major on the res x res crop (epsm.py:250); 32-bit arithmetic where it fits
+__device__ __forceinline__ const float *pixel_grad(const TangentIn &A, int64_t i) {
+    const int64_t p = A.path_offset + i;
+    int64_t pix, y, x;
+    if (p < (int64_t) 0x7fffffff) { const uint32_t q = (uint32_t) p / (uint32_t) A.spp; pix = q; const uint32_t yy = q / (uint32_t) A.res; y = yy; x = q - yy * (uint32_t) A.res; }
+    else { pix = p / A.spp; y = pix / A.res; x = pix - y * A.res; }
+    return A.grad_img + (y * A.img_width + x) * A.img_channels + 3;
+}
+__device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const LaneId &L, int64_t base) {
+    const LaneRole R = role_of(F, L, base);
+    if (R.live || (R.ok && R.act1)) {     // (a path without a constraint: its tangent needs the first triangle)
+        X.o0 = ldq(R.rec, 0); X.o1 = ldq(R.rec, 1); X.o2 = ldq(R.rec, 2);
     }
-    if (ok && first) {
-        const float *rays = F.pk_rays + 12 * i;
-        X.p[0] = ldq(rays, 0); X.p[1] = ldq(rays, 1); X.p[2] = ldq(rays, 2);
-        // pixel of the path: (path_offset + i) / spp, row-major on the res x res crop (epsm.py:250)
-        const int64_t pix = (F.tin.path_offset + i) / F.tin.spp;
-        const int64_t y = pix / F.tin.res, x = pix - y * F.tin.res;
-        const F2v g = ld2(F.tin.grad_img + (y * F.tin.img_width + x) * F.tin.img_channels + 3);
+    if (R.live) { X.o3 = ldq(R.rec, 3); X.o4 = ldq(R.rec, 4); X.o5 = ldq(R.rec, 5); }
+    if (R.ok && R.first) {
+        const float *rays = F.pk_rays + 12 * R.i;
+        X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
+        const F2v g = ld2(pixel_grad(F.tin, R.i));
         X.gx = g.x; X.gy = g.y;
-        if (d1 && F.pk_shadow) X.sh = load_u4(F.pk_shadow, i);
     }
-    if (end_next) {
-        const float *nx = rec + kRecWords;
-        X.n[0] = ldq(nx, 0); X.n[1] = ldq(nx, 1); X.n_z = lds_(nx, 8);
-        const F2v b = ld2(nx + 18); X.n_b[0] = b.x; X.n_b[1] = b.y;
-        X.n_tid = __float_as_uint(lds_(nx, 28));
+    if (R.end_next) {
+        const float *nx = R.rec + kRecWords;
+        X.n0 = ldq(nx, 0); X.n1 = ldq(nx, 1); X.n_z = lds_(nx, 8);
+        const F2v b = ld2(nx + 18); X.n_b0 = b.x; X.n_b1 = b.y;
+    }
+}
+template <int VARIANT>
+__device__ __forceinline__ void addr_issue(AddrFetch &A, const FusedArgs &F, const LaneId &L, int64_t base) {
+    const LaneRole R = role_of(F, L, base);
+    if (R.live) {
+        if (F.galpha) A.q7 = ldq(R.rec, 7); else A.q7.x = lds_(R.rec, 28);
+        if (VARIANT == EPSM_VARIANT_MANIFOLD && cp::plan_a(L.plan, L.k)) A.q6 = ldq(R.rec, 6);
+    }
+    if (R.d1) {
+        if (!R.live) { A.q7.x = lds_(R.rec, 28); const F2v b = ld2(R.rec + 18); A.b0 = b.x; A.b1 = b.y; }
+        if (F.pk_shadow) A.sh = load_u4(F.pk_shadow, R.i);
+    }
+    if (R.end_next) {
+        const float *nx = R.rec + kRecWords;
+        const F2v b = ld2(nx + 18); A.n_b0 = b.x; A.n_b1 = b.y;
+        A.n_tid = __float_as_uint(lds_(nx, 28));
     }
 }
 
@@ -375,16 +395,13 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
     // (a window costs 6 bytes of LDS per path: the larger one leaves 224 fixed-point / 384 float rows fewer)
     constexpr int kRowsFixed = kWindow > 1024 ? EPSM_CP_ROWS_FIXED - 224 * ((kWindow - 1024) / 1024) : EPSM_CP_ROWS_FIXED;
     constexpr int kRowsFloat = kWindow > 1024 ? EPSM_CP_ROWS_FLOAT - 384 * ((kWindow - 1024) / 1024) : EPSM_CP_ROWS_FLOAT;
+    typedef AccFixed64 AccWide;
     typedef LdsTable<kFloatRows ? kRowsFloat : kRowsFixed, typename std::conditional<kFloatRows, AccFloat, AccFixed64>::type> Table;
     constexpr int kTableSize = Table::kTableSize;
     __shared__ uint32_t s_keys[kTableSize];
     __shared__ typename Table::Val s_vals[kTableSize * 3];
     __shared__ int s_used;
-#ifdef EPSM_CP_DIRECT
-    __shared__ QItem s_queue[kWaves][1];
-#else
     __shared__ QItem s_queue[kWaves][kQueueCap];
-#endif
     __shared__ PtrTable s_ptrs;
     float *const my_rep = F.rep ? F.rep + (blockIdx.x % (unsigned) F.replicas) * F.rep_stride : nullptr;
     const Table T{s_keys, s_vals, &s_used, my_rep ? my_rep : F.gpos, my_rep ? my_rep + 3 * F.V : F.gnrm,
@@ -400,16 +417,8 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
     __shared__ int s_cnt[kEntries];                                  // [m][j][wave]: histogram, then offsets
     __shared__ int s_cls[kKeys + 1];                                 // first sorted position of class m
     V3<float> gd_acc = zero3<float>();                               // kTangentsInKernel: sum of grad_d over this lane's paths
-    Fetch X;                                                         // (all fields defined: a conditionally loaded, conditionally read struct
-    {                                                                //  otherwise carries undef through the round loop)
-        const F4v z4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 7; ++t) X.o[t] = z4;
-        X.p[0] = X.p[1] = X.p[2] = X.n[0] = X.n[1] = z4;
-        X.o_tid = X.n_tid = kNoIndex;
-        X.dhf[0] = X.dhf[1] = X.dhf[2] = X.n_z = X.n_b[0] = X.n_b[1] = X.gx = X.gy = 0.f;
-        X.sh.x = kNoIndex; X.sh.y = X.sh.z = X.sh.w = 0u;
-    }
+    Touch C;                                                         // (defined: a conditionally loaded struct otherwise carries undef through the round loop)
+    C.own = C.ray0 = C.ray1 = C.nxt = 0.f;
     T.clear();                                                       // ends with a barrier: the table of pointers is visible too
     const int64_t n_windows = (F.g.N + window - 1) / window;
 #pragma unroll 1
@@ -494,9 +503,11 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
         // Software pipeline: the records of the wave's NEXT round are requested before this round's rows go into the
         // queue / table, so the HBM round trip of one round runs under the LDS work of the other (measured apart they
         // were 1.6 ms and 1.5 ms per 2^24-path slab, and their sum when a wave did one after the other).
+        // (Round r goes to wave r mod 4.  Handing the rounds out dynamically -- a wave takes the next one nobody has, one LDS
+        // atomic per round -- measured 2.15 against 2.08 ms; the classes with the longest chains first, so that a window's tail
+        // is made of cheap rounds: 6.3 ms, three times slower, for no reason found.)
         const int n_rounds = RS.rb[kKeys];
         LaneId L = RS.lane_of(wv, lane);
-        if (wv < n_rounds) fetch_issue<VARIANT, DMODE, PACKED>(X, F, L, base);
 #pragma unroll 1
         for (int r = wv; r < n_rounds; r += kWaves) {
             const int q = L.q, c = L.c, k = L.k;
@@ -510,52 +521,57 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             const bool d1 = ok && first && cp::plan_diffuse1(plan);
             const bool act1 = (plan & cp::kPlanActive1) != 0;
 
+            asm volatile("; EPSM_MARK round_begin");
             // ---- geometry: own vertex; the two neighbours from the lanes that hold them (or from the words fetched for that)
             cp::Own<float> own;
             own.x = own.e1 = own.e2 = own.n = own.dn1 = own.dn2 = own.light = zero3<float>();
             own.b0 = own.b1 = own.eta = 0.f;
             cp::Nbr<float> prev, next;
             prev.x = prev.e1 = prev.e2 = next.x = next.e1 = next.e2 = zero3<float>();
+            V2<float> dk = mk2<float>(0.f, 0.f);
+            V3<float> dp = zero3<float>();
+            const bool wN = VARIANT == EPSM_VARIANT_MANIFOLD && live && cp::plan_a(plan, k);
+            // what only the emission needs (per-field arrays: loaded here; native log: addr_issue, after the recursions)
             float nb0 = 0.f, nb1 = 0.f;                              // barycentrics of vertex k+1
             uint32_t tid_own = kNoIndex, tid_next = kNoIndex, bid = kNoIndex, etri = kNoIndex;
             V3<float> dhf = zero3<float>();
             float eb0 = 0.f, eb1 = 0.f, ew = 0.f;
-            V2<float> dk = mk2<float>(0.f, 0.f);
-            V3<float> dp = zero3<float>();
             U4 sh; sh.x = kNoIndex; sh.y = sh.z = sh.w = 0u;
-            const bool wN = VARIANT == EPSM_VARIANT_MANIFOLD && live && cp::plan_a(plan, k);
             if (PACKED) {
+                GeoFetch X;                                          // (every field defined: a conditionally loaded, conditionally read
+                {                                                    //  struct with undefined fields is kept in scratch memory)
+                    const F4v z4 = {0.f, 0.f, 0.f, 0.f};
+                    X.o0 = X.o1 = X.o2 = X.o3 = X.o4 = X.o5 = X.p0 = X.p1 = X.p2 = X.n0 = X.n1 = z4;
+                    X.n_z = X.n_b0 = X.n_b1 = X.gx = X.gy = 0.f;
+                }
+                geo_issue(X, F, L, base);
+                // (the touches' destination registers stay reserved until here: a pending load's destination that nobody reads
+                // is free for the allocator, and the hardware's write to it would have to be waited for in the middle of the emission)
+                asm volatile("" :: "v"(C.own), "v"(C.ray0), "v"(C.ray1), "v"(C.nxt));
                 if (live) {
-                    const Geo<float> g = geo_from(X.o[0], X.o[1], X.o[2], X.o[4].z, X.o[4].w);
-                    const Nrm<float> nr = nrm_from(X.o[2], X.o[3], X.o[4], X.o[4].z, X.o[4].w);
+                    const Geo<float> g = geo_from(X.o0, X.o1, X.o2, X.o4.z, X.o4.w);
+                    const Nrm<float> nr = nrm_from(X.o2, X.o3, X.o4, X.o4.z, X.o4.w);
                     own.x = g.x; own.e1 = g.e1; own.e2 = g.e2; own.b0 = g.b0; own.b1 = g.b1;
                     own.n = nr.n; own.dn1 = nr.dn1; own.dn2 = nr.dn2;
-                    own.eta = X.o[5].x; own.light = mk3<float>(X.o[5].y, X.o[5].z, X.o[5].w);
-                    tid_own = X.o_tid;
-                    if (F.galpha) dhf = mk3<float>(X.dhf[0], X.dhf[1], X.dhf[2]);
-                    if (wN) { etri = __float_as_uint(X.o[6].x); eb0 = X.o[6].y; eb1 = X.o[6].z; ew = X.o[6].w; }      // (caustic: light_grad == 0)
+                    own.eta = X.o5.x; own.light = mk3<float>(X.o5.y, X.o5.z, X.o5.w);
                 }
                 if (c > 1) {                                         // wave-uniform: paths on several lanes exchange their vertices
                     const V3<float> ux = up1(own.x), ue1 = up1(own.e1), ue2 = up1(own.e2);
                     const V3<float> dx = down1(own.x), de1 = down1(own.e1), de2 = down1(own.e2);
-                    const float db0 = down1(own.b0), db1 = down1(own.b1);
-                    const uint32_t dt = down1(tid_own);
                     if (live && !first) { prev.x = ux; prev.e1 = ue1; prev.e2 = ue2; }
-                    if (has_next && k < c) { next.x = dx; next.e1 = de1; next.e2 = de2; nb0 = db0; nb1 = db1; tid_next = dt; }
+                    if (has_next && k < c) { next.x = dx; next.e1 = de1; next.e2 = de2; }
                 }
-                if (live && first) prev.x = mk3<float>(X.p[0].x, X.p[0].y, X.p[0].z);
+                if (live && first) prev.x = mk3<float>(X.p0.x, X.p0.y, X.p0.z);
                 if (has_next && k == c) {
                     const F4v nq2 = {X.n_z, 0.f, 0.f, 0.f};
-                    const Geo<float> gq = geo_from(X.n[0], X.n[1], nq2, X.n_b[0], X.n_b[1]);
-                    next.x = gq.x; next.e1 = gq.e1; next.e2 = gq.e2; nb0 = gq.b0; nb1 = gq.b1;
-                    tid_next = X.n_tid;
+                    const Geo<float> gq = geo_from(X.n0, X.n1, nq2, X.n_b0, X.n_b1);
+                    next.x = gq.x; next.e1 = gq.e1; next.e2 = gq.e2;
                 }
-                if (d1) { own.b0 = X.o[4].z; own.b1 = X.o[4].w; tid_own = X.o_tid; if (F.pk_shadow) sh = X.sh; }
                 if (ok && first) {       // epsm.py:250-272 in registers
-                    const V3<float> ro = mk3<float>(X.p[0].x, X.p[0].y, X.p[0].z), rd = mk3<float>(X.p[0].w, X.p[1].x, X.p[1].y),
-                                    rdx = mk3<float>(X.p[1].z, X.p[1].w, X.p[2].x), rdy = mk3<float>(X.p[2].y, X.p[2].z, X.p[2].w);
+                    const V3<float> ro = mk3<float>(X.p0.x, X.p0.y, X.p0.z), rd = mk3<float>(X.p0.w, X.p1.x, X.p1.y),
+                                    rdx = mk3<float>(X.p1.z, X.p1.w, X.p2.x), rdy = mk3<float>(X.p2.y, X.p2.z, X.p2.w);
                     V3<float> p0 = zero3<float>(), p1 = p0, p2 = p0;
-                    if (act1) { p0 = mk3<float>(X.o[0].x, X.o[0].y, X.o[0].z); p1 = mk3<float>(X.o[0].w, X.o[1].x, X.o[1].y); p2 = mk3<float>(X.o[1].z, X.o[1].w, X.o[2].x); }
+                    if (act1) { p0 = mk3<float>(X.o0.x, X.o0.y, X.o0.z); p1 = mk3<float>(X.o0.w, X.o1.x, X.o1.y); p2 = mk3<float>(X.o1.z, X.o1.w, X.o2.x); }
                     const Tangent t = tangent_from(ro, rd, rdx, rdy, X.gx, X.gy, p0, p1, p2, act1);
                     dk = mk2<float>(t.db0, t.db1);
                     dp = t.dp;
@@ -593,26 +609,32 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     if (ok && first) dp = load3(F.g.dldp, i);
                 }
             }
-            // Addressing of the rows this lane will emit, requested BEFORE the arithmetic: under load every dependent global
-            // load is a multi-microsecond round trip, so the chain is kept at two levels -- records (with the emitter / BSDF
-            // words of the same record), then the rows of the scene table they name.
-            const U4 t_own = table_row(F.tab, tid_own), t_next = table_row(F.tab, tid_next);
-            const U4 er = table_row(F.tab, etri), t_sh = table_row(F.tab, sh.x);
-
-            // what the second pass needs of the geometry: positions only (epsm_cp_core.h, Pts)
+            // what the second sweep needs of the geometry: positions only (epsm_cp_core.h, Pts); the flat-normal rows need the
+            // triangle's edges, the normal rows its interpolated normal (Emitter::vertex)
             cp::Pts<float> pts;
             pts.x = own.x; pts.n = own.n; pts.light = own.light; pts.eta = own.eta; pts.xp = prev.x; pts.xn = next.x;
-            // the flat-normal rows need the triangle's edges, the normal rows its interpolated normal (rows_of)
             const V3<float> keep_e1 = own.e1, keep_e2 = own.e2;
+            const float kb0 = own.b0, kb1 = own.b1;
 
+            asm volatile("; EPSM_MARK solve");
             V3<float> Gx = zero3<float>(), gn = Gx, gm = Gx, glight = Gx, gdiff = Gx;
             bool emit_vertex = live;
+            AddrFetch A;
+            {
+                const F4v z4 = {0.f, 0.f, 0.f, 0.f};
+                A.q6 = A.q7 = z4;
+                A.q7.x = __uint_as_float(kNoIndex); A.n_tid = kNoIndex; A.sh.x = kNoIndex; A.sh.y = A.sh.z = A.sh.w = 0u;
+                A.b0 = A.b1 = A.n_b0 = A.n_b1 = 0.f;
+            }
 #ifdef EPSM_CPKO_NOSOLVE
-            gd_acc.x += own.x.x + own.n.y + own.light.z + own.eta + prev.x.x + prev.e1.y + next.x.z + next.e2.x + nb0 + dk.x + dp.y;
+            gd_acc.x += own.x.x + own.n.y + own.light.z + own.eta + prev.x.x + prev.e1.y + next.x.z + next.e2.x + dk.x + dp.y;
+            if (PACKED) addr_issue<VARIANT>(A, F, L, base);
             if (false) {
 #else
             if (VARIANT == EPSM_VARIANT_MANIFOLD) {
 #endif
+                cp::MSeeds<float> sd;
+                sd.sN = sd.sC = mk2<float>(0.f, 0.f); sd.useN = sd.useC = sd.fC = false;
                 if (q > 0) {
                     const bool wC = live && cp::plan_b(plan, k);
                     // pass 1: the 2x2 blocks of the lane's constraint(s)
@@ -627,8 +649,6 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                         if (k == s) f = g;
                     }
                     cp::MBwd<float> mine; mine.q = mk2<float>(0.f, 0.f); mine.W = 0;
-                    cp::MSeeds<float> sd;
-                    sd.sN = sd.sC = mk2<float>(0.f, 0.f); sd.useN = sd.useC = sd.fC = false;
 #pragma unroll 1
                     for (int s = c; s >= 1; --s) {                   // backward recursion of the adjoint seeds, on the blocks alone
                         cp::MBwd<float> nb;
@@ -638,6 +658,12 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                         const cp::MSeeds<float> s2 = cp::manifold_bwd(e, f, nb, wN, wC, has_next, m2);
                         if (k == s) { sd = s2; mine = m2; }
                     }
+                }
+                // the words only the emission needs, on their way (vector-cache hits) under the second sweep
+                __builtin_amdgcn_sched_barrier(0);
+                if (PACKED) addr_issue<VARIANT>(A, F, L, base);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q > 0) {
                     // pass 2: the constraint(s) swept once more with the final seeds
                     const cp::MOut<float> o = cp::manifold_contract(pts, sd, has_next);
                     const V3<float> from_next = down1(o.GP);         // d/dx_k through constraint k+1
@@ -645,10 +671,12 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     gn = o.gn; gm = o.gm; glight = o.glight; gdiff = o.gdiff;
                 }
             } else {
+                cp::CFwd<float> f = cp::cfwd_zero<float>();
+                bool poisoned = false;
+                const int idstar = cp::plan_idstar(plan);
                 if (q > 0) {
-                    const int idstar = cp::plan_idstar(plan);
                     const cp::CBlocks<float> e = cp::caustic_blocks(own, prev, next, first);
-                    cp::CFwd<float> f = cp::caustic_fwd(e, dk, true, cp::cfwd_zero<float>(), e.Aup);
+                    f = cp::caustic_fwd(e, dk, true, cp::cfwd_zero<float>(), e.Aup);
 #pragma unroll 1
                     for (int s = 2; s <= c; ++s) {
                         cp::CFwd<float> pf = cp::cfwd_zero<float>();
@@ -660,7 +688,12 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     // a non-finite term at id* drops every parameter row of the path (nan_to_num, epsm.py:1076-1079)
                     const unsigned long long bad = __ballot(live && k == idstar && !f.fin);
                     const unsigned long long seg = ((1ull << c) - 1ull) << (lane - (k - 1));
-                    const bool poisoned = (bad & seg) != 0ull;
+                    poisoned = (bad & seg) != 0ull;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (PACKED) addr_issue<VARIANT>(A, F, L, base);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q > 0) {
                     const cp::COut<float> o = cp::caustic_finish(pts, f, first, live && k <= idstar, live && k == idstar, live && cp::plan_b(plan, k));
                     const V3<float> from_next = down1(o.gxp_prev);
                     Gx = k < c ? o.Gx + from_next : o.Gx;
@@ -668,37 +701,52 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     emit_vertex = live && k <= idstar && !poisoned;
                 }
             }
-            // ---- the seeds of this lane's rows (the table rows have landed by now)
+            // ---- addressing of the rows this lane will emit: the rows of the scene table its ids name, requested before the
+            // next round's touches and the bookkeeping around them
+            asm volatile("; EPSM_MARK addressing");
+            float fb0 = kb0, fb1 = kb1;                              // barycentrics of the lane's own vertex
+            if (PACKED) {
+                if (live) {
+                    tid_own = __float_as_uint(A.q7.x);
+                    if (F.galpha) dhf = mk3<float>(A.q7.y, A.q7.z, A.q7.w);
+                    if (wN) { etri = __float_as_uint(A.q6.x); eb0 = A.q6.y; eb1 = A.q6.z; ew = A.q6.w; }      // (caustic: light_grad == 0)
+                }
+                if (d1) {
+                    if (!live) { tid_own = __float_as_uint(A.q7.x); fb0 = A.b0; fb1 = A.b1; }
+                    if (F.pk_shadow) sh = A.sh;
+                }
+                if (c > 1) {                                         // wave-uniform
+                    const float db0 = down1(kb0), db1 = down1(kb1);
+                    const uint32_t dt = down1(tid_own);
+                    if (has_next && k < c) { nb0 = db0; nb1 = db1; tid_next = dt; }
+                }
+                if (has_next && k == c) { nb0 = A.n_b0; nb1 = A.n_b1; tid_next = A.n_tid; }
+            }
+            const U4 t_own = table_row(F.tab, tid_own), t_next = table_row(F.tab, tid_next);
+            const U4 er = table_row(F.tab, etri), t_sh = table_row(F.tab, sh.x);
+            // ---- the next round's records on their way (one word per cache line: touch_issue) while this round's rows are
+            // formed, merged and inserted
+            asm volatile("; EPSM_MARK prefetch");
+            const LaneId Ln = RS.lane_of(r + kWaves, lane);          // (past the last round: no lane has a path)
+            __builtin_amdgcn_sched_barrier(0);
+            if (PACKED) touch_issue(C, F, Ln, base);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- emission
+            asm volatile("; EPSM_MARK emit");
             if (PACKED) bid = (t_own.w >> 8) - 1u;                    // packed log: alpha slot + 1 in the table row
 #ifdef EPSM_CPKO_NOEMIT
             gd_acc.x += Gx.x + gn.y + gm.x + glight.z + gdiff.x + dp.x + (float) (t_own.x + t_next.y + er.z + bid + t_sh.x) + dhf.x + eb0 + eb1 + ew + (emit_vertex ? 1.f : 0.f);
 #else
-            const RowSeeds S = E.rows_of(emit_vertex && q > 0, live, d1, Gx, gn, gm, glight, gdiff, dp, pts.n, keep_e1, keep_e2, own.b0, own.b1,
-                                         nb0, nb1, bid, dhf, eb0, eb1, ew, t_own, t_next, er, sh, t_sh);
+            E.vertex(emit_vertex && q > 0, live, d1, Gx, gn, gm, glight, gdiff, dp, pts.n, keep_e1, keep_e2, fb0, fb1,
+                     nb0, nb1, bid, dhf, eb0, eb1, ew, t_own, t_next, er, sh, t_sh);
 #endif
-            // ---- the next round's records, on their way while this round's rows are merged and inserted.  Every load issued
-            // so far has LANDED (rows_of read the table rows): the prefetch sits in branches the wave may skip, so behind it the
-            // compiler can only wait for "all loads" (s_waitcnt vmcnt(0)) -- a later first use of an earlier load would drain the
-            // prefetch with it.
-            const LaneId Ln = RS.lane_of(r + kWaves, lane);          // (past the last round: no lane has a path)
-            __builtin_amdgcn_sched_barrier(0);                       // nothing of rows_of may sink below the prefetch (its first use would wait for ALL loads)
-#ifndef EPSM_CP_NOPIPE
-            fetch_issue<VARIANT, DMODE, PACKED>(X, F, Ln, base);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- emission
-#ifndef EPSM_CPKO_NOEMIT
-            E.emit(S);
-#endif
-#ifdef EPSM_CP_NOPIPE
-            fetch_issue<VARIANT, DMODE, PACKED>(X, F, Ln, base);
-#endif
+            asm volatile("; EPSM_MARK round_end");
             L = Ln;
         }
         Q.drain(T);
         // workgroup-uniform census once per window; a table that fills up in between sends the overflow straight to HBM
         // (not after the workgroup's last window: the final flush follows at once)
-        if ((window == kWindow || (wi + 1 < windows_per_block && win + 1 < n_windows)) && T.crowded(6)) T.flush();
+        if (wi + 1 < windows_per_block && win + 1 < n_windows && T.crowded(6)) T.flush();
     }
     T.flush();
     if (DMODE == kTangentsInKernel && F.grad_o_sum) {      // epsm.py:260-261: d/d ray.o = -sum grad_d, one atomic triple per workgroup
@@ -719,15 +767,17 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
 template <int VARIANT, int DMODE, bool PACKED>
 hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
     FusedArgs F = F0;
-    // Window size: 1024 paths, fewer for a small wavefront (the reference's own backward sizes are 16 384 .. 524 288 paths)
-    // so that the ~512 workgroups the chip holds at a time all get one: a wave works through its rounds of a window one
-    // after the other, a few microseconds each, and that latency is the run time of a launch with fewer windows than
-    // workgroup slots.  Measured (ms, K = 2 / K = 4): 524 288 paths with windows of 128 / 256 / 512: 0.218 / 0.156 / 0.120;
-    // 16 384 paths: 0.034 / 0.046 / 0.061.  (epsm_set_option(EPSM_OPT_SMALL_WAVEFRONT_PATHS) moves the switch: tests.)
+    // Window size: 2048 paths; a small wavefront (the reference's own backward sizes are 16 384 .. 524 288 paths) is cut so that
+    // the ~768 workgroups the chip holds at a time (three per CU) all get ONE window: a wave works through its rounds of a
+    // window one after the other, a few microseconds each, and that latency is the run time of a launch with fewer windows
+    // than workgroup slots.  (epsm_set_option(EPSM_OPT_SMALL_WAVEFRONT_PATHS) moves the switch: tests.)
     const bool small = F.g.N <= fused_option(EPSM_OPT_SMALL_WAVEFRONT_PATHS);
-    constexpr int kLarge = EPSM_CP_WINDOW, kSmall = 1024;
+    constexpr int kLarge = EPSM_CP_WINDOW, kSmall = 1024, kSlots = 768;
     int window = kLarge;
-    if (small) { window = 128; while (window < kSmall && F.g.N > 512 * (int64_t) window) window *= 2; }
+    if (small) {
+        const int64_t w = ((F.g.N + kSlots - 1) / kSlots + 63) / 64 * 64;       // a multiple of 64 paths
+        window = (int) (w < 128 ? 128 : w > kSmall ? kSmall : w);
+    }
     const int64_t windows = (F.g.N + window - 1) / window;
     const int64_t blocks = windows < EPSM_CP_BLOCKS ? windows : EPSM_CP_BLOCKS;
     const int64_t per = (windows + blocks - 1) / blocks;

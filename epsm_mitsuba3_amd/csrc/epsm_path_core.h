@@ -455,7 +455,11 @@ template <typename R> EPSM_HD R GradArgs<R>::eta(int k, int64_t i) const { retur
 // cond_2 < 1e4 were off by more than 4 eps cond, up to O(1).  Doing the ~60 flops per vertex of the recursion in
 // float64 (the 2x2 blocks themselves come out of float32 sweeps) removes that: 0.05 %, worst 4e-2 at cond 6e3
 // (tests/test_kernel_core_host.py, test_gpu_parity.py); +0.6 % kernel time fused, +4 % for the dense kernel.
+#ifdef EPSM_REC_FLOAT      // (A/B build: the recursion in the scalar type itself -- 0.7 % of the `specular` paths leave the bound)
+template <typename R> struct RecType { typedef R type; };
+#else
 template <typename R> struct RecType { typedef double type; };
+#endif
 template <typename Q, typename R> EPSM_HD M2<Q> cvm(M2<R> m) { M2<Q> o; o.a = Q(m.a); o.b = Q(m.b); o.c = Q(m.c); o.d = Q(m.d); return o; }
 template <typename Q, typename R> EPSM_HD V2<Q> cvv(V2<R> v) { return mk2<Q>(Q(v.x), Q(v.y)); }
 

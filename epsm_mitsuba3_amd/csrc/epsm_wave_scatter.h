@@ -106,6 +106,10 @@ struct AccFixed64 {
     __device__ __forceinline__ static float get(T q) { return (float) ((double) q * 5.6843418860808015e-14); }      // 2^-44
 };
 
+// (float64 rows -- ds_add_f64, one v_cvt_f64_f32 per term instead of the ten instructions of to_fixed, the LDS atomic at half
+// the rate of ds_add_u64: 3.1 against 6.1 lane-operations per clock and CU, tools/micro/lds_atomics.hip -- measured the same
+// kernel time, 2.168 against 2.171 ms on the headline slab: the drain is bound by neither.  Not kept: fixed-point sums do not
+// depend on the order of the additions.)
 template <int kRows, typename Acc = AccFloat>
 struct LdsTable {
     static constexpr int kTableSize = kRows;             // rows: 4 B key + 3 values each; any count (multiply-shift hash)
@@ -261,7 +265,11 @@ __device__ __forceinline__ V3<float> wave_total_lane63(V3<float> v) {
 // other merged lanes are zeroed.  Out of line: it is used ~20 times per kernel and the fused kernel has to
 // stay inside the instruction cache.
 struct Rows3 { float v[9]; };
+#ifdef EPSM_MERGE_INLINE
+__device__ __forceinline__ Rows3 merge_rows3(Rows3 r, bool mine, bool carrier) {
+#else
 __device__ __attribute__((noinline)) Rows3 merge_rows3(Rows3 r, bool mine, bool carrier) {
+#endif
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
         const float tot = lane63(wave_total_lane63(mine ? r.v[c] : 0.f));
@@ -269,7 +277,11 @@ __device__ __attribute__((noinline)) Rows3 merge_rows3(Rows3 r, bool mine, bool 
     }
     return r;
 }
+#ifdef EPSM_MERGE_INLINE
+__device__ __forceinline__ float merge_row1(float v, bool mine, bool carrier) {
+#else
 __device__ __attribute__((noinline)) float merge_row1(float v, bool mine, bool carrier) {
+#endif
     const float tot = lane63(wave_total_lane63(mine ? v : 0.f));
     return carrier ? tot : (mine ? 0.f : v);
 }
@@ -286,8 +298,8 @@ constexpr int kMinMergeLanes = 16, kMinMergeLanesAlpha = 4;
 template <int ROWS, int ROUNDS>
 __device__ __forceinline__ void merge_equal(bool &any, const uint32_t id[3], V3<float> vals[ROWS], int live_rows = ROWS) {
     constexpr int kMin = ROWS == 1 ? kMinMergeLanesAlpha : kMinMergeLanes;
-#ifdef EPSM_KO_NOMERGE
-    return;
+#ifndef EPSM_CP_MERGE       // Round 4: OFF.  With integer LDS rows same-address lanes no longer serialise as float atomics did, and at three
+    return;                 // waves per SIMD the DPP sums cost more issue slots than the table saves: 2.22 -> 2.17 ms without them.
 #endif
     unsigned long long pending = __ballot(any);
 #pragma unroll 1

@@ -56,13 +56,14 @@ def sinkhorn_divergence(x: torch.Tensor, y: torch.Tensor, blur: float = 0.01, sc
             f_aa = 0.5 * (f_aa + _softmin(eps, C_xx, a_log + f_aa / eps))
             g_bb = 0.5 * (g_bb + _softmin(eps, C_yy, b_log + g_bb / eps))
         eps = eps_list[-1]
-    # last extrapolation with the graph attached to x (duals detached)
-    f_ba = _softmin(eps, _cost(x, yd), b_log + g_ab / eps)
+    # last extrapolation with the graph attached to x (duals detached); both cross terms from the OLD duals, as geomloss's
+    # sinkhorn_loop writes its last step (one simultaneous assignment)
+    f_ba_new = _softmin(eps, _cost(x, yd), b_log + g_ab / eps)
     f_aa_new = _softmin(eps, _cost(x, xd), a_log + f_aa / eps)
     with torch.no_grad():
-        g_ab_new = _softmin(eps, C_yx, a_log + f_ba.detach() / eps)
+        g_ab_new = _softmin(eps, C_yx, a_log + f_ba / eps)
         g_bb_new = _softmin(eps, C_yy, b_log + g_bb / eps)
-    return (f_ba - f_aa_new).mean() + (g_ab_new - g_bb_new).mean()
+    return (f_ba_new - f_aa_new).mean() + (g_ab_new - g_bb_new).mean()
 
 
 _scratch = {}
@@ -144,11 +145,11 @@ def sinkhorn_divergence_and_grad_hip(x: torch.Tensor, y: torch.Tensor, blur: flo
             f_aa = update_hip(eps, x, x, f_aa, la, prev=f_aa)
             g_bb = update_hip(eps, y, y, g_bb, lb, prev=g_bb)
         eps = eps_list[-1]
-        f_ba, w_ba = update_hip(eps, x, y, g_ab, lb, want_wsum=True)
+        f_ba_new, w_ba = update_hip(eps, x, y, g_ab, lb, want_wsum=True)
         f_aa_new, w_aa = update_hip(eps, x, x, f_aa, la, want_wsum=True)
-        g_ab_new = update_hip(eps, y, x, f_ba, la)
+        g_ab_new = update_hip(eps, y, x, f_ba, la)                      # from the OLD f_ba (geomloss: one simultaneous assignment)
         g_bb_new = update_hip(eps, y, y, g_bb, lb)
-        loss = (f_ba - f_aa_new).mean() + (g_ab_new - g_bb_new).mean()
+        loss = (f_ba_new - f_aa_new).mean() + (g_ab_new - g_bb_new).mean()
         grad = (w_aa - w_ba) / n                  # d/dx_i of mean_i( softmin over y - softmin over (detached) x )
     return loss, grad
 

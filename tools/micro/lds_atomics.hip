@@ -14,7 +14,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *out, uint32_
     float acc = 0.f;
     for (int it = 0; it < kIters; ++it) {
         x = x * 1664525u + 1013904223u;
-        const uint32_t slot = ((MODE == 4 || MODE == 8 || MODE == 9 || MODE == 10) ? (x >> 8) & 15u : (x >> 8)) & (kRows - 1);     // MODE 4, 8, 9, 10: 16 hot rows
+        const uint32_t slot = ((MODE == 4 || MODE == 8 || MODE == 9 || MODE == 10 || MODE == 12) ? (x >> 8) & 15u : (x >> 8)) & (kRows - 1);     // MODE 4, 8, 9, 10: 16 hot rows
         if (MODE == 0) { atomicAdd(&vals[3 * slot], 1.f); atomicAdd(&vals[3 * slot + 1], 2.f); atomicAdd(&vals[3 * slot + 2], 3.f); }
         if (MODE == 1) { const uint32_t p = atomicCAS(&keys[slot], 0xFFFFFFFFu, slot); acc += p; }
         if (MODE == 2) { vals[3 * slot] += 1.f; vals[3 * slot + 1] += 2.f; vals[3 * slot + 2] += 3.f; }     // racy plain RMW: rate only
@@ -31,6 +31,8 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *out, uint32_
         if (MODE == 6 || MODE == 9) { uint32_t *a = (uint32_t *) vals; atomicAdd(&a[3 * slot], 1u); atomicAdd(&a[3 * slot + 1], 2u); atomicAdd(&a[3 * slot + 2], 3u); }
         if (MODE == 7 || MODE == 10) { unsigned long long *a = (unsigned long long *) vals; const uint32_t s2 = slot & 511u;
                          atomicAdd(&a[3 * s2], 1ull); atomicAdd(&a[3 * s2 + 1], 2ull); atomicAdd(&a[3 * s2 + 2], 3ull); }
+        if (MODE == 11 || MODE == 12) { double *a = (double *) vals; const uint32_t s2 = slot & 511u;      // ds_add_f64 (gfx90a+)
+                         atomicAdd(&a[3 * s2], 1.0); atomicAdd(&a[3 * s2 + 1], 2.0); atomicAdd(&a[3 * s2 + 2], 3.0); }
     }
     __syncthreads();
     if (threadIdx.x == 0) out[blockIdx.x] = vals[0] + acc;
@@ -58,5 +60,7 @@ int main() {
     run<7>("3 x ds_add_u64, scattered", 3);
     run<9>("3 x ds_add_u32, 16 hot rows", 3);
     run<10>("3 x ds_add_u64, 16 hot rows", 3);
+    run<11>("3 x ds_add_f64, scattered", 3);
+    run<12>("3 x ds_add_f64, 16 hot rows", 3);
     return 0;
 }
