@@ -111,11 +111,42 @@ __global__ __launch_bounds__(1024) void epsm_wf_scan_kernel(TraceArgs A, WfState
 // (Tried: grouping the survivors of a chunk by the octant of their new direction, 8-bucket counting sort in LDS --
 // 4.95 -> 5.85 ms at 128 k triangles, 8.1 -> 9.3 ms at 512 k: path order keeps the samples of a pixel, which start
 // from almost the same point, next to each other, and that is worth more than a shared direction octant.)
+// Round 4, EPSM_WF_REKEY=<shift>: inside its 256-slot chunk a queue is written grouped by the triangle the
+// rays LEAVE (key = leaf-order triangle id >> shift hashed into 64 buckets, counting sort in LDS) instead of in path order:
+// rays that leave one triangle (or one BVH leaf: ids are leaf-ordered) start together.  Different from the octant sort above:
+// the chunk, and with it the pixel neighbourhood, is kept.
 __global__ __launch_bounds__(kWfChunk) void epsm_wf_compact_kernel(TraceArgs A, WfState W, int b) {
     const int64_t count = wf_count(A, W, b), q = (int64_t) blockIdx.x * kWfChunk + threadIdx.x;
     if ((int64_t) blockIdx.x * kWfChunk >= count) return;           // workgroup-uniform
     const uint8_t f = q < count ? W.flags[q] : (uint8_t) 0;
     const uint32_t i = q < count ? (b == 0 ? (uint32_t) q : W.queue[b & 1][q]) : 0u;
+#ifdef EPSM_WF_REKEY
+    __shared__ uint32_t s_hist[2][64];
+    if (threadIdx.x < 128) s_hist[threadIdx.x >> 6][threadIdx.x & 63] = 0u;
+    const uint32_t tri = f ? W.hit[i].x : 0u;
+    const uint32_t key = (((tri >> EPSM_WF_REKEY) * 2654435761u) >> 26) & 63u;
+    __syncthreads();
+    uint32_t rank[2] = {0u, 0u};
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+        if ((f >> which) & 1) rank[which] = atomicAdd(&s_hist[which][key], 1u);
+    __syncthreads();
+    if (threadIdx.x < 128) {                                         // exclusive scan of the 64 buckets of both queues (one wave each)
+        const int which = threadIdx.x >> 6, l = threadIdx.x & 63;
+        const uint32_t c = s_hist[which][l];
+        uint32_t inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t) __shfl_up((int) inc, off); if (l >= off) inc += t; }
+        s_hist[which][l] = inc - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (!((f >> which) & 1)) continue;
+        const uint32_t off = W.chunk_counts[which * W.chunks + blockIdx.x] + s_hist[which][key] + rank[which];
+        (which == 0 ? W.queue[(b + 1) & 1] : W.shadow_queue)[off] = i;
+    }
+#else
     __shared__ uint32_t s_n[2][kWfChunk / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long m[2] = {__ballot((f & kWfAlive) != 0), __ballot((f & kWfShadow) != 0)};
@@ -129,6 +160,7 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_compact_kernel(TraceArgs A, 
         off += (uint32_t) __popcll(m[which] & ((1ull << lane) - 1ull));
         (which == 0 ? W.queue[(b + 1) & 1] : W.shadow_queue)[off] = i;
     }
+#endif
 }
 __global__ __launch_bounds__(kWfThreads) void epsm_wf_shadow_kernel(TraceArgs A, WfState W, int b) {
     __shared__ uint32_t s_stack[kWfStackLds * kWfThreads];

@@ -149,6 +149,19 @@ def assert_two_routes_agree(a, b, lo, hi, name="", rel=2e-4, rel_all=1e-2):
     rep = two_routes_report(a, b, lo, hi, rel=rel, rel_all=rel_all)
     assert rep["m"] > 0, (name, rep)
     assert rep["mean_excess_rel"] <= rel, (name, rep)
-    assert rep["frac_all"] >= 0.999 or a.numel() < 1000 and rep["worst_rel"] <= rel_all * 2, (name, rep)
+    assert rep["frac_all"] >= 0.999 or (a.numel() < 1000 and rep["worst_rel"] <= rel_all * 2), (name, rep)
     assert rep["worst_rel"] <= 0.1, (name, rep)
     return rep
+
+
+def select_paths(trace, idx):
+    """The paths ``idx`` (int64 tensor, ascending) of a per-field PathTrace as a PathTrace of its own: records, rays and
+    addressing gathered; ``path_offset`` is dropped (the result is not a pixel-ordered wavefront: use it with explicit
+    tangents, not with the in-kernel first-vertex tangent)."""
+    import epsm_mitsuba3_amd as epsm
+    cut = lambda t: None if t is None else t[idx.to(t.device)].contiguous()
+    deep = lambda v: ([cut(x) for x in v] if isinstance(v, (list, tuple)) else (cut(v) if torch.is_tensor(v) and v.shape[:1] == trace.ray_d.shape[:1] else v))
+    pi = [{"cam": cut(trace.path_info[0]["cam"])}] + [{k: deep(v) for k, v in r.items()} for r in trace.path_info[1:]]
+    si = [{k: deep(v) for k, v in r.items()} for r in trace.scatter_info]
+    return epsm.PathTrace(res=trace.res, spp=trace.spp, ray_o=cut(trace.ray_o), ray_d=cut(trace.ray_d), ray_dx=cut(trace.ray_dx),
+                          ray_dy=cut(trace.ray_dy), path_info=pi, scatter_info=si, path_offset=0, n_paths_total=int(idx.numel()))

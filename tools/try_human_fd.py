@@ -129,13 +129,19 @@ print(f"# exp/human.py at the reference's settings, primal / differential seeds 
 
 # ---- the angles the image determines best: largest diagonal of J at the zero pose (one seed, central differences of the field)
 zero = poses["zero pose (iteration 0)"]
-diag = torch.zeros(72)
-for j in range(72):
-    e = torch.zeros(1, 72, device=dev); e[0, j] = 0.03
-    diag[j] = float((epsm_grad(zero + e, ref_integ, [0], gt_loop)[j] - epsm_grad(zero - e, ref_integ, [0], gt_loop)[j]) / 0.06)
-angles = diag.argsort(descending=True)[:NA].tolist()
-print(f"# angles (joint, axis) with the largest diagonal of J at the zero pose: {[(a // 3, a % 3) for a in angles]}; "
-      f"J_jj from {float(diag[angles[0]]):.2f} down to {float(diag[angles[-1]]):.2f} (median of all 72: {float(diag.median()):.3f})")
+if os.environ.get("HUMAN_FD_ANGLES"):                # (a previous run's list: skips the 144 gradient evaluations)
+    angles = [int(a) for a in os.environ["HUMAN_FD_ANGLES"].split(",")][:NA]
+    print(f"# angles (joint, axis) taken from HUMAN_FD_ANGLES: {[(a // 3, a % 3) for a in angles]}")
+else:
+    diag = torch.zeros(72)
+    for j in range(72):
+        e = torch.zeros(1, 72, device=dev); e[0, j] = 0.03
+        diag[j] = float((epsm_grad(zero + e, ref_integ, [0], gt_loop)[j] - epsm_grad(zero - e, ref_integ, [0], gt_loop)[j]) / 0.06)
+    angles = diag.argsort(descending=True)[:NA].tolist()
+    print(f"# angles (joint, axis) with the largest diagonal of J at the zero pose: {[(a // 3, a % 3) for a in angles]}; "
+          f"J_jj from {float(diag[angles[0]]):.2f} down to {float(diag[angles[-1]]):.2f} (median of all 72: {float(diag.median()):.3f})")
+tp = tasks.target_pose().to(dev)
+print(f"# target pose at those angles: {[round(float(tp[0, a]), 3) for a in angles]}")
 
 cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-30))
 for name, pose in poses.items():
@@ -153,7 +159,12 @@ for name, pose in poses.items():
     dist = output(opt)
     at_clamp = int((pose.abs() >= tasks.POSE_CLAMP - 1e-6).sum())
     print(f"\n## {name}: vertex distance {dist * 100:.2f} cm, matcher loss x res^2 = {L0:.4f}, {at_clamp} of 72 angles at the clamp")
+    print(f"   pose at those angles (clamp +-{tasks.POSE_CLAMP}):      {[round(float(pose[0, a]), 3) for a in angles]}")
     print(f"   FD of the loss (h = {H}, {FD_SPP} spp):        {[round(float(v), 3) for v in fd]}")
+    # a clamped angle whose loss gradient points OUT of the box is held by the clamp, not by the field: leave those out
+    free = torch.tensor([not ((float(pose[0, a]) >= tasks.POSE_CLAMP - 1e-6 and float(fd[n]) < 0) or
+                              (float(pose[0, a]) <= -tasks.POSE_CLAMP + 1e-6 and float(fd[n]) > 0)) for n, a in enumerate(angles)])
+    print(f"   angles NOT held by the clamp: {int(free.sum())} of {NA}")
     print(f"   (first four under another seed:               {[round(float(v), 3) for v in fd2[:4]]})")
     for mode in ("ref", "first", "shadow"):
         Probe.mode = mode
@@ -161,5 +172,6 @@ for name, pose in poses.items():
         signs = int(((g * fd) > 0).sum())
         big = fd.abs() > 0.25 * fd.abs().max()
         print(f"   EPSM pose gradient, {mode:6s} ({S} seeds):      {[round(float(v), 3) for v in g]}")
+        print(f"      free angles only: cosine {cos(g[free], fd[free]):+.3f}, same sign on {int(((g * fd) > 0)[free].sum())} of {int(free.sum())}")
         print(f"      cosine with FD {cos(g, fd):+.3f}; same sign on {signs} of {NA} angles ({int(((g * fd) > 0)[big].sum())} of the {int(big.sum())} "
               f"with |FD| > a quarter of the largest); |g| / |FD| = {float(g.norm() / fd.norm().clamp_min(1e-30)):.3f}")
