@@ -677,6 +677,9 @@ def main():
                                          "`value` is the backward pass alone on resident synthetic records")
             torch.cuda.empty_cache()
             result["hybrid_phase2"] = hybrid_phase2_leg(256, 16, 16, dev)
+            torch.cuda.empty_cache()
+            # the same pass at the film of BASELINE.json configs[3] (`manifold_hybrid`, 1024 x 1024) at 16 spp
+            result["hybrid_phase2_1024"] = hybrid_phase2_leg(1024, 16, 16, dev)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -125,6 +125,9 @@ def declare_tracer(lib):
     lib.epsm_trace_workspace_bytes.argtypes = [C.c_int64]
     lib.epsm_film_splat.restype = C.c_int
     lib.epsm_film_splat.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.epsm_film_adjoint_reparam.restype = C.c_int
+    lib.epsm_film_adjoint_reparam.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
     lib.epsm_film_develop.restype = C.c_int
     lib.epsm_film_develop.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib

@@ -327,7 +327,7 @@ __device__ __forceinline__ LaneRole role_of(const FusedArgs &F, const LaneId &L,
 }
 __device__ __forceinline__ void touch_issue(Touch &C, const FusedArgs &F, const LaneId &L, int64_t base) {
     const LaneRole R = role_of(F, L, base);
-    if (R.live || (R.ok && (R.act1 || R.d1))) C.own = lds_(R.rec, 0);
+    if (R.live || R.d1) C.own = lds_(R.rec, 0);
     if (R.ok && R.first) { const float *rays = F.pk_rays + 12 * R.i; C.ray0 = lds_(rays, 0); C.ray1 = lds_(rays, 11); }
     if (R.end_next) C.nxt = lds_(R.rec + kRecWords, 0);
 }
@@ -341,9 +341,9 @@ __device__ __forceinline__ const float *pixel_grad(const TangentIn &A, int64_t i
 }
 __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const LaneId &L, int64_t base) {
     const LaneRole R = role_of(F, L, base);
-    if (R.live || (R.ok && R.act1)) {     // (a path without a constraint: its tangent needs the first triangle)
-        X.o0 = ldq(R.rec, 0); X.o1 = ldq(R.rec, 1); X.o2 = ldq(R.rec, 2);
-    }
+    // (a path WITHOUT a constraint reads its first record only when its first hit is diffuse: diffuse_grad[0] = dldp needs the
+    // triangle; otherwise all it gives is its share of d/d ray.o, which needs the rays alone -- 27 % of the bathroom paths)
+    if (R.live || (R.d1 && R.act1)) { X.o0 = ldq(R.rec, 0); X.o1 = ldq(R.rec, 1); X.o2 = ldq(R.rec, 2); }
     if (R.live) { X.o3 = ldq(R.rec, 3); X.o4 = ldq(R.rec, 4); X.o5 = ldq(R.rec, 5); }
     if (R.ok && R.first) {
         const float *rays = F.pk_rays + 12 * R.i;
@@ -571,8 +571,9 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     const V3<float> ro = mk3<float>(X.p0.x, X.p0.y, X.p0.z), rd = mk3<float>(X.p0.w, X.p1.x, X.p1.y),
                                     rdx = mk3<float>(X.p1.z, X.p1.w, X.p2.x), rdy = mk3<float>(X.p2.y, X.p2.z, X.p2.w);
                     V3<float> p0 = zero3<float>(), p1 = p0, p2 = p0;
-                    if (act1) { p0 = mk3<float>(X.o0.x, X.o0.y, X.o0.z); p1 = mk3<float>(X.o0.w, X.o1.x, X.o1.y); p2 = mk3<float>(X.o1.z, X.o1.w, X.o2.x); }
-                    const Tangent t = tangent_from(ro, rd, rdx, rdy, X.gx, X.gy, p0, p1, p2, act1);
+                    const bool need_tri = act1 && (live || d1);      // (dlduv / dldp of a path with no term are never used)
+                    if (need_tri) { p0 = mk3<float>(X.o0.x, X.o0.y, X.o0.z); p1 = mk3<float>(X.o0.w, X.o1.x, X.o1.y); p2 = mk3<float>(X.o1.z, X.o1.w, X.o2.x); }
+                    const Tangent t = tangent_from(ro, rd, rdx, rdy, X.gx, X.gy, p0, p1, p2, need_tri);
                     dk = mk2<float>(t.db0, t.db1);
                     dp = t.dp;
                     gd_acc = gd_acc + t.gd;
@@ -772,7 +773,10 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
     // window one after the other, a few microseconds each, and that latency is the run time of a launch with fewer windows
     // than workgroup slots.  (epsm_set_option(EPSM_OPT_SMALL_WAVEFRONT_PATHS) moves the switch: tests.)
     const bool small = F.g.N <= fused_option(EPSM_OPT_SMALL_WAVEFRONT_PATHS);
-    constexpr int kLarge = EPSM_CP_WINDOW, kSmall = 1024, kSlots = 768;
+#ifndef EPSM_CP_SLOTS
+#define EPSM_CP_SLOTS 768
+#endif
+    constexpr int kLarge = EPSM_CP_WINDOW, kSmall = 1024, kSlots = EPSM_CP_SLOTS;
     int window = kLarge;
     if (small) {
         const int64_t w = ((F.g.N + kSlots - 1) / kSlots + 63) / 64 * 64;       // a multiple of 64 paths

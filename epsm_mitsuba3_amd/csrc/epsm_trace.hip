@@ -273,6 +273,55 @@ __global__ __launch_bounds__(256) void epsm_film_splat_kernel(int64_t N, const f
         }
     }
 }
+// Adjoint of the gaussian splat + weight division w.r.t. a sample's radiance, its FILM POSITION and the determinant of the
+// reparameterisation that multiplies both its value and its weight (common.py:880-920; prb_reparam's pass between its two
+// traces):   image[p] = sum_i w_ip L_i det_i / sum_i w_ip det_i,   w_ip = f(p - pos_i).
+// One lane per sample, its 5 x 5 window of pixels: dL = sum_p w_ip grad_p / W_p;  A_p = grad_p . (L_i - image_p) / W_p;
+// d/d pos.x = sum_p A_p wy dwx,  d/d pos.y = sum_p A_p dwy wx,  d/d det = sum_p A_p w.  (Round 3 ran this as ~40 small torch
+// kernels per tile: integrators.film_adjoint_reparam, kept as the checker.)
+__global__ __launch_bounds__(256) void epsm_film_adjoint_reparam_kernel(int64_t N, const float *pos, const float *rad, const float *grad,
+                                                                        int grad_stride, const float *accum, int W, int H,
+                                                                        float *dL, float *adj) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float px = pos[2 * i], py = pos[2 * i + 1];
+    const float r = rad[3 * i], g = rad[3 * i + 1], b = rad[3 * i + 2];
+    const float radius = 2.f, alpha = -1.f / (2.f * 0.5f * 0.5f), bias = expf(alpha * radius * radius);
+    const int X = (int) floorf(px), Y = (int) floorf(py);
+    float wx[5], wy[5], dwx[5], dwy[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int x = X + j - 2, y = Y + j - 2;
+        const float dx = (x + 0.5f) - px, dy = (y + 0.5f) - py;
+        const float ex = expf(alpha * dx * dx), ey = expf(alpha * dy * dy);
+        const bool lx = fabsf(dx) <= radius && x >= 0 && x < W && ex - bias > 0.f;
+        const bool ly = fabsf(dy) <= radius && y >= 0 && y < H && ey - bias > 0.f;
+        wx[j] = lx ? ex - bias : 0.f; dwx[j] = lx ? -2.f * alpha * dx * ex : 0.f;      // d w / d pos (dx = pixel centre - pos)
+        wy[j] = ly ? ey - bias : 0.f; dwy[j] = ly ? -2.f * alpha * dy * ey : 0.f;
+    }
+    float lr = 0.f, lg = 0.f, lb = 0.f, ax = 0.f, ay = 0.f, ad = 0.f;
+#pragma unroll
+    for (int jy = 0; jy < 5; ++jy) {
+        const int y = min(max(Y + jy - 2, 0), H - 1);
+#pragma unroll
+        for (int jx = 0; jx < 5; ++jx) {
+            const int x = min(max(X + jx - 2, 0), W - 1);
+            const float w2 = wy[jy] * wx[jx], wdx = wy[jy] * dwx[jx], wdy = dwy[jy] * wx[jx];
+            if (w2 == 0.f && wdx == 0.f && wdy == 0.f) continue;
+            const int64_t p = (int64_t) y * W + x;
+            const float Wp = accum[4 * p + 3];
+            const float inv = Wp > 0.f ? 1.f / fmaxf(Wp, 1e-30f) : 0.f;
+            const float *gp = grad + p * grad_stride;
+            const float gr = gp[0] * inv, gg = gp[1] * inv, gb = gp[2] * inv;             // grad / W_p
+            const float gi = (gr * accum[4 * p] + gg * accum[4 * p + 1] + gb * accum[4 * p + 2]) * inv;   // (grad . image) / W_p
+            const float A = gr * r + gg * g + gb * b - gi;
+            lr += gr * w2; lg += gg * w2; lb += gb * w2;
+            ax += A * wdx; ay += A * wdy; ad += A * w2;
+        }
+    }
+    dL[3 * i] = lr; dL[3 * i + 1] = lg; dL[3 * i + 2] = lb;
+    adj[3 * i] = ax; adj[3 * i + 1] = ay; adj[3 * i + 2] = ad;
+}
 __global__ __launch_bounds__(256) void epsm_film_develop_kernel(int64_t n, const float *accum, float *image) {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -417,6 +466,19 @@ extern "C" int epsm_film_splat(int64_t N, const float *film_pos, const float *ra
                        N, film_pos, radiance, width, height, rfilter, accum);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_film_splat", e);
+    return EPSM_OK;
+}
+extern "C" int epsm_film_adjoint_reparam(int64_t N, const float *film_pos, const float *radiance, const float *grad_img,
+                                         int grad_channels, const float *accum, int width, int height, float *dL, float *adj,
+                                         void *stream) {
+    epsm_host::err_buf()[0] = 0;
+    if (N == 0) return EPSM_OK;
+    if (N < 0 || !film_pos || !radiance || !grad_img || !accum || !dL || !adj || width < 1 || height < 1 || grad_channels < 3)
+        return fail(EPSM_EINVAL, "epsm_film_adjoint_reparam: bad argument");
+    hipLaunchKernelGGL(epsm_film_adjoint_reparam_kernel, dim3((unsigned) ((N + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                       N, film_pos, radiance, grad_img, grad_channels, accum, width, height, dL, adj);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return epsm_host::hip_fail("epsm_film_adjoint_reparam", e);
     return EPSM_OK;
 }
 extern "C" int epsm_film_develop(int width, int height, const float *accum, float *image, void *stream) {

@@ -257,7 +257,27 @@ def film_adjoint_reparam(film_pos: torch.Tensor, radiance: torch.Tensor, grad_im
     of the reparameterisation that multiplies both its value and its weight (common.py:880-920):
         image[p] = sum_i w_ip L_i det_i / sum_i w_ip det_i,   w_ip = f(p - pos_i)
     ``accum (H,W,4)``: the film [r,g,b,w] of the primal pass.  Returns ``dL (n,3)`` and ``adj (n,3)`` =
-    [d loss / d pos.x, d loss / d pos.y, d loss / d det] at det = 1."""
+    [d loss / d pos.x, d loss / d pos.y, d loss / d det] at det = 1.
+    On the GPU: ONE kernel (``epsm_film_adjoint_reparam``, include/epsm_trace.h); the torch form below is what it is checked
+    against (tests/test_gpu_reparam.py) and what the host build of the tracer runs with."""
+    if film_pos.is_cuda:
+        import ctypes as C
+        from . import _lib
+        n = int(film_pos.shape[0])
+        fp, rad = film_pos.detach().float().contiguous(), radiance.detach().float().contiguous()
+        g, acc = grad_img.detach().float().contiguous(), accum.detach().float().contiguous()
+        dL = torch.empty((n, 3), device=film_pos.device, dtype=torch.float32)
+        adj = torch.empty((n, 3), device=film_pos.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(film_pos.device).cuda_stream
+        _lib.check(_lib.lib().epsm_film_adjoint_reparam(n, fp.data_ptr(), rad.data_ptr(), g.data_ptr(), int(g.shape[-1]), acc.data_ptr(),
+                                                         int(acc.shape[1]), int(acc.shape[0]), dL.data_ptr(), adj.data_ptr(),
+                                                         C.c_void_p(stream)), "epsm_film_adjoint_reparam")
+        return dL, adj
+    return film_adjoint_reparam_torch(film_pos, radiance, grad_img, accum)
+
+
+def film_adjoint_reparam_torch(film_pos: torch.Tensor, radiance: torch.Tensor, grad_img: torch.Tensor, accum: torch.Tensor):
+    """``film_adjoint_reparam`` as dense torch operations (the checker of the HIP kernel; the CPU path of the host harness)."""
     H, W = accum.shape[:2]
     Wp = accum[..., 3]
     ok = (Wp > 0)[..., None]
@@ -424,7 +444,9 @@ class PRBReparamIntegrator(PRBIntegrator):
         stream = torch.cuda.current_stream(scene.device).cuda_stream if scene.device.type == "cuda" else None
         # pass 1 (common.py:872-882): the primal estimate of every sample and the film they make
         accum = torch.zeros((s.height, s.width, 4), device=scene.device, dtype=torch.float32)
-        tiles = _dist.tile_ranges(n_total, scene.tile_paths)
+        # tiles as large as the sharding allows, up to 2^23 paths (7 GB of warp requests): the later stages of a tile carry
+        # a fraction of its paths and under-fill the chip in 2^20-path tiles (4.26 M paths: 62 ms in five tiles, 57 ms in one)
+        tiles = _dist.tile_ranges(n_total, min(1 << 23, max(int(scene.tile_paths), -(-n_total // world))))
         mine = list(_dist.my_tiles(len(tiles), rank, world))
         kept = {}
         for t in mine:

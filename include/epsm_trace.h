@@ -233,6 +233,16 @@ int epsm_film_splat(int64_t N, const float *film_pos, const float *radiance, int
                     int rfilter, float *accum, void *stream);
 int epsm_film_develop(int width, int height, const float *accum, float *image, void *stream);
 
+/* epsm_film_adjoint_reparam -- the adjoint of splat + weight division between the two passes of prb_reparam's render_backward
+ * (common.py:880-920: image[p] = sum_i w_ip L_i det_i / sum_i w_ip det_i with the gaussian reconstruction filter, radius 2):
+ * per sample i of the primal pass, from its film position (N,2), its radiance (N,3), the gradient image grad_img
+ * (height,width,grad_channels >= 3; the first three channels are read) and the primal film accum (height,width,4) [r,g,b,w]:
+ *   dL  (N,3)  d loss / d radiance_i
+ *   adj (N,3)  d loss / d film_pos_i.x, d loss / d film_pos_i.y, d loss / d det_i   (at det = 1)
+ * which epsm_trace_paths_reparam takes as adj_radiance / adj_film.  One kernel, no allocation. */
+int epsm_film_adjoint_reparam(int64_t N, const float *film_pos, const float *radiance, const float *grad_img, int grad_channels,
+                              const float *accum, int width, int height, float *dL, float *adj, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

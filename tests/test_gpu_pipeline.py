@@ -330,7 +330,7 @@ def test_two_routes_agree_tightly_on_well_conditioned_paths(kind, profile):
     dldp = torch.randn((N, 3), generator=g) * 2e-5
     cond = oracle_cond(kind, path_info_to(trace.path_info, device="cpu"), dlduv.double(), dldp.double())
     idx = torch.nonzero(cond < 100.0).flatten()
-    assert idx.numel() > 0.5 * N
+    assert idx.numel() > 0.25 * N
     sub = select_paths(trace, idx)
     d, q = dlduv[idx][:, :, :2].contiguous().to(dev), dldp[idx].contiguous().to(dev)
     rec, sc = PackedRecords(sub.path_info, device=dev), PackedScatter(sub.scatter_info, device=dev)

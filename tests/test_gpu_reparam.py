@@ -121,3 +121,29 @@ def test_prb_reparam_alone_refines_a_nearby_start():
         shadow._TARGET_SHIFT[:] = old
     print([round(h, 4) for h in hist])
     assert np.mean(hist[-8:]) < 0.4 * hist[0], hist
+
+
+def test_film_adjoint_kernel_matches_the_torch_form():
+    """``epsm_film_adjoint_reparam`` (one HIP kernel; include/epsm_trace.h) against the dense torch form it replaced
+    (integrators.film_adjoint_reparam_torch, itself checked against autograd of the splat in tests/test_reparam.py): samples
+    inside the film, in its two-pixel border and beyond it, pixels without weight."""
+    from epsm_mitsuba3_amd.integrators import film_adjoint_reparam, film_adjoint_reparam_torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(4)
+    H, W, n = 37, 53, 20000
+    pos = torch.stack([torch.rand(n, generator=g) * (W + 6) - 3, torch.rand(n, generator=g) * (H + 6) - 3], dim=1)
+    pos[:50] = torch.tensor([10.5, 7.5])                              # exactly on a pixel centre
+    rad = torch.rand((n, 3), generator=g) * 2
+    grad = torch.randn((H, W, 3), generator=g)
+    accum = torch.rand((H, W, 4), generator=g) + 0.2
+    accum[5:8, 9:12] = 0.0                                             # pixels no sample reached
+    a = film_adjoint_reparam(pos.to(dev), rad.to(dev), grad.to(dev), accum.to(dev))
+    b = film_adjoint_reparam_torch(pos.to(dev), rad.to(dev), grad.to(dev), accum.to(dev))
+    torch.cuda.synchronize()
+    for x, y, name in zip(a, b, ("dL", "adj")):
+        m = float(y.abs().max())
+        assert m > 0 and float((x - y).abs().max()) <= 2e-5 * m, (name, float((x - y).abs().max()) / m)
+    # a gradient image with more channels than three (the caller's (H,W,5) crop): the first three are read
+    grad5 = torch.cat([grad, torch.randn((H, W, 2), generator=g)], dim=2).to(dev)
+    c = film_adjoint_reparam(pos.to(dev), rad.to(dev), grad5, accum.to(dev))
+    assert torch.equal(c[0], a[0]) and torch.equal(c[1], a[1])

@@ -17,6 +17,8 @@ depth = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 d = clutter.scene_dict(100, res, spp)
 d["sensor0"]["film"]["sample_border"] = True
 scene = Scene.from_dict(d, device="cuda")
+if len(sys.argv) > 5:
+    scene.tile_paths = int(sys.argv[5])
 for i in range(0, 100, 10):
     scene.attach(f"s{i}", positions=True, normals=True)
 integ = epsm.load_dict({"type": "prb_reparam", "max_depth": depth, "reparam_rays": rays})
