@@ -385,6 +385,7 @@ __device__ __forceinline__ void addr_issue(AddrFetch &A, const FusedArgs &F, con
 #ifndef EPSM_CP_WINDOW
 #define EPSM_CP_WINDOW 2048
 #endif
+
 template <int VARIANT, int DMODE, bool PACKED, bool FLOAT_ROWS, int kWindow>
 __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel(FusedArgs F, int dcols, int64_t windows_per_block, int window) {
     // float rows where the window's distinct rows need the larger table (epsm_wave_scatter.h, AccFixed64)
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             asm volatile("; EPSM_MARK prefetch");
             const LaneId Ln = RS.lane_of(r + kWaves, lane);          // (past the last round: no lane has a path)
             __builtin_amdgcn_sched_barrier(0);
-            if (PACKED) touch_issue(C, F, Ln, base);
+            if (PACKED) touch_issue(C, F, Ln, base);                 // (two rounds ahead instead of one: 2.08 -> 2.21 ms)
             __builtin_amdgcn_sched_barrier(0);
             // ---- emission
             asm volatile("; EPSM_MARK emit");

@@ -100,3 +100,18 @@ def test_cxx_host_driver_builds_and_reports_missing_device():
     if torch.cuda.device_count() == 0:
         r = subprocess.run([exe, "1000", "2"], capture_output=True, text=True, timeout=120)
         assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def test_launch_options_round_trip_without_a_device(lib):
+    """include/epsm.h, epsm_set_option / epsm_get_option: process-wide launch options of the fused entry points; their initial
+    values come from the environment when the library is loaded (no entry point calls getenv), unknown options and negative
+    values are refused with -EINVAL."""
+    from epsm_mitsuba3_amd import _lib
+    small, rep = lib.epsm_get_option(_lib.OPT_SMALL_WAVEFRONT_PATHS), lib.epsm_get_option(_lib.OPT_REPLICAS)
+    assert small >= 0 and rep in (0, 1)
+    with _lib.options(small_wavefront_paths=12345, replicas=False):
+        assert lib.epsm_get_option(_lib.OPT_SMALL_WAVEFRONT_PATHS) == 12345 and lib.epsm_get_option(_lib.OPT_REPLICAS) == 0
+    assert lib.epsm_get_option(_lib.OPT_SMALL_WAVEFRONT_PATHS) == small and lib.epsm_get_option(_lib.OPT_REPLICAS) == rep
+    assert lib.epsm_set_option(7, 1) == -22 and b"epsm_set_option" in lib.epsm_last_error()
+    assert lib.epsm_set_option(_lib.OPT_REPLICAS, -1) == -22
+    assert lib.epsm_get_option(99) == -1

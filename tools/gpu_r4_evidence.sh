@@ -1,8 +1,7 @@
-# Round-4 evidence run: tools/gpu_r4_evidence.sh OUTPREFIX TAG  (full GPU suite, smoke, the bench line, kernel-trace stats,
+# Round-4 evidence run: tools/gpu_r4_evidence.sh OUTPREFIX TAG  (smoke, the bench line, kernel-trace stats,
 # PMC traffic + SQ counters of the same command, profiles/traffic.json entry)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 T=gpurun_out/${1:-r4}; mkdir -p $(dirname $T)
-timeout -k 10 1000 python -m pytest tests -m gpu -q > ${T}_pytest.log 2>&1; echo "pytest rc $?" >> ${T}_pytest.log; tail -4 ${T}_pytest.log
 timeout -k 10 300 python __graft_entry__.py smoke > ${T}_smoke.log 2>&1; tail -4 ${T}_smoke.log
 B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --max-resident-gb 45"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d ${T}_trace -- $B > ${T}_trace.log 2>&1
