@@ -312,8 +312,39 @@ struct AddrFetch {
 typedef float F2v __attribute__((ext_vector_type(2)));
 typedef float F3v __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ F2v ld2(const float *p) { return *(const __attribute__((address_space(1))) F2v *) p; }
-struct LaneRole { bool ok, first, live, end_next, d1, act1; int64_t i; const float *rec; };
-__device__ __forceinline__ LaneRole role_of(const FusedArgs &F, const LaneId &L, int64_t base) {
+// Window-uniform bases (scalar registers): a lane's addresses are these plus a 32-bit offset -- `global_load ... v_off, s[base]`
+// instead of 64-bit multiply-adds per lane and load group -- and its pixel comes from the window's first pixel by two small
+// divisions (float reciprocal + one correction step each way, exact below 2^24) instead of two 32-bit integer divisions.
+struct WinBase {
+    const float *verts, *rays;
+    const uint32_t *shadow;
+    int64_t base;
+    uint32_t pix0, rem0;             // (path_offset + base) / spp and the remainder
+    float rcp_spp, rcp_res;
+    bool small;                      // pixel indices of this film stay below 2^24
+};
+__device__ __forceinline__ WinBase win_base(const FusedArgs &F, int64_t base) {
+    WinBase B;
+    B.base = base;
+    B.verts = F.pk_verts + base * F.K * kRecWords;
+    B.rays = F.pk_rays + 12 * base;
+    B.shadow = F.pk_shadow ? F.pk_shadow + 4 * base : nullptr;
+    const int64_t p0 = F.tin.path_offset + base, q0 = p0 / F.tin.spp;
+    B.small = (int64_t) F.tin.res * F.tin.res < (1 << 24) && q0 + 4096 < (1 << 24) && F.tin.spp < (1 << 20);
+    B.pix0 = (uint32_t) q0; B.rem0 = (uint32_t) (p0 - q0 * F.tin.spp);
+    B.rcp_spp = 1.f / (float) F.tin.spp; B.rcp_res = 1.f / (float) F.tin.res;
+    return B;
+}
+// x / d and x % d for 0 <= x < 2^24, d >= 1 (float reciprocal + one correction step each way)
+__device__ __forceinline__ void divmod24(uint32_t x, uint32_t d, float rcp_d, uint32_t &qo, uint32_t &ro) {
+    uint32_t q = (uint32_t) ((float) x * rcp_d);
+    int32_t r = (int32_t) x - (int32_t) (q * d);
+    if (r < 0) { --q; r += (int32_t) d; }
+    if (r >= (int32_t) d) { ++q; r -= (int32_t) d; }
+    qo = q; ro = (uint32_t) r;
+}
+struct LaneRole { bool ok, first, live, end_next, d1, act1; uint32_t loc; const float *rec; };
+__device__ __forceinline__ LaneRole role_of(const FusedArgs &F, const LaneId &L, const WinBase &B) {
     LaneRole R;
     R.ok = L.plan != 0u;
     R.first = L.k == 1;
@@ -321,34 +352,40 @@ __device__ __forceinline__ LaneRole role_of(const FusedArgs &F, const LaneId &L,
     R.end_next = R.live && L.k == L.c && L.k + 1 <= cp::plan_nv(L.plan);      // vertex k+1 exists and has no lane
     R.d1 = R.ok && R.first && cp::plan_diffuse1(L.plan);
     R.act1 = (L.plan & cp::kPlanActive1) != 0;
-    R.i = base + L.loc;
-    R.rec = F.pk_verts + (R.i * F.K + (L.k - 1)) * kRecWords;
+    R.loc = (uint32_t) L.loc;
+    R.rec = B.verts + (uint32_t) ((R.loc * (uint32_t) F.K + (uint32_t) (L.k - 1)) * (uint32_t) kRecWords);
     return R;
 }
-__device__ __forceinline__ void touch_issue(Touch &C, const FusedArgs &F, const LaneId &L, int64_t base) {
-    const LaneRole R = role_of(F, L, base);
+__device__ __forceinline__ void touch_issue(Touch &C, const FusedArgs &F, const LaneId &L, const WinBase &B) {
+    const LaneRole R = role_of(F, L, B);
     if (R.live || R.d1) C.own = lds_(R.rec, 0);
-    if (R.ok && R.first) { const float *rays = F.pk_rays + 12 * R.i; C.ray0 = lds_(rays, 0); C.ray1 = lds_(rays, 11); }
+    if (R.ok && R.first) { const float *rays = B.rays + 12u * R.loc; C.ray0 = lds_(rays, 0); C.ray1 = lds_(rays, 11); }
     if (R.end_next) C.nxt = lds_(R.rec + kRecWords, 0);
 }
-// pixel of path i: (path_offset + i) / spp, row-major on the res x res crop (epsm.py:250); 32-bit arithmetic where it fits
-__device__ __forceinline__ const float *pixel_grad(const TangentIn &A, int64_t i) {
-    const int64_t p = A.path_offset + i;
-    int64_t pix, y, x;
-    if (p < (int64_t) 0x7fffffff) { const uint32_t q = (uint32_t) p / (uint32_t) A.spp; pix = q; const uint32_t yy = q / (uint32_t) A.res; y = yy; x = q - yy * (uint32_t) A.res; }
-    else { pix = p / A.spp; y = pix / A.res; x = pix - y * A.res; }
+// pixel of path i: (path_offset + i) / spp, row-major on the res x res crop (epsm.py:250)
+__device__ __forceinline__ const float *pixel_grad(const TangentIn &A, const WinBase &B, uint32_t loc) {
+    int64_t y, x;
+    if (B.small) {
+        uint32_t q1, r1, yy, xx;
+        divmod24(B.rem0 + loc, (uint32_t) A.spp, B.rcp_spp, q1, r1);
+        divmod24(B.pix0 + q1, (uint32_t) A.res, B.rcp_res, yy, xx);
+        y = yy; x = xx;
+    } else {
+        const int64_t pix = (A.path_offset + B.base + loc) / A.spp;
+        y = pix / A.res; x = pix - y * A.res;
+    }
     return A.grad_img + (y * A.img_width + x) * A.img_channels + 3;
 }
-__device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const LaneId &L, int64_t base) {
-    const LaneRole R = role_of(F, L, base);
+__device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B) {
+    const LaneRole R = role_of(F, L, B);
     // (a path WITHOUT a constraint reads its first record only when its first hit is diffuse: diffuse_grad[0] = dldp needs the
     // triangle; otherwise all it gives is its share of d/d ray.o, which needs the rays alone -- 27 % of the bathroom paths)
     if (R.live || (R.d1 && R.act1)) { X.o0 = ldq(R.rec, 0); X.o1 = ldq(R.rec, 1); X.o2 = ldq(R.rec, 2); }
     if (R.live) { X.o3 = ldq(R.rec, 3); X.o4 = ldq(R.rec, 4); X.o5 = ldq(R.rec, 5); }
     if (R.ok && R.first) {
-        const float *rays = F.pk_rays + 12 * R.i;
+        const float *rays = B.rays + 12u * R.loc;
         X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
-        const F2v g = ld2(pixel_grad(F.tin, R.i));
+        const F2v g = ld2(pixel_grad(F.tin, B, R.loc));
         X.gx = g.x; X.gy = g.y;
     }
     if (R.end_next) {
@@ -358,15 +395,15 @@ __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const
     }
 }
 template <int VARIANT>
-__device__ __forceinline__ void addr_issue(AddrFetch &A, const FusedArgs &F, const LaneId &L, int64_t base) {
-    const LaneRole R = role_of(F, L, base);
+__device__ __forceinline__ void addr_issue(AddrFetch &A, const FusedArgs &F, const LaneId &L, const WinBase &B) {
+    const LaneRole R = role_of(F, L, B);
     if (R.live) {
         if (F.galpha) A.q7 = ldq(R.rec, 7); else A.q7.x = lds_(R.rec, 28);
         if (VARIANT == EPSM_VARIANT_MANIFOLD && cp::plan_a(L.plan, L.k)) A.q6 = ldq(R.rec, 6);
     }
     if (R.d1) {
         if (!R.live) { A.q7.x = lds_(R.rec, 28); const F2v b = ld2(R.rec + 18); A.b0 = b.x; A.b1 = b.y; }
-        if (F.pk_shadow) A.sh = load_u4(F.pk_shadow, R.i);
+        if (B.shadow) A.sh = load_u4(B.shadow, R.loc);
     }
     if (R.end_next) {
         const float *nx = R.rec + kRecWords;
@@ -428,6 +465,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
         const int64_t win = (int64_t) blockIdx.x * windows_per_block + wi;
         if (win >= n_windows) break;                                 // workgroup-uniform
         const int64_t base = win * window;
+        const WinBase WB = win_base(F, base);
         // ---- plan + histogram of m: thread t plans paths base + j*kThreads + t
         int key[kPer], rank[kPer];
         {
@@ -545,7 +583,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     X.o0 = X.o1 = X.o2 = X.o3 = X.o4 = X.o5 = X.p0 = X.p1 = X.p2 = X.n0 = X.n1 = z4;
                     X.n_z = X.n_b0 = X.n_b1 = X.gx = X.gy = 0.f;
                 }
-                geo_issue(X, F, L, base);
+                geo_issue(X, F, L, WB);
                 // (the touches' destination registers stay reserved until here: a pending load's destination that nobody reads
                 // is free for the allocator, and the hardware's write to it would have to be waited for in the middle of the emission)
                 asm volatile("" :: "v"(C.own), "v"(C.ray0), "v"(C.ray1), "v"(C.nxt));
@@ -630,7 +668,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             }
 #ifdef EPSM_CPKO_NOSOLVE
             gd_acc.x += own.x.x + own.n.y + own.light.z + own.eta + prev.x.x + prev.e1.y + next.x.z + next.e2.x + dk.x + dp.y;
-            if (PACKED) addr_issue<VARIANT>(A, F, L, base);
+            if (PACKED) addr_issue<VARIANT>(A, F, L, WB);
             if (false) {
 #else
             if (VARIANT == EPSM_VARIANT_MANIFOLD) {
@@ -663,7 +701,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                 }
                 // the words only the emission needs, on their way (vector-cache hits) under the second sweep
                 __builtin_amdgcn_sched_barrier(0);
-                if (PACKED) addr_issue<VARIANT>(A, F, L, base);
+                if (PACKED) addr_issue<VARIANT>(A, F, L, WB);
                 __builtin_amdgcn_sched_barrier(0);
                 if (q > 0) {
                     // pass 2: the constraint(s) swept once more with the final seeds
@@ -693,7 +731,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     poisoned = (bad & seg) != 0ull;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (PACKED) addr_issue<VARIANT>(A, F, L, base);
+                if (PACKED) addr_issue<VARIANT>(A, F, L, WB);
                 __builtin_amdgcn_sched_barrier(0);
                 if (q > 0) {
                     const cp::COut<float> o = cp::caustic_finish(pts, f, first, live && k <= idstar, live && k == idstar, live && cp::plan_b(plan, k));
@@ -731,7 +769,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             asm volatile("; EPSM_MARK prefetch");
             const LaneId Ln = RS.lane_of(r + kWaves, lane);          // (past the last round: no lane has a path)
             __builtin_amdgcn_sched_barrier(0);
-            if (PACKED) touch_issue(C, F, Ln, base);                 // (two rounds ahead instead of one: 2.08 -> 2.21 ms)
+            if (PACKED) touch_issue(C, F, Ln, WB);                 // (two rounds ahead instead of one: 2.08 -> 2.21 ms)
             __builtin_amdgcn_sched_barrier(0);
             // ---- emission
             asm volatile("; EPSM_MARK emit");
