@@ -161,6 +161,73 @@ def load_obj(path: str):
     return v, (n if has_n else None), np.asarray(faces, dtype=np.int64).reshape(-1, 3)
 
 
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",
+              "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def load_ply(path: str):
+    """Minimal PLY reader (src/shapes/ply.cpp reads the same subset for the experiment files, e.g. EPSM/exp/glassslab.py:150):
+    ascii / binary_little_endian / binary_big_endian; element ``vertex`` with x y z (and nx ny nz), element ``face`` with one list
+    property (``vertex_indices`` / ``vertex_index``), polygons triangulated as fans.  Returns (v (V,3), n (V,3) | None, f (F,3))."""
+    with open(path, "rb") as fh:
+        if fh.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, elements = None, []
+        while True:
+            t = fh.readline().decode("ascii", "replace").split()
+            if not t or t[0] == "comment" or t[0] == "obj_info":
+                continue
+            if t[0] == "format":
+                fmt = t[1]
+            elif t[0] == "element":
+                elements.append({"name": t[1], "count": int(t[2]), "props": []})
+            elif t[0] == "property":
+                elements[-1]["props"].append(("list", t[2], t[3], t[4]) if t[1] == "list" else ("scalar", t[1], t[2]))
+            elif t[0] == "end_header":
+                break
+        if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+            raise ValueError(f"{path}: unsupported PLY format {fmt!r}")
+        end = "<" if fmt != "binary_big_endian" else ">"
+        verts = faces = None
+        tokens = fh.read().split() if fmt == "ascii" else None
+        pos = 0
+        for el in elements:
+            scalars_only = all(p_[0] == "scalar" for p_ in el["props"])
+            if scalars_only:
+                names = [p_[2] for p_ in el["props"]]
+                if fmt == "ascii":
+                    k = len(names)
+                    arr = np.asarray(tokens[pos:pos + el["count"] * k], dtype=np.float64).reshape(el["count"], k)
+                    pos += el["count"] * k
+                    table = {nm: arr[:, j] for j, nm in enumerate(names)}
+                else:
+                    dt = np.dtype([(nm, end + _PLY_TYPES[p_[1]]) for p_, nm in zip(el["props"], names)])
+                    rec = np.frombuffer(fh.read(dt.itemsize * el["count"]), dtype=dt, count=el["count"])
+                    table = {nm: rec[nm].astype(np.float64) for nm in names}
+                if el["name"] == "vertex":
+                    verts = table
+            else:
+                if len(el["props"]) != 1:
+                    raise ValueError(f"{path}: element {el['name']} mixes list and scalar properties (unsupported)")
+                _, ct, it, _nm = el["props"][0]
+                tris = []
+                for _ in range(el["count"]):
+                    if fmt == "ascii":
+                        n_ = int(tokens[pos]); idx = [int(x) for x in tokens[pos + 1:pos + 1 + n_]]; pos += 1 + n_
+                    else:
+                        n_ = int(np.frombuffer(fh.read(np.dtype(_PLY_TYPES[ct]).itemsize), dtype=end + _PLY_TYPES[ct])[0])
+                        idx = np.frombuffer(fh.read(np.dtype(_PLY_TYPES[it]).itemsize * n_), dtype=end + _PLY_TYPES[it]).tolist()
+                    for j in range(1, n_ - 1):
+                        tris.append([idx[0], idx[j], idx[j + 1]])
+                if el["name"] == "face":
+                    faces = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
+    if verts is None or faces is None or not all(k in verts for k in ("x", "y", "z")):
+        raise ValueError(f"{path}: needs a vertex element with x y z and a face element")
+    v = np.stack([verts["x"], verts["y"], verts["z"]], axis=1)
+    n = np.stack([verts["nx"], verts["ny"], verts["nz"]], axis=1) if all(k in verts for k in ("nx", "ny", "nz")) else None
+    return v, n, faces
+
+
 def vertex_normals(v: np.ndarray, f: np.ndarray) -> np.ndarray:
     """Angle-weighted vertex normals (Mesh::recompute_vertex_normals, src/render/mesh.cpp)."""
     n = np.zeros_like(v)
@@ -549,10 +616,12 @@ class Scene:
             elif t == "point":
                 emitters.append(dict(type=1, mesh=-1, radiance=_rgb(val.get("intensity"), [1, 1, 1]),
                                      position=np.asarray(val.get("position", [0, 0, 0]), np.float32)))
-            elif t in ("obj", "mesh", "rectangle"):
+            elif t in ("obj", "ply", "mesh", "rectangle"):
                 tw = np.asarray(val.get("to_world", np.eye(4)), dtype=np.float64)
                 if t == "obj":
                     v, n, f = load_obj(os.path.join(base_dir, val["filename"]))
+                elif t == "ply":
+                    v, n, f = load_ply(os.path.join(base_dir, val["filename"]))
                 elif t == "mesh":
                     v, f = np.asarray(val["vertices"], np.float64), np.asarray(val["faces"], np.int64)
                     n = np.asarray(val["normals"], np.float64) if "normals" in val else None
