@@ -815,8 +815,16 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
 #ifndef EPSM_CP_SLOTS
 #define EPSM_CP_SLOTS 768
 #endif
-    constexpr int kLarge = EPSM_CP_WINDOW, kSmall = 1024, kSlots = EPSM_CP_SLOTS;
-    int window = kLarge;
+    // `manifold_caustic` walks windows of 1024 paths: its paths carry three to four constraint vertices with normal and alpha rows
+    // each, and 2048 of them overflow the 960-row table into global atomics (pool slab 3.18 -> 2.80 ms; `manifold`, whose
+    // windows hold fewer rows, loses 5 % with the smaller ones -- every class of paths ends in a partly filled round).
+#ifndef EPSM_CP_WINDOW_CAUSTIC
+#define EPSM_CP_WINDOW_CAUSTIC 1024
+#endif
+    constexpr int kSmall = 1024, kSlots = EPSM_CP_SLOTS;
+    constexpr int kLargeRT = VARIANT == EPSM_VARIANT_MANIFOLD ? EPSM_CP_WINDOW : EPSM_CP_WINDOW_CAUSTIC;      // paths per window of a large wavefront
+    constexpr int kLarge = kLargeRT > 1024 ? EPSM_CP_WINDOW : 1024;                                         // ... and the instantiation that plans them
+    int window = kLargeRT;
     if (small) {
         const int64_t w = ((F.g.N + kSlots - 1) / kSlots + 63) / 64 * 64;       // a multiple of 64 paths
         window = (int) (w < 128 ? 128 : w > kSmall ? kSmall : w);
