@@ -380,13 +380,8 @@ __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const
     const LaneRole R = role_of(F, L, B);
     // (a path WITHOUT a constraint reads its first record only when its first hit is diffuse: diffuse_grad[0] = dldp needs the
     // triangle; otherwise all it gives is its share of d/d ray.o, which needs the rays alone -- 27 % of the bathroom paths)
-#ifdef EPSM_CPKO_ONEQUAD                   // (knock-out: ONE 16-byte load per record instead of six -- is it the NUMBER of loads?)
-    if (R.live || (R.d1 && R.act1)) { X.o0 = ldq(R.rec, 0); X.o1 = X.o0 * 1.5f; X.o2 = X.o0 * 0.5f; }
-    if (R.live) { X.o3 = X.o0 + 1.f; X.o4 = X.o0 * 0.25f + 0.1f; X.o5 = X.o0 * 0.75f + 1.f; }
-#else
     if (R.live || (R.d1 && R.act1)) { X.o0 = ldq(R.rec, 0); X.o1 = ldq(R.rec, 1); X.o2 = ldq(R.rec, 2); }
     if (R.live) { X.o3 = ldq(R.rec, 3); X.o4 = ldq(R.rec, 4); X.o5 = ldq(R.rec, 5); }
-#endif
     if (R.ok && R.first) {
         const float *rays = B.rays + 12u * R.loc;
         X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
