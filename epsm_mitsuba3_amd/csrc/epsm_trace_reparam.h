@@ -181,7 +181,7 @@ struct Warp {
     F3 dZ, o, d;
     Aux a[kMaxAux];
 };
-struct ReparamCfg { int max_depth, rays; float kappa, exponent; };
+struct ReparamCfg { int max_depth, rays; float kappa, exponent; uint32_t flags; };      // flags: EPSM_REPARAM_* (epsm_trace.h)
 
 // Boundary term of a hit (mesh.cpp:832-887; rectangle.cpp:320-321 for the tessellated rectangles)
 EPSM_HD float boundary_test(const EpsmScene &S, const TriHit &th, F3 ray_d) {
@@ -225,7 +225,11 @@ EPSM_HD float boundary_test(const EpsmScene &S, const TriHit &th, F3 ray_d) {
 // (the host build) with the same numbers.
 struct WarpId { uint32_t key, widx; int n; };
 EPSM_HD Aux aux_ray(const EpsmScene &S, const ReparamCfg &cfg, const WarpId &id, int r, F3 o, F3 d, F3 fs, F3 ft, const BvhStack &st) {
-    Pcg32 rng = seed_sampler(id.key ^ (0x9E3779B9u * (uint32_t) (id.n * 64 + r + 1)), id.widx);
+    // antithetic pairs (reparam.py:82-84, 189-196): rays 2m and 2m + 1 share one sample; the even one mirrors it about the
+    // ray (omega_local.x, .y negated), which cancels the odd part of the warp field's estimator
+    const bool anti = (cfg.flags & EPSM_REPARAM_ANTITHETIC) != 0;
+    const int rs = anti ? (r & ~1) : r;
+    Pcg32 rng = seed_sampler(id.key ^ (0x9E3779B9u * (uint32_t) (id.n * 64 + rs + 1)), id.widx);
     const float kappa = cfg.kappa;
     const float sx = rng.next_1d(), sy_ = rng.next_1d();
     // warp.h:559-566 square_to_von_mises_fisher (1 - cos^2 formed without the cancellation of fp32)
@@ -233,7 +237,8 @@ EPSM_HD Aux aux_ray(const EpsmScene &S, const ReparamCfg &cfg, const WarpId &id,
     const float e = logf(sy + (1.f - sy) * expf(-2.f * kappa)) / kappa;             // cos_theta - 1 <= 0
     const float cos_theta = 1.f + e, sin_theta = safe_sqrt(-e * (2.f + e));
     const float phi = 2.f * kPi * sx;
-    const F3 ol = f3(cosf(phi) * sin_theta, sinf(phi) * sin_theta, cos_theta);
+    const float mirror = anti && !(r & 1) ? -1.f : 1.f;
+    const F3 ol = f3(mirror * cosf(phi) * sin_theta, mirror * sinf(phi) * sin_theta, cos_theta);
     Ray ar; ar.o = o; ar.d = fs * ol.x + ft * ol.y + d * ol.z; ar.maxt = kInf;
     const TriHit th = intersect<false>(S, ar, st);
     Aux A;

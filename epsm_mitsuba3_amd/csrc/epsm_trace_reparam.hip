@@ -120,7 +120,7 @@ extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor
                                         uint32_t seed, int spp, int max_depth, int rr_depth,
                                         int64_t path_offset, int64_t N,
                                         const float *radiance, const float *adj_radiance, const float *adj_film,
-                                        int reparam_max_depth, int reparam_rays, float kappa, float exponent,
+                                        int reparam_max_depth, int reparam_rays, float kappa, float exponent, uint32_t flags,
                                         float *grad_pos, float *grad_nrm, void *workspace, size_t workspace_bytes, void *stream) {
     epsm_host::err_buf()[0] = 0;
     auto bad = [&](const char *what) { char msg[200]; snprintf(msg, sizeof(msg), "epsm_trace_paths_reparam: %s", what); return fail(EPSM_EINVAL, msg); };
@@ -136,6 +136,7 @@ extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor
         return bad("workspace: 16-byte aligned, >= epsm_trace_reparam_workspace_bytes(N)");
     if (reparam_rays < 1 || reparam_rays > rp::kMaxAux || reparam_max_depth < 0 || !(kappa > 0.f) || !(exponent > 0.f))
         return bad("need 1 <= reparam_rays <= 64, reparam_max_depth >= 0, kappa > 0, exponent > 0");
+    if (flags & ~EPSM_REPARAM_ANTITHETIC) return bad("unknown flag");
     if (scene->n_triangles <= 0 || !scene->positions || !scene->normals || !scene->tri || !scene->tri_mesh || !scene->meshes ||
         !scene->bsdfs || !scene->bvh || !scene->prim_index || !scene->tri_verts)
         return bad("NULL scene array");
@@ -145,7 +146,7 @@ extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor
     R.A.S = *scene; R.A.C = *sensor;
     R.A.seed = seed; R.A.spp = spp; R.A.max_depth = max_depth; R.A.rr_depth = rr_depth; R.A.K_log = 0;
     R.A.path_offset = path_offset; R.A.N = N;
-    R.cfg.max_depth = reparam_max_depth; R.cfg.rays = reparam_rays; R.cfg.kappa = kappa; R.cfg.exponent = exponent;
+    R.cfg.max_depth = reparam_max_depth; R.cfg.rays = reparam_rays; R.cfg.kappa = kappa; R.cfg.exponent = exponent; R.cfg.flags = flags;
     R.radiance = radiance; R.adj_radiance = adj_radiance; R.adj_film = adj_film;
     R.G.pos = grad_pos; R.G.nrm = grad_nrm;
     rp::WarpReq *req = (rp::WarpReq *) workspace;

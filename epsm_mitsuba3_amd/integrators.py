@@ -401,8 +401,8 @@ class PRBReparamIntegrator(PRBIntegrator):
     d sum(image * grad_in) / d vertex positions (and vertex normals) of the attached meshes into ``params.pos`` /
     ``params.nrm`` through silhouettes, shadow boundaries and shading, and the colour adjoint of ``PRBIntegrator`` into
     ``params.color``.  Properties as in prb_reparam.py:226-250: ``reparam_max_depth`` (default: max_depth),
-    ``reparam_rays`` (16; at most 64 here), ``reparam_kappa`` (1e5), ``reparam_exp`` (3.0).  ``reparam_antithetic`` is not
-    implemented (the reference's default is False).  The pass replays the estimator of ``Scene.render_primal`` under the
+    ``reparam_rays`` (16; at most 64 here), ``reparam_kappa`` (1e5), ``reparam_exp`` (3.0), ``reparam_antithetic`` (False:
+    auxiliary rays in mirrored pairs, reparam.py:82-84, 189-196).  The pass replays the estimator of ``Scene.render_primal`` under the
     same seed (csrc/epsm_trace_reparam.h); a box reconstruction filter is refused as in common.py:379-388."""
     reparam = True
 
@@ -413,8 +413,7 @@ class PRBReparamIntegrator(PRBIntegrator):
         self.reparam_rays = int(props.get("reparam_rays", 16))
         self.reparam_kappa = float(props.get("reparam_kappa", 1e5))
         self.reparam_exp = float(props.get("reparam_exp", 3.0))
-        if props.get("reparam_antithetic", False):
-            raise NotImplementedError("prb_reparam: reparam_antithetic is not implemented")
+        self.reparam_antithetic = bool(props.get("reparam_antithetic", False))
         if not 1 <= self.reparam_rays <= 64:
             raise ValueError("prb_reparam: 1 <= reparam_rays <= 64")
 
@@ -466,7 +465,8 @@ class PRBReparamIntegrator(PRBIntegrator):
             film_pos, radiance = kept.pop(t)
             dL, adj = film_adjoint_reparam(film_pos, radiance, g, accum)
             scene.trace_reparam(si, seed, spp, self._depth(), lo, hi, radiance, dL, adj, out.pos, out.nrm,
-                                int(self.reparam_max_depth), self.reparam_rays, self.reparam_kappa, self.reparam_exp)
+                                int(self.reparam_max_depth), self.reparam_rays, self.reparam_kappa, self.reparam_exp,
+                                antithetic=self.reparam_antithetic)
         if world > 1:
             _dist.allreduce_param_grads(out.flat)
             params.flat += out.flat

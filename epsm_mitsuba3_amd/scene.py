@@ -875,10 +875,12 @@ class Scene:
         return film_pos, radiance, sums
 
     def trace_reparam(self, sensor_index: int, seed: int, spp: int, max_depth: int, lo: int, hi: int, radiance, adj_radiance,
-                      adj_film, grad_pos, grad_nrm, reparam_max_depth: int, reparam_rays: int, kappa: float, exponent: float):
+                      adj_film, grad_pos, grad_nrm, reparam_max_depth: int, reparam_rays: int, kappa: float, exponent: float,
+                      antithetic: bool = False):
         """``epsm_trace_paths_reparam``: the reparameterised backward pass of paths [lo, hi) -- accumulates d loss / d vertex
         positions (and normals) into ``grad_pos`` / ``grad_nrm`` (V,3) given, per path, the radiance of the primal pass under
-        the same seed, its adjoint and the adjoint of the film position + determinant (integrators.film_adjoint_reparam)."""
+        the same seed, its adjoint and the adjoint of the film position + determinant (integrators.film_adjoint_reparam).
+        ``antithetic``: EPSM_REPARAM_ANTITHETIC (auxiliary rays in mirrored pairs, reparam.py:82-84)."""
         dev = self.device
         if dev.type != "cuda" and self._backend is None:
             raise _lib.EpsmError("the tracer runs on the GPU only (no CPU fallback)")
@@ -901,7 +903,7 @@ class Scene:
         rc = fn(C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
                 C.c_int64(lo), C.c_int64(n), C.c_void_p(radiance.data_ptr()), C.c_void_p(adj_radiance.data_ptr()),
                 C.c_void_p(adj_film.data_ptr()), int(reparam_max_depth), int(reparam_rays), C.c_float(kappa), C.c_float(exponent),
-                C.c_void_p(grad_pos.data_ptr()), C.c_void_p(grad_nrm.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()),
+                C.c_uint32(1 if antithetic else 0), C.c_void_p(grad_pos.data_ptr()), C.c_void_p(grad_nrm.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()),
                 C.c_void_p(stream))
         if rc != 0:
             _lib.check(rc, "epsm_trace_paths_reparam") if self._backend is None else (_ for _ in ()).throw(RuntimeError(f"host tracer rc={rc}"))

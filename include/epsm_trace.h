@@ -211,6 +211,8 @@ int epsm_trace_paths_color(const EpsmScene *scene, const EpsmSensor *sensor,
  *     adj_film      (N,3) d loss / d film position (x, y in pixels) and d loss / d det of the primary ray's
  *                         reparameterisation (common.py:405-418, 888-903)
  *     reparam_max_depth, reparam_rays (<= 64), kappa, exponent   prb_reparam.py:226-250
+ *     flags         EPSM_REPARAM_ANTITHETIC: auxiliary rays 2m and 2m + 1 of a warp share one sample, the even one mirrored
+ *                   about the ray (`reparam_antithetic`, prb_reparam.py:243-246, reparam.py:82-84, 189-196)
  *     grad_pos, grad_nrm   (V,3) f32 device buffers, float atomics; grad_nrm may be NULL
  *     workspace            device memory, 16-byte aligned, >= epsm_trace_reparam_workspace_bytes(N); scratch
  *   Two launches: (1) a lane replays its path, differentiates each vertex (dual numbers) and leaves one 64-byte REQUEST
@@ -218,12 +220,13 @@ int epsm_trace_paths_color(const EpsmScene *scene, const EpsmSensor *sensor,
  *   13 per path; (2) one lane per AUXILIARY RAY: the 16 / 32 / 64 lanes of a request trace its rays side by side, reduce
  *   the weights over the group and scatter the warp field's adjoint.
  * ------------------------------------------------------------------------- */
+#define EPSM_REPARAM_ANTITHETIC 1u
 size_t epsm_trace_reparam_workspace_bytes(int64_t N);
 int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor *sensor,
                              uint32_t seed, int spp, int max_depth, int rr_depth,
                              int64_t path_offset, int64_t N,
                              const float *radiance, const float *adj_radiance, const float *adj_film,
-                             int reparam_max_depth, int reparam_rays, float kappa, float exponent,
+                             int reparam_max_depth, int reparam_rays, float kappa, float exponent, uint32_t flags,
                              float *grad_pos, float *grad_nrm, void *workspace, size_t workspace_bytes, void *stream);
 
 /* epsm_film_splat -- ImageBlock::put + weight division (film.develop): accumulates

@@ -52,14 +52,15 @@ extern "C" int epsm_trace_paths_color(const EpsmScene *scene, const EpsmSensor *
 extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor *sensor, uint32_t seed, int spp, int max_depth,
                                         int rr_depth, int64_t path_offset, int64_t N, const float *radiance,
                                         const float *adj_radiance, const float *adj_film, int reparam_max_depth, int reparam_rays,
-                                        float kappa, float exponent, float *grad_pos, float *grad_nrm, void *, size_t, void *) {
+                                        float kappa, float exponent, uint32_t flags, float *grad_pos, float *grad_nrm, void *, size_t,
+                                        void *) {
     if (reparam_rays < 1 || reparam_rays > rp::kMaxAux) return -22;
     rp::ReparamArgs R;
     memset(&R, 0, sizeof(R));
     R.A.S = *scene; R.A.C = *sensor;
     R.A.seed = seed; R.A.spp = spp; R.A.max_depth = max_depth; R.A.rr_depth = rr_depth; R.A.K_log = 0;
     R.A.path_offset = path_offset; R.A.N = N;
-    R.cfg.max_depth = reparam_max_depth; R.cfg.rays = reparam_rays; R.cfg.kappa = kappa; R.cfg.exponent = exponent;
+    R.cfg.max_depth = reparam_max_depth; R.cfg.rays = reparam_rays; R.cfg.kappa = kappa; R.cfg.exponent = exponent; R.cfg.flags = flags;
     R.radiance = radiance; R.adj_radiance = adj_radiance; R.adj_film = adj_film;
     R.G.pos = grad_pos; R.G.nrm = grad_nrm;
 #pragma omp parallel for schedule(dynamic, 64)
@@ -77,8 +78,8 @@ extern "C" size_t epsm_trace_reparam_workspace_bytes(int64_t) { return 0; }
 // Test probe: the warp field's value and divergence at one ray when only the ray ORIGIN moves with velocity `odot`
 // (forward mode of reparam.py:155-221): out = [V_theta (3), div V_theta, Z].
 extern "C" int epsm_debug_warp(const EpsmScene *scene, const float *o, const float *d, const float *odot, int rays, float kappa,
-                               float exponent, uint32_t seed, float *out) {
-    rp::ReparamCfg cfg; cfg.max_depth = 8; cfg.rays = rays; cfg.kappa = kappa; cfg.exponent = exponent;
+                               float exponent, uint32_t flags, uint32_t seed, float *out) {
+    rp::ReparamCfg cfg; cfg.max_depth = 8; cfg.rays = rays; cfg.kappa = kappa; cfg.exponent = exponent; cfg.flags = flags;
     uint32_t stack[kBvhStack];
     rp::Warp W;
     rp::warp_collect(*scene, cfg, rp::WarpId{seed, 0u, 0}, ld3(o), ld3(d), BvhStack{stack, 1}, W);
@@ -100,8 +101,8 @@ extern "C" int epsm_debug_warp(const EpsmScene *scene, const float *o, const flo
 // Test probe: the hand-written ADJOINT of the same warp (same seed -> same auxiliary rays): d loss / d ray.o for given
 // d loss / d direction and d loss / d divergence.  No mesh need be attached: grad_pos may be null-sized.
 extern "C" int epsm_debug_warp_adjoint(const EpsmScene *scene, const float *o, const float *d, const float *g_dir, float g_div, int rays,
-                                       float kappa, float exponent, uint32_t seed, float *grad_pos, float *out) {
-    rp::ReparamCfg cfg; cfg.max_depth = 8; cfg.rays = rays; cfg.kappa = kappa; cfg.exponent = exponent;
+                                       float kappa, float exponent, uint32_t flags, uint32_t seed, float *grad_pos, float *out) {
+    rp::ReparamCfg cfg; cfg.max_depth = 8; cfg.rays = rays; cfg.kappa = kappa; cfg.exponent = exponent; cfg.flags = flags;
     uint32_t stack[kBvhStack];
     rp::Warp W;
     rp::warp_collect(*scene, cfg, rp::WarpId{seed, 0u, 0}, ld3(o), ld3(d), BvhStack{stack, 1}, W);

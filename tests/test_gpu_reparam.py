@@ -17,15 +17,19 @@ def rel(got, fd):
     return abs(g - f) / max(abs(f), 1e-3), g, f
 
 
-@pytest.mark.parametrize("name,rays", [("diffuse_sphere_area_light", 16), ("sphere_on_glossy_floor", 16), ("occluder_area_light", 16),
-                                       ("diffuse_sphere_area_light", 24), ("diffuse_sphere_area_light", 5), ("sphere_on_glossy_floor", 64)])
-def test_device_pass_equals_the_host_build(name, rays):
+@pytest.mark.parametrize("name,rays,antithetic", [
+    ("diffuse_sphere_area_light", 16, False), ("sphere_on_glossy_floor", 16, False), ("occluder_area_light", 16, False),
+    ("diffuse_sphere_area_light", 24, False), ("diffuse_sphere_area_light", 5, False), ("sphere_on_glossy_floor", 64, False),
+    ("diffuse_sphere_area_light", 16, True), ("occluder_area_light", 5, True)])
+def test_device_pass_equals_the_host_build(name, rays, antithetic):
     """Same seed, same auxiliary rays (every ray has its own stream): the device's two stages -- requests, then one lane per
     auxiliary ray in groups of 16 / 32 / 64, partly filled for 5 and 24 rays -- against the host build's inline warps; per-vertex
-    gradients agree up to what fma contraction flips (a hit that becomes a miss moves one auxiliary ray's share)."""
+    gradients agree up to what fma contraction flips (a hit that becomes a miss moves one auxiliary ray's share).  With
+    ``reparam_antithetic`` the lanes 2m and 2m + 1 of a group draw the same sample (an odd count leaves the last one alone)."""
     res, spp = 16, 32
     cfg = CONFIGS[name]
-    integ = epsm.load_dict({"type": "prb_reparam", "max_depth": cfg["max_depth"], "reparam_rays": rays, "reparam_kappa": cfg.get("kappa", 1e5)})
+    integ = epsm.load_dict({"type": "prb_reparam", "max_depth": cfg["max_depth"], "reparam_rays": rays, "reparam_kappa": cfg.get("kappa", 1e5),
+                            "reparam_antithetic": antithetic})
     g = torch.ones((res, res, 3)) * (0.5 + torch.arange(res, dtype=torch.float32) / res)[None, :, None]
     out = []
     for dev in ("cpu", "cuda"):
