@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define EPSM_FAST_RCP64                 // epsm_path_core.h: 1 / x in float64 by v_rcp_f64 + two Newton steps
 #include "epsm_fused.h"
 #include "epsm_cp_core.h"
 #include "epsm_wave_scatter.h"
@@ -163,8 +164,7 @@ template <typename Table> struct Emitter {
 
     template <int ROWS>
     __device__ __forceinline__ void push(bool valid, const uint32_t key[ROWS], const V3<float> val[ROWS]) const {
-        Q.reserve(T, ROWS);
-        Q.template push_rows<ROWS>(valid, key, val);
+        Q.template push_rows<ROWS>(T, valid, key, val);
     }
     __device__ __forceinline__ V3<float> fin(V3<float> g) const {
         return mk3<float>(finalize(g.x, F.g.clip), finalize(g.y, F.g.clip), finalize(g.z, F.g.clip));
@@ -363,16 +363,20 @@ __device__ __forceinline__ void touch_issue(Touch &C, const FusedArgs &F, const 
     if (R.end_next) C.nxt = lds_(R.rec + kRecWords, 0);
 }
 // pixel of path i: (path_offset + i) / spp, row-major on the res x res crop (epsm.py:250)
+// (films of 2^24 pixels and more: two 64-bit divisions, ~200 instructions that the round loop carried inline without ever
+// running them -- out of line: headline slab 2.07 -> 2.06 ms, pool slab 2.79 -> 2.70)
+__device__ __attribute__((noinline)) int64_t pixel_offset_large(int64_t path, int spp, int res, int img_width) {
+    const int64_t pix = path / spp, y = pix / res;
+    return y * img_width + (pix - y * res);
+}
 __device__ __forceinline__ const float *pixel_grad(const TangentIn &A, const WinBase &B, uint32_t loc) {
+    if (!B.small) return A.grad_img + pixel_offset_large(A.path_offset + B.base + loc, A.spp, A.res, A.img_width) * A.img_channels + 3;
     int64_t y, x;
-    if (B.small) {
+    {
         uint32_t q1, r1, yy, xx;
         divmod24(B.rem0 + loc, (uint32_t) A.spp, B.rcp_spp, q1, r1);
         divmod24(B.pix0 + q1, (uint32_t) A.res, B.rcp_res, yy, xx);
         y = yy; x = xx;
-    } else {
-        const int64_t pix = (A.path_offset + B.base + loc) / A.spp;
-        y = pix / A.res; x = pix - y * A.res;
     }
     return A.grad_img + (y * A.img_width + x) * A.img_channels + 3;
 }
@@ -433,7 +437,6 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
     // (a window costs 6 bytes of LDS per path: the larger one leaves 224 fixed-point / 384 float rows fewer)
     constexpr int kRowsFixed = kWindow > 1024 ? EPSM_CP_ROWS_FIXED - 224 * ((kWindow - 1024) / 1024) : EPSM_CP_ROWS_FIXED;
     constexpr int kRowsFloat = kWindow > 1024 ? EPSM_CP_ROWS_FLOAT - 384 * ((kWindow - 1024) / 1024) : EPSM_CP_ROWS_FLOAT;
-    typedef AccFixed64 AccWide;
     typedef LdsTable<kFloatRows ? kRowsFloat : kRowsFixed, typename std::conditional<kFloatRows, AccFloat, AccFixed64>::type> Table;
     constexpr int kTableSize = Table::kTableSize;
     __shared__ uint32_t s_keys[kTableSize];
@@ -449,11 +452,14 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
     const Emitter<Table> E{F, T, Q};
     if (!PACKED && threadIdx.x < F.K) { s_ptrs.v[threadIdx.x] = F.g.v[threadIdx.x]; s_ptrs.s[threadIdx.x] = F.s[threadIdx.x]; }
     constexpr int kPer = (kWindow + kThreads - 1) / kThreads;        // paths a thread plans
-    constexpr int kStride = kPer * kWaves, kEntries = kKeys * kStride;
+    // classes the window is sorted into: the kKeys classes of the rounds; with the caller's tangents one more, the paths without a
+    // term, which then take no lane of any round (with in-kernel tangents they give their share of d/d ray.o on a lane of class 0)
+    constexpr int kSortKeys = DMODE == kTangentsInKernel ? kKeys : kKeys + 1;
+    constexpr int kStride = kPer * kWaves, kEntries = kSortKeys * kStride;
     __shared__ uint32_t s_plan[kWindow];
     __shared__ uint16_t s_perm[kWindow];
     __shared__ int s_cnt[kEntries];                                  // [m][j][wave]: histogram, then offsets
-    __shared__ int s_cls[kKeys + 1];                                 // first sorted position of class m
+    __shared__ int s_cls[kKeys + 2];                                 // first sorted position of class m; [kKeys]: of the paths without a term
     V3<float> gd_acc = zero3<float>();                               // kTangentsInKernel: sum of grad_d over this lane's paths
     Touch C;                                                         // (defined: a conditionally loaded struct otherwise carries undef through the round loop)
     C.own = C.ray0 = C.ray1 = C.nxt = 0.f;
@@ -466,7 +472,11 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
         if (win >= n_windows) break;                                 // workgroup-uniform
         const int64_t base = win * window;
         const WinBase WB = win_base(F, base);
-        // ---- plan + histogram of m: thread t plans paths base + j*kThreads + t
+        // ---- plan + histogram of m: thread t plans paths base + j*kThreads + t.  With the caller's tangents a path WITHOUT ANY
+        // TERM -- no constraint vertex, first hit not diffuse: 27 % of the bathroom paths -- gets key kKeys, a class sorted behind
+        // the others and handed to no round.  (With in-kernel tangents such a path still owes its share of d/d ray.o = -sum grad_d,
+        // epsm.py:260-261; taking that here, from coalesced loads of the rays, and keeping the path out of the rounds measured
+        // 2.07 -> 2.15 ms on the headline slab: the planning runs before a barrier, a class-0 round under the other waves.)
         int key[kPer], rank[kPer];
         {
             uint32_t fw[kPer];
@@ -485,7 +495,8 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                 if (F.K < 5) w &= (1u << (5 * F.K)) - 1u;
                 uint32_t plan = VARIANT == EPSM_VARIANT_MANIFOLD ? cp::manifold_plan(w) : cp::caustic_plan(w);
                 plan = in ? (plan | cp::kPlanInRange | ((w & 4u) ? cp::kPlanActive1 : 0u)) : 0u;
-                key[j] = cp::plan_m(plan);
+                const bool none = kSortKeys > kKeys && (!in || (cp::plan_m(plan) == 0 && !cp::plan_diffuse1(plan)));
+                key[j] = none ? kKeys : cp::plan_m(plan);
                 if (loc < window) s_plan[loc] = plan;
             }
         }
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
         for (int j = 0; j < kPer; ++j) {
             const bool has = j * kThreads + (int) threadIdx.x < window;
 #pragma unroll
-            for (int q = 0; q < kKeys; ++q) {
+            for (int q = 0; q < kSortKeys; ++q) {
                 const unsigned long long m = __ballot(has && key[j] == q);
                 if (key[j] == q) rank[j] = __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
                 if (lane == 0) s_cnt[(q * kPer + j) * kWaves + wv] = __popcll(m);
@@ -516,7 +527,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                 }
                 carry += __shfl(inc, 63);
             }
-            if (lane == 0) s_cls[kKeys] = window;
+            if (lane == 0) s_cls[kSortKeys] = window;
         }
         __syncthreads();
 #pragma unroll

@@ -122,7 +122,18 @@ EPSM_HD float rsqrt_(float x) { return 1.0f / sqrtf(x); }
 EPSM_HD float rcp_(float x) { return 1.0f / x; }
 #endif
 EPSM_HD double rsqrt_(double x) { return 1.0 / sqrt(x); }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(EPSM_FAST_RCP64)
+// (the IEEE expansion of 1.0 / x in float64 is 13 instructions -- two scalings, v_rcp_f64, two Newton steps, a fused fix-up;
+// the 2x2 recursions of the backward kernel take v_rcp_f64 and the two Newton steps alone: determinants there are far from the
+// ends of the exponent range, and x = 0 still gives inf -> NaN)
+EPSM_HD double rcp_(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+}
+#else
 EPSM_HD double rcp_(double x) { return 1.0 / x; }
+#endif
 EPSM_HD float realmax_(float) { return 3.402823466e+38f; }
 EPSM_HD double realmax_(double) { return 1.7976931348623157e+308; }
 

@@ -15,7 +15,7 @@ namespace {
 #define EPSM_RP_THREADS 64
 #endif
 #ifndef EPSM_RP_OCC
-#define EPSM_RP_OCC 4
+#define EPSM_RP_OCC 2                   // 256 registers: 3.4 KB of scratch per lane instead of 4.0 at four waves; render_backward 47.4 -> 44.9 ms (3: 46.5, 1: 45.2)
 #endif
 // Stage 1: one lane = one path, replayed; every vertex differentiated (dual numbers, scratch: three vertex records);
 // its warps are left as requests.  (First version, auxiliary rays traced by the same lane: 182 ms per render_backward
@@ -33,80 +33,106 @@ __global__ __launch_bounds__(EPSM_RP_THREADS, EPSM_RP_OCC) void epsm_reparam_pat
     count[i] = sink.n;
 }
 
-// Stage 2: one lane = one auxiliary ray.  Group g of G lanes (G = 16, 32 or 64 >= reparam_rays) serves request
-// n = g / N of path i = g % N: neighbouring groups hold the same call of neighbouring paths -- rays that start next to each
-// other and point the same way.  Z, dZ and the origin's adjoint are reduced over the group with xor shuffles.
+// Stage 2: one lane = one auxiliary ray, a group of G lanes (G = 16, 32 or 64 >= reparam_rays) = one request.  A workgroup
+// serves the requests of 256 consecutive paths: it lists the ones that exist -- (call n, path), n-major, so that neighbouring
+// groups hold the same call of neighbouring paths: rays that start next to each other and point the same way -- and works
+// through the list 256 / G requests at a time.  (Round 3 launched one group per (n, path) slot and let the empty ones leave:
+// 29 % of the slots exist -- 2.06 requests per path of 7 at max_depth 3 -- and the waves that held any were 75 % full.)
+// Z, dZ and the origin's adjoint are reduced over the group with xor shuffles.
 template <int G>
 __global__ __launch_bounds__(256) void epsm_reparam_warp_kernel(rp::ReparamArgs R, const rp::WarpReq *req, const int *count, int n_max) {
-    constexpr int kLds = 32;
+    constexpr int kLds = 32, kPaths = 256, kGroups = 256 / G;
     __shared__ uint32_t s_stack[kLds * 256];
+    __shared__ uint16_t s_list[kPaths * rp::kMaxReq];                      // (n << 8) | path of the block
+    __shared__ int s_off[rp::kMaxReq * 4 + 1];
     uint32_t deep[kBvhStack - kLds];
-    const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x, g = t / G;
-    const int r = (int) (t % G);
-    const int64_t N = R.A.N;
-    if (g >= (int64_t) n_max * N) return;
-    const int n = (int) (g / N);
-    const int64_t i = g - (int64_t) n * N;
-    if (n >= count[i]) return;                                             // (the whole group)
+    const int64_t N = R.A.N, p0 = (int64_t) blockIdx.x * kPaths;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    int c = p0 + tid < N ? count[p0 + tid] : 0;
+    c = c < n_max ? c : n_max;
+    int rank[rp::kMaxReq];
+#pragma unroll
+    for (int n = 0; n < rp::kMaxReq; ++n) {
+        const unsigned long long m = __ballot(c > n);
+        rank[n] = __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
+        if (lane == 0) s_off[n * 4 + wv] = __popcll(m);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int e = 0; e < rp::kMaxReq * 4; ++e) { const int v = s_off[e]; s_off[e] = run; run += v; }
+        s_off[rp::kMaxReq * 4] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < rp::kMaxReq; ++n)
+        if (c > n) s_list[s_off[n * 4 + wv] + rank[n]] = (uint16_t) ((n << 8) | tid);
+    __syncthreads();
+    const int total = s_off[rp::kMaxReq * 4];
+    const int r = tid % G;
     BvhStack st{s_stack + threadIdx.x, 256};
     st.cap = kLds; st.ovf = deep; st.ovf_stride = 1;
-    const rp::WarpReq q = req[(int64_t) n * N + i];
-    const F3 o = f3(q.o[0], q.o[1], q.o[2]), d = f3(q.d[0], q.d[1], q.d[2]), g_dir = f3(q.gdir[0], q.gdir[1], q.gdir[2]);
-    F3 fs, ft;
-    coordinate_system(d, fs, ft);
-    rp::Aux A;
-    A.w = 0.f; A.dw = zero3<float>(); A.v = d; A.tri = kNoIndex; A.b1 = A.b2 = A.inv_dist = 0.f;
-    const bool mine = r < R.cfg.rays;
-    if (mine) A = rp::aux_ray(R.A.S, R.cfg, rp::WarpId{0xffffffffu ^ R.A.seed, (uint32_t) (R.A.path_offset + i), n}, r, o, d, fs, ft, st);
-    float Z = A.w; F3 dZ = A.dw;
+    for (int b = tid / G; b < total; b += kGroups) {                       // (uniform over the group)
+        const int e = s_list[b], n = e >> 8;
+        const int64_t i = p0 + (e & 255);
+        const rp::WarpReq q = req[(int64_t) n * N + i];
+        const F3 o = f3(q.o[0], q.o[1], q.o[2]), d = f3(q.d[0], q.d[1], q.d[2]), g_dir = f3(q.gdir[0], q.gdir[1], q.gdir[2]);
+        F3 fs, ft;
+        coordinate_system(d, fs, ft);
+        rp::Aux A;
+        A.w = 0.f; A.dw = zero3<float>(); A.v = d; A.tri = kNoIndex; A.b1 = A.b2 = A.inv_dist = 0.f;
+        const bool mine = r < R.cfg.rays;
+        if (mine) A = rp::aux_ray(R.A.S, R.cfg, rp::WarpId{0xffffffffu ^ R.A.seed, (uint32_t) (R.A.path_offset + i), n}, r, o, d, fs, ft, st);
+        float Z = A.w; F3 dZ = A.dw;
 #pragma unroll
-    for (int m = 1; m < G; m <<= 1) { Z += __shfl_xor(Z, m); dZ.x += __shfl_xor(dZ.x, m); dZ.y += __shfl_xor(dZ.y, m); dZ.z += __shfl_xor(dZ.z, m); }
-    // the adjoint of reparam.py:269-327 at V = 0 (warp_backward, one auxiliary ray per lane)
-    Z = fmaxf(Z, 1e-8f);
-    const float iZ = 1.f / Z;
-    const F3 g_V = (g_dir - d * dot(d, g_dir)) * iZ - dZ * (q.gdiv * iZ * iZ);
-    const F3 g_v = mine ? g_V * A.w + A.dw * (q.gdiv * iZ) : zero3<float>();
-    F3 g_o = zero3<float>(), g_d = zero3<float>(), g_p = zero3<float>();
-    uint32_t pending = 0xFFFFFFFFu;                                        // the triangle this lane still owes its share to
-    if (mine) {
-        if (A.tri == kNoIndex) g_d = g_v;
-        else {
-            g_p = (g_v - A.v * dot(A.v, g_v)) * A.inv_dist;
-            g_o = -g_p;
-            if (R.A.S.meshes[R.A.S.tri_mesh[A.tri]].flags & EPSM_MESH_POS_ATTACHED) pending = A.tri;
+        for (int m = 1; m < G; m <<= 1) { Z += __shfl_xor(Z, m); dZ.x += __shfl_xor(dZ.x, m); dZ.y += __shfl_xor(dZ.y, m); dZ.z += __shfl_xor(dZ.z, m); }
+        // the adjoint of reparam.py:269-327 at V = 0 (warp_backward, one auxiliary ray per lane)
+        Z = fmaxf(Z, 1e-8f);
+        const float iZ = 1.f / Z;
+        const F3 g_V = (g_dir - d * dot(d, g_dir)) * iZ - dZ * (q.gdiv * iZ * iZ);
+        const F3 g_v = mine ? g_V * A.w + A.dw * (q.gdiv * iZ) : zero3<float>();
+        F3 g_o = zero3<float>(), g_d = zero3<float>(), g_p = zero3<float>();
+        uint32_t pending = 0xFFFFFFFFu;                                    // the triangle this lane still owes its share to
+        if (mine) {
+            if (A.tri == kNoIndex) g_d = g_v;
+            else {
+                g_p = (g_v - A.v * dot(A.v, g_v)) * A.inv_dist;
+                g_o = -g_p;
+                if (R.A.S.meshes[R.A.S.tri_mesh[A.tri]].flags & EPSM_MESH_POS_ATTACHED) pending = A.tri;
+            }
         }
-    }
-    // The rays of a warp mostly hit the same one or two triangles: their shares are summed over the group first, triangle
-    // by triangle, and added by one lane.  (One float atomic per ray loses the small ones: a vertex's sum over 10^7 rays
-    // is 10^5 times a single share, which then falls under half an ulp of it -- 2 % of a four-vertex wall's gradient at
-    // 256 spp.)
-    for (int round = 0; round < G; ++round) {
-        uint32_t t = pending;
+        // The rays of a warp mostly hit the same one or two triangles: their shares are summed over the group first, triangle
+        // by triangle, and added by one lane.  (One float atomic per ray loses the small ones: a vertex's sum over 10^7 rays
+        // is 10^5 times a single share, which then falls under half an ulp of it -- 2 % of a four-vertex wall's gradient at
+        // 256 spp.)
+        for (int round = 0; round < G; ++round) {
+            uint32_t t = pending;
 #pragma unroll
-        for (int m = 1; m < G; m <<= 1) { const uint32_t u = (uint32_t) __shfl_xor((int) t, m); t = u < t ? u : t; }
-        if (t == 0xFFFFFFFFu) break;                                       // (uniform over the group)
-        const bool sel = pending == t;
-        const float b1 = sel ? A.b1 : 0.f, b2 = sel ? A.b2 : 0.f, b0 = sel ? 1.f - A.b1 - A.b2 : 0.f;
-        float acc[9] = {g_p.x * b0, g_p.y * b0, g_p.z * b0, g_p.x * b1, g_p.y * b1, g_p.z * b1, g_p.x * b2, g_p.y * b2, g_p.z * b2};
+            for (int m = 1; m < G; m <<= 1) { const uint32_t u = (uint32_t) __shfl_xor((int) t, m); t = u < t ? u : t; }
+            if (t == 0xFFFFFFFFu) break;                                   // (uniform over the group)
+            const bool sel = pending == t;
+            const float b1 = sel ? A.b1 : 0.f, b2 = sel ? A.b2 : 0.f, b0 = sel ? 1.f - A.b1 - A.b2 : 0.f;
+            float acc[9] = {g_p.x * b0, g_p.y * b0, g_p.z * b0, g_p.x * b1, g_p.y * b1, g_p.z * b1, g_p.x * b2, g_p.y * b2, g_p.z * b2};
 #pragma unroll
-        for (int m = 1; m < G; m <<= 1)
+            for (int m = 1; m < G; m <<= 1)
 #pragma unroll
-            for (int k = 0; k < 9; ++k) acc[k] += __shfl_xor(acc[k], m);
-        if (r == 0) {
-            const uint32_t *iv = R.A.S.tri + 3 * (int64_t) t;
-            rp::add_vertex(R.G.pos, iv[0], f3(acc[0], acc[1], acc[2])); rp::add_vertex(R.G.pos, iv[1], f3(acc[3], acc[4], acc[5]));
-            rp::add_vertex(R.G.pos, iv[2], f3(acc[6], acc[7], acc[8]));
+                for (int k = 0; k < 9; ++k) acc[k] += __shfl_xor(acc[k], m);
+            if (r == 0) {
+                const uint32_t *iv = R.A.S.tri + 3 * (int64_t) t;
+                rp::add_vertex(R.G.pos, iv[0], f3(acc[0], acc[1], acc[2])); rp::add_vertex(R.G.pos, iv[1], f3(acc[3], acc[4], acc[5]));
+                rp::add_vertex(R.G.pos, iv[2], f3(acc[6], acc[7], acc[8]));
+            }
+            if (sel) pending = 0xFFFFFFFFu;
         }
-        if (sel) pending = 0xFFFFFFFFu;
-    }
 #pragma unroll
-    for (int m = 1; m < G; m <<= 1) {
-        g_o.x += __shfl_xor(g_o.x, m); g_o.y += __shfl_xor(g_o.y, m); g_o.z += __shfl_xor(g_o.z, m);
-        g_d.x += __shfl_xor(g_d.x, m); g_d.y += __shfl_xor(g_d.y, m); g_d.z += __shfl_xor(g_d.z, m);
-    }
-    if (r == 0 && q.ftri != kNoIndex) {
-        if (q.em_inv_dist != 0.f) g_o = g_o - (g_d - d * dot(d, g_d)) * q.em_inv_dist;
-        rp::add_follow_point(R.A.S, R.G, q.ftri, q.fb1, q.fb2, g_o);
+        for (int m = 1; m < G; m <<= 1) {
+            g_o.x += __shfl_xor(g_o.x, m); g_o.y += __shfl_xor(g_o.y, m); g_o.z += __shfl_xor(g_o.z, m);
+            g_d.x += __shfl_xor(g_d.x, m); g_d.y += __shfl_xor(g_d.y, m); g_d.z += __shfl_xor(g_d.z, m);
+        }
+        if (r == 0 && q.ftri != kNoIndex) {
+            if (q.em_inv_dist != 0.f) g_o = g_o - (g_d - d * dot(d, g_d)) * q.em_inv_dist;
+            rp::add_follow_point(R.A.S, R.G, q.ftri, q.fb1, q.fb2, g_o);
+        }
     }
 }
 
@@ -160,9 +186,7 @@ extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor
         const int depth = max_depth < 6 ? max_depth : 6;
         const int n_max = 1 + 2 * depth < rp::kMaxReq ? 1 + 2 * depth : rp::kMaxReq;
         const int G = reparam_rays <= 16 ? 16 : reparam_rays <= 32 ? 32 : 64;
-        const int64_t threads = (int64_t) n_max * N * G;
-        const dim3 grid((unsigned) ((threads + 255) / 256));
-        if ((threads + 255) / 256 > 0x7fffffffLL) return bad("too many auxiliary rays for one launch: use smaller tiles");
+        const dim3 grid((unsigned) ((N + 255) / 256));                     // one workgroup per 256 paths (N < 2^32: checked above)
         if (G == 16) hipLaunchKernelGGL(epsm_reparam_warp_kernel<16>, grid, dim3(256), 0, (hipStream_t) stream, R, req, count, n_max);
         else if (G == 32) hipLaunchKernelGGL(epsm_reparam_warp_kernel<32>, grid, dim3(256), 0, (hipStream_t) stream, R, req, count, n_max);
         else hipLaunchKernelGGL(epsm_reparam_warp_kernel<64>, grid, dim3(256), 0, (hipStream_t) stream, R, req, count, n_max);

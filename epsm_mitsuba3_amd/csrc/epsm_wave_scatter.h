@@ -80,6 +80,7 @@ constexpr int kMaxProbe = 8;
 struct AccFloat {
     typedef float T;
     static constexpr bool kBucketed = false;         // see LdsTable::add
+    __device__ __forceinline__ static bool fits(float, float, float) { return true; }
     __device__ __forceinline__ static void add(T *p, float x) { if (fabsf(x) < __builtin_inff()) atomicAdd(p, x); }   // non-finite terms add nothing (AccFixed64::to_fixed)
     __device__ __forceinline__ static float get(T q) { return q; }
 };
@@ -87,20 +88,22 @@ __device__ __forceinline__ bool adds_something(float x) { return x != 0.f && fab
 struct AccFixed64 {
     typedef long long T;
     static constexpr bool kBucketed = true;
+    // Terms below this magnitude go into the LDS rows; anything else -- a product with an unbounded emitter weight, inf, NaN --
+    // takes LdsTable::global_add (exact float atomics; non-finite terms add nothing: the reference's buffers would hold NaN
+    // there and its optimiser loop scrubs that to 0, EPSM/optim.py:143-154).  Terms are clamped to +-clip <= 1 before any
+    // weight multiplies them, so the slow way is taken by emitter weights beyond ~10^3 only.
+    static constexpr float kLimit = 127.f;
+    __device__ __forceinline__ static bool fits(float x, float y, float z) {
+        return fabsf(x) < kLimit && fabsf(y) < kLimit && fabsf(z) < kLimit;        // three compares, each false on NaN (a max3 would skip it)
+    }
     __device__ __forceinline__ static T to_fixed(float x) {
-        // sign * trunc(|x| * 2^44), |x| saturated below 2^20: |x| * 2^12 is split into its integer part and its fraction,
-        // converted separately (there is no float -> int64 instruction; the library conversion is ~20 VALU instructions per
-        // value, this is 10).  a - trunc(a) is exact in float, and so is its scaling by 2^32.  Truncation instead of
-        // rounding: < 5.7e-14 per term.  A NON-FINITE term (a zero-length interpolated normal: il = inf, sh = NaN; an unbounded
-        // emitter weight) adds NOTHING -- the reference's buffers would hold NaN there and its optimiser loop scrubs that to 0
-        // (EPSM/optim.py:143-154); a finite one beyond the range saturates at 2^19 - 2^-5, below the sign bit.  (The kernel
-        // runs with IEEE mode on: v_min_f32(NaN, c) returns c, so a bare fminf would turn NaN into the largest magnitude.)
-        const float ax = fabsf(x) * 4096.f;
-        const float a = ax < __builtin_inff() ? fminf(ax, 2147483520.f) : 0.f;     // NaN and inf fail the compare
-        const unsigned hi = (unsigned) a;                          // v_cvt_u32_f32: truncates; hi < 2^31
-        const unsigned lo = (unsigned) ((a - (float) hi) * 4294967296.f);
-        const T mag = (T) (((unsigned long long) hi << 32) | lo);
-        return x < 0.f ? -mag : mag;
+        // round(x * 2^44) for |x| < 2^7 in THREE instructions: x 2^44 + 1.5 2^52 in float64 (one fma, round to nearest) keeps
+        // the exponent of the constant, so the integer sits in the mantissa in two's complement and the constant's bit
+        // pattern -- whose low word is zero -- comes off with one 32-bit subtraction.  (Round 3 split |x| 2^12 into integer
+        // part and fraction and negated in 64 bits: ~15 instructions per value, 45 per row, the larger half of a drain
+        // iteration; there is no float -> int64 instruction.  Headline slab 2.10 -> 2.07 ms, config 2 2.53 -> 2.46.)
+        const double y = __builtin_fma((double) x, 17592186044416.0, 6755399441055744.0);
+        return __double_as_longlong(y) - 0x4338000000000000LL;
     }
     __device__ __forceinline__ static void add(T *p, float x) { atomicAdd((unsigned long long *) p, (unsigned long long) to_fixed(x)); }
     __device__ __forceinline__ static float get(T q) { return (float) ((double) q * 5.6843418860808015e-14); }      // 2^-44
@@ -166,6 +169,7 @@ struct LdsTable {
     }
     __device__ __forceinline__ void add(uint32_t key, float x, float y, float z) const {
         if (x == 0.f && y == 0.f && z == 0.f) return;
+        if (!Acc::fits(x, y, z)) { global_add(key, x, y, z); return; }
         uint32_t slot = home(key);
         bool placed = false;
 #pragma unroll 1
@@ -402,11 +406,19 @@ struct WaveQueue {
     QItem *q;          // this wave's CAP slots
     int count;         // wave-uniform
 
-    // Every valid lane appends ROWS consecutive items (one ballot for the whole group).
-    template <int ROWS>
-    __device__ __forceinline__ void push_rows(bool valid, const uint32_t key[ROWS], const V3<float> val[ROWS]) {
+    // Every valid lane appends ROWS consecutive items (one ballot for the whole group); the queue is drained first when THESE
+    // items would not fit (round 3 drained whenever 64 lanes' worth might not: with a queue of one full group -- 192 items -- that
+    // was before every group, and the drain's last iteration ran partly filled each time).
+    template <int ROWS, typename Table>
+    __device__ __forceinline__ void push_rows(const Table &T, bool valid, const uint32_t key[ROWS], const V3<float> val[ROWS]) {
         const unsigned long long m = __ballot(valid);
         if (m == 0ull) return;
+        const int n = ROWS * __popcll(m);
+#ifdef EPSM_QUEUE_RESERVE_WORST            // (A/B build)
+        if (count + 64 * ROWS > CAP) drain(T);
+#else
+        if (count + n > CAP) drain(T);
+#endif
         const int below = __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
         if (valid) {
             QItem *dst = q + count + ROWS * below;
@@ -416,7 +428,7 @@ struct WaveQueue {
                 dst[j] = it;
             }
         }
-        count += ROWS * __popcll(m);
+        count += n;
     }
     template <typename Table> __device__ __forceinline__ void drain(const Table &T) {
         if (count > 0) drain_queue(q, count, T);

@@ -22,6 +22,7 @@ if len(sys.argv) > 5:
 for i in range(0, 100, 10):
     scene.attach(f"s{i}", positions=True, normals=True)
 integ = epsm.load_dict({"type": "prb_reparam", "max_depth": depth, "reparam_rays": rays})
+torch.manual_seed(0)
 g = torch.randn((res, res, 3), device="cuda") * 1e-2
 params = scene.param_grads()
 

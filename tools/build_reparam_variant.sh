@@ -4,5 +4,5 @@ cd "$(dirname "$0")/../epsm_mitsuba3_amd/csrc"
 make -s
 F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=fast -fno-slp-vectorize -Wall -Wno-unused-function"
 /opt/rocm/bin/hipcc $F $2 -Rpass-analysis=kernel-resource-usage -c -o build/rp_$1.o epsm_trace_reparam.hip 2> build/rp_$1.txt || { grep -A3 error build/rp_$1.txt; exit 1; }
-grep -A12 "epsm_reparam_kernel" build/rp_$1.txt | grep -E "VGPRs:|ScratchSize|Occupancy" | sed 's/.*remark: [^ ]* //; s/\[-Rpass.*//' | tr '\n' ' '; echo " <- $1"
+grep -A12 "epsm_reparam_path_kernel" build/rp_$1.txt | grep -E "VGPRs:|ScratchSize|Occupancy" | sed 's/.*remark: [^ ]* //; s/\[-Rpass.*//' | tr '\n' ' '; echo " <- $1"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libepsm_$1.so build/epsm_grad.o build/epsm_tangent.o build/epsm_scatter.o build/epsm_grad_scatter.o build/epsm_backward_cp.o build/epsm_matcher.o build/epsm_trace.o build/rp_$1.o
