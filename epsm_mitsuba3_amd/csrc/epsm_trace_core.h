@@ -513,6 +513,81 @@ EPSM_HD F3 emitter_normal(const EpsmScene &S, const EpsmMesh &m, const uint32_t 
     if (m.flags & EPSM_MESH_FLIP_NORMALS) n = -n;
     return n;
 }
+// ---- the environment emitter (include/epsm_trace.h, EpsmEnvironment; src/emitters/constant.cpp, envmap.cpp)
+EPSM_HD bool has_environment(const EpsmScene &S) { return S.env.emitter >= 0; }
+EPSM_HD F3 env_to_local(const EpsmEnvironment &E, F3 d) {
+    return f3(E.to_local[0] * d.x + E.to_local[1] * d.y + E.to_local[2] * d.z, E.to_local[3] * d.x + E.to_local[4] * d.y + E.to_local[5] * d.z,
+              E.to_local[6] * d.x + E.to_local[7] * d.y + E.to_local[8] * d.z);
+}
+EPSM_HD F3 env_to_world(const EpsmEnvironment &E, F3 d) {                  // the transpose: a rotation
+    return f3(E.to_local[0] * d.x + E.to_local[3] * d.y + E.to_local[6] * d.z, E.to_local[1] * d.x + E.to_local[4] * d.y + E.to_local[7] * d.z,
+              E.to_local[2] * d.x + E.to_local[5] * d.y + E.to_local[8] * d.z);
+}
+// continuous cell coordinates of a direction of the emitter's frame: x in [0, width), y in [0, height - 1]  (envmap.cpp:416-422)
+EPSM_HD void env_cell_coords(const EpsmEnvironment &E, F3 v, float &x, float &y) {
+    float u = atan2f(v.x, -v.z) * (0.5f / kPi) - 0.5f / (float) E.width;
+    u -= floorf(u);
+    const float w = acosf(fminf(fmaxf(v.y, -1.f), 1.f)) * (1.f / kPi);
+    x = fminf(u * (float) E.width, (float) E.width - 1e-3f);
+    y = fminf(w * (float) (E.height - 1), (float) (E.height - 1));
+}
+// radiance seen along the WORLD direction d (a ray that left the scene)
+EPSM_HD F3 env_eval(const EpsmScene &S, F3 d) {
+    const EpsmEnvironment &E = S.env;
+    const EpsmEmitter em = S.emitters[E.emitter];
+    if (em.type == EPSM_EMITTER_CONSTANT) return ld3(em.radiance);
+    float x, y;
+    env_cell_coords(E, env_to_local(E, d), x, y);
+    const int i = (int) x, j = (int) fminf(y, (float) (E.height - 2));
+    const float fx = x - (float) i, fy = y - (float) j;
+    const int64_t row = (int64_t) (E.width + 1) * 3;
+    const float *t00 = E.texels + j * row + 3 * (int64_t) i, *t01 = t00 + 3, *t10 = t00 + row, *t11 = t10 + 3;
+    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+    return ld3(t00) * w00 + ld3(t01) * w01 + ld3(t10) * w10 + ld3(t11) * w11;
+}
+// density, per solid angle, of sample_environment producing the WORLD direction d (the emitter choice not included)
+EPSM_HD float env_pdf(const EpsmScene &S, F3 d) {
+    const EpsmEnvironment &E = S.env;
+    if (S.emitters[E.emitter].type == EPSM_EMITTER_CONSTANT) return 0.25f / kPi;
+    const F3 v = env_to_local(E, d);
+    float x, y;
+    env_cell_coords(E, v, x, y);
+    const int i = (int) x, j = (int) fminf(y, (float) (E.height - 2));
+    const float inv_sin = 1.f / sqrtf(fmaxf(v.x * v.x + v.z * v.z, 1e-14f));                 // envmap.cpp:401-402
+    return E.cell_pdf[(int64_t) j * E.width + i] * inv_sin * (1.f / (2.f * kPi * kPi));
+}
+// direction + density of an environment sample (u, v uniform in [0,1)); false: the map is black
+EPSM_HD bool env_sample(const EpsmScene &S, float u, float v, F3 &d, float &pdf) {
+    const EpsmEnvironment &E = S.env;
+    if (S.emitters[E.emitter].type == EPSM_EMITTER_CONSTANT) {               // warp.h square_to_uniform_sphere
+        const float z = 1.f - 2.f * v, r = safe_sqrt(1.f - z * z), phi = 2.f * kPi * u;
+        d = f3(r * cosf(phi), r * sinf(phi), z);
+        pdf = 0.25f / kPi;
+        return true;
+    }
+    const int rows = E.height - 1;
+    int lo = 0, hi = rows - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (E.row_cdf[mid] < v) lo = mid + 1; else hi = mid; }
+    const int j = lo;
+    const float r0 = j > 0 ? E.row_cdf[j - 1] : 0.f, r1 = E.row_cdf[j];
+    const float fy = r1 > r0 ? fminf((v - r0) / (r1 - r0), 0.999999f) : 0.5f;
+    const float *cc = E.col_cdf + (int64_t) j * E.width;
+    lo = 0; hi = E.width - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cc[mid] < u) lo = mid + 1; else hi = mid; }
+    const int i = lo;
+    const float c0 = i > 0 ? cc[i - 1] : 0.f, c1 = cc[i];
+    const float fx = c1 > c0 ? fminf((u - c0) / (c1 - c0), 0.999999f) : 0.5f;
+    const float cell = E.cell_pdf[(int64_t) j * E.width + i];
+    if (!(cell > 0.f)) { pdf = 0.f; d = f3(0.f, 1.f, 0.f); return false; }
+    const float uu = ((float) i + fx + 0.5f) / (float) E.width, vv = ((float) j + fy) / (float) rows;
+    const float theta = vv * kPi, phi = uu * 2.f * kPi;
+    const float st = sinf(theta);
+    const F3 l = f3(sinf(phi) * st, cosf(theta), -cosf(phi) * st);           // envmap.cpp:392-395
+    pdf = cell / (2.f * kPi * kPi * fmaxf(st, 1e-7f));
+    d = env_to_world(E, l);
+    return true;
+}
+
 // `test_now` = false leaves the visibility test (scene.cpp:270-275) to the caller, which may know that the sample
 // contributes nothing whatever the test says (path_bounce).
 template <class Vis>
@@ -534,7 +609,16 @@ EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit
     const EpsmEmitter em = S.emitters[index];
     e.emitter = (int) index;
     F3 radiance = ld3(em.radiance);
-    if (em.type == EPSM_EMITTER_POINT) {                                  // point.cpp:96-115
+    if (em.type == EPSM_EMITTER_CONSTANT || em.type == EPSM_EMITTER_ENVMAP) {   // constant.cpp:105-133, envmap.cpp:380-418
+        F3 d; float pdf;
+        if (env_sample(S, u, v, d, pdf)) {
+            const F3 off = ref.p - ld3(S.env.center);
+            e.dist = 2.f * fmaxf(S.env.radius, sqrtf(dot(off, off)));
+            e.d = d; e.p = ref.p + d * e.dist; e.n = -d;
+            e.pdf = pdf;
+            e.weight = env_eval(S, d) * (1.f / pdf);
+        }
+    } else if (em.type == EPSM_EMITTER_POINT) {                           // point.cpp:96-115
         e.p = ld3(em.position);
         F3 d = e.p - ref.p;
         const float dist2 = dot(d, d);
@@ -810,6 +894,10 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
         const float em_pdf = s.prev_bsdf_delta ? 0.f : pdf_emitter_direction(S, s.prev_p, si);
         const float mis = mis_weight(s.prev_bsdf_pdf, em_pdf);
         Le = mul3(s.beta, ld3(S.emitters[si.emitter].radiance)) * mis;
+    } else if (!si.valid && has_environment(S)) {                          // the ray left the scene: the environment's radiance
+        float em_pdf = s.prev_bsdf_delta ? 0.f : env_pdf(S, s.ray.d);
+        if (S.n_emitters > 1) em_pdf /= (float) S.n_emitters;
+        Le = mul3(s.beta, env_eval(S, s.ray.d)) * mis_weight(s.prev_bsdf_pdf, em_pdf);
     }
     // ---- emitter sampling (epsm.py:582-605)
     bool active_next = (s.depth + 1 < A.max_depth) && si.valid;

@@ -349,6 +349,7 @@ EPSM_HD void warp_backward(const EpsmScene &S, const GradOut &G, const Warp &W, 
 // ---------------------------------------------------------------------------
 struct Vertex {
     bool valid;              // the path was alive and its ray hit something
+    bool escaped;            // the path was alive and its ray left the scene (an environment emitter may shine along it)
     Ray ray;                 // the ray that arrived here
     TriHit th;
     SurfHit si;
@@ -362,7 +363,7 @@ struct Vertex {
     F3 wo_world;             // direction of the ray to the next vertex
     int depth;               // valid vertices before this one
 };
-EPSM_HD void vertex_clear(Vertex &v) { v.valid = false; v.L_in = v.L_after = v.Le = v.Lr_dir = zero3<float>(); v.active_em = false; v.bs_valid = false; v.depth = 0; }
+EPSM_HD void vertex_clear(Vertex &v) { v.valid = false; v.escaped = false; v.L_in = v.L_after = v.Le = v.Lr_dir = zero3<float>(); v.active_em = false; v.bs_valid = false; v.depth = 0; }
 
 // path_bounce observer: copies what the bounce computed
 struct Capture {
@@ -596,14 +597,22 @@ EPSM_HD void reparam_one_path(const ReparamArgs &R, int64_t i, const BvhStack &s
             Capture cap{&nx};
             path_bounce(A, i, j, s, th, vis, cap);
             nx.valid = nx.valid && was_active;
+            nx.escaped = was_active && !th.hit;
             nx.L_in = L_run;
             L_run = L_run - nx.Le - nx.Lr_dir;
             nx.L_after = L_run;
         }
         if (j == 0) continue;
         const Vertex &cur = v[(j - 1) % 3];
-        if (!cur.valid) continue;                                          // (a dead or escaped path: every term is zero)
         const Vertex *prev = j >= 2 ? &v[(j - 2) % 3] : nullptr;
+        if (!cur.valid) {
+            // a dead path: every term is zero.  A ray that left the scene towards an environment emitter carries that emitter's
+            // radiance: its warp's divergence multiplies it (prb_reparam.py:341-358 reparameterises every ray before it is known
+            // to hit); the radiance itself is not differentiated w.r.t. the direction.  (The camera ray: below.)
+            if (cur.escaped && prev && has_environment(A.S) && cur.depth < R.cfg.max_depth && (cur.Le.x != 0.f || cur.Le.y != 0.f || cur.Le.z != 0.f))
+                sink.warp(cur.ray.o, cur.ray.d, zero3<float>(), dot(dL, cur.L_in), prev->th.tri, prev->th.u, prev->th.v, 0.f);
+            continue;
+        }
         differential(R, sink, prev, cur, &nx, dL, &g_first);
         if (j == 1 && R.cfg.max_depth > 0) {
             sink.warp(pr.ray.o, pr.ray.d, g_film + g_first, g_det_film, kNoIndex, 0.f, 0.f, 0.f);

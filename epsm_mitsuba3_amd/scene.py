@@ -1,6 +1,6 @@
 """Scene description for the native tracer: the subset of ``mi.load_dict`` that the EPSM
 experiments use (EPSM/exp/*.py): ``obj`` / inline meshes / ``rectangle``, ``diffuse``,
-``conductor``, ``roughconductor``, ``dielectric``, ``twosided``, ``area`` / ``point`` emitters,
+``conductor``, ``roughconductor``, ``dielectric``, ``twosided``, ``area`` / ``point`` / ``constant`` / ``envmap`` emitters,
 ``perspective`` sensors with ``hdrfilm`` (+ ``box`` / ``gaussian`` rfilter) and an
 ``independent`` sampler.  Geometry is flattened into the arrays of ``EpsmScene``
 (include/epsm_trace.h); a median-split BVH is built on the host with numpy.
@@ -68,12 +68,18 @@ class EpsmSensor(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32), ("border", C.c_int32), ("pad", C.c_int32)]
 
 
+class EpsmEnvironment(C.Structure):
+    _fields_ = [("emitter", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("texels", C.c_void_p), ("row_cdf", C.c_void_p),
+                ("col_cdf", C.c_void_p), ("cell_pdf", C.c_void_p), ("to_local", C.c_float * 9), ("center", C.c_float * 3),
+                ("radius", C.c_float)]
+
+
 class EpsmSceneC(C.Structure):
     _fields_ = [("positions", C.c_void_p), ("normals", C.c_void_p), ("tri", C.c_void_p), ("tri_mesh", C.c_void_p),
                 ("meshes", C.c_void_p), ("n_meshes", C.c_int32), ("bsdfs", C.c_void_p), ("n_bsdfs", C.c_int32),
                 ("emitters", C.c_void_p), ("n_emitters", C.c_int32), ("emitter_cdf", C.c_void_p),
                 ("bvh", C.c_void_p), ("n_nodes", C.c_int32), ("prim_index", C.c_void_p), ("tri_verts", C.c_void_p),
-                ("n_vertices", C.c_int64), ("n_triangles", C.c_int64)]
+                ("n_vertices", C.c_int64), ("n_triangles", C.c_int64), ("env", EpsmEnvironment)]
 
 
 class EpsmRecordOut(C.Structure):
@@ -494,6 +500,47 @@ def _rgb(x, default):
     return np.repeat(a, 3) if a.size == 1 else a[:3]
 
 
+def _envmap_bitmap(val: dict, base_dir: str) -> np.ndarray:
+    """(H, W, 3) float32 radiance of an ``envmap`` emitter, ``scale`` applied: ``bitmap`` / ``data`` (an array, as
+    ``mi.Bitmap(array)`` would carry it) or ``filename`` (.npy -- there is no OpenEXR reader here; the reference's experiments
+    load .exr files that are not part of the repository, EPSM/exp/glossyball.py:107-108)."""
+    a = val.get("bitmap", val.get("data"))
+    if a is None:
+        fn = val.get("filename")
+        if fn is None:
+            raise ValueError("envmap: give 'bitmap' (an array) or 'filename' (.npy)")
+        if not fn.endswith(".npy"):
+            raise ValueError(f"envmap: cannot read {fn!r}: only .npy arrays (H, W, 3) are supported (no OpenEXR reader)")
+        a = np.load(os.path.join(base_dir, fn))
+    a = np.asarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a, dtype=np.float32)
+    if a.ndim == 2:
+        a = np.repeat(a[:, :, None], 3, axis=2)
+    if a.ndim != 3 or a.shape[2] < 3 or a.shape[0] < 2 or a.shape[1] < 2:
+        raise ValueError("envmap: the bitmap must be (H >= 2, W >= 2, 3)")
+    return np.ascontiguousarray(a[:, :, :3] * float(val.get("scale", 1.0)))
+
+
+def environment_tables(bitmap: np.ndarray):
+    """The arrays of ``EpsmEnvironment`` for an (H, W, 3) lat-long map: texels (H, W + 1, 3), column W a copy of column 0 (the
+    extra column envmap.cpp:205-229 appends, so that the interpolation wraps), and the piecewise-constant
+    sampling distribution over the W x (H - 1) bilinear cells -- weight = mean over a cell's corners of luminance x sin(theta)
+    (envmap.cpp:268-296 weighs texels the same way; its hierarchical warp follows the bilinear interpolant, this one is constant
+    per cell).  Returns texels, row_cdf (H - 1), col_cdf (H - 1, W), cell_pdf (H - 1, W) in (u, v) in [0, 1)^2."""
+    H, W = bitmap.shape[:2]
+    t = np.concatenate([bitmap, bitmap[:, :1]], axis=1).astype(np.float64)
+    lum = (0.212671 * t[..., 0] + 0.715160 * t[..., 1] + 0.072169 * t[..., 2]) * np.sin(np.arange(H) * math.pi / (H - 1))[:, None]
+    w = 0.25 * (lum[:-1, :-1] + lum[:-1, 1:] + lum[1:, :-1] + lum[1:, 1:])             # (H - 1, W)
+    total = float(w.sum())
+    rows = w.sum(1)
+    row_cdf = np.cumsum(rows) / total if total > 0 else np.linspace(1.0 / (H - 1), 1.0, H - 1)
+    col_cdf = np.cumsum(w, axis=1) / np.where(rows > 0, rows, 1.0)[:, None]
+    col_cdf[rows <= 0] = np.linspace(1.0 / W, 1.0, W)
+    row_cdf[-1] = 1.0; col_cdf[:, -1] = 1.0
+    cell_pdf = w / total * (W * (H - 1)) if total > 0 else np.zeros_like(w)
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    return f(t), f(row_cdf), f(col_cdf), f(cell_pdf)
+
+
 def _ior(x, default):
     if x is None:
         return default
@@ -616,6 +663,15 @@ class Scene:
             elif t == "point":
                 emitters.append(dict(type=1, mesh=-1, radiance=_rgb(val.get("intensity"), [1, 1, 1]),
                                      position=np.asarray(val.get("position", [0, 0, 0]), np.float32)))
+            elif t in ("constant", "envmap"):
+                if any(e["type"] in (2, 3) for e in emitters):
+                    raise ValueError("a scene has at most one environment emitter")
+                e = dict(type=2 if t == "constant" else 3, mesh=-1, radiance=_rgb(val.get("radiance"), [1, 1, 1]),
+                         position=np.zeros(3, np.float32))
+                if t == "envmap":
+                    e["bitmap"] = _envmap_bitmap(val, base_dir)
+                    e["to_world"] = np.asarray(val.get("to_world", np.eye(4)), dtype=np.float64)
+                emitters.append(e)
             elif t in ("obj", "ply", "mesh", "rectangle"):
                 tw = np.asarray(val.get("to_world", np.eye(4)), dtype=np.float64)
                 if t == "obj":
@@ -835,6 +891,31 @@ class Scene:
             s.bvh, s.n_nodes = self.bvh.nodes.data_ptr(), int(self.bvh.nodes.shape[0])
             s.prim_index, s.tri_verts = self.bvh.prim_index.data_ptr(), self.bvh.tri_verts.data_ptr()
         s.n_vertices, s.n_triangles = self.V, self.T
+        # ---- the environment emitter: sampling tables + the bounding sphere of shapes and sensors (scene.cpp expands the
+        #      scene's box by its sensors; constant.cpp:76-79, envmap.cpp:311-314)
+        s.env.emitter = -1
+        for i, e in enumerate(self.emitter_desc):
+            if e["type"] not in (2, 3):
+                continue
+            s.env.emitter = i
+            pts = [P.reshape(-1, 3)] if self.V else []
+            pts.append(np.array([sn.to_world[:3, 3] for sn in self.sensors], np.float64).reshape(-1, 3))
+            pts = np.concatenate(pts) if pts else np.zeros((1, 3))
+            lo, hi = pts.min(0), pts.max(0)
+            ctr = 0.5 * (lo + hi)
+            s.env.center[:] = [float(x) for x in ctr]
+            s.env.radius = float(max(8.9e-5, np.linalg.norm(hi - ctr) * (1.0 + 8.9e-5)))
+            R = np.eye(3)
+            if e["type"] == 3:
+                R = np.asarray(e["to_world"], np.float64)[:3, :3]
+                R = R / np.cbrt(abs(np.linalg.det(R)))
+                if not np.allclose(R @ R.T, np.eye(3), atol=1e-5):
+                    raise ValueError("envmap: to_world must be a rotation")
+                tex, row_cdf, col_cdf, cell_pdf = environment_tables(e["bitmap"])
+                self._env_buf = [torch.from_numpy(a).to(dev) for a in (tex, row_cdf, col_cdf, cell_pdf)]
+                s.env.height, s.env.width = int(e["bitmap"].shape[0]), int(e["bitmap"].shape[1])
+                s.env.texels, s.env.row_cdf, s.env.col_cdf, s.env.cell_pdf = (t.data_ptr() for t in self._env_buf)
+            s.env.to_local[:] = [float(x) for x in R.T.reshape(-1)]       # world -> emitter frame
         self.c_scene = s
 
     # -- tracing ---------------------------------------------------------------------------------

@@ -41,7 +41,7 @@ extern "C" {
 
 enum { EPSM_BSDF_DIFFUSE_T = 0, EPSM_BSDF_CONDUCTOR_T = 1, EPSM_BSDF_ROUGHCONDUCTOR_T = 2, EPSM_BSDF_DIELECTRIC_T = 3 };
 enum { EPSM_DISTR_BECKMANN = 0, EPSM_DISTR_GGX = 1 };
-enum { EPSM_EMITTER_AREA = 0, EPSM_EMITTER_POINT = 1 };
+enum { EPSM_EMITTER_AREA = 0, EPSM_EMITTER_POINT = 1, EPSM_EMITTER_CONSTANT = 2, EPSM_EMITTER_ENVMAP = 3 };
 enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
 
 /* Tracer flags.
@@ -86,7 +86,7 @@ typedef struct EpsmBsdf {
 typedef struct EpsmEmitter {
     uint32_t type;                   /* EPSM_EMITTER_* */
     int32_t mesh;                    /* area: emitting mesh */
-    float radiance[3];               /* area: radiance; point: intensity */
+    float radiance[3];               /* area, constant: radiance; point: intensity; envmap: unused (EpsmEnvironment.texels) */
     float position[3];               /* point */
     int32_t color_slot;              /* slot of `radiance` in the colour adjoint, -1 = not optimised */
     uint32_t pad;
@@ -113,6 +113,27 @@ typedef struct EpsmSensor {
     int32_t pad;
 } EpsmSensor;
 
+/* The scene's environment emitter (src/emitters/constant.cpp, envmap.cpp): at most one, `emitter` = its index in
+ * EpsmScene.emitters (-1: none).  A ray that leaves the scene sees its radiance (MIS against emitter sampling as for an area
+ * light); an emitter sample is the point ref + 2 max(radius, |ref - center|) d (constant.cpp:113-116, envmap.cpp:398-399) -- what
+ * the vertex log records as `light` -- with d uniform on the sphere (constant) or drawn from the map.
+ * envmap: `texels` is the (height, width + 1, 3) lat-long map, `scale` applied, column `width` a copy of column 0; texel (i, j)
+ * sits at phi = 2 pi (i + 1/2) / width, theta = pi j / (height - 1) (envmap.cpp:387-395, 416-422), direction
+ * (sin phi sin theta, cos theta, -cos phi sin theta) in the emitter's frame; radiance is bilinear in between.  Sampling is by
+ * CELL (the width x (height - 1) bilinear patches): weight = mean over the four corners of luminance x sin theta, rows by
+ * `row_cdf`, columns by `col_cdf`, uniform inside a cell -- a piecewise-constant stand-in for the reference's hierarchical
+ * sample warp (same support, same estimator up to variance). */
+typedef struct EpsmEnvironment {
+    int32_t emitter;                 /* -1 = the scene has no environment emitter */
+    int32_t width, height;           /* envmap only */
+    const float *texels;             /* (height, width + 1, 3) */
+    const float *row_cdf;            /* (height - 1) cumulative, normalised */
+    const float *col_cdf;            /* (height - 1, width) cumulative per row, normalised */
+    const float *cell_pdf;           /* (height - 1, width) density of a cell in (u, v) in [0,1)^2 */
+    float to_local[9];               /* world -> emitter frame, row-major rotation */
+    float center[3], radius;         /* bounding sphere of shapes and sensors */
+} EpsmEnvironment;
+
 typedef struct EpsmScene {           /* host struct holding DEVICE pointers */
     const float *positions;          /* (V,3) world space */
     const float *normals;            /* (V,3) (zero rows for meshes without vertex normals) */
@@ -126,6 +147,7 @@ typedef struct EpsmScene {           /* host struct holding DEVICE pointers */
     const uint32_t *prim_index;      /* leaf entries: BVH order -> triangle id (triangles stay mesh-contiguous) */
     const float *tri_verts;          /* (T,9) p0,p1,p2 of the triangles in BVH (leaf) order */
     int64_t n_vertices, n_triangles;
+    EpsmEnvironment env;
 } EpsmScene;
 
 /* Writable twin of EpsmVertexRecord + EpsmScatterRecord for one logged bounce. */

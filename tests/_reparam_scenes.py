@@ -1,7 +1,8 @@
 """Restatements of the reference's test scenes for reparameterised integrators (src/integrators/tests/
 test_ad_integrators.py:268-640) with the plugins this library has: obj meshes become inline meshes (a lat-long sphere with
-vertex normals, a two-triangle rectangle with face normals), the `constant` environment emitter a large area light behind
-the camera where a config needs light from everywhere.  ``build(name, theta)`` translates the config's moving meshes by
+vertex normals, a two-triangle rectangle with face normals).  The configs of the reference that are lit by a `constant`
+environment emitter come twice: with an area light in its place (rounds 1-3, before the tracer had that emitter) and, as
+`*_constant`, as the reference states them.  ``build(name, theta)`` translates the config's moving meshes by
 ``theta`` along x, as TranslateShapeConfigBase.update does."""
 import numpy as np
 
@@ -61,6 +62,14 @@ CONFIGS = {
     "receiver_point_light": dict(max_depth=2, moving=["plane"], fd_eps=5e-3, dir=(0, 0, 1)),
     # the same with interreflection between two walls (three vertices: the `extra` terms of the neighbours' BSDFs)
     "corner_along_normal": dict(max_depth=3, moving=["plane"], fd_eps=5e-3, dir=(0, 0, 1)),
+    # TranslateDiffuseSphereConstantConfig (:317-338), TranslateDiffuseRectangleConstantConfig (:341-363): a diffuse body in a
+    # uniform environment -- all the gradient there is comes from the silhouette against the background
+    "diffuse_sphere_constant": dict(max_depth=2, moving=["sphere"], fd_eps=1e-3),
+    "diffuse_rectangle_constant": dict(max_depth=2, moving=["rectangle"], fd_eps=8e-4),
+    # TranslateShadowReceiverAreaLightConfig (:482-520) as committed there: the light is the constant emitter, the PLANE moves
+    "shadow_receiver_constant": dict(max_depth=2, moving=["plane"], fd_eps=1e-3),
+    # TranslateSphereOnGlossyFloorConfig (:600-637) as stated: constant emitter of radiance 1
+    "sphere_on_glossy_floor_constant": dict(max_depth=3, moving=["sphere"], fd_eps=1e-3, kappa=2e5),
 }
 
 
@@ -139,6 +148,30 @@ def build(name, theta=0.0, res=32, spp=64, device="cpu", theta_n=0.0):
         else:
             d["light"] = {"type": "mesh", "vertices": v, "faces": f[:, ::-1], "face_normals": True,
                           "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [40.0, 40.0, 40.0]}}}
+    elif name == "diffuse_sphere_constant":
+        v, n, f = sphere(1.0, (0, 0, 0))
+        d["sphere"] = {"type": "mesh", "vertices": v + off, "normals": n, "faces": f, "bsdf": white}
+        d["light"] = {"type": "constant"}
+    elif name == "diffuse_rectangle_constant":
+        v, f = rect(1.0)
+        d["rectangle"] = {"type": "mesh", "vertices": v + off, "faces": f, "face_normals": True, "bsdf": white}
+        d["light"] = {"type": "constant"}
+    elif name == "shadow_receiver_constant":
+        v, f = rect(1.0)
+        d["plane"] = {"type": "mesh", "vertices": v + off, "faces": f, "face_normals": True, "bsdf": white}
+        v, n, f = sphere(0.25, (2.0, 0, 2.0))
+        d["occluder"] = {"type": "mesh", "vertices": v, "normals": n, "faces": f, "bsdf": white}
+        d["light"] = {"type": "constant"}
+    elif name == "sphere_on_glossy_floor_constant":
+        v, f = rect(4.0)
+        c, s = np.cos(np.radians(-45)), np.sin(np.radians(-45))
+        R = np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+        d["floor"] = {"type": "mesh", "vertices": (R @ v.T).T + np.array([0, 1.5, 0]), "faces": f, "face_normals": True,
+                      "bsdf": {"type": "roughconductor", "alpha": 0.025}}
+        v, n, f = sphere(1.0, (0.5, 2.0, 1.5))
+        d["sphere"] = {"type": "mesh", "vertices": v + off, "normals": n, "faces": f,
+                       "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 0.5, 0.0]}}}
+        d["light"] = {"type": "constant", "radiance": 1.0}
     else:
         raise KeyError(name)
     if theta_n:

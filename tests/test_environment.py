@@ -1,0 +1,193 @@
+"""Environment emitters of the native tracer (`constant`, `envmap`: src/emitters/constant.cpp, envmap.cpp; used by
+EPSM/exp/glossyball.py:107-108, highlight.py:220-221) against answers no renderer is needed for, on the HOST build of the per-path
+code (the GPU twin: test_gpu_environment.py):
+
+* a convex diffuse body of albedo rho in a uniform environment L has exitant radiance rho L everywhere (no facet sees another),
+  the background is L;
+* a perfect mirror shows the map along the reflected direction, the background the map along the camera ray -- the lat-long
+  convention of envmap.cpp:387-395, 416-422 restated in numpy here (`lookup`);
+* a diffuse plane under a map has radiance rho / pi * integral of L cos over its hemisphere -- by quadrature of the same
+  bilinear field, with a small bright patch so that emitter sampling, BSDF sampling and their MIS weights all matter;
+* the emitter sample the vertex log records is the far point p + 2 max(R, |p - c|) d.
+The radiometry is parity-unpinned like the rest of the tracer's (no Mitsuba here); the sampling distribution is piecewise
+constant per bilinear cell where the reference's follows the interpolant -- same estimator, different variance."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from _reparam_scenes import rect, sphere
+from _scenes import on_host, sensor
+from epsm_mitsuba3_amd import scene as S
+
+
+def smooth_map(H=32, W=64, patch=True):
+    """A map with structure in both directions, no symmetry that would hide a flipped axis, and (optionally) a bright patch."""
+    j, i = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    th, ph = math.pi * j / (H - 1), 2 * math.pi * (i + 0.5) / W
+    a = np.stack([0.6 + 0.4 * np.cos(ph) * np.sin(th), 0.5 + 0.3 * np.cos(th), 0.4 + 0.3 * np.sin(ph + 1.0) * np.sin(th)], -1)
+    if patch:
+        a[5:8, 10:14] += 40.0
+    return a.astype(np.float32)
+
+
+def lookup(bitmap, d, to_world=np.eye(3)):
+    """Radiance of an (H, W, 3) lat-long map along world directions d (..., 3): the convention of include/epsm_trace.h."""
+    H, W = bitmap.shape[:2]
+    t = np.concatenate([bitmap, bitmap[:, :1]], axis=1).astype(np.float64)
+    v = np.asarray(d, np.float64) @ to_world                              # world -> emitter frame: R^T d, as rows
+    v = v / np.linalg.norm(v, axis=-1, keepdims=True)
+    u = np.arctan2(v[..., 0], -v[..., 2]) / (2 * math.pi) - 0.5 / W
+    u = u - np.floor(u)
+    w = np.arccos(np.clip(v[..., 1], -1, 1)) / math.pi
+    x, y = u * W, w * (H - 1)
+    i, j = np.minimum(x.astype(int), W - 1), np.minimum(y.astype(int), H - 2)
+    fx, fy = (x - i)[..., None], (y - j)[..., None]
+    return (t[j, i] * (1 - fx) * (1 - fy) + t[j, i + 1] * fx * (1 - fy) + t[j + 1, i] * (1 - fx) * fy + t[j + 1, i + 1] * fx * fy)
+
+
+def rot(axis, deg):
+    a = np.asarray(axis, float) / np.linalg.norm(axis)
+    c, s = math.cos(math.radians(deg)), math.sin(math.radians(deg))
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    M = np.eye(4)
+    M[:3, :3] = np.eye(3) * c + s * K + (1 - c) * np.outer(a, a)
+    return M
+
+
+def camera_dirs(origin, target, up, fov, res):
+    """Directions through the pixel centres of a square perspective film (row y from the top, column x from the left)."""
+    M = S.look_at(origin, target, up)
+    t = math.tan(math.radians(fov) / 2)
+    ys, xs = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
+    px, py = (xs + 0.5) / res, (ys + 0.5) / res
+    local = np.stack([(1 - 2 * px) * t, (1 - 2 * py) * t, np.ones_like(px)], -1)     # perspective.cpp: x to the left of +z looking down it
+    d = local @ np.asarray(M)[:3, :3].T
+    return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+def check_uniform_environment(make, tracer, device="cpu", spp=256):
+    L, rho = np.array([1.0, 2.0, 0.5]), np.array([0.5, 0.3, 0.8])
+    v, n, f = sphere(1.0, (0, 0, 0), 8, 16)
+    d = {"type": "scene", "cam": sensor([0, 0, 5], [0, 0, 0], fov=40, res=16, spp=spp),
+         "ball": {"type": "mesh", "vertices": v, "faces": f, "face_normals": True,
+                  "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": list(rho)}}},
+         "sky": {"type": "constant", "radiance": {"type": "rgb", "value": list(L)}}}
+    sc = make(S.Scene.from_dict(d, device=device))
+    sc.tracer = tracer
+    for depth, body in ((1, 0 * rho), (2, rho * L), (4, rho * L)):           # depth 1: no emitter sample, no bounce -- the body is black
+        img = sc.render_primal(sensor=0, seed=3, spp=spp, max_depth=depth).cpu().double().numpy()
+        assert np.allclose(img[0, 0], L, rtol=1e-5) and np.allclose(img[-1, -1], L, rtol=1e-5), (tracer, depth, img[0, 0])
+        centre = img[6:10, 6:10].reshape(-1, 3)
+        assert np.allclose(centre.mean(0), body, rtol=0.02, atol=1e-6), (tracer, depth, centre.mean(0), body)
+        if depth > 1:
+            assert np.abs(centre / body - 1).max() < 0.15, (tracer, depth)
+
+
+def check_mirror_and_background(make, tracer, device="cpu", spp=16):
+    bm = smooth_map(patch=False)
+    tw = rot((0.3, 1.0, 0.2), 37.0)
+    v, f = rect(0.6, (0, 0, 0))
+    origin, res, fov = [0.4, 0.3, 3.0], 24, 40
+    d = {"type": "scene", "cam": sensor(origin, [0, 0, 0], fov=fov, res=res, spp=spp),
+         "mirror": {"type": "mesh", "vertices": v, "faces": f, "face_normals": True, "bsdf": {"type": "conductor", "material": "none"}},
+         "sky": {"type": "envmap", "bitmap": bm, "scale": 2.0, "to_world": tw}}
+    sc = make(S.Scene.from_dict(d, device=device))
+    sc.tracer = tracer
+    img = sc.render_primal(sensor=0, seed=1, spp=spp, max_depth=3).cpu().double().numpy()
+    dirs = camera_dirs(origin, [0, 0, 0], (0, 1, 0), fov, res)
+    o = np.asarray(origin)
+    t = -o[2] / dirs[..., 2]
+    hit = o + dirs * t[..., None]
+    on = (np.abs(hit[..., 0]) < 0.55) & (np.abs(hit[..., 1]) < 0.55)          # pixel centres well inside the mirror
+    off = (np.abs(hit[..., 0]) > 0.68) | (np.abs(hit[..., 1]) > 0.68)
+    refl = dirs * np.array([1.0, 1.0, -1.0])
+    want = np.where(on[..., None], lookup(2.0 * bm, refl, tw[:3, :3]), lookup(2.0 * bm, dirs, tw[:3, :3]))
+    sel = on | off
+    assert on.sum() > 40 and off.sum() > 100
+    # (a pixel averages the smooth map over its footprint: 1 % of the value)
+    assert np.abs(img[sel] / want[sel] - 1).max() < 0.02, (tracer, float(np.abs(img[sel] / want[sel] - 1).max()))
+
+
+def plane_radiance(bm, rho, normal=(0, 0, 1.0), to_world=np.eye(3), n=512):
+    """rho / pi * integral of L(w) max(0, n.w) dw by the midpoint rule over the sphere."""
+    th = (np.arange(n) + 0.5) * math.pi / n
+    ph = (np.arange(2 * n) + 0.5) * math.pi / n
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    w = np.stack([np.sin(T) * np.cos(P), np.sin(T) * np.sin(P), np.cos(T)], -1)
+    cosn = np.clip(w @ np.asarray(normal, float), 0, None)
+    Lw = lookup(bm, w, to_world)
+    dw = np.sin(T) * (math.pi / n) ** 2
+    return np.asarray(rho) / math.pi * (Lw * (cosn * dw)[..., None]).sum((0, 1))
+
+
+def check_plane_under_a_map(make, tracer, device="cpu", spp=1024):
+    bm = smooth_map(patch=True)
+    tw = rot((1.0, 0.2, 0.0), -60.0)
+    rho = np.array([0.7, 0.5, 0.3])
+    v, f = rect(3.0, (0, 0, 0))
+    want = plane_radiance(bm, rho, to_world=tw[:3, :3])
+    for bsdf in ({"type": "diffuse", "reflectance": {"type": "rgb", "value": list(rho)}},):
+        d = {"type": "scene", "cam": sensor([0, 0, 3.0], [0, 0, 0], fov=30, res=8, spp=spp),
+             "plane": {"type": "mesh", "vertices": v, "faces": f, "face_normals": True, "bsdf": bsdf},
+             "sky": {"type": "envmap", "bitmap": bm, "to_world": tw}}
+        sc = make(S.Scene.from_dict(d, device=device))
+        sc.tracer = tracer
+        img = sc.render_primal(sensor=0, seed=11, spp=spp, max_depth=2).cpu().double().numpy().reshape(-1, 3)
+        assert np.allclose(img.mean(0), want, rtol=0.015), (tracer, img.mean(0), want)
+        assert np.abs(img / want - 1).max() < 0.12, (tracer, float(np.abs(img / want - 1).max()))
+
+
+@pytest.mark.parametrize("tracer", ["mega", "wavefront"])
+def test_convex_body_in_a_uniform_environment(tracer):
+    check_uniform_environment(on_host, tracer)
+
+
+@pytest.mark.parametrize("tracer", ["mega", "wavefront"])
+def test_mirror_and_background_show_the_map(tracer):
+    check_mirror_and_background(on_host, tracer)
+
+
+@pytest.mark.parametrize("tracer", ["mega", "wavefront"])
+def test_diffuse_plane_under_a_map_matches_quadrature(tracer):
+    check_plane_under_a_map(on_host, tracer)
+
+
+def test_sampling_tables_are_a_distribution_with_the_maps_support():
+    bm = smooth_map(patch=True)
+    bm[20:, :] = 0.0                                                      # a black cap: cells with no radiance get no samples
+    tex, row_cdf, col_cdf, cell_pdf = S.environment_tables(bm)
+    H, W = bm.shape[:2]
+    assert tex.shape == (H, W + 1, 3) and np.array_equal(tex[:, W], tex[:, 0])
+    assert row_cdf.shape == (H - 1,) and col_cdf.shape == (H - 1, W) and cell_pdf.shape == (H - 1, W)
+    assert abs(float(cell_pdf.mean()) - 1.0) < 1e-5                        # integrates to one over [0,1)^2
+    assert np.all(np.diff(row_cdf) >= 0) and row_cdf[-1] == 1.0 and np.all(np.diff(col_cdf, axis=1) >= -1e-7)
+    assert np.all(cell_pdf[21:] == 0) and np.all(cell_pdf[:19] > 0)
+    with pytest.raises(ValueError):
+        S.Scene.from_dict({"type": "scene", "a": {"type": "constant"}, "b": {"type": "envmap", "bitmap": bm}}, device="cpu")
+    with pytest.raises(ValueError):
+        S.Scene.from_dict({"type": "scene", "b": {"type": "envmap", "filename": "sky.exr"}}, device="cpu")
+
+
+def test_logged_emitter_sample_is_the_far_point():
+    """`light` of the vertex log (epsm.py:648-654: ds.p) for an environment sample: p + 2 max(R, |p - c|) d, no emitter triangle."""
+    v, n, f = sphere(0.5, (0.1, 0.0, 0.0), 8, 16)
+    res, spp = 8, 4
+    d = {"type": "scene", "cam": sensor([0, 0, 4], [0, 0, 0], fov=30, res=res, spp=spp),
+         "ball": {"type": "mesh", "vertices": v, "normals": n, "faces": f,
+                  "bsdf": {"type": "roughconductor", "alpha": 0.2, "distribution": "ggx"}},
+         "sky": {"type": "envmap", "bitmap": smooth_map(), "to_world": rot((0, 1, 0), 20.0)}}
+    sc = on_host(S.Scene.from_dict(d, device="cpu"))
+    tr = sc._trace(0, 2, spp, 3, 2, 0, res * res * spp)            # (sensor, seed, spp, max_depth, K, lo, hi)
+    r = tr.path_info[1]
+    act = r["active_em"].bool()
+    assert int(act.sum()) > 20
+    p, light = r["points"][3][act].double(), r["light"][act].double()
+    c = torch.tensor([float(x) for x in sc.c_scene.env.center], dtype=torch.float64)
+    R = float(sc.c_scene.env.radius)
+    dist = (light - p).norm(dim=1)
+    want = 2 * torch.maximum(torch.full_like(dist, R), (p - c).norm(dim=1))
+    assert torch.allclose(dist, want, rtol=1e-4), (dist[:4], want[:4])
+    emit = tr.scatter_info[0]["emit"][act]
+    assert bool((emit[:, 0] == -1).all() or (emit[:, 0].to(torch.int64) & 0xFFFFFFFF == 0xFFFFFFFF).all())

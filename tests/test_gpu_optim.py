@@ -14,6 +14,15 @@ def test_plate_translation_is_recovered():
     assert min(hist[-10:]) < 0.25 * hist[0], hist
 
 
+def test_plate_translation_is_recovered_under_an_environment_map():
+    """The same with an `envmap` fill light (EPSM/exp/highlight.py:218-222): two emitters, half of the emitter samples go to the
+    sky and log a far point without parameter rows."""
+    from epsm_mitsuba3_amd.optim import run
+    hist, opt = run("manifold", "highlight", iterations=45, lr=0.03, log=lambda s: None)
+    assert hist[0] > 0.7
+    assert min(hist[-10:]) < 0.3 * hist[0], hist
+
+
 def test_caustic_light_translation_is_recovered():
     """manifold_caustic: camera -> diffuse floor -> glass slab (two refractions) -> area light; the light's
     gradient arrives through diffuse_grad of the chain's end point (epsm.py:1178-1184)."""
