@@ -48,7 +48,7 @@ CONFIGS = {
     # ScaleSphereEmitterOnBlackConfig (:438-460): vertex positions * (1 + theta)
     "scale_sphere_emitter_on_black": dict(max_depth=3, moving=["light"], fd_eps=1e-3, motion="scale"),
     # TranslateSelfShadowAreaLightConfig (:551-596): a plane and an upright rectangle on it move TOGETHER under a point
-    # light; max_depth 3 (its dim constant emitter is left out: not in this tracer's plugin set)
+    # light and a dim constant environment; max_depth 3
     "self_shadow_point_light": dict(max_depth=3, moving=["plane", "occluder"], fd_eps=1e-3),
     # TranslateOccluderAreaLightConfig (:463-500): a small sphere between a small bright light and a diffuse plane
     "occluder_area_light": dict(max_depth=2, moving=["occluder"], fd_eps=2e-4, kappa=5e5),
@@ -105,7 +105,8 @@ def build(name, theta=0.0, res=32, spp=64, device="cpu", theta_n=0.0):
         v = (v - np.array([-1.0, 0, 0.5])) * np.array([1.0, 1.0, 0.5]) + np.array([-1.0, 0, 0.5])     # 2 x 1, standing on the plane
         d["occluder"] = {"type": "mesh", "vertices": v + off, "faces": f, "face_normals": True,
                          "bsdf": {"type": "twosided", "bsdf": white}}
-        d["light"] = {"type": "point", "position": [-4.0, 0.0, 6.0], "intensity": {"type": "rgb", "value": [50.0, 0.0, 0.0]}}
+        d["light"] = {"type": "point", "position": [-4.0, 0.0, 6.0], "intensity": {"type": "rgb", "value": [5.0, 0.0, 0.0]}}
+        d["light2"] = {"type": "constant", "radiance": 0.1}
     elif name == "occluder_area_light":
         v, f = rect(1.0)
         d["plane"] = {"type": "mesh", "vertices": v, "faces": f, "face_normals": True, "bsdf": white}
