@@ -69,74 +69,39 @@ __device__ __forceinline__ M2<float> up1(M2<float> m) { M2<float> o; o.a = up1(m
 __device__ __forceinline__ V3<float> down1(V3<float> v) { return mk3<float>(down1(v.x), down1(v.y), down1(v.z)); }
 __device__ __forceinline__ V3<float> up1(V3<float> v) { return mk3<float>(up1(v.x), up1(v.y), up1(v.z)); }
 
-// ---- record access: the native packed log or the reference's per-field arrays
+// ---- record access on the reference's per-field arrays (the native log is read by geo_issue / addr_issue below); the flag
+// word of a path from either
 template <bool PACKED> struct Records {
     const FusedArgs &F;
     const PtrTable &P;                   // LDS (per-field arrays)
     int64_t i;
-    __device__ __forceinline__ const float *rec(int k) const { return F.pk_verts + (i * F.K + (k - 1)) * kRecWords; }
     __device__ __forceinline__ cp::Own<float> own(int k) const {
         cp::Own<float> o;
-        Raw<float> r;
-        if (PACKED) {
-            const float *p = rec(k);
-            const F4v q0 = ldq(p, 0), q1 = ldq(p, 1), q2 = ldq(p, 2), q3 = ldq(p, 3), q4 = ldq(p, 4), q5 = ldq(p, 5);
-            r.g = geo_from(q0, q1, q2, q4.z, q4.w);
-            r.nr = nrm_from(q2, q3, q4, q4.z, q4.w);
-            r.eta = q5.x;
-            r.light = mk3<float>(q5.y, q5.z, q5.w);
-        } else {
-            const VertexPtrs<float> &v = P.v[k - 1];
-            r.g = load_geo(v, i);
-            r.nr = load_nrm(v, i, r.g.b0, r.g.b1);
-            r.eta = lds_(v.eta, i);
-            r.light = load3(v.light, i);
-        }
-        o.x = r.g.x; o.e1 = r.g.e1; o.e2 = r.g.e2; o.b0 = r.g.b0; o.b1 = r.g.b1;
-        o.n = r.nr.n; o.dn1 = r.nr.dn1; o.dn2 = r.nr.dn2; o.eta = r.eta; o.light = r.light;
+        const VertexPtrs<float> &v = P.v[k - 1];
+        const Geo<float> g = load_geo(v, i);
+        const Nrm<float> nr = load_nrm(v, i, g.b0, g.b1);
+        o.x = g.x; o.e1 = g.e1; o.e2 = g.e2; o.b0 = g.b0; o.b1 = g.b1;
+        o.n = nr.n; o.dn1 = nr.dn1; o.dn2 = nr.dn2; o.eta = lds_(v.eta, i); o.light = load3(v.light, i);
         return o;
     }
-    __device__ __forceinline__ Geo<float> geo(int k) const {
-        if (PACKED) {
-            const float *p = rec(k);
-            const F4v q4 = ldq(p, 4);
-            return geo_from(ldq(p, 0), ldq(p, 1), ldq(p, 2), q4.z, q4.w);
-        }
-        return load_geo(P.v[k - 1], i);
-    }
-    __device__ __forceinline__ V3<float> cam() const {
-        if (PACKED) { const F4v q = ldq(F.pk_rays + 12 * i, 0); return mk3<float>(q.x, q.y, q.z); }
-        return load3(F.g.cam, i);
-    }
-    __device__ __forceinline__ uint32_t tri_id(int k) const { return PACKED ? __float_as_uint(lds_(rec(k), 28)) : lds_(P.s[k - 1].tri, i); }
-    __device__ __forceinline__ void b0b1(int k, float &b0, float &b1) const {
-        if (PACKED) { const F4v q = ldq(rec(k), 4); b0 = q.z; b1 = q.w; }
-        else { b0 = lds_(P.v[k - 1].b0, i); b1 = lds_(P.v[k - 1].b1, i); }
-    }
+    __device__ __forceinline__ Geo<float> geo(int k) const { return load_geo(P.v[k - 1], i); }
+    __device__ __forceinline__ V3<float> cam() const { return load3(F.g.cam, i); }
+    __device__ __forceinline__ uint32_t tri_id(int k) const { return lds_(P.s[k - 1].tri, i); }
+    __device__ __forceinline__ void b0b1(int k, float &b0, float &b1) const { b0 = lds_(P.v[k - 1].b0, i); b1 = lds_(P.v[k - 1].b1, i); }
     // emitter-sample record [etri, eb0, eb1, eweight]
     __device__ __forceinline__ bool emit(int k, uint32_t &etri, float &eb0, float &eb1, float &ew) const {
-        if (PACKED) {
-            const F4v q = ldq(rec(k), 6);
-            etri = __float_as_uint(q.x); eb0 = q.y; eb1 = q.z; ew = q.w;
-            return true;
-        }
         const uint32_t *p = P.s[k - 1].emit;
         if (!p) return false;
         const U4 e4 = load_u4(p, i);
         etri = e4.x; eb0 = bits_to_float(e4.y); eb1 = bits_to_float(e4.z); ew = bits_to_float(e4.w);
         return true;
     }
-    // BSDF record: alpha slot (per-field arrays only; the packed log carries it in the triangle's table row) and d hf / d alpha
+    // BSDF record: alpha slot and d hf / d alpha
     __device__ __forceinline__ void aux(int k, uint32_t &bid, V3<float> &dhf) const {
         bid = kNoIndex; dhf = zero3<float>();
-        if (!F.galpha) return;
-        if (PACKED) {
-            const F4v q = ldq(rec(k), 7);
-            dhf = mk3<float>(q.y, q.z, q.w);
-        } else if (P.s[k - 1].aux) {
-            const U4 a4 = load_u4(P.s[k - 1].aux, i);
-            bid = a4.x; dhf = mk3<float>(bits_to_float(a4.y), bits_to_float(a4.z), bits_to_float(a4.w));
-        }
+        if (!F.galpha || !P.s[k - 1].aux) return;
+        const U4 a4 = load_u4(P.s[k - 1].aux, i);
+        bid = a4.x; dhf = mk3<float>(bits_to_float(a4.y), bits_to_float(a4.z), bits_to_float(a4.w));
     }
     __device__ __forceinline__ uint32_t flag_word() const {
         if (PACKED) return lds_(F.pk_flags, i);
@@ -279,38 +244,35 @@ struct Rounds {
     }
 };
 
-// ---- what a round reads of the native log, in three steps (round 4; round 3 prefetched all of it -- 62 registers -- one round
-// ahead and held it across the whole emission, which pinned the kernel at 256 registers = two waves per SIMD):
-//   touch   ONE word per cache line the NEXT round will read, issued between this round's solve and its emission: the lines
-//           travel from HBM to L2 while the rows are merged and inserted (4 registers, nobody reads them);
-//   geo     at the start of a round: the lane's own record, quads 0..5; the FIRST lane of a path its rays (12 words) and the
-//           image gradient of its pixel; the LAST lane of a path whose chain ends on a vertex without a lane of its own (the
-//           diffuse end point: k + 1 = nv > m) quads 0, 1, word 8 and words 18, 19 of record k + 1.  L2 hits, consumed at
-//           once.  The geometry of vertices k - 1 and k + 1 that DO have a lane comes from that lane (one shuffle per word)
-//           instead of being read again: round 3 re-read 2 x (2 quads + 4 words) per lane;
-//   addr    after the recursions: the words only the EMISSION needs -- emitter sample (quad 6), triangle id and d hf / d alpha
-//           (quad 7), triangle id and barycentrics of the end point, the occluder record -- from lines the geo step has just
-//           pulled into the vector cache; they and the rows of the scene table they name (requested after the second sweep)
-//           are NOT live across the recursions, where the 2x2 blocks in float64 need the registers.
-// A record is one 128-byte line; the 48 bytes of a path's rays may straddle two.
-struct Touch { float own, ray0, ray1, nxt; };
+// ---- what a round reads of the native log (include/epsm.h, EpsmPackedLog: a record is one 128-byte line = two 64-byte sectors;
+// a CU's vector L1 keeps ~64 sector misses in flight, so what a round costs is the sectors it touches times their latency):
+//   geo     at the start of a round: the lane's own record -- quads 0..5 of a constraint vertex (both sectors), quads 0..2
+//           (geometry, barycentrics, triangle id: the FIRST sector only) of a first hit that is diffuse without being a
+//           constraint; the first lane of a path its rays (12 words) and the image gradient of its pixel; the LAST lane of a
+//           path whose chain ends on a vertex without a lane of its own (the diffuse end point: k + 1 = nv > m) quads 0..2 of
+//           record k + 1 -- one sector.  The geometry of vertices k - 1 and k + 1 that DO have a lane comes from that lane (one
+//           shuffle per word) instead of being read again;
+//   addr    after the recursions: the words only the EMISSION needs -- emitter sample (quad 6), d hf / d alpha (quad 7), the
+//           occluder record; they and the rows of the scene table (requested after the second sweep: rows of triangles that
+//           neighbouring paths hit too, mostly found in the vector cache) are NOT live across the recursions, where the 2x2
+//           blocks in float64 need the registers.  (Rounds 3 and 4 prefetched -- into 62 registers, then by one-word touches;
+//           the triangle's vertex rows INSIDE the record instead of the table lookup measured slower: MEASUREMENTS.md 9.9.)
+typedef float F2v __attribute__((ext_vector_type(2)));
+typedef float F3v __attribute__((ext_vector_type(3)));
 struct GeoFetch {                    // (named fields, no arrays: the struct has to end up in registers, not in scratch memory)
     F4v o0, o1, o2, o3, o4, o5;      // own record, quads 0..5
+    float o_lz;                      // ... word 28: light.z (constraint versions with an emitter sample)
     F4v p0, p1, p2;                  // first lane: the rays
-    F4v n0, n1; float n_z, n_b0, n_b1;   // last lane, record k+1: quads 0, 1, word 8, words 18, 19
+    F4v n0, n1, n2;                  // last lane, record k+1: quads 0..2
     float gx, gy;
 };
 struct AddrFetch {
     F4v q6;                          // emitter sample [etri, eb0, eb1, eweight]
-    F4v q7;                          // [triangle id, d hf / d alpha]
-    float b0, b1;                    // a path without a constraint whose first hit is diffuse: its barycentrics ...
-    U4 sh;                           // ... and the first vertex's occluder record (max_depth <= 3 logs)
-    float n_b0, n_b1; uint32_t n_tid;    // last lane: barycentrics and triangle id of the end point
+    F4v q7;                          // [light.z, d hf / d alpha]
+    U4 sh;                           // the first vertex's occluder record (max_depth <= 3 logs)
 };
 // (Only words that are USED are loaded: a register of a pending load's destination that nobody reads is free for the
 // register allocator, and the hardware's write to it then has to be waited for.)
-typedef float F2v __attribute__((ext_vector_type(2)));
-typedef float F3v __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ F2v ld2(const float *p) { return *(const __attribute__((address_space(1))) F2v *) p; }
 // Window-uniform bases (scalar registers): a lane's addresses are these plus a 32-bit offset -- `global_load ... v_off, s[base]`
 // instead of 64-bit multiply-adds per lane and load group -- and its pixel comes from the window's first pixel by two small
@@ -356,12 +318,6 @@ __device__ __forceinline__ LaneRole role_of(const FusedArgs &F, const LaneId &L,
     R.rec = B.verts + (uint32_t) ((R.loc * (uint32_t) F.K + (uint32_t) (L.k - 1)) * (uint32_t) kRecWords);
     return R;
 }
-__device__ __forceinline__ void touch_issue(Touch &C, const FusedArgs &F, const LaneId &L, const WinBase &B) {
-    const LaneRole R = role_of(F, L, B);
-    if (R.live || R.d1) C.own = lds_(R.rec, 0);
-    if (R.ok && R.first) { const float *rays = B.rays + 12u * R.loc; C.ray0 = lds_(rays, 0); C.ray1 = lds_(rays, 11); }
-    if (R.end_next) C.nxt = lds_(R.rec + kRecWords, 0);
-}
 // pixel of path i: (path_offset + i) / spp, row-major on the res x res crop (epsm.py:250)
 // (films of 2^24 pixels and more: two 64-bit divisions, ~200 instructions that the round loop carried inline without ever
 // running them -- out of line: headline slab 2.07 -> 2.06 ms, pool slab 2.79 -> 2.70)
@@ -380,12 +336,16 @@ __device__ __forceinline__ const float *pixel_grad(const TangentIn &A, const Win
     }
     return A.grad_img + (y * A.img_width + x) * A.img_channels + 3;
 }
+template <int VARIANT>
 __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B) {
     const LaneRole R = role_of(F, L, B);
     // (a path WITHOUT a constraint reads its first record only when its first hit is diffuse: diffuse_grad[0] = dldp needs the
     // triangle; otherwise all it gives is its share of d/d ray.o, which needs the rays alone -- 27 % of the bathroom paths)
-    if (R.live || (R.d1 && R.act1)) { X.o0 = ldq(R.rec, 0); X.o1 = ldq(R.rec, 1); X.o2 = ldq(R.rec, 2); }
-    if (R.live) { X.o3 = ldq(R.rec, 3); X.o4 = ldq(R.rec, 4); X.o5 = ldq(R.rec, 5); }
+    if (R.live || R.d1) { X.o0 = ldq(R.rec, 0); X.o1 = ldq(R.rec, 1); X.o2 = ldq(R.rec, 2); }
+    if (R.live) {
+        X.o3 = ldq(R.rec, 3); X.o4 = ldq(R.rec, 4); X.o5 = ldq(R.rec, 5);
+        if (VARIANT == EPSM_VARIANT_MANIFOLD && cp::plan_a(L.plan, L.k)) X.o_lz = lds_(R.rec, 28);
+    }
     if (R.ok && R.first) {
         const float *rays = B.rays + 12u * R.loc;
         X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
@@ -394,26 +354,17 @@ __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const
     }
     if (R.end_next) {
         const float *nx = R.rec + kRecWords;
-        X.n0 = ldq(nx, 0); X.n1 = ldq(nx, 1); X.n_z = lds_(nx, 8);
-        const F2v b = ld2(nx + 18); X.n_b0 = b.x; X.n_b1 = b.y;
+        X.n0 = ldq(nx, 0); X.n1 = ldq(nx, 1); X.n2 = ldq(nx, 2);
     }
 }
 template <int VARIANT>
 __device__ __forceinline__ void addr_issue(AddrFetch &A, const FusedArgs &F, const LaneId &L, const WinBase &B) {
     const LaneRole R = role_of(F, L, B);
     if (R.live) {
-        if (F.galpha) A.q7 = ldq(R.rec, 7); else A.q7.x = lds_(R.rec, 28);
+        if (F.galpha) A.q7 = ldq(R.rec, 7);
         if (VARIANT == EPSM_VARIANT_MANIFOLD && cp::plan_a(L.plan, L.k)) A.q6 = ldq(R.rec, 6);
     }
-    if (R.d1) {
-        if (!R.live) { A.q7.x = lds_(R.rec, 28); const F2v b = ld2(R.rec + 18); A.b0 = b.x; A.b1 = b.y; }
-        if (B.shadow) A.sh = load_u4(B.shadow, R.loc);
-    }
-    if (R.end_next) {
-        const float *nx = R.rec + kRecWords;
-        const F2v b = ld2(nx + 18); A.n_b0 = b.x; A.n_b1 = b.y;
-        A.n_tid = __float_as_uint(lds_(nx, 28));
-    }
+    if (R.d1 && B.shadow) A.sh = load_u4(B.shadow, R.loc);
 }
 
 // kWindow: the largest window (paths a workgroup plans, sorts and works through at a time); `window` <= kWindow, a multiple
@@ -461,8 +412,6 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
     __shared__ int s_cnt[kEntries];                                  // [m][j][wave]: histogram, then offsets
     __shared__ int s_cls[kKeys + 2];                                 // first sorted position of class m; [kKeys]: of the paths without a term
     V3<float> gd_acc = zero3<float>();                               // kTangentsInKernel: sum of grad_d over this lane's paths
-    Touch C;                                                         // (defined: a conditionally loaded struct otherwise carries undef through the round loop)
-    C.own = C.ray0 = C.ray1 = C.nxt = 0.f;
     T.clear();                                                       // ends with a barrier: the table of pointers is visible too
     const int64_t n_windows = (F.g.N + window - 1) / window;
 #pragma unroll 1
@@ -591,20 +540,19 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                 GeoFetch X;                                          // (every field defined: a conditionally loaded, conditionally read
                 {                                                    //  struct with undefined fields is kept in scratch memory)
                     const F4v z4 = {0.f, 0.f, 0.f, 0.f};
-                    X.o0 = X.o1 = X.o2 = X.o3 = X.o4 = X.o5 = X.p0 = X.p1 = X.p2 = X.n0 = X.n1 = z4;
-                    X.n_z = X.n_b0 = X.n_b1 = X.gx = X.gy = 0.f;
+                    X.o0 = X.o1 = X.o2 = X.o3 = X.o4 = X.o5 = X.p0 = X.p1 = X.p2 = X.n0 = X.n1 = X.n2 = z4;
+                    X.o_lz = X.gx = X.gy = 0.f;
                 }
-                geo_issue(X, F, L, WB);
-                // (the touches' destination registers stay reserved until here: a pending load's destination that nobody reads
-                // is free for the allocator, and the hardware's write to it would have to be waited for in the middle of the emission)
-                asm volatile("" :: "v"(C.own), "v"(C.ray0), "v"(C.ray1), "v"(C.nxt));
+                geo_issue<VARIANT>(X, F, L, WB);
                 if (live) {
-                    const Geo<float> g = geo_from(X.o0, X.o1, X.o2, X.o4.z, X.o4.w);
-                    const Nrm<float> nr = nrm_from(X.o2, X.o3, X.o4, X.o4.z, X.o4.w);
+                    const Geo<float> g = geo_from(X.o0, X.o1, X.o2);
+                    const Nrm<float> nr = nrm_from(X.o3, X.o4, X.o5, g.b0, g.b1);
                     own.x = g.x; own.e1 = g.e1; own.e2 = g.e2; own.b0 = g.b0; own.b1 = g.b1;
                     own.n = nr.n; own.dn1 = nr.dn1; own.dn2 = nr.dn2;
-                    own.eta = X.o5.x; own.light = mk3<float>(X.o5.y, X.o5.z, X.o5.w);
+                    own.eta = X.o3.w; own.light = mk3<float>(X.o5.z, X.o5.w, X.o_lz);
                 }
+                if (d1 && !live) { own.b0 = X.o2.y; own.b1 = X.o2.z; }
+                if (live || d1) tid_own = __float_as_uint(X.o2.w);
                 if (c > 1) {                                         // wave-uniform: paths on several lanes exchange their vertices
                     const V3<float> ux = up1(own.x), ue1 = up1(own.e1), ue2 = up1(own.e2);
                     const V3<float> dx = down1(own.x), de1 = down1(own.e1), de2 = down1(own.e2);
@@ -613,9 +561,9 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                 }
                 if (live && first) prev.x = mk3<float>(X.p0.x, X.p0.y, X.p0.z);
                 if (has_next && k == c) {
-                    const F4v nq2 = {X.n_z, 0.f, 0.f, 0.f};
-                    const Geo<float> gq = geo_from(X.n0, X.n1, nq2, X.n_b0, X.n_b1);
+                    const Geo<float> gq = geo_from(X.n0, X.n1, X.n2);
                     next.x = gq.x; next.e1 = gq.e1; next.e2 = gq.e2;
+                    nb0 = gq.b0; nb1 = gq.b1; tid_next = __float_as_uint(X.n2.w);
                 }
                 if (ok && first) {       // epsm.py:250-272 in registers
                     const V3<float> ro = mk3<float>(X.p0.x, X.p0.y, X.p0.z), rd = mk3<float>(X.p0.w, X.p1.x, X.p1.y),
@@ -674,8 +622,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             {
                 const F4v z4 = {0.f, 0.f, 0.f, 0.f};
                 A.q6 = A.q7 = z4;
-                A.q7.x = __uint_as_float(kNoIndex); A.n_tid = kNoIndex; A.sh.x = kNoIndex; A.sh.y = A.sh.z = A.sh.w = 0u;
-                A.b0 = A.b1 = A.n_b0 = A.n_b1 = 0.f;
+                A.sh.x = kNoIndex; A.sh.y = A.sh.z = A.sh.w = 0u;
             }
 #ifdef EPSM_CPKO_NOSOLVE
             gd_acc.x += own.x.x + own.n.y + own.light.z + own.eta + prev.x.x + prev.e1.y + next.x.z + next.e2.x + dk.x + dp.y;
@@ -758,30 +705,25 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             float fb0 = kb0, fb1 = kb1;                              // barycentrics of the lane's own vertex
             if (PACKED) {
                 if (live) {
-                    tid_own = __float_as_uint(A.q7.x);
                     if (F.galpha) dhf = mk3<float>(A.q7.y, A.q7.z, A.q7.w);
                     if (wN) { etri = __float_as_uint(A.q6.x); eb0 = A.q6.y; eb1 = A.q6.z; ew = A.q6.w; }      // (caustic: light_grad == 0)
                 }
-                if (d1) {
-                    if (!live) { tid_own = __float_as_uint(A.q7.x); fb0 = A.b0; fb1 = A.b1; }
-                    if (F.pk_shadow) sh = A.sh;
-                }
+                if (d1 && F.pk_shadow) sh = A.sh;
                 if (c > 1) {                                         // wave-uniform
                     const float db0 = down1(kb0), db1 = down1(kb1);
                     const uint32_t dt = down1(tid_own);
                     if (has_next && k < c) { nb0 = db0; nb1 = db1; tid_next = dt; }
                 }
-                if (has_next && k == c) { nb0 = A.n_b0; nb1 = A.n_b1; tid_next = A.n_tid; }
             }
             const U4 t_own = table_row(F.tab, tid_own), t_next = table_row(F.tab, tid_next);
             const U4 er = table_row(F.tab, etri), t_sh = table_row(F.tab, sh.x);
-            // ---- the next round's records on their way (one word per cache line: touch_issue) while this round's rows are
-            // formed, merged and inserted
             asm volatile("; EPSM_MARK prefetch");
+            // (Until round 4's counter run a "touch" stood here: one word per cache line of the NEXT round's records, so that the
+            // lines travelled HBM -> L2 during the emission.  It cost more than it hid: a CU's vector L1 keeps ~64 misses in
+            // flight, every 64 bytes a wave reads is one of them for as long as its latency, and a touched line is fetched TWICE
+            // through that queue -- by the touch at HBM latency, again by the round that uses it at L2 latency, the L1 having lost
+            // it in between.  TCP_PENDING_STALL_CYCLES: 65 % of the kernel; without the touch 2.046 -> 1.970 ms.)
             const LaneId Ln = RS.lane_of(r + kWaves, lane);          // (past the last round: no lane has a path)
-            __builtin_amdgcn_sched_barrier(0);
-            if (PACKED) touch_issue(C, F, Ln, WB);                 // (two rounds ahead instead of one: 2.08 -> 2.21 ms)
-            __builtin_amdgcn_sched_barrier(0);
             // ---- emission
             asm volatile("; EPSM_MARK emit");
             if (PACKED) bid = (t_own.w >> 8) - 1u;                    // packed log: alpha slot + 1 in the table row

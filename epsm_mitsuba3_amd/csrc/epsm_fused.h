@@ -45,19 +45,20 @@ typedef float F4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ F4v ldq(const float *rec, int q) {
     return *(const __attribute__((address_space(1))) F4v *) (rec + 4 * q);
 }
-// EpsmPackedLog vertex record (32 words): p0 p1 p2 n0 n1 n2 | b0 b1 eta light(3) | etri eb0 eb1 ew | tri dhf(3)
+// EpsmPackedLog vertex record (32 words, include/epsm.h): p0 p1 p2 | b0 b1 tri | n0 eta || n1 n2 | light.xy | etri eb0 eb1 ew |
+// light.z dhf(3) -- the first 64-byte sector holds all an END point or a diffuse first hit is read for
 constexpr int kRecWords = 32;
-__device__ __forceinline__ Geo<float> geo_from(F4v q0, F4v q1, F4v q2, float b0, float b1) {
+__device__ __forceinline__ Geo<float> geo_from(F4v q0, F4v q1, F4v q2) {
     Geo<float> g;
     const V3<float> p0 = mk3<float>(q0.x, q0.y, q0.z), p1 = mk3<float>(q0.w, q1.x, q1.y), p2 = mk3<float>(q1.z, q1.w, q2.x);
-    g.b0 = b0; g.b1 = b1;
-    g.x = p0 * b0 + p1 * b1 + p2 * (1.f - b0 - b1);
+    g.b0 = q2.y; g.b1 = q2.z;
+    g.x = p0 * g.b0 + p1 * g.b1 + p2 * (1.f - g.b0 - g.b1);
     g.e1 = p0 - p2; g.e2 = p1 - p2;
     return g;
 }
-__device__ __forceinline__ Nrm<float> nrm_from(F4v q2, F4v q3, F4v q4, float b0, float b1) {
+__device__ __forceinline__ Nrm<float> nrm_from(F4v q3, F4v q4, F4v q5, float b0, float b1) {
     Nrm<float> o;
-    const V3<float> n0 = mk3<float>(q2.y, q2.z, q2.w), n1 = mk3<float>(q3.x, q3.y, q3.z), n2 = mk3<float>(q3.w, q4.x, q4.y);
+    const V3<float> n0 = mk3<float>(q3.x, q3.y, q3.z), n1 = mk3<float>(q4.x, q4.y, q4.z), n2 = mk3<float>(q4.w, q5.x, q5.y);
     o.n = n0 * b0 + n1 * b1 + n2 * (1.f - b0 - b1);
     o.dn1 = n0 - n2; o.dn2 = n1 - n2;
     return o;

@@ -785,14 +785,15 @@ EPSM_HD void write_record_packed(float *packed, uint32_t *pflags, int K_log, int
     const F3 p0 = mesh ? h.p0 : z, p1 = mesh ? h.p1 : z, p2 = mesh ? h.p2 : z, n0 = mesh ? h.n0 : z, n1 = mesh ? h.n1 : z,
              n2 = mesh ? h.n2 : z;
     float *r = packed + (i * K_log + iteration) * 32;
-    st4(r + 0, p0.x, p0.y, p0.z, p1.x);
+    const float tid = u2f(mesh ? h.tri : kNoIndex);
+    st4(r + 0, p0.x, p0.y, p0.z, p1.x);                                   // (layout: include/epsm.h, EpsmPackedLog)
     st4(r + 4, p1.y, p1.z, p2.x, p2.y);
-    st4(r + 8, p2.z, n0.x, n0.y, n0.z);
-    st4(r + 12, n1.x, n1.y, n1.z, n2.x);
-    st4(r + 16, n2.y, n2.z, mesh ? h.b0 : 0.f, mesh ? h.b1 : 0.f);
-    st4(r + 20, bs.eta, es.p.x, es.p.y, es.p.z);
+    st4(r + 8, p2.z, mesh ? h.b0 : 0.f, mesh ? h.b1 : 0.f, tid);
+    st4(r + 12, n0.x, n0.y, n0.z, bs.eta);
+    st4(r + 16, n1.x, n1.y, n1.z, n2.x);
+    st4(r + 20, n2.y, n2.z, es.p.x, es.p.y);
     st4(r + 24, u2f(es.tri), es.b0, es.b1, eweight);
-    st4(r + 28, u2f(mesh ? h.tri : kNoIndex), bs.dhf.x, bs.dhf.y, bs.dhf.z);
+    st4(r + 28, es.p.z, bs.dhf.x, bs.dhf.y, bs.dhf.z);
     const uint32_t bits = ((flags & 0x6u) ? 1u : 0u) | ((flags & 0x1u) ? 2u : 0u) | (active ? 4u : 0u) | (active_em ? 8u : 0u) |
                           (mesh ? 16u : 0u);
     if (iteration == 0) pflags[i] = bits;

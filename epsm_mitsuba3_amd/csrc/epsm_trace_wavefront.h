@@ -196,7 +196,10 @@ EPSM_HD void wf_shadow_begin(const TraceArgs &A, const WfState &W, int64_t i, Wf
 }
 // ds.p of the first bounce, as logged (per-field array or packed record)
 EPSM_HD F3 wf_logged_light0(const TraceArgs &A, int64_t i) {
-    if (A.flags & EPSM_TRACE_PACKED_LOG) return ld3(A.rec[0].packed + i * A.K_log * 32 + 21);
+    if (A.flags & EPSM_TRACE_PACKED_LOG) {                                 // light = words 22, 23, 28 (include/epsm.h, EpsmPackedLog)
+        const float *r = A.rec[0].packed + i * A.K_log * 32;
+        return f3(r[22], r[23], r[28]);
+    }
     return ld3(A.rec[0].light + 3 * i);
 }
 EPSM_HD bool wf_shadow_round(const TraceArgs &A, const WfState &W, int iteration, WfJob &J, uint32_t *lds, int stride) {

@@ -284,18 +284,21 @@ class PackedLog:
                  m(r["ismesh"]).to(torch.int32) * FLAG_ISMESH)
             flags |= w << (5 * (k - 1))
             v = verts[:, k - 1]
+            iv = iview[:, k - 1]
+            tri = s["tri"].to(dev, torch.int32)
+            # (word layout: include/epsm.h, EpsmPackedLog -- the first sector holds geometry, barycentrics and triangle id)
             for j in range(3):
                 v[:, 3 * j: 3 * j + 3] = f(r["points"][j])
-                v[:, 9 + 3 * j: 12 + 3 * j] = f(r["normals"][j])
-            v[:, 18], v[:, 19], v[:, 20] = f(r["uv"][0]), f(r["uv"][1]), f(r["eta"])
-            v[:, 21:24] = f(r["light"])
-            iv = iview[:, k - 1]
+            v[:, 9], v[:, 10] = f(r["uv"][0]), f(r["uv"][1])
+            iv[:, 11] = tri
+            v[:, 12:15], v[:, 15] = f(r["normals"][0]), f(r["eta"])
+            v[:, 16:19], v[:, 19:22] = f(r["normals"][1]), f(r["normals"][2])
+            light = f(r["light"])
+            v[:, 22:24], v[:, 28] = light[:, 0:2], light[:, 2]
             if s.get("emit") is not None:
                 iv[:, 24:28] = s["emit"].to(dev, torch.int32)
             else:
                 iv[:, 24] = -1
-            tri = s["tri"].to(dev, torch.int32)
-            iv[:, 28] = tri
             if s.get("aux") is not None:
                 aux = s["aux"].to(dev, torch.int32)
                 iv[:, 29:32] = aux[:, 1:4]

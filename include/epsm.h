@@ -30,9 +30,10 @@
 extern "C" {
 #endif
 
-/* Changes when the meaning or signature of an existing entry point changes (4: triangle-id addressing, round 2).  Entry points
- * added since without touching the others: epsm_backward_pass_packed, epsm_release_workspace, epsm_sinkhorn_*. */
-#define EPSM_ABI_VERSION 4
+/* Changes when the meaning or signature of an existing entry point changes (4: triangle-id addressing, round 2; 5: word layout of
+ * the native log's vertex record, round 4 -- EpsmPackedLog below).  Entry points added since without touching the others:
+ * epsm_backward_pass_packed, epsm_release_workspace, epsm_sinkhorn_*, epsm_set_option / epsm_get_option. */
+#define EPSM_ABI_VERSION 5
 
 /* BSDF flag bits tested by the hot path (include/mitsuba/render/bsdf.h:40-46,101). */
 #define EPSM_BSDF_NULL     0x1u
@@ -250,10 +251,13 @@ int epsm_backward_pass(int variant, int64_t N, int K, int64_t path_offset, int s
  *   rays   (N,12) f32   o, d, d_x, d_y of the primary ray (sample_ray_differential)
  *   flags  (N)    u32   5 bits per logged vertex, vertex k at bits 5(k-1)..: 1 = bsdf has a Diffuse lobe, 2 = Null,
  *                       4 = active, 8 = active_em, 16 = ismesh  (the masks of EpsmVertexRecord)
- *   verts  (N,K,32) 32-bit words, record of vertex k of path i at word (i*K + k-1)*32:
- *            0..8   p0 p1 p2          9..17  n0 n1 n2        18 19  b0 b1      20  eta      21..23  light
- *            24..27 etri u32, eb0, eb1, eweight              (EpsmScatterRecord.emit)
- *            28     tri u32 (row of the triangle table)      29..31 d hf / d alpha
+ *   verts  (N,K,32) 32-bit words, record of vertex k of path i at word (i*K + k-1)*32 (16-byte aligned):
+ *            0..8   p0 p1 p2       9 10  b0 b1       11  tri u32 (row of the triangle table)       12..14  n0      15  eta
+ *            16..21 n1 n2          22 23 light.x .y  24..27 etri u32, eb0, eb1, eweight (EpsmScatterRecord.emit)
+ *            28     light.z        29..31 d hf / d alpha
+ *          -- words 0..15 are one 64-byte sector of the record's cache line: all that is read of a vertex that is only the END
+ *          point of a chain or a diffuse first hit (geometry, barycentrics, triangle id) comes with ONE sector (ABI v5; v4 kept
+ *          b0, b1 at 18, 19 and tri at 28: two sectors for such a vertex)
  *          the alpha slot of the vertex's BSDF travels with the triangle: bits 8.. of the table row's mode word hold
  *          slot + 1 (0 = none)
  *   shadow (N,4) as EpsmScatterRecord.shadow, or NULL
