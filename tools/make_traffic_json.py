@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--tag", default="r02")
     ap.add_argument("--packed", action="store_true"); ap.add_argument("--gather-calib", default=None)
     ap.add_argument("--sq-dir", default=None, help="rocprofv3 --pmc run with SQ_INSTS_VALU: stored as sq_insts_valu (bench.py: valu_floor_ms)")
+    ap.add_argument("--rdreq-dir", default=None, help="rocprofv3 --pmc run with TCC_EA0_RDREQ_{32B,64B,128B}_sum: the read traffic is then "
+                    "the requests by size -- no factor, no calibration (FETCH_SIZE tallies every request at 64 B)")
     a = ap.parse_args()
     import bench
     kern = "epsm_backward_cp_kernel"                                        # <VARIANT, DMODE, PACKED, FLOAT_ROWS>
@@ -68,10 +70,19 @@ def main():
         if gv:
             known = (1 << 23) * 128
             factor = known / (sum(gv) / len(gv) * 1024)
-            fnote = (f"x {factor:.3f} (calibrated on tools/micro/gather128 in the kernel's own access pattern -- a one-word touch of every "
-                     f"128-byte record, then per-lane 16-byte gathers: {known / 1e9:.3f} GB read, FETCH_SIZE reported "
-                     f"{sum(gv) / len(gv) * 1024 / 1e9:.3f} GB; without the touch the factor is 2.000)")
+            fnote = (f"x {factor:.3f} (calibrated on tools/micro/gather128: per-lane 16-byte gathers of whole 128-byte records, "
+                     f"{known / 1e9:.3f} GB read, FETCH_SIZE reported {sum(gv) / len(gv) * 1024 / 1e9:.3f} GB)")
     total = int(factor * fetch_kb * 1024 + write_kb * 1024)
+    if a.rdreq_dir:
+        n = {}
+        for size in (32, 64, 128):
+            _, v = pick({k: x for k, x in counters(a.rdreq_dir, f"TCC_EA0_RDREQ_{size}B_sum").items() if kern in k}, needle)
+            n[size] = sum(v) / len(v) if v else None
+        if all(x is not None for x in n.values()):
+            read = 32 * n[32] + 64 * n[64] + 128 * n[128]
+            total = int(read + write_kb * 1024)
+            fnote = (f"tallied at 64 B per request; by request size (TCC_EA0_RDREQ_32B / _64B / _128B_sum = {n[32]:.4g} / {n[64]:.4g} / {n[128]:.4g}) "
+                     f"the reads are {read / 1e9:.3f} GB -- used")
     sq = {}
     if a.sq_dir:
         for name, key in (("SQ_INSTS_VALU", "sq_insts_valu"), ("SQ_INSTS_SALU", "sq_insts_salu"), ("SQ_WAIT_ANY", "sq_wait_any"),
