@@ -545,6 +545,31 @@ EPSM_HD F3 env_eval(const EpsmScene &S, F3 d) {
     const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
     return ld3(t00) * w00 + ld3(t01) * w01 + ld3(t10) * w10 + ld3(t11) * w11;
 }
+// the same with its derivative w.r.t. the world direction (the map is bilinear in (phi, theta): envmap.cpp evaluates it through a
+// differentiable texture lookup, which the reparameterised pass needs where its warp field turns a direction); g[c] = d L_c / d d
+EPSM_HD F3 env_eval_grad(const EpsmScene &S, F3 d, F3 g[3]) {
+    const EpsmEnvironment &E = S.env;
+    g[0] = g[1] = g[2] = zero3<float>();
+    const EpsmEmitter em = S.emitters[E.emitter];
+    if (em.type == EPSM_EMITTER_CONSTANT) return ld3(em.radiance);
+    const F3 v = env_to_local(E, d);
+    float x, y;
+    env_cell_coords(E, v, x, y);
+    const int i = (int) x, j = (int) fminf(y, (float) (E.height - 2));
+    const float fx = x - (float) i, fy = y - (float) j;
+    const int64_t row = (int64_t) (E.width + 1) * 3;
+    const float *t00 = E.texels + j * row + 3 * (int64_t) i, *t01 = t00 + 3, *t10 = t00 + row, *t11 = t10 + 3;
+    const F3 a = ld3(t00), b = ld3(t01), c = ld3(t10), e = ld3(t11);
+    const F3 L = a * ((1.f - fx) * (1.f - fy)) + b * (fx * (1.f - fy)) + c * ((1.f - fx) * fy) + e * (fx * fy);
+    const F3 Lx = (b - a) * (1.f - fy) + (e - c) * fy, Ly = (c - a) * (1.f - fx) + (e - b) * fx;      // per cell coordinate
+    // x = W (atan2(v.x, -v.z) / 2 pi - ...), y = (H - 1) acos(v.y) / pi
+    const float r2 = fmaxf(v.x * v.x + v.z * v.z, 1e-12f);
+    const float xs = (float) E.width * (0.5f / kPi) / r2, ys = -(float) (E.height - 1) * (1.f / kPi) / sqrtf(r2);
+    const float dx_vx = -v.z * xs, dx_vz = v.x * xs, dy_vy = ys;
+    const float Lxc[3] = {Lx.x, Lx.y, Lx.z}, Lyc[3] = {Ly.x, Ly.y, Ly.z};
+    for (int ch = 0; ch < 3; ++ch) g[ch] = env_to_world(E, f3(Lxc[ch] * dx_vx, Lyc[ch] * dy_vy, Lxc[ch] * dx_vz));
+    return L;
+}
 // density, per solid angle, of sample_environment producing the WORLD direction d (the emitter choice not included)
 EPSM_HD float env_pdf(const EpsmScene &S, F3 d) {
     const EpsmEnvironment &E = S.env;

@@ -415,13 +415,32 @@ EPSM_HD T eval_lo(const EpsmScene &S, const Vertex *prev, const Vertex &cur, con
         const V3<T> f = bsdf_eval_t<T>(cur.bsdf, h.wi, wo);
         const F3 k = mul3(mul3(cur.beta, cur.es.weight), dL) * cur.mis_em;
         T em = T(1.f);
+        const bool env_sample = cur.es.emitter >= 0 && !cur.es.delta && cur.es.tri == kNoIndex && has_environment(S) && cur.es.emitter == S.env.emitter;
+        if (env_sample && sd.dem >= 0) {
+            // envmap.cpp:438-443 eval_direction at the reparameterised direction: L(d_em') / L(d_em) per channel, folded into
+            // one factor weighted by what each channel contributes (k . f): d/d d_em of sum_c k_c f_c L_c(d') / L_c
+            F3 g[3];
+            const F3 L0 = env_eval_grad(S, cur.es.d, g);
+            const V3<T> dd = seed3<T>(cur.es.d, sd.dem);
+            const float Lc[3] = {L0.x, L0.y, L0.z};
+            const float kc[3] = {k.x, k.y, k.z};
+            const T fc[3] = {f.x, f.y, f.z};
+            T acc = T(0.f);
+            for (int c2 = 0; c2 < 3; ++c2) {
+                const T ratio = Lc[c2] > 0.f ? T(1.f - dot(g[c2], cur.es.d) / Lc[c2]) + dot3c(g[c2] * (1.f / Lc[c2]), dd) : T(1.f);
+                acc = acc + fc[c2] * T(kc[c2]) * ratio;
+            }
+            s = s + acc;
+        } else
         if (cur.es.delta) {
             // point.cpp:154-164 eval_direction: intensity / |ds.p - it.p|^2 with it = si_cur ATTACHED (an area light's
             // value has no such dependence, area.cpp:182-192; its falloff sits in the detached pdf and the warp's divergence)
             const V3<T> r = lift3<T>(cur.es.p) - h.p;
             em = T(cur.es.dist * cur.es.dist) / dot(r, r);
+            s = s + dot3c(k, f) * em;
+        } else {
+            s = s + dot3c(k, f) * em;
         }
-        s = s + dot3c(k, f) * em;
     }
     // ---- Lr_ind = L * bsdf(wi, to_local(ray_next.d)) / detached (prb_reparam.py:554-568)
     if (cur.bs_valid) {
@@ -607,10 +626,14 @@ EPSM_HD void reparam_one_path(const ReparamArgs &R, int64_t i, const BvhStack &s
         const Vertex *prev = j >= 2 ? &v[(j - 2) % 3] : nullptr;
         if (!cur.valid) {
             // a dead path: every term is zero.  A ray that left the scene towards an environment emitter carries that emitter's
-            // radiance: its warp's divergence multiplies it (prb_reparam.py:341-358 reparameterises every ray before it is known
-            // to hit); the radiance itself is not differentiated w.r.t. the direction.  (The camera ray: below.)
-            if (cur.escaped && prev && has_environment(A.S) && cur.depth < R.cfg.max_depth && (cur.Le.x != 0.f || cur.Le.y != 0.f || cur.Le.z != 0.f))
-                sink.warp(cur.ray.o, cur.ray.d, zero3<float>(), dot(dL, cur.L_in), prev->th.tri, prev->th.u, prev->th.v, 0.f);
+            // radiance: its warp's divergence multiplies it and its direction moves the lookup (prb_reparam.py:341-358
+            // reparameterises every ray before it is known to hit).  (The camera ray: below.)
+            if (cur.escaped && prev && has_environment(A.S) && cur.depth < R.cfg.max_depth && (cur.Le.x != 0.f || cur.Le.y != 0.f || cur.Le.z != 0.f)) {
+                F3 g[3];
+                const F3 L0 = env_eval_grad(A.S, cur.ray.d, g);            // Le = beta mis L(d): d Le / d d = Le / L * grad L, per channel
+                const F3 w = f3(L0.x > 0.f ? dL.x * cur.Le.x / L0.x : 0.f, L0.y > 0.f ? dL.y * cur.Le.y / L0.y : 0.f, L0.z > 0.f ? dL.z * cur.Le.z / L0.z : 0.f);
+                sink.warp(cur.ray.o, cur.ray.d, g[0] * w.x + g[1] * w.y + g[2] * w.z, dot(dL, cur.L_in), prev->th.tri, prev->th.u, prev->th.v, 0.f);
+            }
             continue;
         }
         differential(R, sink, prev, cur, &nx, dL, &g_first);
@@ -619,8 +642,15 @@ EPSM_HD void reparam_one_path(const ReparamArgs &R, int64_t i, const BvhStack &s
             primary_done = true;
         }
     }
-    if (!primary_done && R.cfg.max_depth > 0)                              // the camera ray hit nothing: the film's term alone
-        sink.warp(pr.ray.o, pr.ray.d, g_film, g_det_film, kNoIndex, 0.f, 0.f, 0.f);
+    if (!primary_done && R.cfg.max_depth > 0) {                            // the camera ray hit nothing: the film's term, and the
+        F3 g_env = zero3<float>();                                         // environment's radiance along the reparameterised ray
+        if (has_environment(A.S)) {
+            F3 g[3];
+            env_eval_grad(A.S, pr.ray.d, g);
+            g_env = g[0] * dL.x + g[1] * dL.y + g[2] * dL.z;
+        }
+        sink.warp(pr.ray.o, pr.ray.d, g_film + g_env, g_det_film, kNoIndex, 0.f, 0.f, 0.f);
+    }
 }
 
 }  // namespace rp

@@ -37,6 +37,14 @@ def rect(half=1.0, center=(0, 0, 0), normal="+z"):
     return v + np.asarray(center, float), f
 
 
+def gradient_map(H=24, W=48):
+    """A smooth lat-long map with a strong dependence on direction (factor ~6 between its sides) and no symmetry."""
+    j, i = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    th, ph = np.pi * j / (H - 1), 2 * np.pi * (i + 0.5) / W
+    a = np.stack([1.0 + 0.8 * np.cos(ph) * np.sin(th), 0.8 + 0.6 * np.cos(th), 0.7 + 0.6 * np.sin(ph + 0.7) * np.sin(th)], -1)
+    return a.astype(np.float32)
+
+
 CONFIGS = {
     # TranslateRectangleEmitterOnBlackConfig (:383-410): an emitting rectangle, partly in view, on black
     "rectangle_emitter_on_black": dict(max_depth=2, moving=["light"], fd_eps=1e-3),
@@ -70,6 +78,10 @@ CONFIGS = {
     "shadow_receiver_constant": dict(max_depth=2, moving=["plane"], fd_eps=1e-3),
     # TranslateSphereOnGlossyFloorConfig (:600-637) as stated: constant emitter of radiance 1
     "sphere_on_glossy_floor_constant": dict(max_depth=3, moving=["sphere"], fd_eps=1e-3, kappa=2e5),
+    # the first of them under an `envmap` whose radiance varies strongly with direction: the background behind the silhouette
+    # and the light on the body both depend on where the reparameterised rays point
+    "diffuse_sphere_envmap": dict(max_depth=2, moving=["sphere"], fd_eps=1e-3),
+    "glossy_sphere_envmap": dict(max_depth=2, moving=["sphere"], fd_eps=1e-3),
 }
 
 
@@ -173,6 +185,11 @@ def build(name, theta=0.0, res=32, spp=64, device="cpu", theta_n=0.0):
         d["sphere"] = {"type": "mesh", "vertices": v + off, "normals": n, "faces": f,
                        "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 0.5, 0.0]}}}
         d["light"] = {"type": "constant", "radiance": 1.0}
+    elif name in ("diffuse_sphere_envmap", "glossy_sphere_envmap"):
+        v, n, f = sphere(1.0, (0, 0, 0))
+        bsdf = white if name.startswith("diffuse") else {"type": "roughconductor", "alpha": 0.3, "distribution": "ggx"}
+        d["sphere"] = {"type": "mesh", "vertices": v + off, "normals": n, "faces": f, "bsdf": bsdf}
+        d["light"] = {"type": "envmap", "bitmap": gradient_map(), "to_world": S.rotate([0.3, 1.0, 0.2], 40.0)}
     else:
         raise KeyError(name)
     if theta_n:

@@ -98,6 +98,19 @@ extern "C" int epsm_debug_warp(const EpsmScene *scene, const float *o, const flo
     out[4] = W.Z;
     return 0;
 }
+// Test probe: the environment's radiance along d, its derivative w.r.t. d (3 x 3, row c = d L_c / d d) and the sampling density:
+// out = [L (3), dL/dd (9), pdf]
+extern "C" int epsm_debug_env(const EpsmScene *scene, const float *d, float *out) {
+    if (!has_environment(*scene)) return -22;
+    F3 g[3];
+    const F3 L = env_eval_grad(*scene, ld3(d), g);
+    const F3 L2 = env_eval(*scene, ld3(d));
+    if (L.x != L2.x || L.y != L2.y || L.z != L2.z) return -1;
+    out[0] = L.x; out[1] = L.y; out[2] = L.z;
+    for (int c = 0; c < 3; ++c) { out[3 + 3 * c] = g[c].x; out[4 + 3 * c] = g[c].y; out[5 + 3 * c] = g[c].z; }
+    out[12] = env_pdf(*scene, ld3(d));
+    return 0;
+}
 // Test probe: the hand-written ADJOINT of the same warp (same seed -> same auxiliary rays): d loss / d ray.o for given
 // d loss / d direction and d loss / d divergence.  No mesh need be attached: grad_pos may be null-sized.
 extern "C" int epsm_debug_warp_adjoint(const EpsmScene *scene, const float *o, const float *d, const float *g_dir, float g_div, int rays,

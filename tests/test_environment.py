@@ -191,3 +191,47 @@ def test_logged_emitter_sample_is_the_far_point():
     assert torch.allclose(dist, want, rtol=1e-4), (dist[:4], want[:4])
     emit = tr.scatter_info[0]["emit"][act]
     assert bool((emit[:, 0] == -1).all() or (emit[:, 0].to(torch.int64) & 0xFFFFFFFF == 0xFFFFFFFF).all())
+
+
+def test_radiance_gradient_and_density_of_the_map():
+    """`env_eval_grad` (what prb_reparam needs where its warp field turns a direction: envmap.cpp evaluates the map through a
+    differentiable lookup) against central differences of `env_eval` along the sphere, and `env_pdf` as a density: it integrates
+    to one over the sphere and is proportional to luminance x (what a cell's corners average to)."""
+    import ctypes as C
+    from _scenes import host_tracer
+    bm = smooth_map(patch=False)
+    tw = rot((0.3, 1.0, 0.2), 37.0)
+    d = {"type": "scene", "cam": sensor([0, 0, 4], [0, 0, 0], res=8),
+         "sky": {"type": "envmap", "bitmap": bm, "to_world": tw}}
+    sc = on_host(S.Scene.from_dict(d, device="cpu"))
+    lib = host_tracer()
+    out = (C.c_float * 13)()
+    rng = np.random.default_rng(3)
+
+    def ev(v):
+        v = (v / np.linalg.norm(v)).astype(np.float32)
+        assert lib.epsm_debug_env(C.byref(sc.c_scene), v.ctypes.data_as(C.c_void_p), out) == 0
+        return np.array(out[:], np.float64)
+
+    worst = 0.0
+    for _ in range(40):
+        v = rng.normal(size=3); v /= np.linalg.norm(v)
+        if abs((v @ tw[:3, :3])[1]) > 0.95:                              # (the poles of the map: d phi / d d is unbounded there)
+            continue
+        r = ev(v)
+        L, G = r[:3], r[3:12].reshape(3, 3)
+        assert np.allclose(L, lookup(bm, v, tw[:3, :3]), rtol=2e-5)
+        t = np.cross(v, rng.normal(size=3)); t /= np.linalg.norm(t)
+        h = 2e-3                                                          # inside one cell of the 64 x 32 map most of the time
+        fd = (ev(v + h * t)[:3] - ev(v - h * t)[:3]) / (2 * h)
+        worst = max(worst, float(np.abs(G @ t - fd).max() / (np.abs(fd).max() + 0.05)))
+    assert worst < 0.08, worst                                           # (a difference that straddles a cell edge sees two slopes)
+    n = 256
+    th = (np.arange(n) + 0.5) * math.pi / n
+    ph = (np.arange(2 * n) + 0.5) * math.pi / n
+    tot = 0.0
+    for a in th[::8]:
+        for b in ph[::8]:
+            tot += ev(np.array([math.sin(a) * math.cos(b), math.sin(a) * math.sin(b), math.cos(a)]))[12] * math.sin(a)
+    tot *= (8 * math.pi / n) ** 2
+    assert abs(tot - 1.0) < 0.02, tot
