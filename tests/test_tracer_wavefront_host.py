@@ -211,3 +211,35 @@ def test_packed_log_is_the_per_field_log_in_another_layout(tracer, max_depth, K,
         assert torch.equal(want.shadow, got.shadow)
     else:
         assert got.shadow is None
+
+
+def test_packed_record_words_are_where_the_header_says():
+    """include/epsm.h, EpsmPackedLog (ABI v5): p0 p1 p2 at 0..8, b0 b1 at 9, 10, the triangle id at 11, n0 at 12..14, eta at 15 -- the
+    first 64-byte sector --, n1 n2 at 16..21, light at 22, 23 and 28, the emitter sample at 24..27, d hf / d alpha at 29..31; checked
+    word by word against the per-field log of the same trace."""
+    res, spp, K = 12, 8, 3
+    sc = _rich_scene(res, spp, point_light=False, occluder=True)
+    sc.tracer = "mega"
+    n = res * res * spp
+    a = sc._trace(0, seed=5, spp=spp, max_depth=4, K=K, lo=0, hi=n)
+    b = sc._trace_packed(0, seed=5, spp=spp, max_depth=4, K=K, lo=0, hi=n).log
+    w = b.verts
+    iw = w.view(torch.int32)
+    seen = 0
+    for k in range(K):
+        r, s = a.path_info[k + 1], a.scatter_info[k]
+        live = r["active"].bool()
+        seen += int(live.sum())
+        f = lambda t: t[live].float()
+        for j in range(3):
+            assert torch.equal(w[live, k, 3 * j: 3 * j + 3], f(r["points"][j]))
+        assert torch.equal(w[live, k, 9], f(r["uv"][0])) and torch.equal(w[live, k, 10], f(r["uv"][1]))
+        assert torch.equal(iw[live, k, 11], s["tri"][live].to(torch.int32))
+        assert torch.equal(w[live, k, 12:15], f(r["normals"][0])) and torch.equal(w[live, k, 15], f(r["eta"]))
+        assert torch.equal(w[live, k, 16:19], f(r["normals"][1])) and torch.equal(w[live, k, 19:22], f(r["normals"][2]))
+        light = f(r["light"])
+        assert torch.equal(w[live, k, 22:24], light[:, :2]) and torch.equal(w[live, k, 28], light[:, 2])
+        assert torch.equal(iw[live, k, 24:28], s["emit"][live].to(torch.int32))
+        if s.get("aux") is not None:
+            assert torch.equal(iw[live, k, 29:32], s["aux"][live][:, 1:4].to(torch.int32))
+    assert seen > n
