@@ -982,6 +982,9 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
         if (si.valid && si.emitter >= 0) {
             const int se = S.emitters[si.emitter].color_slot;
             if (se >= 0 && se < A.n_color) { G[3 * se] += Le.x; G[3 * se + 1] += Le.y; G[3 * se + 2] += Le.z; }
+        } else if (!si.valid && has_environment(S)) {                     // the ray left the scene: Le is the environment's
+            const int se = S.emitters[S.env.emitter].color_slot;
+            if (se >= 0 && se < A.n_color) { G[3 * se] += Le.x; G[3 * se + 1] += Le.y; G[3 * se + 2] += Le.z; }
         }
         if (es.emitter >= 0) {
             const int se = S.emitters[es.emitter].color_slot;

@@ -747,6 +747,8 @@ class Scene:
         i = mesh_or_index if isinstance(mesh_or_index, int) else self.mesh(mesh_or_index).emitter
         if not (0 <= i < len(self.emitter_desc)):
             raise ValueError("attach_radiance: not an emitter")
+        if self.emitter_desc[i]["type"] == 3:
+            raise ValueError("attach_radiance: an envmap's radiance is its bitmap (not a colour parameter here); a `constant` emitter's is")
         if ("emitter", i) not in self.color_slots:
             if len(self.color_slots) >= 4:
                 raise ValueError("at most 4 colour parameters")

@@ -31,22 +31,46 @@ def make_scene(device="cpu", res=16, spp=64, rfilter="gaussian", floor=(0.6, 0.4
     return sc
 
 
-def fd_check(sc, res, spp, max_depth, seed=3, h=2e-3):
+def make_constant_scene(device="cpu", res=16, spp=64, albedo=(0.6, 0.4, 0.3), sky=(1.0, 0.8, 1.5)):
+    """DiffuseAlbedoConfig / DiffuseAlbedoGIConfig / ConstantEmitterRadianceConfig of the reference's list
+    (test_ad_integrators.py:116-160, 232-247): diffuse geometry under a `constant` environment emitter -- the derivative w.r.t.
+    the albedo and w.r.t. the emitter's radiance (slot 1, a scale of it: `set_color` keeps the chromaticity test simple)."""
+    fv, ff = quad(0.0, 1.5, up=True)
+    wv = np.array([[-1.5, 1.5, 0], [1.5, 1.5, 0], [1.5, 1.5, 2.0], [-1.5, 1.5, 2.0]], float)
+    wf = np.array([[0, 2, 1], [0, 3, 2]])
+    bsdf = {"type": "twosided", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": list(albedo)}}}
+    d = {"type": "scene", "cam": sensor([0.0, -3.5, 1.6], [0, 0.5, 0.5], up=(0, 0, 1), res=res, spp=spp, rfilter="gaussian"),
+         "floor": {"type": "mesh", "vertices": fv, "faces": ff, "face_normals": True, "bsdf": bsdf},
+         "wall": {"type": "mesh", "vertices": wv, "faces": wf, "face_normals": True, "bsdf": bsdf},
+         "sky": {"type": "constant", "radiance": {"type": "rgb", "value": list(sky)}}}
+    sc = S.Scene.from_dict(d, device=device)
+    if str(device) == "cpu":
+        on_host(sc)
+    sc.tracer = "mega"
+    return sc
+
+
+def fd_check(sc, res, spp, max_depth, seed=3, h=2e-3, attach=None):
     integ = epsm.load_dict({"type": "prb_reparam", "max_depth": max_depth})
     assert isinstance(integ, epsm.integrators.PRBIntegrator) and integ.reparam is True      # the colour adjoint is its base class
-    slots = [sc.attach_color("floor.bsdf"), sc.attach_color("wall.bsdf"), sc.attach_radiance("light")]
-    assert slots == [0, 1, 2]
+    if attach is not None:
+        slots = attach(sc)
+        n_slots = len(slots)
+    else:
+        slots = [sc.attach_color("floor.bsdf"), sc.attach_color("wall.bsdf"), sc.attach_radiance("light")]
+        assert slots == [0, 1, 2]
+        n_slots = 3
     g = torch.Generator().manual_seed(1)
     grad_in = (0.5 + torch.rand((res, res, 3), generator=g)).to(sc.device)
     img = integ.render(sc, sensor=0, seed=seed, spp=spp)
     assert tuple(img.shape) == (res, res, 3) and float(img.max()) > 0
     params = sc.param_grads()
-    assert tuple(params.color.shape) == (3, 3)
+    assert tuple(params.color.shape) == (n_slots, 3)
     integ.render_backward(sc, params, grad_in, sensor=0, seed=seed, spp=spp)
     got = params.color.clone().cpu()
     vals = sc.color_values().cpu()
     want = torch.zeros_like(got)
-    for j in range(3):
+    for j in range(n_slots):
         for c in range(3):
             out = []
             for sgn in (+1, -1):
@@ -67,6 +91,16 @@ def test_color_adjoint_matches_finite_differences_on_the_host_tracer(rfilter, ma
     assert float(want.abs().min()) > 0                       # every parameter matters in this scene
     assert float(rel.mean()) < 0.05 and float(rel.max()) < 0.5, (got, want)      # the reference's thresholds
     assert float(rel.max()) < 0.02, (got, want)              # radiance is multiplicative in these parameters: FD is exact up to fp32
+
+
+@pytest.mark.parametrize("max_depth", [2, 3])
+def test_albedo_and_radiance_under_a_constant_environment(max_depth):
+    res, spp = 12, 48
+    sc = make_constant_scene("cpu", res, spp)
+    env = next(i for i, e in enumerate(sc.emitter_desc) if e["type"] == 2)
+    got, want, rel = fd_check(sc, res, spp, max_depth, attach=lambda s_: [s_.attach_color("floor.bsdf"), s_.attach_radiance(env)])
+    assert float(want.abs().min()) > 0
+    assert float(rel.max()) < 0.02, (got, want)
 
 
 def test_accumulation_and_registry():
