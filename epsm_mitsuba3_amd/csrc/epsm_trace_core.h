@@ -251,6 +251,7 @@ struct SurfHit {
     F3 p, n, shn, fs, ft;             // position, geometric normal, shading frame (s, t, n)
     F3 p0, p1, p2, n0, n1, n2;        // logged triangle (normals post-flip, flat: n0=n1=n2=n)
     F3 wi;                            // -ray.d in the shading frame
+    float uvx, uvy;                   // si.uv: interpolated texture coordinates, (b1, b2) for a mesh without any (mesh.cpp:736-745)
 };
 EPSM_HD F3 to_local(const SurfHit &h, F3 v) { return f3(dot(v, h.fs), dot(v, h.ft), dot(v, h.shn)); }
 EPSM_HD F3 to_world(const SurfHit &h, F3 v) { return h.fs * v.x + h.ft * v.y + h.shn * v.z; }
@@ -264,6 +265,7 @@ EPSM_HD SurfHit surface_interaction(const EpsmScene &S, const Ray &r, const TriH
     h.b0 = h.b1 = h.b2 = 0.f;
     h.p = h.n = h.shn = h.fs = h.ft = h.wi = zero3<float>();
     h.p0 = h.p1 = h.p2 = h.n0 = h.n1 = h.n2 = zero3<float>();
+    h.uvx = h.uvy = 0.f;
     if (!th.hit) return h;
     const uint32_t *iv = S.tri + 3 * (int64_t) th.tri;
     h.vi[0] = iv[0]; h.vi[1] = iv[1]; h.vi[2] = iv[2];
@@ -274,6 +276,11 @@ EPSM_HD SurfHit surface_interaction(const EpsmScene &S, const Ray &r, const TriH
     h.p1 = ld3(S.positions + 3 * (int64_t) iv[1]);
     h.p2 = ld3(S.positions + 3 * (int64_t) iv[2]);
     h.b1 = th.u; h.b2 = th.v; h.b0 = 1.f - th.u - th.v;
+    h.uvx = h.b1; h.uvy = h.b2;
+    if ((m.flags & EPSM_MESH_HAS_UV) && S.texcoords) {
+        const float *t0 = S.texcoords + 2 * (int64_t) iv[0], *t1 = S.texcoords + 2 * (int64_t) iv[1], *t2 = S.texcoords + 2 * (int64_t) iv[2];
+        h.uvx = t0[0] * h.b0 + t1[0] * h.b1 + t2[0] * h.b2; h.uvy = t0[1] * h.b0 + t1[1] * h.b1 + t2[1] * h.b2;
+    }
     h.p = h.p0 * h.b0 + h.p1 * h.b1 + h.p2 * h.b2;                       // mesh.cpp:709
     h.n = normalize3(cross(h.p1 - h.p0, h.p2 - h.p0));                   // mesh.cpp:729
     if (m.flags & EPSM_MESH_VERTEX_NORMALS) {                           // mesh.cpp:784-790
@@ -493,6 +500,30 @@ EPSM_HD void bsdf_eval_pdf(const EpsmBsdf &b, F3 wi, F3 wo, F3 &value, float &pd
         value = mul3(fresnel_conductor3(dot(wi, H), b), ld3(b.reflectance)) * result;
         pdf = mf_pdf(b, wi, H) / (4.f * dot(wo, H));
     }
+}
+
+// ---------------------------------------------------------------------------
+// `bitmap` textures (src/textures/bitmap.cpp:366-418, 585-625): value at (u, v) and -- for the reparameterised pass, where the
+// point a ray sees slides over the texture -- its derivative w.r.t. (u, v)
+// ---------------------------------------------------------------------------
+EPSM_HD int tex_wrap(int i, int n) { int r = i % n; return r < 0 ? r + n : r; }
+EPSM_HD F3 tex_eval(const EpsmTexture &T, float u, float v, F3 *du = nullptr, F3 *dv = nullptr) {
+    const float x = u * (float) T.width - 0.5f, y = v * (float) T.height - 0.5f;
+    if (du) *du = zero3<float>();
+    if (dv) *dv = zero3<float>();
+    if (T.nearest) {
+        const int i = tex_wrap((int) floorf(x + 0.5f), T.width), j = tex_wrap((int) floorf(y + 0.5f), T.height);
+        return ld3(T.texels + 3 * ((int64_t) j * T.width + i));
+    }
+    const float fxf = floorf(x), fyf = floorf(y);
+    const int i0 = tex_wrap((int) fxf, T.width), j0 = tex_wrap((int) fyf, T.height), i1 = tex_wrap((int) fxf + 1, T.width),
+              j1 = tex_wrap((int) fyf + 1, T.height);
+    const float fx = x - fxf, fy = y - fyf;
+    const F3 a = ld3(T.texels + 3 * ((int64_t) j0 * T.width + i0)), b = ld3(T.texels + 3 * ((int64_t) j0 * T.width + i1)),
+             c = ld3(T.texels + 3 * ((int64_t) j1 * T.width + i0)), e = ld3(T.texels + 3 * ((int64_t) j1 * T.width + i1));
+    if (du) *du = ((b - a) * (1.f - fy) + (e - c) * fy) * (float) T.width;
+    if (dv) *dv = ((c - a) * (1.f - fx) + (e - b) * fx) * (float) T.height;
+    return a * ((1.f - fx) * (1.f - fy)) + b * (fx * (1.f - fy)) + c * ((1.f - fx) * fy) + e * (fx * fy);
 }
 
 // ---------------------------------------------------------------------------
@@ -910,9 +941,13 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
     bsdf.type = EPSM_BSDF_DIFFUSE_T; bsdf.twosided = 0; bsdf.distr = 0; bsdf.sample_visible = 1; bsdf.alpha = 0.1f;
     bsdf.reflectance[0] = bsdf.reflectance[1] = bsdf.reflectance[2] = 0.f;
     bsdf.eta[0] = bsdf.eta[1] = bsdf.eta[2] = 0.f; bsdf.k[0] = bsdf.k[1] = bsdf.k[2] = 1.f;
-    bsdf.int_ior = 1.5046f; bsdf.ext_ior = 1.000277f; bsdf.alpha_slot = -1; bsdf.color_slot = -1;
+    bsdf.int_ior = 1.5046f; bsdf.ext_ior = 1.000277f; bsdf.alpha_slot = -1; bsdf.color_slot = -1; bsdf.texture = -1; bsdf.pad = 0;
     uint32_t flags = 0;
     if (si.valid && si.bsdf >= 0) { bsdf = S.bsdfs[si.bsdf]; flags = bsdf_flags(bsdf); }
+    if (si.valid && bsdf.texture >= 0 && bsdf.texture < S.n_textures) {   // the reflectance at this point: everything below sees it as a constant
+        const F3 r = tex_eval(S.textures[bsdf.texture], si.uvx, si.uvy);
+        bsdf.reflectance[0] = r.x; bsdf.reflectance[1] = r.y; bsdf.reflectance[2] = r.z;
+    }
 
     // ---- direct emission, MIS against the emitter sample of the previous bounce (epsm.py:569-577)
     F3 Le = zero3<float>();

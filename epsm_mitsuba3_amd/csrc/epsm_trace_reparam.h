@@ -76,7 +76,7 @@ template <class T> EPSM_HD void t_coordinate_system(V3<T> n, V3<T> &s, V3<T> &t)
 // ---------------------------------------------------------------------------
 // the surface interaction as a function of (ray, triangle) -- mesh.cpp:652-827
 // ---------------------------------------------------------------------------
-template <class T> struct SurfT { V3<T> p, n, shn, fs, ft, wi; T t; };
+template <class T> struct SurfT { V3<T> p, n, shn, fs, ft, wi; T t, bu, bv; };      // bu, bv: the weights of p1, p2 (prim_uv)
 template <class T> EPSM_HD V3<T> to_local_t(const SurfT<T> &h, V3<T> v) { return mk3<T>(dot(v, h.fs), dot(v, h.ft), dot(v, h.shn)); }
 
 // `u0, v0, t0`: the primal hit (prim_uv, t of the preliminary intersection: the derivative rides on them, mesh.cpp:690-695)
@@ -93,6 +93,7 @@ EPSM_HD SurfT<T> surf_t(V3<T> o, V3<T> d, V3<T> P0, V3<T> P1, V3<T> P2, V3<T> N0
     const T v = replace_value(dot(d, qvec) * inv_det, v0);
     h.t = replace_value(dot(e2, qvec) * inv_det, t0);
     const T b0 = T(1.f) - u - v;
+    h.bu = u; h.bv = v;
     h.p = P0 * b0 + P1 * u + P2 * v;                                      // mesh.cpp:709
     h.n = t_normalize(cross(e1, e2));                                     // :729
     if (mesh_flags & EPSM_MESH_VERTEX_NORMALS) h.shn = t_normalize(N0 * b0 + N1 * u + N2 * v);     // :784-790
@@ -409,10 +410,27 @@ EPSM_HD T eval_lo(const EpsmScene &S, const Vertex *prev, const Vertex &cur, con
     const V3<T> N0 = seed3<T>(c.n0 * fl, sd.Nn[0]), N1 = seed3<T>(c.n1 * fl, sd.Nn[1]), N2 = seed3<T>(c.n2 * fl, sd.Nn[2]);
     const SurfT<T> h = surf_t<T>(o, d, P0, P1, P2, N0, N1, N2, c.mesh_flags, cur.th.u, cur.th.v, cur.th.t);
     T s = T(0.f);
+    // ---- a `bitmap` reflectance follows the point the ray sees: rho(uv') / rho(uv) per channel multiplies both BSDF values below
+    //      (bitmap.cpp:366-418: the texture lookup is attached to si.uv, mesh.cpp:736-745)
+    V3<T> tex = mk3<T>(T(1.f), T(1.f), T(1.f));
+    if (cur.bsdf.texture >= 0 && cur.bsdf.texture < S.n_textures && cur.bsdf.type == EPSM_BSDF_DIFFUSE_T) {
+        float a0[2] = {0.f, 0.f}, a1[2] = {1.f, 0.f}, a2[2] = {0.f, 1.f};                    // no texture coordinates: uv = (b1, b2)
+        if ((c.mesh_flags & EPSM_MESH_HAS_UV) && S.texcoords)
+            for (int j = 0; j < 2; ++j) { a0[j] = S.texcoords[2 * (int64_t) c.vi[0] + j]; a1[j] = S.texcoords[2 * (int64_t) c.vi[1] + j]; a2[j] = S.texcoords[2 * (int64_t) c.vi[2] + j]; }
+        const T b0 = T(1.f) - h.bu - h.bv;
+        const T uu = b0 * T(a0[0]) + h.bu * T(a1[0]) + h.bv * T(a2[0]), vv = b0 * T(a0[1]) + h.bu * T(a1[1]) + h.bv * T(a2[1]);
+        F3 du, dv;
+        const F3 r0 = tex_eval(S.textures[cur.bsdf.texture], c.uvx, c.uvy, &du, &dv);
+        const T eu = uu - T(c.uvx), ev = vv - T(c.uvy);                    // zero value, the derivative of uv
+        if (r0.x > 0.f) tex.x = T(1.f) + (eu * T(du.x) + ev * T(dv.x)) * T(1.f / r0.x);
+        if (r0.y > 0.f) tex.y = T(1.f) + (eu * T(du.y) + ev * T(dv.y)) * T(1.f / r0.y);
+        if (r0.z > 0.f) tex.z = T(1.f) + (eu * T(du.z) + ev * T(dv.z)) * T(1.f / r0.z);
+    }
     // ---- Lr_dir = beta * mis * bsdf(wi, to_local(d_em')) * em_weight (prb_reparam.py:413-418)
     if (cur.active_em && (cur.Lr_dir.x != 0.f || cur.Lr_dir.y != 0.f || cur.Lr_dir.z != 0.f)) {
         const V3<T> wo = to_local_t(h, seed3<T>(cur.es.d, sd.dem));
-        const V3<T> f = bsdf_eval_t<T>(cur.bsdf, h.wi, wo);
+        const V3<T> f0_ = bsdf_eval_t<T>(cur.bsdf, h.wi, wo);
+        const V3<T> f = mk3<T>(f0_.x * tex.x, f0_.y * tex.y, f0_.z * tex.z);
         const F3 k = mul3(mul3(cur.beta, cur.es.weight), dL) * cur.mis_em;
         T em = T(1.f);
         const bool env_sample = cur.es.emitter >= 0 && !cur.es.delta && cur.es.tri == kNoIndex && has_environment(S) && cur.es.emitter == S.env.emitter;
@@ -445,7 +463,8 @@ EPSM_HD T eval_lo(const EpsmScene &S, const Vertex *prev, const Vertex &cur, con
     // ---- Lr_ind = L * bsdf(wi, to_local(ray_next.d)) / detached (prb_reparam.py:554-568)
     if (cur.bs_valid) {
         const V3<T> wo = to_local_t(h, lift3<T>(cur.wo_world));
-        const V3<T> f = bsdf_eval_t<T>(cur.bsdf, h.wi, wo);
+        const V3<T> f1_ = bsdf_eval_t<T>(cur.bsdf, h.wi, wo);
+        const V3<T> f = mk3<T>(f1_.x * tex.x, f1_.y * tex.y, f1_.z * tex.z);
         const F3 den = cur.bs.weight * cur.bs.pdf;                         // bsdf_weight * bsdf_sample.pdf
         const V3<T> r = mk3<T>(den.x != 0.f ? f.x * T(cur.L_after.x / den.x) : T(0.f), den.y != 0.f ? f.y * T(cur.L_after.y / den.y) : T(0.f),
                                den.z != 0.f ? f.z * T(cur.L_after.z / den.z) : T(0.f));

@@ -26,7 +26,7 @@ from . import _lib
 from . import dist as _dist
 from .params import ParamGrads
 
-MESH_VERTEX_NORMALS, MESH_FLIP_NORMALS, MESH_POS_ATTACHED, MESH_NRM_ATTACHED, MESH_IS_MESH = 1, 2, 4, 8, 16
+MESH_VERTEX_NORMALS, MESH_FLIP_NORMALS, MESH_POS_ATTACHED, MESH_NRM_ATTACHED, MESH_IS_MESH, MESH_HAS_UV = 1, 2, 4, 8, 16, 32
 BSDF_TYPES = {"diffuse": 0, "conductor": 1, "roughconductor": 2, "dielectric": 3}
 
 # complex IORs at R,G,B for the `material` names the experiments use (approximate: Mitsuba
@@ -54,7 +54,12 @@ class EpsmMesh(C.Structure):
 class EpsmBsdf(C.Structure):
     _fields_ = [("type", C.c_uint32), ("twosided", C.c_uint32), ("distr", C.c_uint32), ("sample_visible", C.c_uint32),
                 ("reflectance", C.c_float * 3), ("alpha", C.c_float), ("eta", C.c_float * 3), ("k", C.c_float * 3),
-                ("int_ior", C.c_float), ("ext_ior", C.c_float), ("alpha_slot", C.c_int32), ("color_slot", C.c_int32)]
+                ("int_ior", C.c_float), ("ext_ior", C.c_float), ("alpha_slot", C.c_int32), ("color_slot", C.c_int32),
+                ("texture", C.c_int32), ("pad", C.c_uint32)]
+
+
+class EpsmTexture(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("nearest", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class EpsmEmitter(C.Structure):
@@ -79,7 +84,8 @@ class EpsmSceneC(C.Structure):
                 ("meshes", C.c_void_p), ("n_meshes", C.c_int32), ("bsdfs", C.c_void_p), ("n_bsdfs", C.c_int32),
                 ("emitters", C.c_void_p), ("n_emitters", C.c_int32), ("emitter_cdf", C.c_void_p),
                 ("bvh", C.c_void_p), ("n_nodes", C.c_int32), ("prim_index", C.c_void_p), ("tri_verts", C.c_void_p),
-                ("n_vertices", C.c_int64), ("n_triangles", C.c_int64), ("env", EpsmEnvironment)]
+                ("n_vertices", C.c_int64), ("n_triangles", C.c_int64), ("env", EpsmEnvironment),
+                ("texcoords", C.c_void_p), ("textures", C.c_void_p), ("n_textures", C.c_int32)]
 
 
 class EpsmRecordOut(C.Structure):
@@ -134,8 +140,11 @@ def _xform_point(m, p):
 
 
 # ---------------------------------------------------------------------------- meshes
-def load_obj(path: str):
-    """Minimal Wavefront OBJ reader: v / vn / f (triangulated fans), vertices merged per (v, vn) pair."""
+def load_obj(path: str, with_uv: bool = False):
+    """Minimal Wavefront OBJ reader: v / vn / f (triangulated fans), vertices merged per (v, vn) pair.  ``with_uv``: also
+    vt, vertices merged per (v, vt, vn) triple, v flipped as obj.cpp:267 does -- returns (v, n, f, uv)."""
+    if with_uv:
+        return _load_obj_uv(path)
     vs, vns, key_to_idx, out_v, out_n, faces = [], [], {}, [], [], []
     with open(path) as f:
         for line in f:
@@ -165,6 +174,37 @@ def load_obj(path: str):
     n = np.asarray(out_n, dtype=np.float64).reshape(-1, 3)
     has_n = len(vns) > 0
     return v, (n if has_n else None), np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+
+
+def _load_obj_uv(path: str):
+    vs, vts, vns, key_to_idx, out_v, out_t, out_n, faces = [], [], [], {}, [], [], [], []
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                vs.append([float(x) for x in t[1:4]])
+            elif t[0] == "vt":
+                vts.append([float(t[1]), 1.0 - float(t[2])])
+            elif t[0] == "vn":
+                vns.append([float(x) for x in t[1:4]])
+            elif t[0] == "f":
+                idx = []
+                for tok in t[1:]:
+                    parts = tok.split("/") + ["", ""]
+                    rel = lambda x, n: (int(x) - 1 if int(x) > 0 else n + int(x)) if x else None
+                    key = (rel(parts[0], len(vs)), rel(parts[1], len(vts)), rel(parts[2], len(vns)))
+                    if key not in key_to_idx:
+                        key_to_idx[key] = len(out_v)
+                        out_v.append(vs[key[0]]); out_t.append(vts[key[1]] if key[1] is not None else [0.0, 0.0])
+                        out_n.append(vns[key[2]] if key[2] is not None else [0.0, 0.0, 0.0])
+                    idx.append(key_to_idx[key])
+                for j in range(1, len(idx) - 1):
+                    faces.append([idx[0], idx[j], idx[j + 1]])
+    n = np.asarray(out_n, dtype=np.float64).reshape(-1, 3)
+    return (np.asarray(out_v, dtype=np.float64).reshape(-1, 3), (n if vns else None), np.asarray(faces, dtype=np.int64).reshape(-1, 3),
+            (np.asarray(out_t, dtype=np.float64).reshape(-1, 2) if vts else None))
 
 
 _PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",
@@ -266,8 +306,9 @@ def vertex_normals_torch(v: torch.Tensor, f: torch.Tensor) -> torch.Tensor:
 
 
 class Mesh:
-    def __init__(self, name, v, f, n=None, bsdf=0, emitter=-1, flip_normals=False, is_mesh=True, face_normals=False):
+    def __init__(self, name, v, f, n=None, bsdf=0, emitter=-1, flip_normals=False, is_mesh=True, face_normals=False, uv=None):
         self.name = name
+        self.uv = None if uv is None else np.asarray(uv, dtype=np.float64).reshape(-1, 2)
         self.v = np.asarray(v, dtype=np.float64).reshape(-1, 3)
         self.f = np.asarray(f, dtype=np.int64).reshape(-1, 3)
         self.face_normals = face_normals
@@ -282,7 +323,7 @@ class Mesh:
     def flags(self) -> int:
         return ((MESH_VERTEX_NORMALS if self.has_normals else 0) | (MESH_FLIP_NORMALS if self.flip_normals else 0) |
                 (MESH_POS_ATTACHED if self.pos_attached else 0) | (MESH_NRM_ATTACHED if self.nrm_attached else 0) |
-                (MESH_IS_MESH if self.is_mesh else 0))
+                (MESH_IS_MESH if self.is_mesh else 0) | (MESH_HAS_UV if self.uv is not None else 0))
 
 
 # ---------------------------------------------------------------------------- BVH
@@ -500,6 +541,29 @@ def _rgb(x, default):
     return np.repeat(a, 3) if a.size == 1 else a[:3]
 
 
+def _bitmap_texture(val: dict, base_dir: str) -> dict:
+    """A ``bitmap`` texture (src/textures/bitmap.cpp) as linear RGB: ``bitmap`` / ``data`` (an array) or ``filename`` (.npy --
+    no image readers here; the reference's .jpg / .png textures are not part of the repository), ``filter_type`` bilinear
+    (default) or nearest, ``wrap_mode`` repeat."""
+    a = val.get("bitmap", val.get("data"))
+    if a is None:
+        fn = val.get("filename")
+        if fn is None or not fn.endswith(".npy"):
+            raise ValueError(f"bitmap: give 'bitmap' (an array) or a .npy 'filename' (got {fn!r}: no image readers here)")
+        a = np.load(os.path.join(base_dir, fn))
+    a = np.asarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a, dtype=np.float32)
+    if a.ndim == 2:
+        a = np.repeat(a[:, :, None], 3, axis=2)
+    if a.ndim != 3 or a.shape[2] < 3:
+        raise ValueError("bitmap: the array must be (H, W) or (H, W, 3)")
+    if val.get("wrap_mode", "repeat") != "repeat":
+        raise ValueError("bitmap: only wrap_mode 'repeat'")
+    ft = val.get("filter_type", "bilinear")
+    if ft not in ("bilinear", "nearest"):
+        raise ValueError("bitmap: filter_type 'bilinear' or 'nearest'")
+    return {"bitmap": np.ascontiguousarray(a[:, :, :3]), "nearest": 1 if ft == "nearest" else 0}
+
+
 def _envmap_bitmap(val: dict, base_dir: str) -> np.ndarray:
     """(H, W, 3) float32 radiance of an ``envmap`` emitter, ``scale`` applied: ``bitmap`` / ``data`` (an array, as
     ``mi.Bitmap(array)`` would carry it) or ``filename`` (.npy -- there is no OpenEXR reader here; the reference's experiments
@@ -625,7 +689,12 @@ class Scene:
             o = dict(type=BSDF_TYPES[t], twosided=0, distr=0, sample_visible=1, reflectance=_rgb(None, [1, 1, 1]),
                      alpha=0.1, eta=np.zeros(3, np.float32), k=np.ones(3, np.float32), int_ior=1.5046, ext_ior=1.000277)
             if t == "diffuse":
-                o["reflectance"] = _rgb(b.get("reflectance"), [0.5, 0.5, 0.5])
+                r = b.get("reflectance")
+                if isinstance(r, dict) and r.get("type") == "bitmap":
+                    o["texture"] = _bitmap_texture(r, base_dir)
+                    o["reflectance"] = o["texture"]["bitmap"].reshape(-1, 3).mean(0).astype(np.float32)      # (a stand-in: the tracer looks the texture up)
+                else:
+                    o["reflectance"] = _rgb(r, [0.5, 0.5, 0.5])
             elif t in ("conductor", "roughconductor"):
                 mat = b.get("material", "Cu")
                 if "eta" in b or "k" in b:
@@ -674,16 +743,21 @@ class Scene:
                 emitters.append(e)
             elif t in ("obj", "ply", "mesh", "rectangle"):
                 tw = np.asarray(val.get("to_world", np.eye(4)), dtype=np.float64)
+                uv = None
                 if t == "obj":
-                    v, n, f = load_obj(os.path.join(base_dir, val["filename"]))
+                    v, n, f, uv = load_obj(os.path.join(base_dir, val["filename"]), with_uv=True)
+                    if uv is None:                                       # (no vt lines: the plain reader's vertex merging)
+                        v, n, f = load_obj(os.path.join(base_dir, val["filename"]))
                 elif t == "ply":
                     v, n, f = load_ply(os.path.join(base_dir, val["filename"]))
                 elif t == "mesh":
                     v, f = np.asarray(val["vertices"], np.float64), np.asarray(val["faces"], np.int64)
                     n = np.asarray(val["normals"], np.float64) if "normals" in val else None
+                    uv = np.asarray(val["texcoords"], np.float64) if "texcoords" in val else None
                 else:
                     v = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float64)
                     f = np.array([[0, 1, 2], [0, 2, 3]], np.int64); n = None
+                    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float64)                # rectangle.cpp: uv over [0,1]^2
                 v = (tw[:3, :3] @ v.T).T + tw[:3, 3]
                 if n is not None:
                     nt = np.linalg.inv(tw[:3, :3]).T
@@ -707,7 +781,7 @@ class Scene:
                 face_normals = bool(val.get("face_normals", False)) or t == "rectangle"
                 meshes.append(Mesh(key, v, f, n, bsdf=bsdf_id, emitter=emitter_id,
                                    flip_normals=bool(val.get("flip_normals", False)), is_mesh=(t != "rectangle"),
-                                   face_normals=face_normals))
+                                   face_normals=face_normals, uv=uv))
         return Scene(meshes, bsdfs, emitters, sensors, device=device, bsdf_names=bsdf_names)
 
     # -- parameters ----------------------------------------------------------------------------
@@ -733,8 +807,8 @@ class Scene:
     def attach_color(self, bsdf_name: str) -> int:
         """``dr.enable_grad(params['<bsdf>.reflectance.value'])`` for the colour adjoint (PRBIntegrator): diffuse BSDFs."""
         i = self.bsdf_names.index(bsdf_name)
-        if self.bsdf_desc[i]["type"] != 0:
-            raise ValueError("attach_color: only the reflectance of a diffuse BSDF is a colour parameter here")
+        if self.bsdf_desc[i]["type"] != 0 or "texture" in self.bsdf_desc[i]:
+            raise ValueError("attach_color: only the CONSTANT reflectance of a diffuse BSDF is a colour parameter here")
         if ("bsdf", i) not in self.color_slots:
             if len(self.color_slots) >= 4:
                 raise ValueError("at most 4 colour parameters")
@@ -783,6 +857,7 @@ class Scene:
             c.int_ior, c.ext_ior = float(b["int_ior"]), float(b["ext_ior"])
             c.alpha_slot = self.alpha_slots.get(i, -1)
             c.color_slot = self.color_slots.index(("bsdf", i)) if ("bsdf", i) in self.color_slots else -1
+            c.texture = b.get("texture_index", -1)
         return bs
 
     def set_vertex_positions(self, mesh_name: str, v):
@@ -873,6 +948,22 @@ class Scene:
         if self.T > 0:
             self.bvh = DeviceBvh(build_bvh(P, TRI), dev)
             self.bvh.refit(self.positions, self.tri)
+        # texture coordinates (rows of the meshes that have none stay zero: they are not flagged EPSM_MESH_HAS_UV) and textures
+        self.texcoords = None
+        if any(m.uv is not None for m in self.meshes):
+            uvs = [m.uv if m.uv is not None else np.zeros((m.v.shape[0], 2)) for m in self.meshes]
+            for m, u in zip(self.meshes, uvs):
+                if u.shape[0] != m.v.shape[0]:
+                    raise ValueError(f"mesh {m.name}: {u.shape[0]} texture coordinates for {m.v.shape[0]} vertices")
+            self.texcoords = f32(np.concatenate(uvs))
+        self._tex_buf = []
+        for b in self.bsdf_desc:
+            if "texture" in b:
+                b["texture_index"] = len(self._tex_buf)
+                self._tex_buf.append((f32(b["texture"]["bitmap"]), b["texture"]["nearest"]))
+        tx = (EpsmTexture * max(1, len(self._tex_buf)))()
+        for i, (t_, nearest) in enumerate(self._tex_buf):
+            tx[i].texels, tx[i].height, tx[i].width, tx[i].nearest = t_.data_ptr(), int(t_.shape[0]), int(t_.shape[1]), int(nearest)
         bs = self._bsdf_structs()
         em = (EpsmEmitter * max(1, len(self.emitter_desc)))()
         for i, e in enumerate(self.emitter_desc):
@@ -882,6 +973,7 @@ class Scene:
             c.color_slot = self.color_slots.index(("emitter", i)) if ("emitter", i) in self.color_slots else -1
         as_dev = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self._mesh_buf, self._bsdf_buf, self._em_buf = as_dev(mesh_c), as_dev(bs), as_dev(em)
+        self._tex_struct_buf = as_dev(tx)
         s = EpsmSceneC()
         s.positions, s.normals = self.positions.data_ptr(), self.normals.data_ptr()
         s.tri, s.tri_mesh = self.tri.data_ptr(), self.tri_mesh.data_ptr()
@@ -893,6 +985,8 @@ class Scene:
             s.bvh, s.n_nodes = self.bvh.nodes.data_ptr(), int(self.bvh.nodes.shape[0])
             s.prim_index, s.tri_verts = self.bvh.prim_index.data_ptr(), self.bvh.tri_verts.data_ptr()
         s.n_vertices, s.n_triangles = self.V, self.T
+        s.texcoords = self.texcoords.data_ptr() if self.texcoords is not None else None
+        s.textures, s.n_textures = self._tex_struct_buf.data_ptr(), len(self._tex_buf)
         # ---- the environment emitter: sampling tables + the bounding sphere of shapes and sensors (scene.cpp expands the
         #      scene's box by its sensors; constant.cpp:76-79, envmap.cpp:311-314)
         s.env.emitter = -1

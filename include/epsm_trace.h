@@ -38,6 +38,7 @@ extern "C" {
 #define EPSM_MESH_POS_ATTACHED   0x4u
 #define EPSM_MESH_NRM_ATTACHED   0x8u
 #define EPSM_MESH_IS_MESH        0x10u   /* 0: tessellated analytic shape (rectangle): si.ismesh stays 0 */
+#define EPSM_MESH_HAS_UV         0x20u   /* EpsmScene.texcoords holds its vertices' (u, v); otherwise si.uv = (b1, b2) (mesh.cpp:736-745) */
 
 enum { EPSM_BSDF_DIFFUSE_T = 0, EPSM_BSDF_CONDUCTOR_T = 1, EPSM_BSDF_ROUGHCONDUCTOR_T = 2, EPSM_BSDF_DIELECTRIC_T = 3 };
 enum { EPSM_DISTR_BECKMANN = 0, EPSM_DISTR_GGX = 1 };
@@ -81,7 +82,18 @@ typedef struct EpsmBsdf {
     int32_t alpha_slot;              /* slot of this BSDF's alpha in grad_alpha, -1 = not optimised */
     int32_t color_slot;              /* diffuse: slot of `reflectance` in the colour adjoint of epsm_trace_paths_color,
                                         -1 = not optimised */
+    int32_t texture;                 /* diffuse: index into EpsmScene.textures of the `bitmap` its reflectance is, -1 = `reflectance` */
+    uint32_t pad;
 } EpsmBsdf;
+
+/* A `bitmap` texture (src/textures/bitmap.cpp): linear RGB texels, looked up at si.uv as there -- uv * (width, height) - 0.5,
+ * bilinear between the four texels around it (or the nearest one), indices wrapped (`repeat`). */
+typedef struct EpsmTexture {
+    const float *texels;             /* (height, width, 3), row 0 at v = 0 */
+    int32_t width, height;
+    uint32_t nearest;                /* filter_type: 0 bilinear, 1 nearest */
+    uint32_t pad;
+} EpsmTexture;
 
 typedef struct EpsmEmitter {
     uint32_t type;                   /* EPSM_EMITTER_* */
@@ -148,6 +160,8 @@ typedef struct EpsmScene {           /* host struct holding DEVICE pointers */
     const float *tri_verts;          /* (T,9) p0,p1,p2 of the triangles in BVH (leaf) order */
     int64_t n_vertices, n_triangles;
     EpsmEnvironment env;
+    const float *texcoords;          /* (V,2) per-vertex (u, v) of the meshes flagged EPSM_MESH_HAS_UV (zero rows elsewhere), or NULL */
+    const EpsmTexture *textures;     int32_t n_textures;
 } EpsmScene;
 
 /* Writable twin of EpsmVertexRecord + EpsmScatterRecord for one logged bounce. */

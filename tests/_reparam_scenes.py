@@ -37,6 +37,14 @@ def rect(half=1.0, center=(0, 0, 0), normal="+z"):
     return v + np.asarray(center, float), f
 
 
+def plane_texture(H=32, W=32):
+    """A texture with structure at the scale of the image: stripes and a blob over a gradient."""
+    j, i = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    x, y = (i + 0.5) / W, (j + 0.5) / H
+    a = np.stack([0.3 + 0.5 * x + 0.15 * np.sin(12 * x), 0.25 + 0.5 * y, 0.4 + 0.4 * np.exp(-((x - 0.6) ** 2 + (y - 0.4) ** 2) / 0.03)], -1)
+    return a.astype(np.float32)
+
+
 def gradient_map(H=24, W=48):
     """A smooth lat-long map with a strong dependence on direction (factor ~6 between its sides) and no symmetry."""
     j, i = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
@@ -80,6 +88,11 @@ CONFIGS = {
     "sphere_on_glossy_floor_constant": dict(max_depth=3, moving=["sphere"], fd_eps=1e-3, kappa=2e5),
     # the first of them under an `envmap` whose radiance varies strongly with direction: the background behind the silhouette
     # and the light on the body both depend on where the reparameterised rays point
+    # TranslateTexturedPlaneConfig (:523-550): a 2 x 2 rectangle (scale 2 of the unit one) with a `bitmap` reflectance under the
+    # constant emitter, res 64 there; its museum.exr is not in the repository: a smooth synthetic texture stands in
+    "textured_plane_constant": dict(max_depth=2, moving=["plane"], fd_eps=1e-3, res=64),
+    # the same plane larger than the image: no silhouette in view, the image changes only because the texture slides with the plane
+    "textured_plane_fills_the_view": dict(max_depth=2, moving=["plane"], fd_eps=2e-3),
     "diffuse_sphere_envmap": dict(max_depth=2, moving=["sphere"], fd_eps=1e-3),
     "glossy_sphere_envmap": dict(max_depth=2, moving=["sphere"], fd_eps=1e-3),
 }
@@ -185,6 +198,12 @@ def build(name, theta=0.0, res=32, spp=64, device="cpu", theta_n=0.0):
         d["sphere"] = {"type": "mesh", "vertices": v + off, "normals": n, "faces": f,
                        "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 0.5, 0.0]}}}
         d["light"] = {"type": "constant", "radiance": 1.0}
+    elif name in ("textured_plane_constant", "textured_plane_fills_the_view"):
+        v, f = rect(2.0 if name == "textured_plane_constant" else 4.0)
+        uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], float) * (1.0 if name == "textured_plane_constant" else 2.0)
+        d["plane"] = {"type": "mesh", "vertices": v + off, "faces": f, "texcoords": uv, "face_normals": True,
+                      "bsdf": {"type": "diffuse", "reflectance": {"type": "bitmap", "bitmap": plane_texture()}}}
+        d["light"] = {"type": "constant"}
     elif name in ("diffuse_sphere_envmap", "glossy_sphere_envmap"):
         v, n, f = sphere(1.0, (0, 0, 0))
         bsdf = white if name.startswith("diffuse") else {"type": "roughconductor", "alpha": 0.3, "distribution": "ggx"}

@@ -22,6 +22,13 @@ def test_environment_closed_forms_on_the_device(tracer):
     check_plane_under_a_map(same, tracer, device="cuda", spp=4096)
 
 
+@pytest.mark.parametrize("tracer", ["mega", "wavefront"])
+def test_bitmap_textures_on_the_device(tracer):
+    from test_textures import check_textured_plane
+    for nearest in (False, True):
+        check_textured_plane(same, tracer, nearest, device="cuda", spp=256)
+
+
 def scene_dict(res, spp):
     v, n, f = sphere(0.6, (0.1, 0.0, 0.0), 12, 24)
     fv = np.array([[-3, -1, -3], [3, -1, -3], [3, -1, 3], [-3, -1, 3]], float)

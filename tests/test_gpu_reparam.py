@@ -67,11 +67,13 @@ def test_device_pass_equals_the_host_build(name, rays, antithetic):
     ("shadow_receiver_constant", 4096, 0.25),        # :482-520
     ("sphere_on_glossy_floor_constant", 2048, 0.2),  # :600-637
     # the first of them under an `envmap` that varies with direction (no counterpart in the reference's list)
+    ("textured_plane_constant", 800, 0.1),           # :523-550 (spp 800, error_mean_threshold 0.1 there)
+    ("textured_plane_fills_the_view", 1024, 0.05),
     ("diffuse_sphere_envmap", 1024, 0.1),
     ("glossy_sphere_envmap", 1024, 0.1),
 ])
 def test_backward_gradient_matches_finite_differences(name, spp, tol):
-    got, fd, dt = fd_check(name, device="cuda", spp=spp, rays=64, seeds=2, fd_eps=0.0 if ("emitter" in name or "constant" in name or "envmap" in name) else 5e-3, fd_spp_mult=2,
+    got, fd, dt = fd_check(name, device="cuda", spp=spp, rays=64, seeds=2, fd_eps=0.0 if ("emitter" in name or "constant" in name or "envmap" in name or "textured" in name) else 5e-3, fd_spp_mult=2,
                            weights="ones" if name == "self_shadow_point_light" else "ramp")
     r, g, f = rel(got, fd)
     print(f"{name}: grad {g:+.3f} per seed {[round(x, 2) for x in got]}, FD {f:+.3f} per seed {[round(x, 2) for x in fd]}, rel {r:.3f}, "

@@ -145,6 +145,8 @@ def test_emitter_moving_inside_the_image_matches_the_closed_form():
     ("scale_sphere_emitter_on_black", 32, 128, 0.1),  # :438-460, its threshold
     ("diffuse_rectangle_constant", 32, 128, 0.15),    # :341-363 under the `constant` environment emitter (its threshold: 0.25)
     ("shadow_receiver_constant", 32, 256, 0.2),       # :482-520 (0.25)
+    ("textured_plane_constant", 32, 128, 0.1),        # :523-550, its mean threshold (a synthetic texture for its museum.exr)
+    ("textured_plane_fills_the_view", 16, 256, 0.08), # no silhouette in view: the derivative of the texture lookup alone
 ])
 def test_smooth_and_silhouette_configs_match_finite_differences(name, rays, spp, tol):
     r, g, f = rel(*fd_check(name, spp=spp, rays=rays, seeds=1, fd_spp_mult=4)[:2])
