@@ -558,6 +558,8 @@ def _bitmap_texture(val: dict, base_dir: str) -> dict:
         raise ValueError("bitmap: the array must be (H, W) or (H, W, 3)")
     if val.get("wrap_mode", "repeat") != "repeat":
         raise ValueError("bitmap: only wrap_mode 'repeat'")
+    if "to_uv" in val:
+        raise ValueError("bitmap: to_uv is not supported (scale the mesh's texture coordinates instead)")
     ft = val.get("filter_type", "bilinear")
     if ft not in ("bilinear", "nearest"):
         raise ValueError("bitmap: filter_type 'bilinear' or 'nearest'")
