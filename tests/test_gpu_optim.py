@@ -32,6 +32,15 @@ def test_three_coloured_lights_are_recovered():
     assert min(hist[-10:]) < 0.25 * hist[0], hist                        # measured: 0.073
 
 
+def test_camera_translation_is_recovered_through_the_ray_origins():
+    """The shape of EPSM/exp/bedroom.py (`trans2` of the camera): the only gradient is d / d ray.o = -sum grad_d (epsm.py:260-261),
+    `ParamGrads.cam_origin` -- its sign and scale carry an Adam loop from 0.43 to 0.02 of distance."""
+    from epsm_mitsuba3_amd.optim import run
+    hist, opt = run("manifold", "camera", iterations=60, lr=0.02, log=lambda s: None)
+    assert hist[0] > 0.4
+    assert min(hist[-10:]) < 0.15 * hist[0] and hist[-1] < 0.25 * hist[0], hist
+
+
 def test_caustic_light_translation_is_recovered():
     """manifold_caustic: camera -> diffuse floor -> glass slab (two refractions) -> area light; the light's
     gradient arrives through diffuse_grad of the chain's end point (epsm.py:1178-1184)."""
