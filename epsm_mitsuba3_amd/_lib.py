@@ -152,15 +152,16 @@ def check(rc: int, what: str):
         raise EpsmError(f"{what} failed with code {rc}: {msg}")
 
 
-OPT_SMALL_WAVEFRONT_PATHS, OPT_REPLICAS = 0, 1       # include/epsm.h EPSM_OPT_*
+OPT_SMALL_WAVEFRONT_PATHS, OPT_REPLICAS, OPT_ONE_LAUNCH = 0, 1, 2       # include/epsm.h EPSM_OPT_*
 
 
 class options:
     """``with options(small_wavefront_paths=0, replicas=False): ...`` -- launch options of the fused entry points
     (include/epsm.h, epsm_set_option) for the duration of a block; the previous values come back on exit."""
 
-    def __init__(self, small_wavefront_paths=None, replicas=None):
-        self.want = {OPT_SMALL_WAVEFRONT_PATHS: small_wavefront_paths, OPT_REPLICAS: None if replicas is None else int(bool(replicas))}
+    def __init__(self, small_wavefront_paths=None, replicas=None, one_launch=None):
+        self.want = {OPT_SMALL_WAVEFRONT_PATHS: small_wavefront_paths, OPT_REPLICAS: None if replicas is None else int(bool(replicas)),
+                     OPT_ONE_LAUNCH: None if one_launch is None else int(bool(one_launch))}
 
     def __enter__(self):
         self.saved = {k: lib().epsm_get_option(k) for k, v in self.want.items() if v is not None}

@@ -755,6 +755,45 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             atomicAdd((my_rep ? my_rep + 6 * F.V + F.B : F.grad_o_sum) + threadIdx.x, tot);
         }
     }
+    // ---- small wavefronts in ONE launch (EPSM_OPT_ONE_LAUNCH, off by default): the last workgroup to have flushed into a replica
+    //      adds it to the caller's buffers and leaves it zero for the next launch (no workgroup waits for another: the counter says
+    //      who is last).  Measured SLOWER than the second, reducing kernel -- 0.144 against 0.086 ms at 524 288 paths: every
+    //      workgroup's release fence is an L2 write-back on a part whose eight L2s are not coherent with each other.
+    if (my_rep && F.rep_done) {
+        __shared__ int s_last;
+        const unsigned rix = blockIdx.x % (unsigned) F.replicas;
+        __threadfence();                                             // this workgroup's atomics have reached the L2 ...
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned members = ((unsigned) F.rep_blocks - rix + (unsigned) F.replicas - 1u) / (unsigned) F.replicas;
+            s_last = atomicAdd(F.rep_done + rix, 1u) + 1u == members;  // ... before it is counted
+        }
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            const int64_t n = 6 * F.V + F.B + 3;
+            constexpr int kU = 8;
+            for (int64_t e0 = threadIdx.x; e0 < n; e0 += (int64_t) kThreads * kU) {
+                float v[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {                       // (agent-scope loads: the sums were made by atomics at the L2)
+                    const int64_t e = e0 + (int64_t) u * kThreads;
+                    v[u] = e < n ? __hip_atomic_load(my_rep + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int64_t e = e0 + (int64_t) u * kThreads;
+                    if (e < n && v[u] != 0.f) {
+                        float *dst = e < 3 * F.V ? F.gpos + e : e < 6 * F.V ? F.gnrm + (e - 3 * F.V) : e < 6 * F.V + F.B ? (F.galpha ? F.galpha + (e - 6 * F.V) : nullptr)
+                                                                                                         : (F.grad_o_sum ? F.grad_o_sum + (e - 6 * F.V - F.B) : nullptr);
+                        if (dst) atomicAdd(dst, v[u]);
+                        my_rep[e] = 0.f;
+                    }
+                }
+            }
+            if (threadIdx.x == 0) F.rep_done[rix] = 0u;
+        }
+    }
 }
 
 template <int VARIANT, int DMODE, bool PACKED>
@@ -786,7 +825,7 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
     const int64_t blocks = windows < EPSM_CP_BLOCKS ? windows : EPSM_CP_BLOCKS;
     const int64_t per = (windows + blocks - 1) / blocks;
     // small wavefronts: replicas of the gradient buffers (epsm_grad_scatter.hip, DESIGN.md section 5 "Small wavefronts")
-    F.rep = nullptr; F.replicas = 1; F.rep_stride = 0;
+    F.rep = nullptr; F.replicas = 1; F.rep_stride = 0; F.rep_done = nullptr; F.rep_blocks = 0;
     if (small) {
         const int64_t stride = (6 * F.V + F.B + 3 + 63) / 64 * 64;        // floats; replicas start on 256-byte boundaries
         int64_t R = blocks / 16;
@@ -795,7 +834,11 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
         if (R >= 4 && fused_option(EPSM_OPT_REPLICAS) != 0) {
             const hipError_t e = fused_workspace(s, (size_t) (R * stride * 4), &F.rep);
             if (e != hipSuccess) return e;
-            if (F.rep) { F.replicas = (int) R; F.rep_stride = stride; }
+            if (F.rep) {
+                F.replicas = (int) R; F.rep_stride = stride;
+                F.rep_blocks = (int) blocks;
+                F.rep_done = fused_option(EPSM_OPT_ONE_LAUNCH) != 0 ? (uint32_t *) ((char *) F.rep + kReplicaBudget) : nullptr;
+            }
         }
     }
     // fixed-point rows hold |sum| < 2^19 at a resolution of 2^-44: fine for terms clamped to +-clip (0.1 in the reference),
@@ -809,7 +852,7 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
         if (small) hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, false, kSmall>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
         else hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, false, kLarge>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
     }
-    if (F.rep) {
+    if (F.rep && !F.rep_done) {
         const int64_t n = 6 * F.V + F.B + 3;
         hipLaunchKernelGGL(reduce_replicas_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, F.rep, F.replicas, F.rep_stride,
                            F.V, F.B, F.gpos, F.gnrm, F.galpha, F.grad_o_sum);

@@ -23,6 +23,9 @@ struct FusedArgs {
     float *rep;                      // replicas x rep_stride floats, each [pos 3V | nrm 3V | alpha B | o_sum 3]; null: none
     int replicas;
     int64_t rep_stride;
+    uint32_t *rep_done;              // per replica: workgroups that have flushed into it; non-null = the LAST of them adds the replica to the
+                                     // caller's buffers and clears it (one launch); null = reduce_replicas_kernel does (two launches)
+    int rep_blocks;                  // workgroups of the launch (b % replicas == r of them feed replica r)
     // epsm_backward_pass_packed: the native log (include/epsm.h, EpsmPackedLog) instead of the per-array records
     const float *pk_rays;            // (N,12)  o, d, d_x, d_y
     const uint32_t *pk_flags;        // (N)     5 bits per vertex
@@ -85,7 +88,7 @@ __device__ __forceinline__ Tangent first_vertex_tangent_packed(const TangentIn &
 
 // ---- small wavefronts: replicas of the gradient buffers (epsm_grad_scatter.hip)
 constexpr size_t kReplicaBudget = 48u << 20;
-hipError_t fused_workspace(hipStream_t s, size_t bytes, float **out);
+hipError_t fused_workspace(hipStream_t s, size_t bytes, float **out);       // kReplicaBudget bytes of replicas + 4 KB of counters behind them
 hipError_t fused_release_workspaces();
 __global__ void reduce_replicas_kernel(float *rep, int replicas, int64_t stride, int64_t V, int64_t B,
                                        float *gpos, float *gnrm, float *galpha, float *go);

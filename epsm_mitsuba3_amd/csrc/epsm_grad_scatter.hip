@@ -56,10 +56,10 @@ hipError_t fused_workspace(hipStream_t s, size_t bytes, float **out) {
     }
     if (w->bytes < bytes) {
         if (w->p) { e = hipFree(w->p); w->p = nullptr; w->bytes = 0; if (e != hipSuccess) return e; }
-        e = hipMalloc((void **) &w->p, kReplicaBudget);
+        e = hipMalloc((void **) &w->p, kReplicaBudget + 4096);
         if (e != hipSuccess) { w->p = nullptr; return e; }
         w->bytes = kReplicaBudget;
-        e = hipMemsetAsync(w->p, 0, kReplicaBudget, s);
+        e = hipMemsetAsync(w->p, 0, kReplicaBudget + 4096, s);
         if (e != hipSuccess) return e;
     }
     *out = w->p;
@@ -126,15 +126,17 @@ static int fill_args(FusedArgs &F, const char *who, int variant, int64_t N, int 
     return EPSM_OK;
 }
 
-// ---- launch options: two process-wide integers, set from the environment by a static initialiser (never by an entry point)
+// ---- launch options: three process-wide integers, set from the environment by a static initialiser (never by an entry point)
 namespace {
-std::atomic<int64_t> g_options[2];
+std::atomic<int64_t> g_options[3];
 struct OptionsInit {
     OptionsInit() {
         const char *e = getenv("EPSM_SMALL_WAVEFRONT");
         g_options[EPSM_OPT_SMALL_WAVEFRONT_PATHS] = e ? atoll(e) : (int64_t) 1 << 20;
         const char *off = getenv("EPSM_NO_REPLICAS");
         g_options[EPSM_OPT_REPLICAS] = (off && off[0] == '1') ? 0 : 1;
+        const char *one = getenv("EPSM_ONE_LAUNCH");
+        g_options[EPSM_OPT_ONE_LAUNCH] = (one && one[0] == '1') ? 1 : 0;
     }
 } g_options_init;
 }  // namespace
@@ -143,12 +145,12 @@ int64_t fused_option(int option) { return g_options[option].load(std::memory_ord
 }
 extern "C" int epsm_set_option(int option, int64_t value) {
     epsm_host::err_buf()[0] = 0;
-    if (option < 0 || option > EPSM_OPT_REPLICAS || value < 0) return fail(EPSM_EINVAL, "epsm_set_option: unknown option or negative value");
+    if (option < 0 || option > EPSM_OPT_ONE_LAUNCH || value < 0) return fail(EPSM_EINVAL, "epsm_set_option: unknown option or negative value");
     g_options[option].store(value, std::memory_order_relaxed);
     return EPSM_OK;
 }
 extern "C" int64_t epsm_get_option(int option) {
-    return (option < 0 || option > EPSM_OPT_REPLICAS) ? -1 : g_options[option].load(std::memory_order_relaxed);
+    return (option < 0 || option > EPSM_OPT_ONE_LAUNCH) ? -1 : g_options[option].load(std::memory_order_relaxed);
 }
 
 extern "C" int epsm_release_workspace(void) {

@@ -300,10 +300,16 @@ int epsm_release_workspace(void);
  *                                   replicas); larger ones walk windows of 2048 paths.  Default 2^20; EPSM_SMALL_WAVEFRONT=<paths>.
  *   EPSM_OPT_REPLICAS               1: small wavefronts accumulate into replicas (above); 0: straight into the caller's
  *                                   buffers.  Default 1; EPSM_NO_REPLICAS=1 sets 0.
+ *   EPSM_OPT_ONE_LAUNCH             0: the replicas are summed by a second small kernel on the same stream; 1: inside the launch --
+ *                                   the last workgroup to flush into a replica adds it to the caller's buffers and clears it.
+ *                                   Default 0 (EPSM_ONE_LAUNCH=1 sets 1): the agent-scope release every workgroup then needs
+ *                                   before it is counted is an L2 write-back on this eight-XCD part -- 0.144 ms against 0.086 ms
+ *                                   with two launches on the reference's own backward size (524 288 paths, K = 2).
  * Results are the same sums either way (the parity tests run both forms at every size).
  * epsm_set_option returns EPSM_OK or -EINVAL (unknown option, negative value); epsm_get_option returns -1 for an unknown option. */
 #define EPSM_OPT_SMALL_WAVEFRONT_PATHS 0
 #define EPSM_OPT_REPLICAS 1
+#define EPSM_OPT_ONE_LAUNCH 2
 int epsm_set_option(int option, int64_t value);
 int64_t epsm_get_option(int option);
 

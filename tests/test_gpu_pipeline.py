@@ -177,10 +177,10 @@ def test_fused_equals_two_stage_at_scale(kind, profile, res, spp, V):
 @pytest.mark.parametrize("kind,profile,K,res,spp,V", [("manifold", "bathroom", 2, 256, 8, 7829), ("manifold_caustic", "pool", 4, 64, 32, 500),
                                                       ("manifold", "mixed", 5, 128, 16, 100000)])
 def test_small_wavefront_forms_agree(kind, profile, K, res, spp, V):
-    """2^17 .. 2^19 paths (the reference's own backward sizes): the three routes a small wavefront can take -- small
-    windows flushed into the library's replicas and summed by the reduction kernel, the same without replicas, and
-    the windows of 1024 paths of the large wavefronts -- and the reference's two stages accumulate the same sums, camera
-    origin included; a second launch finds the replicas zeroed."""
+    """2^17 .. 2^19 paths (the reference's own backward sizes): the routes a small wavefront can take -- small windows flushed
+    into the library's replicas which the second, reducing kernel sums (the default), the same summed inside the launch by the
+    last workgroup of each replica (EPSM_OPT_ONE_LAUNCH), without replicas, and the windows of 1024 paths of the large wavefronts -- and the reference's
+    two stages accumulate the same sums, camera origin included; a second launch finds replicas and counters zeroed."""
     import epsm_mitsuba3_amd as epsm
     dev = torch.device("cuda", 0)
     B = 4
@@ -190,8 +190,10 @@ def test_small_wavefront_forms_agree(kind, profile, K, res, spp, V):
     grad_in = (torch.randn((res, res, 5), generator=g) * 1e-3).to(dev)
     bufs = {}
     from epsm_mitsuba3_amd import _lib
-    default = dict(small_wavefront_paths=1 << 20, replicas=True)          # (include/epsm.h, epsm_set_option)
-    for name, opts, fused in (("replicas", {}, "pass"), ("replicas again", {}, "pass"), ("direct", {"replicas": False}, "pass"),
+    default = dict(small_wavefront_paths=1 << 20, replicas=True, one_launch=False)         # (include/epsm.h, epsm_set_option)
+    for name, opts, fused in (("replicas", {}, "pass"), ("replicas again", {}, "pass"), ("one launch", {"one_launch": True}, "pass"),
+                              ("one launch again", {"one_launch": True}, "pass"), ("two launches after one", {}, "pass"),
+                              ("direct", {"replicas": False}, "pass"),
                               ("windows of 1024", {"small_wavefront_paths": 0}, "pass"), ("two stages", {}, False),
                               ("lo", {}, False), ("hi", {}, False)):
         with _lib.options(**{**default, **opts}):
