@@ -200,16 +200,15 @@ template <int G> __device__ __forceinline__ float group_total(float v) {
 }
 struct SplatWeights { float wx[5], wy[5]; int X, Y; };
 __device__ __forceinline__ SplatWeights gaussian_window(float px, float py) {
-    const float radius = 2.f, alpha = -1.f / (2.f * 0.5f * 0.5f), bias = expf(alpha * radius * radius);
     SplatWeights w;
     w.X = (int) floorf(px); w.Y = (int) floorf(py);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const float dx = (w.X + j - 2 + 0.5f) - px, dy = (w.Y + j - 2 + 0.5f) - py;
-        // pixel centres farther than the radius get exp(..) < bias, i.e. weight 0: the 5x5 window holds
+        // pixel centres farther than the radius get weight 0: the 5x5 window holds
         // exactly the pixels ImageBlock::put visits (ceil(p - r - 0.5) .. floor(p + r - 0.5))
-        w.wx[j] = fabsf(dx) <= radius ? fmaxf(0.f, expf(alpha * dx * dx) - bias) : 0.f;
-        w.wy[j] = fabsf(dy) <= radius ? fmaxf(0.f, expf(alpha * dy * dy) - bias) : 0.f;
+        w.wx[j] = gaussian_rfilter(dx);
+        w.wy[j] = gaussian_rfilter(dy);
     }
     return w;
 }

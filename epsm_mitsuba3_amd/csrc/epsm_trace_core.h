@@ -64,15 +64,19 @@ EPSM_HD void sample_tea_32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1)
     }
     o0 = v0; o1 = v1;
 }
+// PCG32::seed(size, initstate, initseq) of Dr.Jit (the published pcg32_srandom_r)
+EPSM_HD Pcg32 pcg32_seed(uint64_t initstate, uint64_t initseq) {
+    Pcg32 r;
+    r.state = 0; r.inc = (initseq << 1) | 1u;
+    r.next_u32();
+    r.state += initstate;
+    r.next_u32();
+    return r;
+}
 EPSM_HD Pcg32 seed_sampler(uint32_t seed, uint32_t wavefront_index) {
     uint32_t v0, v1;
     sample_tea_32(seed, wavefront_index, v0, v1);       // sampler.cpp:127
-    Pcg32 r;                                             // m_rng.seed(1, v0, v1)
-    r.state = 0; r.inc = ((uint64_t) v1 << 1) | 1u;
-    r.next_u32();
-    r.state += (uint64_t) v0;
-    r.next_u32();
-    return r;
+    return pcg32_seed(v0, v1);                           // m_rng.seed(1, v0, v1)
 }
 
 // ---------------------------------------------------------------------------
@@ -748,14 +752,10 @@ EPSM_HD F3 xform_vec34(const float *m, F3 v) {
     return f3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
 struct PrimaryRay { Ray ray; F3 dx, dy; float px, py; };
-EPSM_HD PrimaryRay sample_primary_ray(const EpsmSensor &C, int64_t wavefront_index, int spp, Pcg32 &rng) {
-    // common.py:320-335: idx // spp -> pixel, pos = pixel + next_2d()
-    const int64_t pix = wavefront_index / spp;
-    const int fw = C.width + 2 * C.border;                                // film_size += 2 * border_size (common.py:314-315)
-    const int py0 = (int) (pix / fw), px = (int) (pix - (int64_t) py0 * fw) - C.border, py = py0 - C.border;
-    const float jx = rng.next_1d(), jy = rng.next_1d();
+// PerspectiveCamera::sample_ray_differential (perspective.cpp:238-279) at the film position (fx, fy) in pixels
+EPSM_HD PrimaryRay primary_ray_at(const EpsmSensor &C, float fx, float fy) {
     PrimaryRay o;
-    o.px = px + jx; o.py = py + jy;
+    o.px = fx; o.py = fy;
     const float sx = o.px / C.width, sy = o.py / C.height;
     const F3 near_p = xform_point(C.sample_to_camera, f3(sx, sy, 0.f));   // perspective.cpp:255-258
     const F3 d = normalize3(near_p);
@@ -769,6 +769,22 @@ EPSM_HD PrimaryRay sample_primary_ray(const EpsmSensor &C, int64_t wavefront_ind
     o.dx = xform_vec34(W, normalize3(near_p + ld3(C.dx)));               // perspective.cpp:274-275
     o.dy = xform_vec34(W, normalize3(near_p + ld3(C.dy)));
     return o;
+}
+EPSM_HD PrimaryRay sample_primary_ray(const EpsmSensor &C, int64_t wavefront_index, int spp, Pcg32 &rng) {
+    // common.py:320-335: idx // spp -> pixel, pos = pixel + next_2d()
+    const int64_t pix = wavefront_index / spp;
+    const int fw = C.width + 2 * C.border;                                // film_size += 2 * border_size (common.py:314-315)
+    const int py0 = (int) (pix / fw), px = (int) (pix - (int64_t) py0 * fw) - C.border, py = py0 - C.border;
+    const float jx = rng.next_1d(), jy = rng.next_1d();
+    return primary_ray_at(C, px + jx, py + jy);
+}
+
+// GaussianFilter::eval (src/rfilters/gaussian.cpp): stddev 0.5, cut off after 4 standard deviations, shifted so that
+// it reaches 0 at the radius; the film kernels evaluate it exactly (no discretisation table)
+constexpr float kGaussRadius = 2.f, kGaussAlpha = -1.f / (2.f * 0.5f * 0.5f);
+EPSM_HD float gaussian_rfilter(float x) {
+    const float bias = expf(kGaussAlpha * kGaussRadius * kGaussRadius);
+    return fabsf(x) <= kGaussRadius ? fmaxf(0.f, expf(kGaussAlpha * x * x) - bias) : 0.f;
 }
 
 // ---------------------------------------------------------------------------

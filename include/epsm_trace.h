@@ -282,6 +282,26 @@ int epsm_film_develop(int width, int height, const float *accum, float *image, v
 int epsm_film_adjoint_reparam(int64_t N, const float *film_pos, const float *radiance, const float *grad_img, int grad_channels,
                               const float *accum, int width, int height, float *dL, float *adj, void *stream);
 
+/* epsm_probe -- evaluates ONE of the tracer's per-path functions on n rows of plain numbers, on the device, with the very
+ * code the tracer runs (csrc/epsm_probe_core.h).  It exists so that the known answers the reference's own unit tests hold
+ * for these functions can be checked against the product (tests/golden/reference_vectors.py):
+ *   EPSM_PROBE_TEA                in v0, v1 (u32 bits)                          out v0', v1' (bits)     include/mitsuba/core/random.h:77-104  (src/core/tests/test_random.py:9-27)
+ *   EPSM_PROBE_PCG32              in initstate lo, hi, initseq lo, hi (bits)    out 6 draws (bits), then 6 x next_1d()   drjit PCG32::seed / next (src/samplers/tests/test_independent.py:16-28)
+ *   EPSM_PROBE_SAMPLER            in seed, wavefront index (bits)               out 12 x next_1d() of that path's stream    src/render/sampler.cpp:115-134
+ *   EPSM_PROBE_MICROFACET         in m (3), wi (3); cfg = EpsmBsdf (distr, alpha, sample_visible)    out D(m), pdf(wi, m), smith_g1(m, wi)    include/mitsuba/render/microfacet.h (src/render/tests/test_microfacet.py)
+ *   EPSM_PROBE_MICROFACET_SAMPLE  in u1, u2; cfg = EpsmBsdf                     out m (3), pdf, d m / d alpha (3)
+ *   EPSM_PROBE_FRESNEL            in cos_theta_i, eta                           out F, cos_theta_t, eta_it, eta_ti          include/mitsuba/render/fresnel.h:34-72 (src/render/tests/test_fresnel.py)
+ *   EPSM_PROBE_FRESNEL_CONDUCTOR  in cos_theta_i, eta, k                        out F                                        fresnel.h:92-117
+ *   EPSM_PROBE_RFILTER            in x                                          out gaussian reconstruction filter at x      src/rfilters/gaussian.cpp (src/rfilters/tests/test_rfilter.py:14-19)
+ *   EPSM_PROBE_PRIMARY_RAY        in film position (pixels); cfg = EpsmSensor   out o, d, d_x, d_y (3 each)                  src/sensors/perspective.cpp:238-279 (src/sensors/tests/test_perspective.py:89-135)
+ * in: (n, EPSM_PROBE_IN) floats, out: (n, EPSM_PROBE_OUT) floats, device pointers; cfg: HOST pointer to the struct named
+ * above (NULL otherwise).  Not on any hot path. */
+enum { EPSM_PROBE_TEA = 0, EPSM_PROBE_PCG32 = 1, EPSM_PROBE_SAMPLER = 2, EPSM_PROBE_MICROFACET = 3, EPSM_PROBE_MICROFACET_SAMPLE = 4,
+       EPSM_PROBE_FRESNEL = 5, EPSM_PROBE_FRESNEL_CONDUCTOR = 6, EPSM_PROBE_RFILTER = 7, EPSM_PROBE_PRIMARY_RAY = 8, EPSM_PROBE_COUNT = 9 };
+#define EPSM_PROBE_IN 8
+#define EPSM_PROBE_OUT 16
+int epsm_probe(int what, int64_t n, const float *in, float *out, const void *cfg, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

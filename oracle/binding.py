@@ -128,6 +128,19 @@ def oracle_first_vertex_tangent(ray_o, ray_d, ray_dx, ray_dy, grad_in, spp, res,
     return dlduv, dldp, go
 
 
+def oracle_intersect_tangent(o, d, odot, ddot, p0, p1, p2):
+    """One ray / one triangle in float64 dual numbers (oracle/epsm_oracle_aux.c, mesh.h:349-362 + mesh.cpp:698-709):
+    dict(t, u, v, dt, du, dv, dp (3)) when the origin moves with ``odot`` and the direction with ``ddot``."""
+    import numpy as np
+    l = _aux()
+    arr = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(3)) for a in (o, d, odot, ddot, p0, p1, p2)]
+    out = np.zeros(9)
+    l.epsm_oracle_intersect_tangent.restype = C.c_int
+    rc = l.epsm_oracle_intersect_tangent(*[a.ctypes.data_as(C.c_void_p) for a in arr], out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return dict(t=out[0], u=out[1], v=out[2], dt=out[3], du=out[4], dv=out[5], dp=out[6:9].copy())
+
+
 def oracle_scatter(variant, path_info, scatter_info, out_param, out_light, out_diffuse, V, B):
     """Deterministic float64 accumulation; returns (grad_pos, grad_nrm, grad_alpha)."""
     from epsm_mitsuba3_amd.records import PackedScatter

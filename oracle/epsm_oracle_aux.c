@@ -15,12 +15,14 @@
  *       adjoints of include/mitsuba/render/mesh.h:94-106 and the shading-normal code
  *       of src/render/mesh.cpp:729,784-790,811-827.
  *
- * PARITY UNPINNED: these parts of the reference need Dr.Jit/Mitsuba, which can be
- * neither built nor imported here, and the reference has no test for them
- * (SURVEY.md 4, 8c).  They are pinned instead by known-answer tests in
- * tests/test_tangent_scatter_oracle.py: finite differences of the float64
- * ray/triangle intersection, and torch autograd (float64) of the reference's own
- * loss expressions.
+ * PINNED BY REFERENCE-HELD KNOWN ANSWERS: these parts of the reference need Dr.Jit/Mitsuba, which
+ * can be neither built nor imported here, but its own unit tests hold known answers for exactly
+ * these derivatives -- src/render/tests/test_mesh.py:380-455 (d p, d uv, d t under d ray.o / d ray.d
+ * and the adjoints to ray.o) and :560-640 (gather adjoints of si.p, si.n, si.sh_frame.n into
+ * vertex_positions) -- typed as VALUES into tests/golden/reference_vectors.py and checked by
+ * tests/test_reference_vectors.py.  In addition: finite differences of the float64 ray/triangle
+ * intersection and torch autograd (float64) of the reference's own loss expressions
+ * (tests/test_tangent_scatter_oracle.py).
  */
 #include <math.h>
 #include <stdint.h>
@@ -48,6 +50,36 @@ static inline dvec dvcross(dvec a, dvec b) {
 }
 static inline dvec dconst(const float *p) { dvec r = {dmk(p[0], 0), dmk(p[1], 0), dmk(p[2], 0)}; return r; }
 
+/* Moeller-Trumbore (include/mitsuba/render/mesh.h:349-362) in dual numbers: t, u, v and their tangents when the ray's origin
+ * and direction move */
+static void mt_dual(dvec o, dvec d, dvec q0, dvec q1, dvec q2, dual *t, dual *u, dual *v) {
+    dvec e1 = dvsub(q1, q0), e2 = dvsub(q2, q0);
+    dvec pvec = dvcross(d, e2);
+    dual inv_det = drcp(dvdot(e1, pvec));
+    dvec tvec = dvsub(o, q0);
+    *u = dmul(dvdot(tvec, pvec), inv_det);
+    dvec qvec = dvcross(tvec, e1);
+    *v = dmul(dvdot(d, qvec), inv_det);
+    *t = dmul(dvdot(e2, qvec), inv_det);
+}
+
+/* One ray, one triangle, forward mode: the origin moves with velocity odot, the direction with ddot (what
+ * dr.forward(ray.o.x) / dr.forward(ray.d.x) do in src/render/tests/test_mesh.py:380-421).
+ * out = [t, u, v,  dt, du, dv,  dp (3)]  with  si.p = p0 b0 + p1 b1 + p2 b2,  b1 = u, b2 = v, b0 = 1 - u - v (mesh.cpp:698-709). */
+int epsm_oracle_intersect_tangent(const double *o, const double *d, const double *odot, const double *ddot,
+                                  const double *p0, const double *p1, const double *p2, double *out) {
+    dvec O = {dmk(o[0], odot[0]), dmk(o[1], odot[1]), dmk(o[2], odot[2])};
+    dvec D = {dmk(d[0], ddot[0]), dmk(d[1], ddot[1]), dmk(d[2], ddot[2])};
+    dvec q0 = {dmk(p0[0], 0), dmk(p0[1], 0), dmk(p0[2], 0)}, q1 = {dmk(p1[0], 0), dmk(p1[1], 0), dmk(p1[2], 0)},
+         q2 = {dmk(p2[0], 0), dmk(p2[1], 0), dmk(p2[2], 0)};
+    dual t, u, v;
+    mt_dual(O, D, q0, q1, q2, &t, &u, &v);
+    out[0] = t.v; out[1] = u.v; out[2] = v.v; out[3] = t.d; out[4] = u.d; out[5] = v.d;
+    const double db0 = -u.d - v.d;
+    for (int c = 0; c < 3; ++c) out[6 + c] = p0[c] * db0 + p1[c] * u.d + p2[c] * v.d;
+    return 0;
+}
+
 int epsm_oracle_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, int res,
                                      const float *ray_o, const float *ray_d,
                                      const float *ray_dx, const float *ray_dy,
@@ -73,14 +105,9 @@ int epsm_oracle_first_vertex_tangent(int64_t N, int64_t path_offset, int spp, in
         /* ray.d carries the tangent grad_d (dr.set_grad(ray.d, grad_d), epsm.py:264) */
         dvec d = {dmk(ray_d[3 * i], gd[0]), dmk(ray_d[3 * i + 1], gd[1]), dmk(ray_d[3 * i + 2], gd[2])};
         dvec o = dconst(ray_o + 3 * i), q0 = dconst(p0 + 3 * i), q1 = dconst(p1 + 3 * i), q2 = dconst(p2 + 3 * i);
-        /* mesh.h:349-362 */
-        dvec e1 = dvsub(q1, q0), e2 = dvsub(q2, q0);
-        dvec pvec = dvcross(d, e2);
-        dual inv_det = drcp(dvdot(e1, pvec));
-        dvec tvec = dvsub(o, q0);
-        dual u = dmul(dvdot(tvec, pvec), inv_det);
-        dvec qvec = dvcross(tvec, e1);
-        dual v = dmul(dvdot(d, qvec), inv_det);
+        dual t, u, v;
+        mt_dual(o, d, q0, q1, q2, &t, &u, &v);   /* mesh.h:349-362 */
+        (void) t;
         /* mesh.cpp:698-709 */
         dual b1 = u, b2 = v, b0 = dsub(dsub(dmk(1, 0), b1), b2);
         row[0] = b0.d;   /* epsm.py:268 */

@@ -15,7 +15,7 @@ _CSRC = os.path.join(os.path.dirname(_DIR), "..", "epsm_mitsuba3_amd", "csrc")
 #   "path": epsm_path_core.h, one lane = one path (the dense calc_grad kernel)
 #   "cp":   epsm_cp_core.h, one lane = one (path, constraint vertex) (the fused backward kernel)
 CORES = {
-    "path": ("libpath_core_host.so", "path_core_host.cpp", ("epsm_path_core.h",), "epsm_host_core_grad"),
+    "path": ("libpath_core_host.so", "path_core_host.cpp", ("epsm_path_core.h", "epsm_tangent_core.h"), "epsm_host_core_grad"),
     "cp": ("libcp_core_host.so", "cp_core_host.cpp", ("epsm_path_core.h", "epsm_cp_core.h"), "epsm_host_cp_grad"),
 }
 _libs = {}

@@ -4,6 +4,7 @@
 // vectors on machines without a GPU (`pytest -m "not gpu"`).  Not shipped, not a
 // fallback: the product library (libepsm_hip.so) exports the HIP path only.
 #include "../../epsm_mitsuba3_amd/csrc/epsm_path_core.h"
+#include "../../epsm_mitsuba3_amd/csrc/epsm_tangent_core.h"
 #include "../../include/epsm.h"
 
 using namespace epsm;
@@ -71,4 +72,13 @@ extern "C" int epsm_host_core_grad_f64(int variant, int64_t N, int K, const void
                                        const void *dlduv, int64_t stride, int dcols, const void *dldp, double clip,
                                        void *op, void *ol, void *od, int) {
     return run<double>(variant, N, K, cam, verts, dlduv, stride, dcols, dldp, clip, op, ol, od);
+}
+
+// the first-vertex tangent's arithmetic (epsm_tangent_core.h, what epsm_tangent_kernel and the backward kernel run) on one
+// path: in = o, d, d_x, d_y (3 each), gx, gy, p0, p1, p2 (3 each); out = d b0, d b1, d p (3), grad_d (3)
+extern "C" int epsm_host_tangent_from(const float *in, float *out) {
+    auto v = [&](int j) { V3<float> r; r.x = in[j]; r.y = in[j + 1]; r.z = in[j + 2]; return r; };
+    const Tangent t = tangent_from(v(0), v(3), v(6), v(9), in[12], in[13], v(14), v(17), v(20), true);
+    out[0] = t.db0; out[1] = t.db1; out[2] = t.dp.x; out[3] = t.dp.y; out[4] = t.dp.z; out[5] = t.gd.x; out[6] = t.gd.y; out[7] = t.gd.z;
+    return 0;
 }

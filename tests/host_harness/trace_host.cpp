@@ -6,6 +6,7 @@
 #include "../../epsm_mitsuba3_amd/csrc/epsm_trace_core.h"
 #include "../../epsm_mitsuba3_amd/csrc/epsm_trace_wavefront.h"
 #include "../../epsm_mitsuba3_amd/csrc/epsm_trace_reparam.h"
+#include "../../epsm_mitsuba3_amd/csrc/epsm_probe_core.h"
 
 using namespace epsm;
 
@@ -172,15 +173,15 @@ extern "C" int epsm_film_splat(int64_t N, const float *pos, const float *rad, in
             a[0] += rad[3 * i]; a[1] += rad[3 * i + 1]; a[2] += rad[3 * i + 2]; a[3] += 1.f;
             continue;
         }
-        const float radius = 2.f, alpha = -1.f / (2.f * 0.5f * 0.5f), bias = expf(alpha * radius * radius);
+        const float radius = kGaussRadius;
         const int x0 = (int) ceilf(px - radius - 0.5f), x1 = (int) floorf(px + radius - 0.5f);
         const int y0 = (int) ceilf(py - radius - 0.5f), y1 = (int) floorf(py + radius - 0.5f);
         for (int y = y0; y <= y1; ++y) {
             if (y < 0 || y >= H) continue;
-            const float dy = (y + 0.5f) - py, wy = fmaxf(0.f, expf(alpha * dy * dy) - bias);
+            const float dy = (y + 0.5f) - py, wy = gaussian_rfilter(dy);
             for (int x = x0; x <= x1; ++x) {
                 if (x < 0 || x >= W) continue;
-                const float dx = (x + 0.5f) - px, w = wy * fmaxf(0.f, expf(alpha * dx * dx) - bias);
+                const float dx = (x + 0.5f) - px, w = wy * gaussian_rfilter(dx);
                 float *a = accum + 4 * ((int64_t) y * W + x);
                 a[0] += rad[3 * i] * w; a[1] += rad[3 * i + 1] * w; a[2] += rad[3 * i + 2] * w; a[3] += w;
             }
@@ -193,5 +194,17 @@ extern "C" int epsm_film_develop(int W, int H, const float *accum, float *image,
         const float w = accum[4 * i + 3], iw = w != 0.f ? 1.f / w : 0.f;
         image[3 * i] = accum[4 * i] * iw; image[3 * i + 1] = accum[4 * i + 1] * iw; image[3 * i + 2] = accum[4 * i + 2] * iw;
     }
+    return 0;
+}
+
+// epsm_probe (include/epsm_trace.h) on host pointers: the same probe_row the device kernel runs
+extern "C" int epsm_probe(int what, int64_t n, const float *in, float *out, const void *cfg, void *) {
+    if (what < 0 || what >= EPSM_PROBE_COUNT || n < 0 || (n > 0 && (!in || !out))) return -22;
+    if ((probe_needs_bsdf(what) || probe_needs_sensor(what)) && !cfg) return -22;
+    EpsmBsdf bsdf = {};
+    EpsmSensor sensor = {};
+    if (probe_needs_bsdf(what)) bsdf = *(const EpsmBsdf *) cfg;
+    if (probe_needs_sensor(what)) sensor = *(const EpsmSensor *) cfg;
+    for (int64_t i = 0; i < n; ++i) probe_row(what, in + i * EPSM_PROBE_IN, out + i * EPSM_PROBE_OUT, &bsdf, &sensor);
     return 0;
 }
