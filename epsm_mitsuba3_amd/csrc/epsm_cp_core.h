@@ -98,6 +98,18 @@ EPSM_HD uint32_t caustic_plan(uint32_t w) {
     return a | (b << 5) | ((uint32_t) nv << 10) | ((uint32_t) idstar << 13) | ((uint32_t) m << 16) | (d1 ? 1u << 19 : 0u);
 }
 
+// Can a vertex AFTER vertex k still produce, or be read by, a term?  `w` = the flag word of vertices 1..k.  The masks above:
+// every term at depth id needs `valid` (vertices 1..id mesh hits, fewer than two of them Diffuse) and, for manifold,
+// hasdiffuse == 0 over 1..id; a term at id < k reads vertices <= id + 1 <= k.  So once the condition fails at k it fails
+// for every id >= k and nothing behind vertex k is ever looked at (the tracer's EPSM_TRACE_GRADIENT_ONLY retires the path).
+EPSM_HD bool gradient_live(uint32_t w, int k, bool caustic) {
+    bool all_mesh = true;
+    int ndiffuse = 0;
+    for (int j = 1; j <= 5; ++j)
+        if (j <= k) { all_mesh = all_mesh && fbit(w, j, 16u); ndiffuse += fbit(w, j, 1u) ? 1 : 0; }
+    return caustic ? (fbit(w, 1, 1u) && all_mesh && ndiffuse < 2) : (all_mesh && ndiffuse == 0);
+}
+
 // ----------------------------------------------------------------------------
 // geometry a lane holds
 // ----------------------------------------------------------------------------

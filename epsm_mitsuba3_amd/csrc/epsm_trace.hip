@@ -353,8 +353,11 @@ static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene
     if (scene->n_triangles > 0 && (!scene->positions || !scene->normals || !scene->tri || !scene->tri_mesh ||
                                    !scene->meshes || !scene->bsdfs || !scene->bvh || !scene->prim_index || !scene->tri_verts))
         return bad("NULL scene array");
-    if (scene->n_emitters > 0 && !scene->emitters) return bad("NULL emitters");
-    if (flags & ~(uint32_t) (EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG)) return bad("unknown flag");
+    if (const char *why = epsm_host::scene_tables_invalid(scene)) return bad(why);
+    if (flags & ~(uint32_t) (EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG | EPSM_TRACE_GRADIENT_ONLY | EPSM_TRACE_GRADIENT_CAUSTIC))
+        return bad("unknown flag");
+    if ((flags & EPSM_TRACE_GRADIENT_CAUSTIC) && !(flags & EPSM_TRACE_GRADIENT_ONLY)) return bad("EPSM_TRACE_GRADIENT_CAUSTIC modifies EPSM_TRACE_GRADIENT_ONLY");
+    if ((flags & EPSM_TRACE_GRADIENT_ONLY) && K_log < 1) return bad("EPSM_TRACE_GRADIENT_ONLY needs a vertex log (K_log >= 1)");
     memset(&A, 0, sizeof(A));
     A.flags = flags;
     A.S = *scene; A.C = *sensor;

@@ -9,6 +9,7 @@
 #pragma once
 
 #include "epsm_path_core.h"
+#include "epsm_cp_core.h"
 #include "epsm_scatter_core.h"
 #include "../../include/epsm_trace.h"
 
@@ -549,7 +550,7 @@ EPSM_HD F3 emitter_normal(const EpsmScene &S, const EpsmMesh &m, const uint32_t 
     return n;
 }
 // ---- the environment emitter (include/epsm_trace.h, EpsmEnvironment; src/emitters/constant.cpp, envmap.cpp)
-EPSM_HD bool has_environment(const EpsmScene &S) { return S.env.emitter >= 0; }
+EPSM_HD bool has_environment(const EpsmScene &S) { return S.env.kind != EPSM_ENV_NONE; }
 EPSM_HD F3 env_to_local(const EpsmEnvironment &E, F3 d) {
     return f3(E.to_local[0] * d.x + E.to_local[1] * d.y + E.to_local[2] * d.z, E.to_local[3] * d.x + E.to_local[4] * d.y + E.to_local[5] * d.z,
               E.to_local[6] * d.x + E.to_local[7] * d.y + E.to_local[8] * d.z);
@@ -569,8 +570,7 @@ EPSM_HD void env_cell_coords(const EpsmEnvironment &E, F3 v, float &x, float &y)
 // radiance seen along the WORLD direction d (a ray that left the scene)
 EPSM_HD F3 env_eval(const EpsmScene &S, F3 d) {
     const EpsmEnvironment &E = S.env;
-    const EpsmEmitter em = S.emitters[E.emitter];
-    if (em.type == EPSM_EMITTER_CONSTANT) return ld3(em.radiance);
+    if (E.kind == EPSM_ENV_CONSTANT) return ld3(S.emitters[E.emitter].radiance);
     float x, y;
     env_cell_coords(E, env_to_local(E, d), x, y);
     const int i = (int) x, j = (int) fminf(y, (float) (E.height - 2));
@@ -585,8 +585,7 @@ EPSM_HD F3 env_eval(const EpsmScene &S, F3 d) {
 EPSM_HD F3 env_eval_grad(const EpsmScene &S, F3 d, F3 g[3]) {
     const EpsmEnvironment &E = S.env;
     g[0] = g[1] = g[2] = zero3<float>();
-    const EpsmEmitter em = S.emitters[E.emitter];
-    if (em.type == EPSM_EMITTER_CONSTANT) return ld3(em.radiance);
+    if (E.kind == EPSM_ENV_CONSTANT) return ld3(S.emitters[E.emitter].radiance);
     const F3 v = env_to_local(E, d);
     float x, y;
     env_cell_coords(E, v, x, y);
@@ -608,7 +607,7 @@ EPSM_HD F3 env_eval_grad(const EpsmScene &S, F3 d, F3 g[3]) {
 // density, per solid angle, of sample_environment producing the WORLD direction d (the emitter choice not included)
 EPSM_HD float env_pdf(const EpsmScene &S, F3 d) {
     const EpsmEnvironment &E = S.env;
-    if (S.emitters[E.emitter].type == EPSM_EMITTER_CONSTANT) return 0.25f / kPi;
+    if (E.kind == EPSM_ENV_CONSTANT) return 0.25f / kPi;
     const F3 v = env_to_local(E, d);
     float x, y;
     env_cell_coords(E, v, x, y);
@@ -619,7 +618,7 @@ EPSM_HD float env_pdf(const EpsmScene &S, F3 d) {
 // direction + density of an environment sample (u, v uniform in [0,1)); false: the map is black
 EPSM_HD bool env_sample(const EpsmScene &S, float u, float v, F3 &d, float &pdf) {
     const EpsmEnvironment &E = S.env;
-    if (S.emitters[E.emitter].type == EPSM_EMITTER_CONSTANT) {               // warp.h square_to_uniform_sphere
+    if (E.kind == EPSM_ENV_CONSTANT) {                                       // warp.h square_to_uniform_sphere
         const float z = 1.f - 2.f * v, r = safe_sqrt(1.f - z * z), phi = 2.f * kPi * u;
         d = f3(r * cosf(phi), r * sinf(phi), z);
         pdf = 0.25f / kPi;
@@ -671,7 +670,8 @@ EPSM_HD EmitterSample sample_emitter_direction(const EpsmScene &S, const SurfHit
     F3 radiance = ld3(em.radiance);
     if (em.type == EPSM_EMITTER_CONSTANT || em.type == EPSM_EMITTER_ENVMAP) {   // constant.cpp:105-133, envmap.cpp:380-418
         F3 d; float pdf;
-        if (env_sample(S, u, v, d, pdf)) {
+        // (an environment-typed emitter that is not THE environment of EpsmScene.env has no tables: it yields no sample)
+        if (has_environment(S) && (int) index == S.env.emitter && env_sample(S, u, v, d, pdf)) {
             const F3 off = ref.p - ld3(S.env.center);
             e.dist = 2.f * fmaxf(S.env.radius, sqrtf(dot(off, off)));
             e.d = d; e.p = ref.p + d * e.dist; e.n = -d;
@@ -833,8 +833,7 @@ EPSM_HD void write_record(const EpsmRecordOut &R, int64_t i, bool active, const 
 }
 
 // EPSM_TRACE_PACKED_LOG: the same record as ONE 128-byte row of the native log (include/epsm.h, EpsmPackedLog): eight
-// 16-byte stores instead of twenty scattered ones, plus this bounce's five flag bits in the path's flag word (the
-// path's lane is its only writer: bounce 0 sets the word, later bounces OR into it).
+// 16-byte stores instead of twenty scattered ones, plus the path's flag word so far (five bits per logged bounce).
 EPSM_HD void st4(float *p, float a, float b, float c, float d) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float F4s __attribute__((ext_vector_type(4)));
@@ -849,8 +848,14 @@ EPSM_HD void st4(float *p, float a, float b, float c, float d) {
 #endif
 }
 EPSM_HD float u2f(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
-EPSM_HD void write_record_packed(float *packed, uint32_t *pflags, int K_log, int64_t i, int iteration, bool active,
-                                 const SurfHit &h, uint32_t flags, const EmitterSample &es, bool active_em,
+// the five bits of a logged vertex in a path's flag word (include/epsm.h EPSM_FLAG_*): Diffuse, Null, active, active_em, mesh
+EPSM_HD uint32_t vertex_flag_bits(bool active, const SurfHit &h, uint32_t flags, bool active_em) {
+    const bool mesh = h.valid && (h.mesh_flags & EPSM_MESH_IS_MESH);
+    return ((flags & 0x6u) ? 1u : 0u) | ((flags & 0x1u) ? 2u : 0u) | (active ? 4u : 0u) | (active_em ? 8u : 0u) | (mesh ? 16u : 0u);
+}
+// `word` = the path's flag word INCLUDING this vertex (PathState::gword)
+EPSM_HD void write_record_packed(float *packed, uint32_t *pflags, int K_log, int64_t i, int iteration, uint32_t word,
+                                 const SurfHit &h, const EmitterSample &es,
                                  const BsdfSample &bs, float eweight) {
     const bool mesh = h.valid && (h.mesh_flags & EPSM_MESH_IS_MESH);
     const F3 z = zero3<float>();
@@ -866,10 +871,7 @@ EPSM_HD void write_record_packed(float *packed, uint32_t *pflags, int K_log, int
     st4(r + 20, n2.y, n2.z, es.p.x, es.p.y);
     st4(r + 24, u2f(es.tri), es.b0, es.b1, eweight);
     st4(r + 28, es.p.z, bs.dhf.x, bs.dhf.y, bs.dhf.z);
-    const uint32_t bits = ((flags & 0x6u) ? 1u : 0u) | ((flags & 0x1u) ? 2u : 0u) | (active ? 4u : 0u) | (active_em ? 8u : 0u) |
-                          (mesh ? 16u : 0u);
-    if (iteration == 0) pflags[i] = bits;
-    else pflags[i] |= bits << (5 * iteration);
+    pflags[i] = word;                                                     // (the path's lane is the word's only writer)
 }
 
 // EPSM_TRACE_SPARSE_LOG: a bounce the path did not reach leaves only the fields the gradient kernels' masks read
@@ -907,6 +909,7 @@ struct PathState {
     bool active, prev_bsdf_delta;
     Pcg32 rng;
     uint32_t cnt;                    // colour adjoint: vertices passed so far per BSDF colour slot, 8 bits each
+    uint32_t gword;                  // flag word of the vertices logged so far (five bits each, vertex_flag_bits)
 };
 
 // sample_rays (common.py:291-422) + the initial loop state
@@ -933,6 +936,7 @@ EPSM_HD PathState path_begin(const TraceArgs &A, int64_t i, bool log = true) {
     s.depth = 0;
     s.active = true; s.prev_bsdf_delta = true;
     s.cnt = 0u;
+    s.gword = 0u;
     return s;
 }
 EPSM_HD int path_max_depth(const TraceArgs &A) { return A.max_depth < 6 ? A.max_depth : 6; }   // epsm.py:549
@@ -1009,10 +1013,11 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
     const BsdfSample bs = bsdf_sample(bsdf, si.wi, s1, s2x, s2y, active_next);
     // ---- log (epsm.py:648-654)
     if (iteration < A.K_log) {
+        if (s.active || iteration == 0) s.gword |= vertex_flag_bits(s.active && si.valid, si, flags, active_em) << (5 * iteration);
         if (A.flags & EPSM_TRACE_PACKED_LOG) {
             if (s.active || iteration == 0)                                // (every path passes bounce 0: its flag word exists)
-                write_record_packed(A.rec[0].packed, A.rec[0].pflags, A.K_log, i, iteration, s.active && si.valid, si, flags, es,
-                                    active_em, bs, Lr_dir.x + Lr_dir.y + Lr_dir.z);
+                write_record_packed(A.rec[0].packed, A.rec[0].pflags, A.K_log, i, iteration, s.gword, si, es, bs,
+                                    Lr_dir.x + Lr_dir.y + Lr_dir.z);
         } else if (s.active || !(A.flags & EPSM_TRACE_SPARSE_LOG)) {
             write_record(A.rec[iteration], i, s.active && si.valid, si, flags, es, active_em, bs,
                          Lr_dir.x + Lr_dir.y + Lr_dir.z, bsdf.alpha_slot);
@@ -1062,6 +1067,10 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
     active_next = active_next && (!rr_active || rr_continue);
     if (si.valid && s.active) s.depth += 1;                               // :734
     s.active = s.active && active_next;                                   // :735
+    // EPSM_TRACE_GRADIENT_ONLY (include/epsm_trace.h): nothing behind this vertex can reach calc_grad -> the path ends here
+    if ((A.flags & EPSM_TRACE_GRADIENT_ONLY) &&
+        (iteration + 1 >= A.K_log || !cp::gradient_live(s.gword, iteration + 1, (A.flags & EPSM_TRACE_GRADIENT_CAUSTIC) != 0)))
+        s.active = false;
 }
 template <class Vis>
 EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState &s, const TriHit &th, Vis &vis) {

@@ -166,7 +166,7 @@ extern "C" int epsm_trace_paths_reparam(const EpsmScene *scene, const EpsmSensor
     if (scene->n_triangles <= 0 || !scene->positions || !scene->normals || !scene->tri || !scene->tri_mesh || !scene->meshes ||
         !scene->bsdfs || !scene->bvh || !scene->prim_index || !scene->tri_verts)
         return bad("NULL scene array");
-    if (scene->n_emitters > 0 && !scene->emitters) return bad("NULL emitters");
+    if (const char *why = epsm_host::scene_tables_invalid(scene)) return bad(why);
     rp::ReparamArgs R;
     memset(&R, 0, sizeof(R));
     R.A.S = *scene; R.A.C = *sensor;

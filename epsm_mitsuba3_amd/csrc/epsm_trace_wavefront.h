@@ -43,7 +43,7 @@ struct WfState {                              // device pointers into the worksp
     W4 *hit;          // tri (kNoIndex: miss), t, u, v
     W4 *beta;         // beta, prev_bsdf_pdf
     W4 *L;            // L, depth | prev_bsdf_delta << 8 | bounces done << 16
-    W4 *prev_p;       // prev_p, -
+    W4 *prev_p;       // prev_p, flag word of the vertices logged so far (PathState::gword)
     W4 *rng;          // state lo, hi, inc lo, hi
     W4 *sh_o;         // visibility ray o, maxt
     W4 *sh_d;         // visibility ray d, kWfOccluder
@@ -96,7 +96,7 @@ EPSM_HD void wf_store(const WfState &W, int64_t i, const PathState &s, int done)
     W.ray_d[i] = pack4(s.ray.d, s.eta);
     W.beta[i] = pack4(s.beta, s.prev_bsdf_pdf);
     W.L[i] = pack4u(s.L, (uint32_t) s.depth | (s.prev_bsdf_delta ? 0x100u : 0u) | ((uint32_t) done << 16));
-    W.prev_p[i] = pack4(s.prev_p, 0.f);
+    W.prev_p[i] = pack4u(s.prev_p, s.gword);
     W4 r; r.x = (uint32_t) s.rng.state; r.y = (uint32_t) (s.rng.state >> 32); r.z = (uint32_t) s.rng.inc; r.w = (uint32_t) (s.rng.inc >> 32);
     W.rng[i] = r;
 }
@@ -107,7 +107,8 @@ EPSM_HD PathState wf_load(const WfState &W, int64_t i) {
     s.ray.d = xyz(d); s.eta = u2f(d.w);
     s.beta = xyz(b); s.prev_bsdf_pdf = u2f(b.w);
     s.L = xyz(l); s.depth = (int) (l.w & 0xFFu); s.prev_bsdf_delta = (l.w & 0x100u) != 0;
-    s.prev_p = xyz(W.prev_p[i]);
+    const W4 pp = W.prev_p[i];
+    s.prev_p = xyz(pp); s.gword = pp.w;
     s.rng.state = (uint64_t) r.x | ((uint64_t) r.y << 32); s.rng.inc = (uint64_t) r.z | ((uint64_t) r.w << 32);
     s.active = true;                                                     // only live paths are queued
     return s;

@@ -99,6 +99,10 @@ class EPSMIntegrator:
         # True: render_backward asks the tracer for the native packed log (one 128-byte record per path vertex) and runs
         # epsm_backward_pass_packed on it; False: the reference's per-field tensors all the way
         self.packed_log = bool(props.get("packed_log", True))
+        # True: the backward trace retires a path as soon as nothing behind its last logged vertex can reach calc_grad
+        # (EPSM_TRACE_GRADIENT_ONLY, include/epsm_trace.h): identical gradients, the image of that pass -- which the 5-channel
+        # branch never uses (epsm.py:729-732) -- is not formed
+        self.gradient_only = bool(props.get("gradient_only", True))
 
     def to_string(self):
         md = 0xFFFFFFFF if self.max_depth < 0 else self.max_depth
@@ -151,6 +155,8 @@ class EPSMIntegrator:
         kw = {}
         if self.fused and self.fuse_tangent and self.packed_log and getattr(scene, "supports_packed_log", False):
             kw["packed_log"] = True        # the tracer writes the backward kernel's native layout (EpsmPackedLog)
+        if self.gradient_only and getattr(scene, "supports_gradient_only", False):
+            kw["gradient_only"] = self.variant
         traces = tracer(sensor=self.backward_sensor, seed=seed, spp=self.backward_spp,
                         max_depth=self.tracer_depth(), max_log_depth=self.max_log_depth, rank=rank, world_size=world,
                         sparse_log=True,   # the log is consumed here and nowhere else: skip the zeros of dead bounces

@@ -44,6 +44,8 @@ IOR = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "bk7": 1.5046, "glass": 
 # ---------------------------------------------------------------------------- ctypes mirrors
 EPSM_TRACE_SPARSE_LOG = 0x1          # include/epsm_trace.h
 EPSM_TRACE_PACKED_LOG = 0x2
+EPSM_TRACE_GRADIENT_ONLY = 0x4
+EPSM_TRACE_GRADIENT_CAUSTIC = 0x8
 
 
 class EpsmMesh(C.Structure):
@@ -74,7 +76,7 @@ class EpsmSensor(C.Structure):
 
 
 class EpsmEnvironment(C.Structure):
-    _fields_ = [("emitter", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("texels", C.c_void_p), ("row_cdf", C.c_void_p),
+    _fields_ = [("kind", C.c_int32), ("emitter", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("texels", C.c_void_p), ("row_cdf", C.c_void_p),
                 ("col_cdf", C.c_void_p), ("cell_pdf", C.c_void_p), ("to_local", C.c_float * 9), ("center", C.c_float * 3),
                 ("radius", C.c_float)]
 
@@ -991,11 +993,11 @@ class Scene:
         s.textures, s.n_textures = self._tex_struct_buf.data_ptr(), len(self._tex_buf)
         # ---- the environment emitter: sampling tables + the bounding sphere of shapes and sensors (scene.cpp expands the
         #      scene's box by its sensors; constant.cpp:76-79, envmap.cpp:311-314)
-        s.env.emitter = -1
+        s.env.kind, s.env.emitter = 0, 0                        # EPSM_ENV_NONE
         for i, e in enumerate(self.emitter_desc):
             if e["type"] not in (2, 3):
                 continue
-            s.env.emitter = i
+            s.env.kind, s.env.emitter = e["type"] - 1, i       # EPSM_ENV_CONSTANT = 1, EPSM_ENV_ENVMAP = 2
             pts = [P.reshape(-1, 3)] if self.V else []
             pts.append(np.array([sn.to_world[:3, 3] for sn in self.sensors], np.float64).reshape(-1, 3))
             pts = np.concatenate(pts) if pts else np.zeros((1, 3))
@@ -1087,7 +1089,26 @@ class Scene:
         if rc != 0:
             _lib.check(rc, "epsm_trace_paths_reparam") if self._backend is None else (_ for _ in ()).throw(RuntimeError(f"host tracer rc={rc}"))
 
-    def _trace_packed(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int):
+    @staticmethod
+    def _gradient_only_flags(gradient_only) -> int:
+        """EPSM_TRACE_GRADIENT_ONLY (+ _CAUSTIC) for the variant named (None / False: the full trace)."""
+        if not gradient_only:
+            return 0
+        if gradient_only not in ("manifold", "manifold_caustic"):
+            raise ValueError(f"gradient_only: 'manifold', 'manifold_caustic' or None, got {gradient_only!r}")
+        return EPSM_TRACE_GRADIENT_ONLY | (EPSM_TRACE_GRADIENT_CAUSTIC if gradient_only == "manifold_caustic" else 0)
+
+    def wavefront_queue_lengths(self):
+        """Paths alive into bounce 0..5 and visibility rays of bounce 0..5 of the LAST wavefront trace on the current stream
+        (the counters the stages keep on the device; a host read, for reports)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+        ws = self._wf_workspace.get(stream)
+        if ws is None:
+            return None
+        c = ws[:64].view(torch.int32).cpu().tolist()
+        return {"alive": c[0:6], "shadow": c[8:14]}
+
+    def _trace_packed(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int, gradient_only=None):
         """The same trace with the vertex log in the NATIVE layout of the backward kernel (EPSM_TRACE_PACKED_LOG,
         include/epsm.h EpsmPackedLog): the PathTrace carries ``log`` (a PackedLog) instead of per-field arrays."""
         from .integrators import PathTrace
@@ -1114,7 +1135,8 @@ class Scene:
         args = [C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
                 C.c_int64(lo), C.c_int64(n), K, C.c_void_p(rays.data_ptr()), None, None, None,
                 C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()), C.c_void_p(valid.data_ptr()),
-                C.c_void_p(C.addressof(recs)), C.c_uint32(EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG)]
+                C.c_void_p(C.addressof(recs)),
+                C.c_uint32(EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG | self._gradient_only_flags(gradient_only))]
         if self.use_wavefront() and n > 0:
             need = int(lib.epsm_trace_workspace_bytes(C.c_int64(n)))
             ws = self._wf_workspace.get(stream)
@@ -1132,7 +1154,7 @@ class Scene:
         return tr
 
     def _trace(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int,
-               want_radiance: bool = True, sparse_log: bool = False):
+               want_radiance: bool = True, sparse_log: bool = False, gradient_only=None):
         from .integrators import PathTrace
         dev = self.device
         if dev.type != "cuda" and self._backend is None:
@@ -1181,7 +1203,8 @@ class Scene:
                 C.c_int64(lo), C.c_int64(n), K, C.c_void_p(ray[0].data_ptr()), C.c_void_p(ray[1].data_ptr()),
                 C.c_void_p(ray[2].data_ptr()), C.c_void_p(ray[3].data_ptr()),
                 C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()), C.c_void_p(valid.data_ptr()),
-                C.c_void_p(C.addressof(recs)), C.c_uint32(EPSM_TRACE_SPARSE_LOG if sparse_log else 0)]
+                C.c_void_p(C.addressof(recs)),
+                C.c_uint32((EPSM_TRACE_SPARSE_LOG if sparse_log else 0) | (self._gradient_only_flags(gradient_only) if K >= 1 else 0))]
         if self.use_wavefront() and n > 0:
             # queues of live paths, three small kernels per bounce (include/epsm_trace.h); the workspace is scratch
             # and is kept between calls
@@ -1201,14 +1224,17 @@ class Scene:
         return tr
 
     supports_packed_log = True
+    supports_gradient_only = True
 
     def iter_traces(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1, sparse_log=False,
-                    packed_log=False):
+                    packed_log=False, gradient_only=None):
         """Generator over this rank's tiles of the backward wavefront of ``sensors[sensor]`` (epsm.py:142-181): a tile
         is traced when the consumer asks for it, so ``render_backward`` holds ONE tile's records (~0.8 KB per path at
         K = 5) at a time whatever the size of the wavefront.  ``sparse_log``: EPSM_TRACE_SPARSE_LOG -- bounces a path
         did not reach carry only their (zero) mask fields, which is all the gradient kernels read of them; the other
-        arrays are uninitialised there."""
+        arrays are uninitialised there.  ``gradient_only`` = "manifold" / "manifold_caustic": EPSM_TRACE_GRADIENT_ONLY --
+        a path is retired once nothing behind its last logged vertex can reach that variant's calc_grad (identical gradients;
+        ``radiance`` is then NOT the path's radiance)."""
         si = min(sensor, len(self.sensors) - 1)
         s = self.sensors[si]
         if s.width != s.height:
@@ -1226,9 +1252,9 @@ class Scene:
         tiles = _dist.tile_ranges(n_total, tile)
         for t in _dist.my_tiles(len(tiles), rank, world_size):
             if packed_log and K >= 1:
-                yield self._trace_packed(si, seed, spp, max_depth, K, *tiles[t])
+                yield self._trace_packed(si, seed, spp, max_depth, K, *tiles[t], gradient_only=gradient_only)
             else:
-                yield self._trace(si, seed, spp, max_depth, K, *tiles[t], sparse_log=sparse_log)
+                yield self._trace(si, seed, spp, max_depth, K, *tiles[t], sparse_log=sparse_log, gradient_only=gradient_only)
 
     def trace_paths(self, *args, **kw):
         """All of this rank's tiles at once (``list(iter_traces(...))``): for small wavefronts and the tests."""

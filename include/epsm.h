@@ -32,8 +32,10 @@ extern "C" {
 
 /* Changes when the meaning or signature of an existing entry point changes (4: triangle-id addressing, round 2; 5: word layout of
  * the native log's vertex record, round 4 -- EpsmPackedLog below).  Entry points added since without touching the others:
- * epsm_backward_pass_packed, epsm_release_workspace, epsm_sinkhorn_*, epsm_set_option / epsm_get_option. */
-#define EPSM_ABI_VERSION 5
+ * epsm_backward_pass_packed, epsm_release_workspace, epsm_sinkhorn_*, epsm_set_option / epsm_get_option, epsm_probe.
+ * 6 (round 5): EpsmEnvironment starts with `kind` (0 = none: a zeroed EpsmScene has no environment; until 5 `emitter = -1` said
+ * so); note of 5, late: epsm_trace_paths_reparam had gained its `flags` parameter mid-signature in that version. */
+#define EPSM_ABI_VERSION 6
 
 /* BSDF flag bits tested by the hot path (include/mitsuba/render/bsdf.h:40-46,101). */
 #define EPSM_BSDF_NULL     0x1u

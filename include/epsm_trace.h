@@ -59,6 +59,19 @@ enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
  * still used.  The alpha slot of a vertex's BSDF is NOT in the record: the consumer takes it from the triangle table
  * (bits 8.. of the mode word). */
 #define EPSM_TRACE_PACKED_LOG 0x2u
+/* EPSM_TRACE_GRADIENT_ONLY: the trace feeds calc_grad and nothing else (render_backward's 5-channel branch, epsm.py:235-297:
+ * the image of that pass is never used, :729-732) -- a path is RETIRED after the bounce that logs vertex k as soon as no
+ * later vertex can produce, or be read by, a term of calc_grad, i.e. when the masks of epsm.py:793-803, 852-856, 916-921
+ * (`valid`: every vertex so far is a mesh hit; `hasdiffuse == 0`) can no longer hold for any id >= k:
+ *     manifold           goes on while every vertex so far is a mesh hit and none is Diffuse
+ *     manifold_caustic   (with EPSM_TRACE_GRADIENT_CAUSTIC) goes on while vertex 1 is Diffuse, every vertex so far is a
+ *                        mesh hit and fewer than two are Diffuse (epsm.py:998-999, 1172-1183)
+ * and after vertex K_log in any case.  The bounce that retires a path is complete (emitter sample, its visibility ray, the
+ * occluder record of vertex 1, the logged weight eweight = sum Lr_dir), so every record calc_grad reads is the one the
+ * full trace writes and the gradients are identical; `radiance` is then the radiance gathered up to that bounce only and
+ * must not be used as an image.  bench.py's real_scene leg: trace + log 14.3 -> see DESIGN.md 5b. */
+#define EPSM_TRACE_GRADIENT_ONLY    0x4u
+#define EPSM_TRACE_GRADIENT_CAUSTIC 0x8u
 
 typedef struct EpsmMesh {
     uint32_t tri_begin, tri_count;   /* this mesh's range in the triangle arrays */
@@ -125,8 +138,9 @@ typedef struct EpsmSensor {
     int32_t pad;
 } EpsmSensor;
 
-/* The scene's environment emitter (src/emitters/constant.cpp, envmap.cpp): at most one, `emitter` = its index in
- * EpsmScene.emitters (-1: none).  A ray that leaves the scene sees its radiance (MIS against emitter sampling as for an area
+/* The scene's environment emitter (src/emitters/constant.cpp, envmap.cpp): at most one, `kind` says which (0: none) and
+ * `emitter` = its index in EpsmScene.emitters.  Every tracer entry point checks: kind in {0, 1, 2}; kind != 0 => 0 <= emitter <
+ * n_emitters; kind == ENVMAP => the four tables non-NULL and width, height >= 2; n_textures > 0 => textures non-NULL (EPSM_EINVAL).  A ray that leaves the scene sees its radiance (MIS against emitter sampling as for an area
  * light); an emitter sample is the point ref + 2 max(radius, |ref - center|) d (constant.cpp:113-116, envmap.cpp:398-399) -- what
  * the vertex log records as `light` -- with d uniform on the sphere (constant) or drawn from the map.
  * envmap: `texels` is the (height, width + 1, 3) lat-long map, `scale` applied, column `width` a copy of column 0; texel (i, j)
@@ -135,8 +149,12 @@ typedef struct EpsmSensor {
  * CELL (the width x (height - 1) bilinear patches): weight = mean over the four corners of luminance x sin theta, rows by
  * `row_cdf`, columns by `col_cdf`, uniform inside a cell -- a piecewise-constant stand-in for the reference's hierarchical
  * sample warp (same support, same estimator up to variance). */
+enum { EPSM_ENV_NONE = 0, EPSM_ENV_CONSTANT = 1, EPSM_ENV_ENVMAP = 2 };
 typedef struct EpsmEnvironment {
-    int32_t emitter;                 /* -1 = the scene has no environment emitter */
+    int32_t kind;                    /* EPSM_ENV_*: 0 = the scene has no environment emitter, so a zero-initialised EpsmScene is
+                                        safe (ABI 6; until ABI 5 `emitter = -1` said so and 0 named emitter 0).  `kind`, not
+                                        emitters[emitter].type, decides which tables the device code touches. */
+    int32_t emitter;                 /* kind != 0: its index in EpsmScene.emitters (radiance, colour slot, emitter choice) */
     int32_t width, height;           /* envmap only */
     const float *texels;             /* (height, width + 1, 3) */
     const float *row_cdf;            /* (height - 1) cumulative, normalised */
@@ -188,7 +206,7 @@ typedef struct EpsmRecordOut {
  *   ray_o/d/dx/dy (N,3), film_pos (N,2), radiance (N,3), valid (N) u8: outputs (any may be NULL
  *                                    except ray_*); radiance = L of epsm.py:658, valid = depth != 0
  *   recs                             K_log records to fill (all fields written for every path)
- *   flags                            0 or EPSM_TRACE_SPARSE_LOG and / or EPSM_TRACE_PACKED_LOG
+ *   flags                            0 or any of EPSM_TRACE_SPARSE_LOG, EPSM_TRACE_PACKED_LOG, EPSM_TRACE_GRADIENT_ONLY (+ _CAUSTIC)
  * ------------------------------------------------------------------------- */
 int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor,
                      uint32_t seed, int spp, int max_depth, int rr_depth,

@@ -179,3 +179,7 @@ extern "C" int epsm_host_cp_grad_f64(int variant, int64_t N, int K, const void *
                                      void *op, void *ol, void *od, int) {
     return run<double>(variant, N, K, cam, verts, dlduv, stride, dcols, dldp, clip, op, ol, od);
 }
+
+// the term masks of a flag word (cp::manifold_plan / caustic_plan) and the tracer's retirement rule (cp::gradient_live)
+extern "C" uint32_t epsm_host_plan(int variant, uint32_t w) { return variant == 0 ? cp::manifold_plan(w) : cp::caustic_plan(w); }
+extern "C" int epsm_host_gradient_live(uint32_t w, int k, int caustic) { return cp::gradient_live(w, k, caustic != 0) ? 1 : 0; }

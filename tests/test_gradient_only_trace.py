@@ -1,0 +1,110 @@
+"""EPSM_TRACE_GRADIENT_ONLY (include/epsm_trace.h): the backward trace retires a path once nothing behind its last logged
+vertex can reach calc_grad.  (1) the rule against the term masks themselves (cp::manifold_plan / caustic_plan =
+epsm.py:793-803, 852-856, 916-921, 998-999, 1172-1183) over every flag word of up to three vertices and random longer ones;
+(2) the host build of the tracer with and without the flag: identical logs up to the retirement point, and the float64
+oracle pipeline gives the same parameter gradients from both."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import _scenes as TS
+from tests.host_core import lib as host_core
+
+
+def _plan_fns():
+    l = host_core("cp")
+    l.epsm_host_plan.restype = C.c_uint32
+    l.epsm_host_plan.argtypes = [C.c_int, C.c_uint32]
+    l.epsm_host_gradient_live.restype = C.c_int
+    l.epsm_host_gradient_live.argtypes = [C.c_uint32, C.c_int, C.c_int]
+    return l.epsm_host_plan, l.epsm_host_gradient_live
+
+
+def _retired_word(w, K, caustic, live):
+    """The flag word the gradient-only trace leaves: vertices behind the first k with !live(w, k) are never logged."""
+    for k in range(1, K + 1):
+        if not ((w >> (5 * (k - 1))) & 4):           # the path itself ended before vertex k: nothing more is logged anyway
+            return w & ((1 << (5 * (k - 1))) - 1) | (w & (0x1F << (5 * (k - 1)))), k
+        if not live(w & ((1 << (5 * k)) - 1), k, caustic):
+            return w & ((1 << (5 * k)) - 1), k
+    return w, K
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_retirement_rule_never_changes_the_plan(variant):
+    plan, live = _plan_fns()
+    rng = np.random.default_rng(5)
+    words = [w for w in range(1 << 15)]                                   # every word of up to three vertices
+    words += [int(x) for x in rng.integers(0, 1 << 25, size=200000)]     # and random five-vertex ones
+    # bias towards long live chains: mesh + active set, few diffuse bits
+    base = 0
+    for k in range(5):
+        base |= (4 | 16) << (5 * k)
+    words += [int(base | (x & 0x0B5AD6B)) for x in rng.integers(0, 1 << 25, size=200000)]   # keeps bits 0,1,3 of each vertex random
+    n_retired = 0
+    for w in words:
+        # a path's `active` bits are monotone (epsm.py:735); words that violate this never occur
+        act = [(w >> (5 * k + 2)) & 1 for k in range(5)]
+        if any(act[k + 1] and not act[k] for k in range(4)):
+            continue
+        wr, k = _retired_word(w, 5, variant, live)
+        n_retired += wr != w
+        assert plan(variant, w) == plan(variant, wr), (hex(w), hex(wr), k)
+    assert n_retired > 1000
+
+
+def _scene(tracer):
+    from epsm_mitsuba3_amd.exp import clutter
+    scene = TS.on_host(clutter.load_scene(device="cpu", n_spheres=8, res=24, spp=4))
+    for name in ["floor", "light"] + [f"s{i}" for i in range(8)]:
+        scene.attach(name, positions=True, normals=name.startswith("s"))
+    scene.tracer = tracer
+    return scene
+
+
+def _trace(scene, variant, gradient_only, packed):
+    kw = dict(sensor=2, seed=3, spp=4, max_depth=6, max_log_depth=5, sparse_log=packed, packed_log=packed)
+    if gradient_only:
+        kw["gradient_only"] = variant
+    return scene.trace_paths(**kw)
+
+
+@pytest.mark.parametrize("tracer", ["mega", "wavefront"])
+@pytest.mark.parametrize("variant", ["manifold", "manifold_caustic"])
+def test_host_tracer_logs_agree_up_to_the_retirement_point(variant, tracer):
+    scene = _scene(tracer)
+    plan, live = _plan_fns()
+    (full,) = _trace(scene, variant, False, True)
+    (cut,) = _trace(scene, variant, True, True)
+    wf, wc = full.log.flags.numpy().astype(np.uint32), cut.log.flags.numpy().astype(np.uint32)
+    caustic = int(variant == "manifold_caustic")
+    n_short = 0
+    for i in range(wf.shape[0]):
+        wr, k = _retired_word(int(wf[i]), full.log.K, caustic, live)
+        assert int(wc[i]) == wr, (i, hex(int(wf[i])), hex(int(wc[i])), hex(wr))
+        n_short += wr != int(wf[i])
+        # the records that exist in the cut log are bit for bit those of the full trace
+        nk = max(1, sum(1 for j in range(full.log.K) if (wr >> (5 * j)) & 0x1F))
+        assert torch.equal(full.log.verts[i, :nk].view(torch.int32), cut.log.verts[i, :nk].view(torch.int32)), i
+    assert n_short >= 40, "the scene retires too few paths to test anything"     # (an open scene: most paths leave it by themselves)
+    assert torch.equal(full.log.rays, cut.log.rays)
+
+
+@pytest.mark.parametrize("variant", ["manifold", "manifold_caustic"])
+def test_oracle_pipeline_gives_the_same_gradients_from_both_traces(variant):
+    from tests._pipeline_oracle import oracle_backward
+    scene = _scene("wavefront")
+    g = torch.Generator().manual_seed(2)
+    grad_in = torch.randn((24, 24, 5), generator=g) * 1e-3
+    full = _trace(scene, variant, False, False)
+    cut = _trace(scene, variant, True, False)
+    a = oracle_backward(variant, full, grad_in, scene.V, len(scene.alpha_slots))
+    b = oracle_backward(variant, cut, grad_in, scene.V, len(scene.alpha_slots))
+    assert float(a[0].abs().max()) > 0
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=1e-12, atol=1e-18)        # the same float64 terms (up to the order of the OpenMP sums)
+    # and the cut trace did stop early: fewer active vertices in its log
+    act = lambda trs: sum(int(r["active"].sum()) for tr in trs for r in tr.path_info[1:])
+    assert act(cut) < act(full) - 40
