@@ -237,12 +237,16 @@ def cpu_baseline(trace, grad_in, variant, V, B, target_s):
                                        "only, not measured in this run"}}
 
 
-def secondary_config_leg(index, dev):
+def secondary_config_leg(index, dev, profile_override=None, label_override=None):
     """BASELINE.json configs[index - 1] as a secondary figure next to the headline (round 1's driver line
-    was configs[1]): one resident slab, native packed log, the one-launch backward pass timed with events over 10 launches."""
+    was configs[1]): one resident slab, native packed log, the one-launch backward pass timed with events over 10 launches.
+    ``profile_override``: the same slab shape with another synthetic profile (``dense_specular``: every vertex of every path
+    live, i.e. algorithmic bytes = live bytes and 50 parameter rows per path -- VERDICT r4 item 4)."""
     import epsm_mitsuba3_amd as epsm
     from epsm_mitsuba3_amd.records import PackedLog
     label, variant, profile, res, spp, K, V = CONFIGS[index]
+    profile = profile_override or profile
+    label = label_override or label
     n = min(res * res * spp, SLAB_PATHS)
     scene = epsm.SyntheticScene(res=res, n_vertices=K, n_scene_vertices=V, n_bsdfs=4, profile=profile, device=dev, tile_paths=n)
     integ = epsm.load_dict({"type": variant, "max_depth": 8})
@@ -262,9 +266,18 @@ def secondary_config_leg(index, dev):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     alg = (56 + 116 * K) * n
-    return {"workload": f"{label}: one slab of {n} paths, native packed log", "kernel_ms": ms, "paths_per_s": n / (ms * 1e-3),
-            "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_path": 56 + 116 * K,
-            "note": "secondary figure, outside the timed region"}
+    live = int(live_vertices(log.flags, K, variant).sum())
+    out = {"workload": f"{label}: one slab of {n} paths, native packed log", "kernel_ms": ms, "paths_per_s": n / (ms * 1e-3),
+           "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_path": 56 + 116 * K,
+           "live_vertices_per_path": live / n,
+           "frac_live": (56 * n + 116 * live) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "note": "secondary figure, outside the timed region"}
+    traffic, src, _ = lookup_traffic("epsm_backward_pass_packed", n, K, variant, profile)
+    if traffic is not None:
+        out["traffic"] = traffic
+        out["frac_traffic"] = traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["traffic_source"] = src
+    return out
 
 
 def hybrid_phase2_leg(res, spp, rays, dev):
@@ -636,6 +649,9 @@ def main():
                          # rays + image gradient = 56 this launch reads because it computes the tangent itself)
                          "frac_survey": ((32 + 116 * K) * n_slab0 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fused else None,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         # what the memory system sees: the counters' HBM bytes per launch over the same launch time (VERDICT r4:
+                         # `frac` prices SURVEY's algorithmic bytes, part of which the kernel never has to move)
+                         "frac_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "kernel": ("epsm_backward_cp_kernel<tangents in kernel> (epsm_backward_pass: tangent + calc_grad + scatter)"
                                     if one_launch else "epsm_backward_cp_kernel (fused calc_grad + scatter)") if fused else "epsm_grad_kernel",
                          "kernel_ms": kernel_ms, "launches_timed": len(launch_events), "paths_per_launch": n_slab0,
@@ -665,6 +681,10 @@ def main():
             result["cpu_baseline"] = cpu_baseline(slabs[0][0], grad_in, variant, V, B, args.cpu_seconds)
         if world == 1 and args.config == 0 and not (args.soa or args.two_stage or args.separate_tangent or args.no_secondary):
             result["configs_1"] = secondary_config_leg(2, dev)          # BASELINE.json configs[1]: round 1's driver line
+            # the workload where SURVEY's algorithmic bytes ARE the live bytes: no diffuse vertex, five constraint vertices and
+            # ~50 parameter rows per path
+            result["dense_specular"] = secondary_config_leg(2, dev, profile_override="specular",
+                                                            label_override="dense_specular: configs[1]'s slab with the `specular` profile (every vertex live)")
         if world == 1 and (args.real_scene or (args.config == 0 and not (args.soa or args.two_stage or args.separate_tangent or args.no_secondary))):
             # end to end on records the library's own tracer produces: trace + native log + backward pass
             del slabs, out

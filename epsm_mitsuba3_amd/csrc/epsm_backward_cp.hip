@@ -357,6 +357,104 @@ __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const
         X.n0 = ldq(nx, 0); X.n1 = ldq(nx, 1); X.n2 = ldq(nx, 2);
     }
 }
+// ---- EPSM_CP_DMA (round 5): the lane's OWN record through LDS, as whole 128-byte lines.
+// Per-lane loads ask the vector L1 for one 16-byte piece of 64 DIFFERENT lines per instruction -- six instructions per record,
+// plus two more after the recursions for the words the emission needs: the same gathers with this kernel's amount of work
+// beside them run at 3.6-3.9 TB/s (tools/micro/batch_gather.hip, profiles/r05_d_batch_gather.txt), which IS this kernel's
+// measured HBM rate.  Eight lanes x 16 bytes per record in ONE instruction (LDS-DMA, global_load_lds_dwordx4: no register
+// destination) make every request a whole line: 5.5-5.9 TB/s in the same micro-benchmark at the same three waves per SIMD,
+// in BATCHES of 16 records through 2 304 bytes of staging per wave -- two DMA instructions, wait, the 16 owning lanes read
+// their quads back, next batch.  Lane l of instruction j of batch b serves the record of lane `owner` = 16 b + 8 j + l / 8 and
+// fetches its quad (l % 8) ^ (owner % 8) -- the XOR on the SOURCE side, the LDS image being lane-linear -- so that the 16
+// owners' ds_read_b128 of one quad hit 16 different bank groups (slots 1 152 bytes apart: 1 024 + 128 of padding).
+constexpr int kDmaSlotWords = 288, kDmaBatch = 16;
+constexpr int kDmaStageWords = 2 * kDmaSlotWords;           // per wave
+typedef __attribute__((address_space(3))) const F4v LdsF4;
+__device__ __forceinline__ void dma16(const float *src, float *lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src, (__attribute__((address_space(3))) void *) lds_dst, 16, 0, 0);
+}
+// want: 2 = the whole record (a constraint vertex), 1 = its first sector (a diffuse first hit without a constraint), 0 = nothing
+template <int VARIANT>
+__device__ __forceinline__ void geo_stage_dma(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B, float *stage, int lane) {
+    const LaneRole R = role_of(F, L, B);
+    const uint32_t want = R.live ? 2u : R.d1 ? 1u : 0u;
+    const uint32_t roff = (uint32_t) ((R.loc * (uint32_t) F.K + (uint32_t) (L.k - 1)) * (uint32_t) kRecWords) | want;   // (a multiple of 32: the low bits are free)
+    const int s = lane & 7, grp = lane >> 3;
+    const int quad = s ^ (grp & 7);                          // owner % 8 == (l / 8) % 8 in every instruction
+    const bool want_lz = VARIANT == EPSM_VARIANT_MANIFOLD && R.live && cp::plan_a(L.plan, L.k);
+#pragma unroll 1
+    for (int b = 0; b < 64 / kDmaBatch; ++b) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t o = (uint32_t) __shfl((int) roff, kDmaBatch * b + 8 * j + grp);
+            const uint32_t w = o & 3u;
+            if (w == 2u || (w == 1u && quad < 4)) dma16(B.verts + (o & ~31u) + 4 * quad, stage + j * kDmaSlotWords);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int li = lane - kDmaBatch * b;
+        if (li >= 0 && li < kDmaBatch && want != 0u) {
+            const float *p = stage + (li >> 3) * kDmaSlotWords + s * kRecWords;
+            X.o0 = *(LdsF4 *) (p + 4 * (0 ^ s)); X.o1 = *(LdsF4 *) (p + 4 * (1 ^ s)); X.o2 = *(LdsF4 *) (p + 4 * (2 ^ s));
+            if (want == 2u) {
+                X.o3 = *(LdsF4 *) (p + 4 * (3 ^ s)); X.o4 = *(LdsF4 *) (p + 4 * (4 ^ s)); X.o5 = *(LdsF4 *) (p + 4 * (5 ^ s));
+                if (want_lz) X.o_lz = *(__attribute__((address_space(3))) const float *) (p + 4 * (7 ^ s));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next batch overwrites the slots
+    }
+}
+// ---- EPSM_CP_COOP: the same whole-line requests with REGISTER staging -- all eight cooperative loads of a round in flight at
+// once (32 registers that nothing else needs at the start of a round), ONE wait, then the transposition through the 2 304-byte
+// staging area in four batches of LDS round trips (~100 cycles each) instead of four trips to memory.
+typedef __attribute__((address_space(3))) F4v LdsF4w;
+template <int VARIANT>
+__device__ __forceinline__ void geo_stage_coop(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B, float *stage, int lane) {
+    const LaneRole R = role_of(F, L, B);
+    const uint32_t want = R.live ? 2u : R.d1 ? 1u : 0u;
+    const uint32_t roff = (uint32_t) ((R.loc * (uint32_t) F.K + (uint32_t) (L.k - 1)) * (uint32_t) kRecWords) | want;
+    const int s = lane & 7, grp = lane >> 3;
+    const bool want_lz = VARIANT == EPSM_VARIANT_MANIFOLD && R.live && cp::plan_a(L.plan, L.k);
+    const F4v z4 = {0.f, 0.f, 0.f, 0.f};
+    F4v c0 = z4, c1 = z4, c2 = z4, c3 = z4, c4 = z4, c5 = z4, c6 = z4, c7 = z4;
+    // instruction j: lane l fetches quad l % 8 of the record of lane 8 j + l / 8 (quads 4..7 only of whole records)
+#define EPSM_COOP_LOAD(J, C) { const uint32_t o = (uint32_t) __shfl((int) roff, 8 * J + grp); const uint32_t w = o & 3u; \
+        if (w == 2u || (w == 1u && s < 4)) C = ldq(B.verts + (o & ~31u), s); }
+    EPSM_COOP_LOAD(0, c0) EPSM_COOP_LOAD(1, c1) EPSM_COOP_LOAD(2, c2) EPSM_COOP_LOAD(3, c3)
+    EPSM_COOP_LOAD(4, c4) EPSM_COOP_LOAD(5, c5) EPSM_COOP_LOAD(6, c6) EPSM_COOP_LOAD(7, c7)
+#undef EPSM_COOP_LOAD
+    // transposition: instruction j's lane l holds quad s of local record grp; it goes to slot (j & 1), record grp, position s ^ grp
+    float *const wr0 = stage + grp * kRecWords + 4 * (s ^ grp), *const wr1 = wr0 + kDmaSlotWords;
+#define EPSM_COOP_BATCH(BATCH, CA, CB) { \
+        *(LdsF4w *) wr0 = CA; *(LdsF4w *) wr1 = CB; \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        const int li = lane - kDmaBatch * BATCH; \
+        if (li >= 0 && li < kDmaBatch && want != 0u) { \
+            const float *p = stage + (li >> 3) * kDmaSlotWords + s * kRecWords; \
+            X.o0 = *(LdsF4 *) (p + 4 * (0 ^ s)); X.o1 = *(LdsF4 *) (p + 4 * (1 ^ s)); X.o2 = *(LdsF4 *) (p + 4 * (2 ^ s)); \
+            if (want == 2u) { \
+                X.o3 = *(LdsF4 *) (p + 4 * (3 ^ s)); X.o4 = *(LdsF4 *) (p + 4 * (4 ^ s)); X.o5 = *(LdsF4 *) (p + 4 * (5 ^ s)); \
+                if (want_lz) X.o_lz = *(__attribute__((address_space(3))) const float *) (p + 4 * (7 ^ s)); \
+            } \
+        } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    EPSM_COOP_BATCH(0, c0, c1) EPSM_COOP_BATCH(1, c2, c3) EPSM_COOP_BATCH(2, c4, c5) EPSM_COOP_BATCH(3, c6, c7)
+#undef EPSM_COOP_BATCH
+}
+// what stays a per-lane load beside the staged records: the rays + image gradient of a path's first lane, the first sector of
+// the end-point record of its last lane
+__device__ __forceinline__ void geo_issue_rest(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B) {
+    const LaneRole R = role_of(F, L, B);
+    if (R.ok && R.first) {
+        const float *rays = B.rays + 12u * R.loc;
+        X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
+        const F2v g = ld2(pixel_grad(F.tin, B, R.loc));
+        X.gx = g.x; X.gy = g.y;
+    }
+    if (R.end_next) {
+        const float *nx = R.rec + kRecWords;
+        X.n0 = ldq(nx, 0); X.n1 = ldq(nx, 1); X.n2 = ldq(nx, 2);
+    }
+}
 template <int VARIANT>
 __device__ __forceinline__ void addr_issue(AddrFetch &A, const FusedArgs &F, const LaneId &L, const WinBase &B) {
     const LaneRole R = role_of(F, L, B);
@@ -395,6 +493,9 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
     __shared__ int s_used;
     __shared__ QItem s_queue[kWaves][kQueueCap];
     __shared__ PtrTable s_ptrs;
+#if defined(EPSM_CP_DMA) && !defined(EPSM_CP_DMA_ALIAS)
+    __shared__ __attribute__((aligned(16))) float s_stage[PACKED ? kWaves : 1][PACKED ? kDmaStageWords : 4];
+#endif
     float *const my_rep = F.rep ? F.rep + (blockIdx.x % (unsigned) F.replicas) * F.rep_stride : nullptr;
     const Table T{s_keys, s_vals, &s_used, my_rep ? my_rep : F.gpos, my_rep ? my_rep + 3 * F.V : F.gnrm,
                   my_rep ? my_rep + 6 * F.V : F.galpha, (uint32_t) F.V};
@@ -521,6 +622,9 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             const bool act1 = (plan & cp::kPlanActive1) != 0;
 
             asm volatile("; EPSM_MARK round_begin");
+#ifdef EPSM_CP_DRAIN_EACH_ROUND          // (A/B build: what it costs to start every round with an empty queue)
+            Q.drain(T);
+#endif
             // ---- geometry: own vertex; the two neighbours from the lanes that hold them (or from the words fetched for that)
             cp::Own<float> own;
             own.x = own.e1 = own.e2 = own.n = own.dn1 = own.dn2 = own.light = zero3<float>();
@@ -543,7 +647,21 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     X.o0 = X.o1 = X.o2 = X.o3 = X.o4 = X.o5 = X.p0 = X.p1 = X.p2 = X.n0 = X.n1 = X.n2 = z4;
                     X.o_lz = X.gx = X.gy = 0.f;
                 }
+#if defined(EPSM_CP_COOP)
+                geo_issue_rest(X, F, L, WB);
+                Q.drain(T);                                          // the staging area IS the wave's (now empty) row queue
+                geo_stage_coop<VARIANT>(X, F, L, WB, (float *) s_queue[wv], lane);
+#elif defined(EPSM_CP_DMA)
+                geo_issue_rest(X, F, L, WB);
+#ifdef EPSM_CP_DMA_ALIAS
+                Q.drain(T);                                          // the staging area IS the wave's (now empty) row queue
+                geo_stage_dma<VARIANT>(X, F, L, WB, (float *) s_queue[wv], lane);
+#else
+                geo_stage_dma<VARIANT>(X, F, L, WB, s_stage[wv], lane);
+#endif
+#else
                 geo_issue<VARIANT>(X, F, L, WB);
+#endif
                 if (live) {
                     const Geo<float> g = geo_from(X.o0, X.o1, X.o2);
                     const Nrm<float> nr = nrm_from(X.o3, X.o4, X.o5, g.b0, g.b1);
@@ -739,7 +857,10 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
         Q.drain(T);
         // workgroup-uniform census once per window; a table that fills up in between sends the overflow straight to HBM
         // (not after the workgroup's last window: the final flush follows at once)
-        if (wi + 1 < windows_per_block && win + 1 < n_windows && T.crowded(6)) T.flush();
+        // (flushed after EVERY window -- it holds the next one's rows anyway only when it is far from full -- so that a row's
+        // fixed-point sum is bounded by one window's terms: epsm_wave_scatter.h, AccFixed64::kLimit; a launch has more windows
+        // than workgroups only beyond 2^31 paths)
+        if (wi + 1 < windows_per_block && win + 1 < n_windows) T.flush();
     }
     T.flush();
     if (DMODE == kTangentsInKernel && F.grad_o_sum) {      // epsm.py:260-261: d/d ray.o = -sum grad_d, one atomic triple per workgroup
@@ -786,7 +907,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     if (e < n && v[u] != 0.f) {
                         float *dst = e < 3 * F.V ? F.gpos + e : e < 6 * F.V ? F.gnrm + (e - 3 * F.V) : e < 6 * F.V + F.B ? (F.galpha ? F.galpha + (e - 6 * F.V) : nullptr)
                                                                                                          : (F.grad_o_sum ? F.grad_o_sum + (e - 6 * F.V - F.B) : nullptr);
-                        if (dst) atomicAdd(dst, v[u]);
+                        if (dst && adds_something(v[u])) atomicAdd(dst, v[u]);      // (a non-finite sum adds nothing, as global_add)
                         my_rep[e] = 0.f;
                     }
                 }
@@ -852,12 +973,16 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
         if (small) hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, false, kSmall>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
         else hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, false, kLarge>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
     }
-    if (F.rep && !F.rep_done) {
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess && F.rep && !F.rep_done) {
         const int64_t n = 6 * F.V + F.B + 3;
         hipLaunchKernelGGL(reduce_replicas_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, F.rep, F.replicas, F.rep_stride,
                            F.V, F.B, F.gpos, F.gnrm, F.galpha, F.grad_o_sum);
+        le = hipGetLastError();
     }
-    return hipGetLastError();
+    // a launch that did not go through may leave replicas and counters half-way: the workspace is zeroed again before its next use
+    if (le != hipSuccess && F.rep) fused_workspace_invalidate(s);
+    return le;
 }
 template <int VARIANT, bool PACKED> hipError_t launch_d(int dmode, const FusedArgs &F, int dcols, hipStream_t s) {
     switch (dmode) {

@@ -90,6 +90,7 @@ __device__ __forceinline__ Tangent first_vertex_tangent_packed(const TangentIn &
 constexpr size_t kReplicaBudget = 48u << 20;
 hipError_t fused_workspace(hipStream_t s, size_t bytes, float **out);       // kReplicaBudget bytes of replicas + 4 KB of counters behind them
 hipError_t fused_release_workspaces();
+void fused_workspace_invalidate(hipStream_t s);     // after a failed launch: this stream's workspace is re-allocated and zeroed before its next use
 __global__ void reduce_replicas_kernel(float *rep, int replicas, int64_t stride, int64_t V, int64_t B,
                                        float *gpos, float *gnrm, float *galpha, float *go);
 

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void reduce_replicas_kernel(float *rep, int re
     for (int r = 0; r < replicas; ++r) rep[r * stride + e] = 0.f;
     float *dst = e < 3 * V ? gpos + e : e < 6 * V ? gnrm + (e - 3 * V) : e < 6 * V + B ? (galpha ? galpha + (e - 6 * V) : nullptr)
                                                                                       : (go ? go + (e - 6 * V - B) : nullptr);
-    if (dst && sum != 0.f) atomicAdd(dst, sum);      // atomic like every other add into the caller's buffers: launches on other streams may share them
+    if (dst && sum != 0.f && fabsf(sum) < __builtin_inff()) atomicAdd(dst, sum);   // (a non-finite sum adds nothing)      // atomic like every other add into the caller's buffers: launches on other streams may share them
 }
 
 // Why replicas: the workgroups of a small wavefront all flush at the same moment, and every one of them holds the rows
@@ -64,6 +64,14 @@ hipError_t fused_workspace(hipStream_t s, size_t bytes, float **out) {
     }
     *out = w->p;
     return hipSuccess;
+}
+
+void fused_workspace_invalidate(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (int i = 0; i < g_ws_n; ++i)
+        if (g_ws[i].dev == dev && g_ws[i].stream == s) g_ws[i].bytes = 0;          // fused_workspace(): free, allocate, memset
 }
 
 hipError_t fused_release_workspaces() {

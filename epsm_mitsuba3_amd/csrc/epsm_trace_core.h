@@ -999,7 +999,16 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
         // surface's horizon: half of the samples on a convex object) the ray decides nothing and is not traced.
         // (The occluder record of the first vertex rides on this ray in the wavefront form: always traced then.)
         const bool occluder_wanted = iteration == 0 && A.K_log > 0 && A.rec[0].shadow && A.max_depth <= 3;
-        if (es.valid && (Lr_dir.x != 0.f || Lr_dir.y != 0.f || Lr_dir.z != 0.f || occluder_wanted)) {
+        // EPSM_TRACE_GRADIENT_ONLY: the ray decides Lr_dir, i.e. the logged weight eweight = sum Lr_dir, which calc_grad reads
+        // in ONE place -- light_grad x eweight of a light-sampling term wN(k) (epsm.py:622-627), which needs hasdiffuse == 0 and
+        // every vertex through k a mesh hit (the condition under which a `manifold` path goes on), and which is identically zero
+        // for manifold_caustic (csrc/epsm_path_core.h).  Elsewhere the weight is never looked at: no ray.
+        bool weight_read = true;
+        if (A.flags & EPSM_TRACE_GRADIENT_ONLY) {
+            const uint32_t w = s.gword | (vertex_flag_bits(s.active && si.valid, si, flags, active_em) << (5 * iteration));
+            weight_read = !(A.flags & EPSM_TRACE_GRADIENT_CAUSTIC) && iteration < A.K_log && cp::gradient_live(w, iteration + 1, false);
+        }
+        if (es.valid && ((weight_read && (Lr_dir.x != 0.f || Lr_dir.y != 0.f || Lr_dir.z != 0.f)) || occluder_wanted)) {
             float dist;
             const Ray sr = spawn_ray_to(si, es.p, dist);
             if (vis.occluded(S, sr)) Lr_dir = zero3<float>();

@@ -91,13 +91,17 @@ struct AccFixed64 {
     // Terms below this magnitude go into the LDS rows; anything else -- a product with an unbounded emitter weight, inf, NaN --
     // takes LdsTable::global_add (exact float atomics; non-finite terms add nothing: the reference's buffers would hold NaN
     // there and its optimiser loop scrubs that to 0, EPSM/optim.py:143-154).  Terms are clamped to +-clip <= 1 before any
-    // weight multiplies them, so the slow way is taken by emitter weights beyond ~10^3 only.
-    static constexpr float kLimit = 127.f;
+    // weight multiplies them, so the slow way is taken by emitter weights beyond ~10^2 only.
+    // The limit also bounds the SUM: a row holds |sum| < 2^19; between two flushes a table sees at most one window
+    // of <= 2048 paths (kernel: the table is flushed after every window when a workgroup walks several), and a path adds at
+    // most 3 K + 1 = 16 terms to one row (position, end-point and emitter rows of its K <= 5 vertices + the occluder), each
+    // < 16 in magnitude: 2048 x 16 x 16 = 2^19, never reached -- the int64 cannot wrap.
+    static constexpr float kLimit = 16.f;
     __device__ __forceinline__ static bool fits(float x, float y, float z) {
         return fabsf(x) < kLimit && fabsf(y) < kLimit && fabsf(z) < kLimit;        // three compares, each false on NaN (a max3 would skip it)
     }
     __device__ __forceinline__ static T to_fixed(float x) {
-        // round(x * 2^44) for |x| < 2^7 in THREE instructions: x 2^44 + 1.5 2^52 in float64 (one fma, round to nearest) keeps
+        // round(x * 2^44) for |x| < 2^7 (kLimit keeps it below 2^4) in THREE instructions: x 2^44 + 1.5 2^52 in float64 (one fma, round to nearest) keeps
         // the exponent of the constant, so the integer sits in the mantissa in two's complement and the constant's bit
         // pattern -- whose low word is zero -- comes off with one 32-bit subtraction.  (Round 3 split |x| 2^12 into integer
         // part and fraction and negated in 64 bits: ~15 instructions per value, 45 per row, the larger half of a drain

@@ -23,6 +23,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import torch
 
 from . import dist as _dist
+from . import profiler as _prof
 from .manifold_grad import OUTLIER_CLIP, calc_grad as _calc_grad, manifold_grad_packed
 from .params import ParamGrads
 from .records import PackedLog, PackedRecords, PackedScatter
@@ -123,7 +124,8 @@ class EPSMIntegrator:
             raise Exception("develop=True must be specified when invoking AD integrators")
         if not hasattr(scene, "render_primal"):
             raise NotImplementedError("scene object has no render_primal(sensor, seed, spp, max_depth)")
-        img = scene.render_primal(sensor=sensor, seed=seed, spp=spp, max_depth=self.primal_depth())
+        with _prof.phase("epsm.render.primal"):
+            img = scene.render_primal(sensor=sensor, seed=seed, spp=spp, max_depth=self.primal_depth())
         pad = torch.zeros(img.shape[0], img.shape[1], 2, device=img.device, dtype=img.dtype)
         self.primal_image = torch.cat([img[..., :3], pad], dim=-1)
         return self.primal_image
@@ -163,12 +165,19 @@ class EPSMIntegrator:
                         **kw)
         if isinstance(traces, PathTrace):
             traces = [traces]
-        for trace in traces:                       # this rank's pixel/sample tiles
-            self.backward_from_trace(trace, target, grad_in)
+        traces = iter(traces)
+        while True:                                # this rank's pixel/sample tiles
+            with _prof.phase("epsm.render_backward.trace"):          # (a generator: the tile is traced when asked for)
+                trace = next(traces, None)
+            if trace is None:
+                break
+            with _prof.phase("epsm.render_backward.backward_pass"):
+                self.backward_from_trace(trace, target, grad_in)
             del trace
         if world > 1:
-            _dist.allreduce_param_grads(target.flat)   # one RCCL all-reduce of the whole buffer
-            params.flat += target.flat
+            with _prof.phase("epsm.render_backward.allreduce"):
+                _dist.allreduce_param_grads(target.flat)   # one RCCL all-reduce of the whole buffer
+                params.flat += target.flat
 
     def tracer_depth(self) -> int:
         """``max_depth`` as the tracer takes it: the path loop stops after 6 bounces whatever the integrator says
@@ -364,9 +373,9 @@ class PRBIntegrator:
                 return
             if getattr(scene, "has_attached_geometry", lambda: False)():
                 raise NotImplementedError(
-                    "prb / prb_reparam: geometry is attached but no colour parameter is -- the gradients of vertex positions "
-                    "through visibility need the warp field of ad/reparam.py, which this build does not have (DESIGN.md 6); "
-                    "keep the manifold integrator for geometric parameters")
+                    "prb: geometry is attached but no colour parameter is -- `prb` differentiates colours only (prb.py); the "
+                    "gradients of vertex positions through visibility are what `prb_reparam` (its warp field: "
+                    "csrc/epsm_trace_reparam.h) or the manifold integrators compute")
             return                                  # nothing attached that this phase differentiates
         si = min(sensor, len(scene.sensors) - 1)
         s = scene.sensors[si]
@@ -451,14 +460,19 @@ class PRBReparamIntegrator(PRBIntegrator):
         accum = torch.zeros((s.height, s.width, 4), device=scene.device, dtype=torch.float32)
         # tiles as large as the sharding allows, up to 2^23 paths (7 GB of warp requests): the later stages of a tile carry
         # a fraction of its paths and under-fill the chip in 2^20-path tiles (4.26 M paths: 62 ms in five tiles, 57 ms in one)
-        tiles = _dist.tile_ranges(n_total, min(1 << 23, max(int(scene.tile_paths), -(-n_total // world))))
+        # ... unless the caller set Scene.tile_paths: that is their memory bound and stays an upper bound
+        per_rank = -(-n_total // world)
+        tile = min(1 << 23, int(scene.tile_paths)) if getattr(scene, "tile_paths_explicit", False) else \
+            min(1 << 23, max(int(scene.tile_paths), per_rank))
+        tiles = _dist.tile_ranges(n_total, tile)
         mine = list(_dist.my_tiles(len(tiles), rank, world))
         kept = {}
         for t in mine:
             lo, hi = tiles[t]
-            tr = scene._trace(si, seed, spp, self._depth(), 0, lo, hi)
-            rc = lib.epsm_film_splat(C.c_int64(hi - lo), C.c_void_p(tr.film_pos.data_ptr()), C.c_void_p(tr.radiance.data_ptr()),
-                                     s.width, s.height, s.rfilter, C.c_void_p(accum.data_ptr()), C.c_void_p(stream))
+            with _prof.phase("epsm.prb_reparam.primal_pass"):
+                tr = scene._trace(si, seed, spp, self._depth(), 0, lo, hi)
+                rc = lib.epsm_film_splat(C.c_int64(hi - lo), C.c_void_p(tr.film_pos.data_ptr()), C.c_void_p(tr.radiance.data_ptr()),
+                                         s.width, s.height, s.rfilter, C.c_void_p(accum.data_ptr()), C.c_void_p(stream))
             assert rc == 0, "epsm_film_splat failed"
             kept[t] = (tr.film_pos, tr.radiance.contiguous())
         if world > 1:
@@ -469,10 +483,12 @@ class PRBReparamIntegrator(PRBIntegrator):
         for t in mine:
             lo, hi = tiles[t]
             film_pos, radiance = kept.pop(t)
-            dL, adj = film_adjoint_reparam(film_pos, radiance, g, accum)
-            scene.trace_reparam(si, seed, spp, self._depth(), lo, hi, radiance, dL, adj, out.pos, out.nrm,
-                                int(self.reparam_max_depth), self.reparam_rays, self.reparam_kappa, self.reparam_exp,
-                                antithetic=self.reparam_antithetic)
+            with _prof.phase("epsm.prb_reparam.film_adjoint"):
+                dL, adj = film_adjoint_reparam(film_pos, radiance, g, accum)
+            with _prof.phase("epsm.prb_reparam.reparam_pass"):
+                scene.trace_reparam(si, seed, spp, self._depth(), lo, hi, radiance, dL, adj, out.pos, out.nrm,
+                                    int(self.reparam_max_depth), self.reparam_rays, self.reparam_kappa, self.reparam_exp,
+                                    antithetic=self.reparam_antithetic)
         if world > 1:
             _dist.allreduce_param_grads(out.flat)
             params.flat += out.flat

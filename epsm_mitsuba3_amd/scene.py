@@ -222,7 +222,10 @@ def load_ply(path: str):
             raise ValueError(f"{path}: not a PLY file")
         fmt, elements = None, []
         while True:
-            t = fh.readline().decode("ascii", "replace").split()
+            line = fh.readline()
+            if not line:                                           # end of file inside the header (this looped forever)
+                raise ValueError(f"{path}: truncated PLY header (no end_header)")
+            t = line.decode("ascii", "replace").split()
             if not t or t[0] == "comment" or t[0] == "obj_info":
                 continue
             if t[0] == "format":
@@ -259,6 +262,17 @@ def load_ply(path: str):
                     raise ValueError(f"{path}: element {el['name']} mixes list and scalar properties (unsupported)")
                 _, ct, it, _nm = el["props"][0]
                 tris = []
+                if fmt != "ascii" and el["count"] > 0:
+                    # all-triangle binary faces (the common case): ONE read instead of two per face
+                    rec = np.dtype([("n", end + _PLY_TYPES[ct]), ("i", end + _PLY_TYPES[it], (3,))])
+                    here = fh.tell()
+                    buf = fh.read(rec.itemsize * el["count"])
+                    a = np.frombuffer(buf, dtype=rec, count=el["count"]) if len(buf) == rec.itemsize * el["count"] else None
+                    if a is not None and bool((a["n"] == 3).all()):
+                        if el["name"] == "face":
+                            faces = a["i"].astype(np.int64).reshape(-1, 3)
+                        continue
+                    fh.seek(here)                                  # polygons of other sizes: face by face below
                 for _ in range(el["count"]):
                     if fmt == "ascii":
                         n_ = int(tokens[pos]); idx = [int(x) for x in tokens[pos + 1:pos + 1 + n_]]; pos += 1 + n_
@@ -664,7 +678,8 @@ class Scene:
         self.meshes, self.bsdf_desc, self.emitter_desc, self.sensors = list(meshes), list(bsdfs), list(emitters), list(sensors)
         self.bsdf_names = list(bsdf_names or [f"bsdf{i}" for i in range(len(bsdfs))])
         self.device = torch.device(device)
-        self.tile_paths = tile_paths
+        self._tile_paths = int(tile_paths)
+        self.tile_paths_explicit = False           # set when the caller assigns Scene.tile_paths: then it is an UPPER bound everywhere
         self.alpha_slots: Dict[int, int] = {}
         self.color_slots: List[tuple] = []         # colour parameters attached for the colour adjoint: ("bsdf" | "emitter", index)
         self.rr_depth = 5
@@ -677,6 +692,18 @@ class Scene:
         self.tracer = "auto"
         self._wf_workspace = {}        # scratch of the wavefront tracer, one per stream it was used on
         self._upload()
+
+    @property
+    def tile_paths(self) -> int:
+        """Paths per tile of a pass (the sharding unit).  The wavefront tracer works in tiles of up to WAVEFRONT_TILE_PATHS
+        whatever this says (its workspace is 236 B per path); prb_reparam raises the DEFAULT to as much as the sharding allows
+        (7 GB of warp requests at 2^23 paths) but never exceeds a value the caller ASSIGNED -- their memory bound."""
+        return self._tile_paths
+
+    @tile_paths.setter
+    def tile_paths(self, n: int) -> None:
+        self._tile_paths = int(n)
+        self.tile_paths_explicit = True
 
     # -- construction from the reference's dict shape ---------------------------------------
     @staticmethod

@@ -66,10 +66,12 @@ enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
  *     manifold           goes on while every vertex so far is a mesh hit and none is Diffuse
  *     manifold_caustic   (with EPSM_TRACE_GRADIENT_CAUSTIC) goes on while vertex 1 is Diffuse, every vertex so far is a
  *                        mesh hit and fewer than two are Diffuse (epsm.py:998-999, 1172-1183)
- * and after vertex K_log in any case.  The bounce that retires a path is complete (emitter sample, its visibility ray, the
- * occluder record of vertex 1, the logged weight eweight = sum Lr_dir), so every record calc_grad reads is the one the
- * full trace writes and the gradients are identical; `radiance` is then the radiance gathered up to that bounce only and
- * must not be used as an image.  bench.py's real_scene leg: trace + log 14.3 -> see DESIGN.md 5b. */
+ * and after vertex K_log in any case.  The visibility ray of an emitter sample is traced only where its answer is read: it
+ * decides the logged weight eweight = sum Lr_dir, which calc_grad uses in the light-sampling term of a vertex behind which a
+ * `manifold` path goes on (epsm.py:622-627, 852-855) and nowhere in manifold_caustic (its light terms are identically zero);
+ * the occluder record of vertex 1 (max_depth <= 3, epsm.py:609-620) is traced as always.  Every word calc_grad reads is the
+ * one the full trace writes, so the gradients are identical; `radiance` and the eweight words nobody reads are NOT those of
+ * the full trace and must not be used.  bench.py's real_scene leg: trace + log 14.3 -> see DESIGN.md 5b. */
 #define EPSM_TRACE_GRADIENT_ONLY    0x4u
 #define EPSM_TRACE_GRADIENT_CAUSTIC 0x8u
 

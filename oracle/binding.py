@@ -13,14 +13,16 @@ import torch
 from epsm_mitsuba3_amd.records import PackedRecords, VARIANTS, num_param_grads
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libepsm_oracle.so")
+# EPSM_SAN=1 (tools/run_san.sh): the AddressSanitizer / UBSan build of the same sources (oracle/Makefile SAN=1)
+_SAN = os.environ.get("EPSM_SAN", "0") == "1"
+_LIB_PATH = os.path.join(_HERE, "libepsm_oracle_san.so" if _SAN else "libepsm_oracle.so")
 _lib = None
 
 
 def build(force: bool = False) -> str:
     from epsm_mitsuba3_amd._lib import build_lock
     with build_lock(_HERE):             # the two ranks of a gloo test both come here; the link step renames into place
-        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)    # make decides what is stale
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["SAN=1"] if _SAN else []) + (["-B"] if force else []), check=True)    # make decides what is stale
     return _LIB_PATH
 
 

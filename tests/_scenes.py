@@ -9,22 +9,17 @@ import torch
 from epsm_mitsuba3_amd import scene as S
 
 _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_harness")
-_SO = os.path.join(_DIR, "libtrace_host.so")
+_SAN = os.environ.get("EPSM_SAN", "0") == "1"      # tools/run_san.sh: the AddressSanitizer / UBSan build (Makefile `san`)
+_SO = os.path.join(_DIR, "libtrace_host_san.so" if _SAN else "libtrace_host.so")
 _lib = None
 
 
 def host_tracer():
     global _lib
     if _lib is None:
-        src = os.path.join(_DIR, "trace_host.cpp")
-        csrc = os.path.join(_DIR, "..", "..", "epsm_mitsuba3_amd", "csrc")
-        hdrs = [os.path.join(csrc, h) for h in ("epsm_trace_core.h", "epsm_trace_wavefront.h", "epsm_trace_reparam.h")]
         from epsm_mitsuba3_amd._lib import build_lock
         with build_lock(_DIR):
-            if (not os.path.isfile(_SO)) or any(os.path.getmtime(p) > os.path.getmtime(_SO) for p in [src] + hdrs):
-                subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wno-unknown-pragmas",
-                                "-ffp-contract=off", "-o", _SO + ".tmp", src], check=True)
-                os.replace(_SO + ".tmp", _SO)
+            subprocess.run(["make", "-C", _DIR, "-s", _SO], check=True)            # make decides what is stale
         _lib = C.CDLL(_SO)
         for n in ("epsm_trace_paths", "epsm_trace_paths_wavefront", "epsm_film_splat", "epsm_film_develop"):
             getattr(_lib, n).restype = C.c_int

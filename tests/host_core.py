@@ -21,15 +21,18 @@ CORES = {
 _libs = {}
 
 
+SAN = os.environ.get("EPSM_SAN", "0") == "1"       # tools/run_san.sh: the AddressSanitizer / UBSan builds (Makefile `san`)
+
+
 def lib(core="path"):
     if core not in _libs:
         so, src, hdrs, stem = CORES[core]
-        so, src = os.path.join(_DIR, so), os.path.join(_DIR, src)
-        deps = [src] + [os.path.join(_CSRC, h) for h in hdrs]
-        stale = (not os.path.isfile(so)) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in deps)
-        if stale:
-            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-                            "-ffp-contract=off", "-o", so, src], check=True)
+        if SAN:
+            so = so.replace(".so", "_san.so")
+        from epsm_mitsuba3_amd._lib import build_lock
+        with build_lock(_DIR):
+            subprocess.run(["make", "-C", _DIR, "-s", os.path.join(_DIR, so)], check=True)      # make decides what is stale
+        so = os.path.join(_DIR, so)
         _lib = C.CDLL(so)
         _libs[core] = _lib
         for name in (stem + "_f32", stem + "_f64"):

@@ -85,9 +85,16 @@ def test_host_tracer_logs_agree_up_to_the_retirement_point(variant, tracer):
         wr, k = _retired_word(int(wf[i]), full.log.K, caustic, live)
         assert int(wc[i]) == wr, (i, hex(int(wf[i])), hex(int(wc[i])), hex(wr))
         n_short += wr != int(wf[i])
-        # the records that exist in the cut log are bit for bit those of the full trace
+        # the records that exist in the cut log are bit for bit those of the full trace -- but for word 27, the emitter weight
+        # eweight = sum Lr_dir, where no term reads it (its visibility ray is not traced then): a light-sampling term wN(k),
+        # bit k - 1 of the manifold plan; manifold_caustic has none
         nk = max(1, sum(1 for j in range(full.log.K) if (wr >> (5 * j)) & 0x1F))
-        assert torch.equal(full.log.verts[i, :nk].view(torch.int32), cut.log.verts[i, :nk].view(torch.int32)), i
+        a, b = full.log.verts[i, :nk].view(torch.int32).clone(), cut.log.verts[i, :nk].view(torch.int32).clone()
+        p = plan(caustic, wr)
+        for j in range(nk):
+            if caustic or not ((p >> j) & 1):
+                a[j, 27] = b[j, 27] = 0
+        assert torch.equal(a, b), i
     assert n_short >= 40, "the scene retires too few paths to test anything"     # (an open scene: most paths leave it by themselves)
     assert torch.equal(full.log.rays, cut.log.rays)
 
