@@ -17,6 +17,12 @@
 #include <string.h>
 
 #define EPSM_FAST_RCP64                 // epsm_path_core.h: 1 / x in float64 by v_rcp_f64 + two Newton steps
+// Round 5: ONE trip to memory per record (EPSM_CP_STASH, below) is the product build -- headline slab 1.97 -> 1.90 ms, config 2
+// 2.30 -> 2.25, config 5 0.097 -> 0.092, pool slab 2.61 -> 2.62 (profiles/r05_e_whole_line_ab.txt); -DEPSM_CP_NO_STASH: round 4's
+// second trip after the recursions.  EPSM_CP_DMA / EPSM_CP_DMA_ALIAS / EPSM_CP_COOP: the whole-line request forms, measured slower.
+#if !defined(EPSM_CP_NO_STASH) && !defined(EPSM_CP_STASH)
+#define EPSM_CP_STASH
+#endif
 #include "epsm_fused.h"
 #include "epsm_cp_core.h"
 #include "epsm_wave_scatter.h"
@@ -55,6 +61,8 @@ namespace {
 #endif
 constexpr int kThreads = EPSM_CP_THREADS, kWaves = kThreads / 64, kQueueCap = EPSM_CP_QUEUE;
 constexpr int kKeys = 6;                // m = 0..5
+constexpr int kStashFirstItem = 64;     // EPSM_CP_STASH: queue items [64, 192) = 2 048 bytes hold 32 bytes per lane between a round's loads and its emission
+static_assert(kQueueCap - kStashFirstItem >= 128, "the stash needs 128 queue items");
 
 // lane -> (path slot j, vertex k) inside a round of c lanes per path: j = lane / c without a division
 __device__ __forceinline__ int div_small(int lane, int c) {
@@ -344,7 +352,9 @@ __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const
     if (R.live || R.d1) { X.o0 = ldq(R.rec, 0); X.o1 = ldq(R.rec, 1); X.o2 = ldq(R.rec, 2); }
     if (R.live) {
         X.o3 = ldq(R.rec, 3); X.o4 = ldq(R.rec, 4); X.o5 = ldq(R.rec, 5);
+#ifndef EPSM_CP_STASH                   // (stash build: light.z arrives with quad 7)
         if (VARIANT == EPSM_VARIANT_MANIFOLD && cp::plan_a(L.plan, L.k)) X.o_lz = lds_(R.rec, 28);
+#endif
     }
     if (R.ok && R.first) {
         const float *rays = B.rays + 12u * R.loc;
@@ -459,8 +469,13 @@ template <int VARIANT>
 __device__ __forceinline__ void addr_issue(AddrFetch &A, const FusedArgs &F, const LaneId &L, const WinBase &B) {
     const LaneRole R = role_of(F, L, B);
     if (R.live) {
+        const bool wN = VARIANT == EPSM_VARIANT_MANIFOLD && cp::plan_a(L.plan, L.k);
+#ifdef EPSM_CP_STASH
+        if (F.galpha || wN) A.q7 = ldq(R.rec, 7);                  // d hf / d alpha, and light.z of the emitter sample
+#else
         if (F.galpha) A.q7 = ldq(R.rec, 7);
-        if (VARIANT == EPSM_VARIANT_MANIFOLD && cp::plan_a(L.plan, L.k)) A.q6 = ldq(R.rec, 6);
+#endif
+        if (wN) A.q6 = ldq(R.rec, 6);
     }
     if (R.d1 && B.shadow) A.sh = load_u4(B.shadow, R.loc);
 }
@@ -661,6 +676,25 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
 #endif
 #else
                 geo_issue<VARIANT>(X, F, L, WB);
+#ifdef EPSM_CP_STASH
+                // ONE trip to memory per record: the words only the emission needs (quads 6 and 7: the same line as the geometry,
+                // second sector) are requested together with it and parked in LDS until the emission -- 32 bytes per lane in the
+                // TAIL of the wave's row queue (items 64..191), which holds fewer than 64 items at this point: the full groups of
+                // 64 were drained, the remainder stays at the head.  [q6 | occluder record] [q7]: a lane has either an emitter
+                // sample (a `manifold` constraint vertex) or the occluder record (a diffuse first hit), never both.
+                Q.drain_full_groups(T);
+                {
+                    AddrFetch A0;
+                    const F4v z4s = {0.f, 0.f, 0.f, 0.f};
+                    A0.q6 = A0.q7 = z4s; A0.sh.x = kNoIndex; A0.sh.y = A0.sh.z = A0.sh.w = 0u;
+                    addr_issue<VARIANT>(A0, F, L, WB);
+                    float *st = (float *) s_queue[wv] + 4 * kStashFirstItem + 8 * lane;
+                    const bool has_sh = d1 && F.pk_shadow;
+                    const F4v shv = {__uint_as_float(A0.sh.x), __uint_as_float(A0.sh.y), __uint_as_float(A0.sh.z), __uint_as_float(A0.sh.w)};
+                    *(LdsF4w *) st = has_sh ? shv : A0.q6; *(LdsF4w *) (st + 4) = A0.q7;
+                    X.o_lz = A0.q7.x;                                // light.z: word 28
+                }
+#endif
 #endif
                 if (live) {
                     const Geo<float> g = geo_from(X.o0, X.o1, X.o2);
@@ -777,7 +811,18 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                 }
                 // the words only the emission needs, on their way (vector-cache hits) under the second sweep
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef EPSM_CP_STASH
+                if (PACKED) {
+                    const float *st = (const float *) s_queue[wv] + 4 * kStashFirstItem + 8 * lane;
+                    const F4v a = *(LdsF4 *) st;
+                    A.q7 = *(LdsF4 *) (st + 4);
+                    if (d1 && F.pk_shadow) { A.sh.x = __float_as_uint(a.x); A.sh.y = __float_as_uint(a.y); A.sh.z = __float_as_uint(a.z); A.sh.w = __float_as_uint(a.w); }
+                    else A.q6 = a;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the emission's pushes may overwrite the stash
+                }
+#else
                 if (PACKED) addr_issue<VARIANT>(A, F, L, WB);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (q > 0) {
                     // pass 2: the constraint(s) swept once more with the final seeds
@@ -807,7 +852,18 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     poisoned = (bad & seg) != 0ull;
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef EPSM_CP_STASH
+                if (PACKED) {
+                    const float *st = (const float *) s_queue[wv] + 4 * kStashFirstItem + 8 * lane;
+                    const F4v a = *(LdsF4 *) st;
+                    A.q7 = *(LdsF4 *) (st + 4);
+                    if (d1 && F.pk_shadow) { A.sh.x = __float_as_uint(a.x); A.sh.y = __float_as_uint(a.y); A.sh.z = __float_as_uint(a.z); A.sh.w = __float_as_uint(a.w); }
+                    else A.q6 = a;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the emission's pushes may overwrite the stash
+                }
+#else
                 if (PACKED) addr_issue<VARIANT>(A, F, L, WB);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (q > 0) {
                     const cp::COut<float> o = cp::caustic_finish(pts, f, first, live && k <= idstar, live && k == idstar, live && cp::plan_b(plan, k));

@@ -438,6 +438,13 @@ struct WaveQueue {
         if (count > 0) drain_queue(q, count, T);
         count = 0;
     }
+    // Drains the full groups of 64 items -- every drain iteration with all lanes busy -- and keeps the remainder (< 64 items) at
+    // the head of the queue: afterwards items [64, CAP) are free for the caller until the next push.
+    template <typename Table> __device__ __forceinline__ void drain_full_groups(const Table &T) {
+        const int n_full = count & ~63;
+        if (n_full > 0) drain_queue(q + (count - n_full), n_full, T);
+        count -= n_full;
+    }
     // room for a group of `rows` rows from all 64 lanes?
     template <typename Table> __device__ __forceinline__ void reserve(const Table &T, int rows) {
         if (count + 64 * rows > CAP) drain(T);
