@@ -405,6 +405,14 @@ def lookup_traffic(kernel, paths, K, variant, profile):
                   else "no PMC run for this kernel / workload in profiles/traffic.json"), None
 
 
+_T0 = time.perf_counter()
+
+
+def _phase(name):
+    """Where the wall-clock of a run goes (stderr; the JSON line stays alone on stdout)."""
+    print(f"bench.py [{time.perf_counter() - _T0:7.1f} s] {name}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -465,6 +473,7 @@ def main():
     import epsm_mitsuba3_amd as epsm
     from epsm_mitsuba3_amd import dist as edist
     from epsm_mitsuba3_amd.records import PackedLog, PackedRecords, PackedScatter, num_param_grads
+    _phase("imports done, device ready")
 
     N_image = res * res * spp                                   # paths of ONE gradient image (all ranks together)
     slab_paths = min(SLAB_PATHS, N_image)
@@ -508,6 +517,7 @@ def main():
             live0 = int(live_vertices(packed.flags, K, variant).sum())   # slab 0: vertices its paths' terms reach
         slabs.append((trace, packed))
         torch.cuda.synchronize()
+    _phase(f"{len(slabs)} slab(s) resident")
     if my_slabs and not slabs:
         raise SystemExit("bench.py: not even one slab fits into HBM")
     # (a rank beyond the number of slabs -- --config 1, 2, 5 have one -- launches nothing and still enters the all-reduce)
@@ -549,6 +559,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    _phase("warm-up done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -560,6 +571,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    _phase("timed region done")
     rccl_ranks = 1
     # this rank's own share of a step: its launches (events on the launch stream), without the wait for the slowest rank
     own_ms = (sum(evs[0].elapsed_time(evs[-1]) for evs in launch_events) / args.steps) if launch_events else 0.0
@@ -677,8 +689,10 @@ def main():
                                                 "frac": a2 / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 "algorithmic_bytes_per_path": a2 // n_slab0,
                                                 "note": "outside the timed region; first stage of --two-stage"}
+        _phase("dense-kernel leg done")
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(slabs[0][0], grad_in, variant, V, B, args.cpu_seconds)
+            _phase("cpu baseline done")
         if world == 1 and args.config == 0 and not (args.soa or args.two_stage or args.separate_tangent or args.no_secondary):
             result["configs_1"] = secondary_config_leg(2, dev)          # BASELINE.json configs[1]: round 1's driver line
             # the workload where SURVEY's algorithmic bytes ARE the live bytes: no diffuse vertex, five constraint vertices and
@@ -689,7 +703,9 @@ def main():
             # end to end on records the library's own tracer produces: trace + native log + backward pass
             del slabs, out
             torch.cuda.empty_cache()
+            _phase("configs_1 + dense_specular legs done")
             result["real_scene"] = real_scene_leg(variant, 512, 64, dev)
+            _phase("real_scene leg done")
             # `value` counts the backward pass on RESIDENT synthetic records; with the library's own tracer producing them the
             # whole gradient image runs at this rate (first screen of the line, not a nested key)
             result["end_to_end_paths_per_s"] = result["real_scene"]["paths_per_s"]
@@ -700,6 +716,7 @@ def main():
             torch.cuda.empty_cache()
             # the same pass at the film of BASELINE.json configs[3] (`manifold_hybrid`, 1024 x 1024) at 16 spp
             result["hybrid_phase2_1024"] = hybrid_phase2_leg(1024, 16, 16, dev)
+            _phase("hybrid_phase2 legs done")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -358,7 +358,13 @@ __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const
     }
     if (R.ok && R.first) {
         const float *rays = B.rays + 12u * R.loc;
+#ifdef EPSM_CPKO_NORAYS                 // (knock-out build: what reading the rays costs; results are wrong)
+        { const float v = (float) R.loc * 1e-3f; const F4v f4 = {v, 0.5f, -0.25f, 1.f}; X.p0 = f4; X.p1 = f4 * 0.5f; X.p2 = f4 * 0.25f; }
+#elif defined(EPSM_CPKO_RAYS0)          // (knock-out build: every path takes the rays of its window's first path -- realistic values, no gather)
+        X.p0 = ldq(B.rays, 0); X.p1 = ldq(B.rays, 1); X.p2 = ldq(B.rays, 2); (void) rays;
+#else
         X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
+#endif
         const F2v g = ld2(pixel_grad(F.tin, B, R.loc));
         X.gx = g.x; X.gy = g.y;
     }
@@ -462,7 +468,11 @@ __device__ __forceinline__ void geo_issue_rest(GeoFetch &X, const FusedArgs &F, 
     }
     if (R.end_next) {
         const float *nx = R.rec + kRecWords;
+#ifdef EPSM_CPKO_NOEND                  // (knock-out build: what reading the end-point records costs; results are wrong)
+        X.n0 = X.o0 * 1.5f; X.n1 = X.o1 * 1.5f; X.n2 = X.o2; (void) nx;
+#else
         X.n0 = ldq(nx, 0); X.n1 = ldq(nx, 1); X.n2 = ldq(nx, 2);
+#endif
     }
 }
 template <int VARIANT>

@@ -15,6 +15,7 @@ experiments use (EPSM/exp/*.py): ``obj`` / inline meshes / ``rectangle``, ``diff
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import math
 import os
 from typing import Dict, List, Optional, Sequence
@@ -518,7 +519,7 @@ class DeviceBvh:
 
     def __init__(self, plan: dict, device):
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-        self.nodes = t(plan["nodes"])                              # (n,32) float32
+        self.nodes = t(plan["nodes"]).clone()                      # (n,32) float32; refit() writes the boxes: never the (cached) plan's own array
         self.order = t(plan["order"])
         self.prim_index = self.order.to(torch.int32)
         self.leaf_node, self.leaf_slot, self.leaf_tris = t(plan["leaf_node"]), t(plan["leaf_slot"]), t(plan["leaf_tris"])
@@ -666,6 +667,9 @@ class Sensor:
         s.border, s.pad = self.border, 0
         self._c_key, self._c_struct = key, s
         return s
+
+
+_BVH_CACHE: Dict[bytes, object] = {}        # geometry fingerprint -> host-side tree (build_bvh), a handful of entries
 
 
 class Scene:
@@ -977,7 +981,17 @@ class Scene:
         self.tri_table = torch.from_numpy(np.ascontiguousarray(table, dtype=np.int32)).to(dev)
         self.bvh = None
         if self.T > 0:
-            self.bvh = DeviceBvh(build_bvh(P, TRI), dev)
+            # the tree's topology depends on the geometry alone: attach() / attach_alpha() / set_color() come back here with the
+            # same triangles and must not pay the host-side build again (9 s at 128 k triangles; round 4's bench spent 100 s
+            # attaching 34 meshes), nor does a second Scene over the same geometry (bench.py's legs)
+            key = hashlib.blake2b(P.tobytes() + TRI.tobytes(), digest_size=16).digest()
+            host = _BVH_CACHE.get(key)
+            if host is None:
+                host = build_bvh(P, TRI)
+                if len(_BVH_CACHE) >= 4:
+                    _BVH_CACHE.pop(next(iter(_BVH_CACHE)))
+                _BVH_CACHE[key] = host
+            self.bvh = DeviceBvh(host, dev)
             self.bvh.refit(self.positions, self.tri)
         # texture coordinates (rows of the meshes that have none stay zero: they are not flagged EPSM_MESH_HAS_UV) and textures
         self.texcoords = None
