@@ -272,7 +272,8 @@ def secondary_config_leg(index, dev, profile_override=None, label_override=None)
            "live_vertices_per_path": live / n,
            "frac_live": (56 * n + 116 * live) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "note": "secondary figure, outside the timed region"}
-    traffic, src, _ = lookup_traffic("epsm_backward_pass_packed", n, K, variant, profile)
+    # (a counter run exists per (kernel, slab shape, profile): the headline's entry is NOT config 2's -- another film, another coherence)
+    traffic, src, _ = lookup_traffic("epsm_backward_pass_packed", n, K, variant, profile) if profile_override else (None, None, None)
     if traffic is not None:
         out["traffic"] = traffic
         out["frac_traffic"] = traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -331,12 +332,16 @@ def real_scene_leg(variant, res, spp, dev):
         return sorted(out)[n // 2]
     total = timed(lambda: integ.render_backward(scene, params, grad_in, seed=1))
 
-    kw = dict(sensor=2, seed=1, spp=spp, max_depth=clutter.max_depth, sparse_log=True, packed_log=True)   # as render_backward traces
+    # as render_backward traces: native log, gradient-dead paths retired (EPSM_TRACE_GRADIENT_ONLY, include/epsm_trace.h)
+    kw = dict(sensor=2, seed=1, spp=spp, max_depth=clutter.max_depth, sparse_log=True, packed_log=True, gradient_only=variant)
 
-    def trace_only():
-        for tr in scene.iter_traces(**kw):
+    def trace_only(**over):
+        for tr in scene.iter_traces(**dict(kw, **over)):
             del tr
     trace = timed(trace_only)
+    queues = scene.wavefront_queue_lengths() if scene.use_wavefront() else None
+    trace_full = timed(lambda: trace_only(gradient_only=None))          # the full trace (what `render` and round 4 ran)
+    queues_full = scene.wavefront_queue_lengths() if scene.use_wavefront() else None
     tiles = list(scene.iter_traces(**kw))
 
     def backward_only():
@@ -348,6 +353,11 @@ def real_scene_leg(variant, res, spp, dev):
     return {"scene": f"exp/clutter.py: floor + 100 tessellated spheres + area light = {scene.T} triangles", "variant": variant,
             "paths": n, "max_depth": clutter.max_depth, "tracer": "wavefront" if scene.use_wavefront() else "one launch",
             "grad_image_ms": total, "trace_and_log_ms": trace, "backward_ms": back, "paths_per_s": n / (total * 1e-3),
+            "full_trace_and_log_ms": trace_full,
+            "paths_alive_into_bounce": {"gradient_only": queues["alive"][1:clutter.max_depth] if queues else None,
+                                        "full": queues_full["alive"][1:clutter.max_depth] if queues_full else None},
+            "visibility_rays_per_bounce": {"gradient_only": queues["shadow"][:clutter.max_depth] if queues else None,
+                                           "full": queues_full["shadow"][:clutter.max_depth] if queues_full else None},
             "note": "render_backward on traced records (trace + native vertex log -> one launch of tangent + calc_grad + scatter "
                     "per tile), wall-clock, median of 3 each: the whole call, the trace alone, the backward pass on resident "
                     "tiles; outside the timed region"}

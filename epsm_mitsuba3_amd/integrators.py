@@ -440,8 +440,37 @@ class PRBReparamIntegrator(PRBIntegrator):
 
     def render_backward(self, scene, params: ParamGrads, grad_in: torch.Tensor, sensor=0, seed: int = 0, spp: int = 0) -> None:
         self._color_backward(scene, params, grad_in, sensor, seed, spp)
-        if not scene.has_attached_geometry():
+        cam = bool(getattr(scene, "sensor_attached", False))
+        if not scene.has_attached_geometry() and not cam:
             return
+        if cam:
+            # Moving the sensor by t moves every shape (and every emitter that is one) by -t as the sensor sees it; environment
+            # emitters do not care.  So d loss / d sensor position = - sum over ALL vertices of d loss / d vertex position: the
+            # same reparameterised pass with every mesh attached, summed (the primary rays' warp field carries the silhouettes).
+            if any(e["type"] == 1 for e in scene.emitter_desc):
+                raise NotImplementedError("prb_reparam: a `point` emitter's position would have to move with the shapes for the "
+                                          "sensor's gradient; scenes with point emitters keep the sensor fixed")
+            was = [(m, bool(getattr(m, "pos_attached", False))) for m in scene.meshes]
+            for m, _ in was:
+                m.pos_attached = True
+            scene._upload()
+            try:
+                full = ParamGrads(params.V, params.B, device=params.flat.device, mesh_slices=params.mesh_slices, n_colors=params.C)
+                self._geometry_backward(scene, full, grad_in, sensor, seed, spp)
+            finally:
+                for m, a in was:
+                    m.pos_attached = a
+                scene._upload()
+            params.cam_origin -= full.pos.sum(dim=0)
+            for m, a in was:                                   # the meshes the caller attached keep their own rows
+                if a:
+                    lo, hi = params.mesh_slices[m.name]
+                    params.pos[lo:hi] += full.pos[lo:hi]
+            params.nrm += full.nrm
+            return
+        self._geometry_backward(scene, params, grad_in, sensor, seed, spp)
+
+    def _geometry_backward(self, scene, params: ParamGrads, grad_in: torch.Tensor, sensor=0, seed: int = 0, spp: int = 0) -> None:
         si = min(sensor, len(scene.sensors) - 1)
         s = scene.sensors[si]
         if s.rfilter == 0:

@@ -128,13 +128,18 @@ def rotate(axis, angle_deg) -> np.ndarray:
     m = np.eye(4); m[:3, :3] = r; return m
 
 
-def perspective_projection(width: int, height: int, fov_x_deg: float, near: float, far: float) -> np.ndarray:
-    """camera_to_sample (include/mitsuba/core/transform.h perspective_projection, no crop)."""
+def perspective_projection(width: int, height: int, fov_x_deg: float, near: float, far: float, crop=None) -> np.ndarray:
+    """camera_to_sample (include/mitsuba/render/sensor.h:227-262 perspective_projection): ``width`` x ``height`` = the FULL film,
+    ``crop`` = (crop_width, crop_height, crop_offset_x, crop_offset_y) or None -- the crop window is what maps to [0,1]^2."""
     aspect = width / height
     recip = 1.0 / (far - near)
     cot = 1.0 / math.tan(math.radians(fov_x_deg * 0.5))
     persp = np.array([[cot, 0, 0, 0], [0, cot, 0, 0], [0, 0, far * recip, -near * far * recip], [0, 0, 1, 0]], dtype=np.float64)
-    return scale([-0.5, -0.5 * aspect, 1.0]) @ translate([-1.0, -1.0 / aspect, 0.0]) @ persp
+    m = scale([-0.5, -0.5 * aspect, 1.0]) @ translate([-1.0, -1.0 / aspect, 0.0]) @ persp
+    if crop is not None:
+        cw, ch, ox, oy = crop
+        m = scale([width / cw, height / ch, 1.0]) @ translate([-ox / width, -oy / height, 0.0]) @ m
+    return m
 
 
 def _xform_point(m, p):
@@ -634,7 +639,15 @@ class Sensor:
     def __init__(self, d: dict):
         film = next((v for v in d.values() if isinstance(v, dict) and v.get("type") == "hdrfilm"), {})
         sampler = next((v for v in d.values() if isinstance(v, dict) and v.get("type") == "independent"), {})
-        self.width, self.height = int(film.get("width", 768)), int(film.get("height", 576))
+        # the film and its crop window (hdrfilm: crop_width / crop_height / crop_offset_x / crop_offset_y; src/render/film.cpp): the
+        # image, the wavefront and the position differentials are those of the WINDOW (m_resolution = crop_size,
+        # perspective.cpp:172-183); the full film only fixes the aspect ratio and where the window sits
+        self.film_width, self.film_height = int(film.get("width", 768)), int(film.get("height", 576))
+        self.width, self.height = int(film.get("crop_width", self.film_width)), int(film.get("crop_height", self.film_height))
+        self.crop_offset = (int(film.get("crop_offset_x", 0)), int(film.get("crop_offset_y", 0)))
+        if (self.width < 1 or self.height < 1 or min(self.crop_offset) < 0 or self.crop_offset[0] + self.width > self.film_width
+                or self.crop_offset[1] + self.height > self.film_height):
+            raise ValueError("film: invalid crop window")          # film.cpp: "Invalid crop window specification!"
         rf = film.get("rfilter", {"type": "gaussian"})
         self.rfilter = {"box": 0, "gaussian": 1}[rf.get("type", "gaussian")]
         # film.sample_border (hdrfilm): samples are also generated in a border of rfilter.border_size() pixels around the
@@ -652,11 +665,14 @@ class Sensor:
         return (self.width + 2 * self.border) * (self.height + 2 * self.border) * int(spp)
 
     def c_struct(self) -> EpsmSensor:
-        key = (self.width, self.height, self.fov, self.near, self.far, self.to_world.tobytes(), self.border)
+        key = (self.width, self.height, self.film_width, self.film_height, self.crop_offset, self.fov, self.near, self.far,
+               self.to_world.tobytes(), self.border)
         if getattr(self, "_c_key", None) == key:
             return self._c_struct
         s = EpsmSensor()
-        c2s = perspective_projection(self.width, self.height, self.fov, self.near, self.far)
+        cropped = (self.width, self.height) != (self.film_width, self.film_height) or self.crop_offset != (0, 0)
+        c2s = perspective_projection(self.film_width, self.film_height, self.fov, self.near, self.far,
+                                     (self.width, self.height) + tuple(self.crop_offset) if cropped else None)
         s2c = np.linalg.inv(c2s)
         s.to_world[:] = self.to_world[:3, :].astype(np.float32).reshape(-1).tolist()
         s.sample_to_camera[:] = s2c.astype(np.float32).reshape(-1).tolist()
@@ -828,6 +844,12 @@ class Scene:
         m = self.mesh(mesh_name)
         m.pos_attached, m.nrm_attached = positions, normals
         self._upload()
+
+    def attach_sensor(self, attached: bool = True):
+        """``dr.enable_grad(params['sensor.to_world'])`` for its translation: ``prb_reparam``'s render_backward then leaves
+        d loss / d (world-space position of the sensor) in ``ParamGrads.cam_origin`` (test_ad_integrators.py:639-674,
+        TranslateCameraConfig; EPSM/exp/bedroom.py:18-36 optimises the camera in the hybrid scheme)."""
+        self.sensor_attached = bool(attached)
 
     def has_attached_geometry(self) -> bool:
         """Any mesh whose vertex positions / normals receive gradients?"""

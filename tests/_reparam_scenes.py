@@ -93,6 +93,11 @@ CONFIGS = {
     "textured_plane_constant": dict(max_depth=2, moving=["plane"], fd_eps=1e-3, res=64),
     # the same plane larger than the image: no silhouette in view, the image changes only because the texture slides with the plane
     "textured_plane_fills_the_view": dict(max_depth=2, moving=["plane"], fd_eps=2e-3),
+    # TranslateCameraConfig (:639-674): a sphere under the constant emitter, the SENSOR moves along its own x axis
+    # (to_world @ translate(theta, 0, 0)); res 16, spp 1024, max_depth 2, 64 rays, kappa 1e4 there
+    "translate_camera": dict(max_depth=2, moving=[], camera=True, fd_eps=1e-3, res=16, kappa=1e4),
+    # the same with an area light and a floor: shading, shadow and silhouettes all move in the image when the sensor does
+    "translate_camera_lit": dict(max_depth=3, moving=[], camera=True, fd_eps=2e-3, res=32),
     "diffuse_sphere_envmap": dict(max_depth=2, moving=["sphere"], fd_eps=1e-3),
     "glossy_sphere_envmap": dict(max_depth=2, moving=["sphere"], fd_eps=1e-3),
 }
@@ -105,6 +110,9 @@ def build(name, theta=0.0, res=32, spp=64, device="cpu", theta_n=0.0):
     if CONFIGS[name].get("motion") == "scale":
         off = 0.0
     cam = sensor([0, 0, 4], [0, 0, 0], up=(0, 1, 0), fov=28.8415, res=res, spp=spp, rfilter="gaussian", sample_border=True)   # mi default fov; film as in test_ad_integrators.py:60-70
+    if CONFIGS[name].get("camera"):          # the sensor moves along ITS x axis: to_world @ translate(theta, 0, 0)  (:669-672)
+        cam["to_world"] = np.asarray(cam["to_world"], float) @ S.translate([theta, 0.0, 0.0])
+        off = 0.0
     d = {"type": "scene", "cam": cam}
     white = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}
     if name == "rectangle_emitter_on_black":
@@ -204,6 +212,19 @@ def build(name, theta=0.0, res=32, spp=64, device="cpu", theta_n=0.0):
         d["plane"] = {"type": "mesh", "vertices": v + off, "faces": f, "texcoords": uv, "face_normals": True,
                       "bsdf": {"type": "diffuse", "reflectance": {"type": "bitmap", "bitmap": plane_texture()}}}
         d["light"] = {"type": "constant"}
+    elif name == "translate_camera":
+        v, n, f = sphere(1.0, (0, 0, 0))
+        d["sphere"] = {"type": "mesh", "vertices": v, "normals": n, "faces": f, "bsdf": white}
+        d["light"] = {"type": "constant"}
+    elif name == "translate_camera_lit":
+        v, f = rect(3.0, (0, 0, -0.6))
+        d["floor"] = {"type": "mesh", "vertices": v, "faces": f, "face_normals": True, "bsdf": white}
+        v, n, f = sphere(0.5, (0.3, 0.1, 0.2))
+        d["sphere"] = {"type": "mesh", "vertices": v, "normals": n, "faces": f,
+                       "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.9, 0.5, 0.1]}}}
+        v, f = rect(0.5, (1.0, 1.5, 3.0))
+        d["light"] = {"type": "mesh", "vertices": v, "faces": f[:, ::-1], "face_normals": True,
+                      "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [30.0, 30.0, 30.0]}}}
     elif name in ("diffuse_sphere_envmap", "glossy_sphere_envmap"):
         v, n, f = sphere(1.0, (0, 0, 0))
         bsdf = white if name.startswith("diffuse") else {"type": "roughconductor", "alpha": 0.3, "distribution": "ggx"}
@@ -269,6 +290,8 @@ def fd_check(name, device="cpu", spp=128, seeds=1, rays=32, weights="ramp", fd_s
     sc = build(name, 0.0, res, spp, device)
     for m in cfg["moving"]:
         sc.attach(m, positions=True, normals=False)
+    if cfg.get("camera"):
+        sc.attach_sensor()
     g = torch.ones((res, res, 3), device=sc.device)
     if weights == "ramp":       # a shadow or an object that merely MOVES inside the image changes this loss at first order
         g = g * (0.5 + torch.arange(res, device=sc.device, dtype=torch.float32) / res)[None, :, None]
@@ -277,7 +300,11 @@ def fd_check(name, device="cpu", spp=128, seeds=1, rays=32, weights="ramp", fd_s
     for seed in range(seeds):
         params = sc.param_grads()
         integ.render_backward(sc, params, g, sensor=0, seed=seed, spp=spp)
-        if cfg.get("motion") == "scale":      # p(theta) = p (1 + theta)
+        if cfg.get("camera"):                 # d / d theta of to_world @ translate(theta, 0, 0): the sensor's x axis in the world
+            ax = torch.tensor(np.asarray(sc.sensors[0].to_world, float)[:3, 0], device=sc.device, dtype=torch.float32)
+            got.append(float((params.cam_origin * ax).sum()))
+            assert float(params.pos.abs().max()) == 0.0          # no mesh was attached by the caller
+        elif cfg.get("motion") == "scale":      # p(theta) = p (1 + theta)
             got.append(sum(float((params.mesh_pos(m) * sc.vertex_positions(m)).sum()) for m in cfg["moving"]))
         else:
             got.append(sum(float((params.mesh_pos(m) @ u).sum()) for m in cfg["moving"]))

@@ -116,3 +116,33 @@ def test_accumulation_and_registry():
     # d sum(image) / d radiance * radiance = sum(image): the image is linear in the only light's radiance
     img = integ.render(sc, sensor=0, seed=1, spp=8)
     assert torch.allclose((once[0] * sc.color_values()[0]).cpu(), img.sum(dim=(0, 1)).cpu(), rtol=1e-3)
+
+
+def test_crop_window_config():
+    """CropWindowConfig (test_ad_integrators.py:250-281): a diffuse rectangle under the constant emitter seen through a 32 x 32
+    window at offset (32, 20) of a 64 x 64 film with a sample border; the parameter is the plane's reflectance.  The image has
+    the window's size, the film splat and its adjoint work on the window, and the derivative matches finite differences at the
+    reference's thresholds (mean 5 %, max 50 %; the radiance is linear in the albedo at max_depth 2, so FD is exact here)."""
+    v = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], float)
+    f = np.array([[0, 1, 2], [0, 2, 3]])
+    cam = sensor([0, 0, 4], [0, 0, 0], up=(0, 1, 0), fov=28.8415, res=64, spp=16, rfilter="gaussian", sample_border=True)
+    cam["film"].update(crop_width=32, crop_height=32, crop_offset_x=32, crop_offset_y=20)
+    d = {"type": "scene", "cam": cam,
+         "plane": {"type": "mesh", "vertices": v, "faces": f, "face_normals": True,
+                   "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.4, 0.6]}}},
+         "light": {"type": "constant"}}
+    sc = on_host(S.Scene.from_dict(d, device="cpu"))
+    sc.tracer = "mega"
+    assert sc.sensors[0].wavefront_size(16) == (32 + 4) * (32 + 4) * 16            # the border surrounds the WINDOW
+    got, want, rel = fd_check(sc, 32, 16, 2, attach=lambda s_: [s_.attach_color("plane.bsdf")])
+    assert float(want.abs().min()) > 0
+    assert float(rel.mean()) < 0.05 and float(rel.max()) < 0.5 and float(rel.max()) < 0.02, (got, want)
+    # the window shows the right part of the plane: its left columns see the plane, the rightmost ones the background only
+    integ = epsm.load_dict({"type": "prb", "max_depth": 2})
+    img = integ.render(sc, sensor=0, seed=1, spp=16)
+    full = dict(cam); full["film"] = {k: v_ for k, v_ in cam["film"].items() if not k.startswith("crop_")}
+    d2 = dict(d); d2["cam"] = full
+    sc2 = on_host(S.Scene.from_dict(d2, device="cpu")); sc2.tracer = "mega"
+    img2 = integ.render(sc2, sensor=0, seed=1, spp=64)[20:52, 32:64]
+    assert tuple(img.shape) == (32, 32, 3)
+    assert float((img - img2).abs().mean()) < 0.06 * float(img2.abs().mean())     # the same picture up to sampling noise (16 vs 64 spp)

@@ -71,9 +71,14 @@ def test_device_pass_equals_the_host_build(name, rays, antithetic):
     ("textured_plane_fills_the_view", 1024, 0.05),
     ("diffuse_sphere_envmap", 1024, 0.1),
     ("glossy_sphere_envmap", 1024, 0.1),
+    # the sensor's own translation (ParamGrads.cam_origin): TranslateCameraConfig as stated (:639-674: res 16, spp 1024, 64 rays,
+    # kappa 1e4; its thresholds are 0.3 / 1.6 forward and 1.3 backward under all-ones weights, where the answer is ~0 -- the ramp
+    # makes the motion of the silhouette count) and a lit scene where shading and shadows move in the image too
+    ("translate_camera", 1024, 0.3),
+    ("translate_camera_lit", 2048, 0.2),
 ])
 def test_backward_gradient_matches_finite_differences(name, spp, tol):
-    got, fd, dt = fd_check(name, device="cuda", spp=spp, rays=64, seeds=2, fd_eps=0.0 if ("emitter" in name or "constant" in name or "envmap" in name or "textured" in name) else 5e-3, fd_spp_mult=2,
+    got, fd, dt = fd_check(name, device="cuda", spp=spp, rays=64, seeds=2, fd_eps=0.0 if ("emitter" in name or "constant" in name or "envmap" in name or "textured" in name or "camera" in name) else 5e-3, fd_spp_mult=2,
                            weights="ones" if name == "self_shadow_point_light" else "ramp")
     r, g, f = rel(got, fd)
     print(f"{name}: grad {g:+.3f} per seed {[round(x, 2) for x in got]}, FD {f:+.3f} per seed {[round(x, 2) for x in fd]}, rel {r:.3f}, "

@@ -285,3 +285,51 @@ def test_warp_adjoint_is_the_transpose_of_its_forward_mode():
         assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), 1e-3), (trial, lhs, rhs)
         # the mesh translated by u with the origin fixed moves every hit point as the origin moved by -u
         assert abs(float(gp.sum(0) @ u) + rhs) <= 2e-3 * max(abs(rhs), 1e-3), (trial, float(gp.sum(0) @ u), rhs)
+
+
+def test_sensor_translation_gradient_on_the_host():
+    """`prb_reparam` w.r.t. the sensor's position (TranslateCameraConfig, test_ad_integrators.py:639-674): every shape moves
+    the other way as the sensor sees it, so the gradient is minus the sum of all vertex gradients (integrators.py).  The
+    plumbing and the sign on the host build at a small sample count; the reference's thresholds at its sample count on the
+    GPU (tests/test_gpu_reparam.py)."""
+    got, fd, _ = fd_check("translate_camera_lit", device="cpu", spp=96, rays=16, seeds=1, fd_spp_mult=2)
+    r, g, f = rel(got, fd)
+    assert g * f > 0 and r < 0.6, (g, f)
+
+
+def test_sensor_gradient_refuses_point_emitters():
+    import epsm_mitsuba3_amd as epsm
+    sc = build("receiver_point_light", 0.0, 16, 4, "cpu")
+    sc.attach_sensor()
+    integ = epsm.load_dict({"type": "prb_reparam", "max_depth": 2, "reparam_rays": 4})
+    with pytest.raises(NotImplementedError):
+        integ.render_backward(sc, sc.param_grads(), torch.ones((16, 16, 3)), sensor=0, seed=0, spp=4)
+
+
+def test_film_crop_window_selects_the_rays_of_the_full_film():
+    """hdrfilm crop_width / crop_height / crop_offset_* (CropWindowConfig, test_ad_integrators.py:250-281; sensor.h:227-262):
+    the ray through the centre of pixel (i, j) of the window is the ray through pixel (i + ox, j + oy) of the full film, and
+    its differentials are one WINDOW pixel wide."""
+    import ctypes as C
+    from _scenes import host_tracer
+    from epsm_mitsuba3_amd import scene as S
+    full = S.Sensor(sensor([0, 0, 4], [0, 0, 0], res=64, rfilter="gaussian"))
+    d = sensor([0, 0, 4], [0, 0, 0], res=64, rfilter="gaussian")
+    d["film"].update(crop_width=32, crop_height=24, crop_offset_x=32, crop_offset_y=20)
+    crop = S.Sensor(d)
+    assert (crop.width, crop.height) == (32, 24) and crop.wavefront_size(2) == 32 * 24 * 2
+    lib = host_tracer()
+    lib.epsm_probe.restype = C.c_int
+
+    def ray(s_, x, y):
+        rows = np.zeros((1, 8), np.float32); rows[0, :2] = (x, y)
+        out = np.zeros((1, 16), np.float32)
+        cs = s_.c_struct()
+        assert lib.epsm_probe(C.c_int(8), C.c_int64(1), rows.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(cs), None) == 0
+        return out[0, :12].astype(np.float64)
+    for i, j in ((0, 0), (5, 7), (31, 23), (16.5, 3.25)):
+        a, b = ray(crop, i + 0.5, j + 0.5), ray(full, i + 32 + 0.5, j + 20 + 0.5)
+        assert np.allclose(a, b, atol=2e-6), (i, j, a - b)
+    with pytest.raises(ValueError):
+        d["film"]["crop_offset_x"] = 40
+        S.Sensor(d)
