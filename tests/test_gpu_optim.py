@@ -50,6 +50,16 @@ def test_caustic_light_translation_is_recovered():
     assert min(hist[-15:]) < 0.35 * hist[0], hist
 
 
+def test_caustic_through_a_glass_sphere_is_recovered():
+    """The stand-in for the reference's `manifold_caustic` box experiments (EPSM/all.sh:7,11: cornellbox, egg) and the shape of
+    BASELINE.json configs[0]: camera -> diffuse floor -> two refractions on a smoothly shaded glass sphere -> area light.
+    Measured: 0.43 -> 0.05-0.06."""
+    from epsm_mitsuba3_amd.optim import run
+    hist, opt = run("manifold_caustic", "caustic_sphere", iterations=60, lr=0.02, log=lambda s: None)
+    assert hist[0] > 0.4
+    assert min(hist[-15:]) < 0.3 * hist[0], hist
+
+
 def test_shadow_occluder_translation_is_recovered():
     """max_depth = 2, everything diffuse: the only gradient path is the occluder term of epsm.py:609-620
     (first hit = floor point in or near the shadow, occluder = closest hit towards the emitter sample)."""
