@@ -873,6 +873,20 @@ EPSM_HD void write_record_packed(float *packed, uint32_t *pflags, int K_log, int
     st4(r + 28, es.p.z, bs.dhf.x, bs.dhf.y, bs.dhf.z);
     pflags[i] = word;                                                     // (the path's lane is the word's only writer)
 }
+// The FIRST SECTOR of the record alone (geometry, barycentrics, triangle id, n0; eta = 0): all that is ever read of a vertex
+// that is only looked at -- a chain's end point, a diffuse first hit (include/epsm.h, EpsmPackedLog)
+EPSM_HD void write_record_packed_first_sector(float *packed, uint32_t *pflags, int K_log, int64_t i, int iteration, uint32_t word,
+                                              const SurfHit &h) {
+    const bool mesh = h.valid && (h.mesh_flags & EPSM_MESH_IS_MESH);
+    const F3 z = zero3<float>();
+    const F3 p0 = mesh ? h.p0 : z, p1 = mesh ? h.p1 : z, p2 = mesh ? h.p2 : z, n0 = mesh ? h.n0 : z;
+    float *r = packed + (i * K_log + iteration) * 32;
+    st4(r + 0, p0.x, p0.y, p0.z, p1.x);
+    st4(r + 4, p1.y, p1.z, p2.x, p2.y);
+    st4(r + 8, p2.z, mesh ? h.b0 : 0.f, mesh ? h.b1 : 0.f, u2f(mesh ? h.tri : kNoIndex));
+    st4(r + 12, n0.x, n0.y, n0.z, 0.f);
+    pflags[i] = word;
+}
 
 // EPSM_TRACE_SPARSE_LOG: a bounce the path did not reach leaves only the fields the gradient kernels' masks read
 EPSM_HD void write_dead_masks(const EpsmRecordOut &R, int64_t i) {
@@ -969,6 +983,21 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
         bsdf.reflectance[0] = r.x; bsdf.reflectance[1] = r.y; bsdf.reflectance[2] = r.z;
     }
 
+    // ---- EPSM_TRACE_GRADIENT_ONLY, native log: a vertex at which the path is retired BY THE RULE (cp::gradient_live: a Diffuse,
+    // non-mesh or missed vertex -- not the K_log limit) is only ever looked at: a chain's end point or a diffuse first hit, of
+    // which the backward kernel reads the first sector of the record and the Diffuse / Null / active / mesh bits.  No emitter
+    // sample, no BSDF sample, no second sector.  (Not when the occluder record of vertex 1 is wanted: it rides on the emitter sample.)
+    if ((A.flags & EPSM_TRACE_GRADIENT_ONLY) && (A.flags & EPSM_TRACE_PACKED_LOG) && iteration < A.K_log && s.active &&
+        !(iteration == 0 && A.rec[0].shadow && A.max_depth <= 3)) {
+        const uint32_t w = s.gword | (vertex_flag_bits(si.valid, si, flags, false) << (5 * iteration));
+        if (!cp::gradient_live(w, iteration + 1, (A.flags & EPSM_TRACE_GRADIENT_CAUSTIC) != 0)) {
+            s.gword = w;
+            write_record_packed_first_sector(A.rec[0].packed, A.rec[0].pflags, A.K_log, i, iteration, w, si);
+            if (si.valid) s.depth += 1;
+            s.active = false;
+            return;
+        }
+    }
     // ---- direct emission, MIS against the emitter sample of the previous bounce (epsm.py:569-577)
     F3 Le = zero3<float>();
     if (si.valid && si.emitter >= 0 && si.wi.z > 0.f) {                    // area.cpp eval: front side only

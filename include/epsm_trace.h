@@ -69,9 +69,11 @@ enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
  * and after vertex K_log in any case.  The visibility ray of an emitter sample is traced only where its answer is read: it
  * decides the logged weight eweight = sum Lr_dir, which calc_grad uses in the light-sampling term of a vertex behind which a
  * `manifold` path goes on (epsm.py:622-627, 852-855) and nowhere in manifold_caustic (its light terms are identically zero);
- * the occluder record of vertex 1 (max_depth <= 3, epsm.py:609-620) is traced as always.  Every word calc_grad reads is the
- * one the full trace writes, so the gradients are identical; `radiance` and the eweight words nobody reads are NOT those of
- * the full trace and must not be used.  bench.py's real_scene leg: trace + log 14.3 -> see DESIGN.md 5b. */
+ * the occluder record of vertex 1 (max_depth <= 3, epsm.py:609-620) is traced as always.  With the native log a vertex that
+ * retires its path by the rule -- a chain's end point, a diffuse first hit: only ever LOOKED at -- gets the first sector of its
+ * record and its Diffuse / Null / active / mesh bits, nothing else (no emitter or BSDF sample is drawn for it; its active_em
+ * bit stays 0).  Every word calc_grad reads is the one the full trace writes, so the gradients are identical; `radiance`,
+ * the eweight words nobody reads and the second sector / active_em bit of such vertices are NOT those of the full trace.  bench.py's real_scene leg: trace + log 14.3 -> see DESIGN.md 5b. */
 #define EPSM_TRACE_GRADIENT_ONLY    0x4u
 #define EPSM_TRACE_GRADIENT_CAUSTIC 0x8u
 
