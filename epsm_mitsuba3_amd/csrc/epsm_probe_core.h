@@ -50,11 +50,23 @@ EPSM_HD void probe_row(int what, const float *in, float *out, const EpsmBsdf *bs
             out[0] = p.ray.o.x; out[1] = p.ray.o.y; out[2] = p.ray.o.z; out[3] = p.ray.d.x; out[4] = p.ray.d.y; out[5] = p.ray.d.z;
             out[6] = p.dx.x; out[7] = p.dx.y; out[8] = p.dx.z; out[9] = p.dy.x; out[10] = p.dy.y; out[11] = p.dy.z;
         } break;
+        case EPSM_PROBE_BSDF_SAMPLE: {                 // in: wi (3), sample1, sample2 (2) -> wo, weight, pdf, eta, sampled_type, valid
+            const BsdfSample b = bsdf_sample(*bsdf, f3(in[0], in[1], in[2]), in[3], in[4], in[5], true);
+            out[0] = b.wo.x; out[1] = b.wo.y; out[2] = b.wo.z; out[3] = b.weight.x; out[4] = b.weight.y; out[5] = b.weight.z;
+            out[6] = b.pdf; out[7] = b.eta; out[8] = u2f(b.sampled_type); out[9] = b.valid ? 1.f : 0.f;
+        } break;
+        case EPSM_PROBE_BSDF_EVAL: {                   // in: wi (3), wo (3) -> value incl. the cosine (3), pdf
+            F3 v; float pdf;
+            bsdf_eval_pdf(*bsdf, f3(in[0], in[1], in[2]), f3(in[3], in[4], in[5]), v, pdf);
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = pdf;
+        } break;
         default: break;
     }
 }
 
-EPSM_HD bool probe_needs_bsdf(int what) { return what == EPSM_PROBE_MICROFACET || what == EPSM_PROBE_MICROFACET_SAMPLE; }
+EPSM_HD bool probe_needs_bsdf(int what) {
+    return what == EPSM_PROBE_MICROFACET || what == EPSM_PROBE_MICROFACET_SAMPLE || what == EPSM_PROBE_BSDF_SAMPLE || what == EPSM_PROBE_BSDF_EVAL;
+}
 EPSM_HD bool probe_needs_sensor(int what) { return what == EPSM_PROBE_PRIMARY_RAY; }
 
 }  // namespace epsm

@@ -316,10 +316,13 @@ int epsm_film_adjoint_reparam(int64_t N, const float *film_pos, const float *rad
  *   EPSM_PROBE_FRESNEL_CONDUCTOR  in cos_theta_i, eta, k                        out F                                        fresnel.h:92-117
  *   EPSM_PROBE_RFILTER            in x                                          out gaussian reconstruction filter at x      src/rfilters/gaussian.cpp (src/rfilters/tests/test_rfilter.py:14-19)
  *   EPSM_PROBE_PRIMARY_RAY        in film position (pixels); cfg = EpsmSensor   out o, d, d_x, d_y (3 each)                  src/sensors/perspective.cpp:238-279 (src/sensors/tests/test_perspective.py:89-135)
+ *   EPSM_PROBE_BSDF_SAMPLE        in wi (3), sample1, sample2 (2); cfg = EpsmBsdf out wo (3), weight (3), pdf, eta, sampled_type (bits), valid   src/bsdfs/{diffuse,conductor,roughconductor,dielectric,twosided}.cpp sample() (src/bsdfs/tests/test_dielectric.py:31-158)
+ *   EPSM_PROBE_BSDF_EVAL          in wi (3), wo (3); cfg = EpsmBsdf             out value incl. cosine (3), pdf              eval_pdf() (src/bsdfs/tests/test_diffuse.py:13-35, test_twosided.py:29-45)
  * in: (n, EPSM_PROBE_IN) floats, out: (n, EPSM_PROBE_OUT) floats, device pointers; cfg: HOST pointer to the struct named
  * above (NULL otherwise).  Not on any hot path. */
 enum { EPSM_PROBE_TEA = 0, EPSM_PROBE_PCG32 = 1, EPSM_PROBE_SAMPLER = 2, EPSM_PROBE_MICROFACET = 3, EPSM_PROBE_MICROFACET_SAMPLE = 4,
-       EPSM_PROBE_FRESNEL = 5, EPSM_PROBE_FRESNEL_CONDUCTOR = 6, EPSM_PROBE_RFILTER = 7, EPSM_PROBE_PRIMARY_RAY = 8, EPSM_PROBE_COUNT = 9 };
+       EPSM_PROBE_FRESNEL = 5, EPSM_PROBE_FRESNEL_CONDUCTOR = 6, EPSM_PROBE_RFILTER = 7, EPSM_PROBE_PRIMARY_RAY = 8, EPSM_PROBE_BSDF_SAMPLE = 9,
+       EPSM_PROBE_BSDF_EVAL = 10, EPSM_PROBE_COUNT = 11 };
 #define EPSM_PROBE_IN 8
 #define EPSM_PROBE_OUT 16
 int epsm_probe(int what, int64_t n, const float *in, float *out, const void *cfg, void *stream);

@@ -15,7 +15,8 @@ import torch
 from epsm_mitsuba3_amd import scene as S
 from tests.golden import reference_vectors as RV
 
-PROBE = dict(TEA=0, PCG32=1, SAMPLER=2, MICROFACET=3, MICROFACET_SAMPLE=4, FRESNEL=5, FRESNEL_CONDUCTOR=6, RFILTER=7, PRIMARY_RAY=8)
+PROBE = dict(TEA=0, PCG32=1, SAMPLER=2, MICROFACET=3, MICROFACET_SAMPLE=4, FRESNEL=5, FRESNEL_CONDUCTOR=6, RFILTER=7, PRIMARY_RAY=8,
+             BSDF_SAMPLE=9, BSDF_EVAL=10)
 PROBE_IN, PROBE_OUT = 8, 16
 
 
@@ -192,7 +193,46 @@ def check_camera(probe):
             assert np.allclose(ray(0.5, 0.5 + 1.0 / H)[3:6], c[9:12], rtol=1e-5, atol=1e-7)
 
 
-ALL_PROBE_CHECKS = (check_tea, check_pcg32, check_microfacet, check_microfacet_sample, check_fresnel, check_rfilter, check_camera)
+def _plugin(kind, twosided=0, reflectance=0.5, int_ior=1.5, ext_ior=1.0):
+    b = S.EpsmBsdf()
+    b.type, b.twosided = {"diffuse": 0, "conductor": 1, "roughconductor": 2, "dielectric": 3}[kind], twosided
+    b.reflectance[:] = [reflectance] * 3
+    b.int_ior, b.ext_ior, b.alpha, b.sample_visible = int_ior, ext_ior, 0.1, 1
+    b.eta[:] = [0.0] * 3; b.k[:] = [1.0] * 3
+    b.alpha_slot = b.color_slot = b.texture = -1
+    return b
+
+
+def check_bsdf_plugins(probe):
+    D = RV.DIELECTRIC
+    glass = _plugin("dielectric", reflectance=D["reflectance"], int_ior=D["int_ior"], ext_ior=D["ext_ior"])
+    o = probe(PROBE["BSDF_SAMPLE"], rows_of([list(wi) + [s1, 0.0, 0.0] for wi, s1, *_ in RV.DIELECTRIC_SAMPLE_ROWS]), glass).astype(np.float64)
+    ob = f32_to_bits(probe(PROBE["BSDF_SAMPLE"], rows_of([list(wi) + [s1, 0.0, 0.0] for wi, s1, *_ in RV.DIELECTRIC_SAMPLE_ROWS]), glass))
+    for row, bits, (wi, s1, weight, pdf, eta, wo, kind) in zip(o, ob, RV.DIELECTRIC_SAMPLE_ROWS):
+        assert np.allclose(row[3:6], [weight] * 3, rtol=1e-5) and np.isclose(row[6], pdf, rtol=1e-5, atol=1e-7), (wi, s1, row)   # test_dielectric.py:40-89
+        assert np.isclose(row[7], eta, rtol=1e-5) and np.allclose(row[0:3], wo, atol=1e-6) and int(bits[8]) == kind and row[9] == 1.0
+    a = math.radians(RV.DIELECTRIC_SPOT_ANGLE_DEG)                                        # :141-158
+    wi = [math.sin(a), 0.0, math.cos(a)]
+    r = probe(PROBE["BSDF_SAMPLE"], rows_of([wi + [0.0, 0.0, 0.0], wi + [1.0, 0.0, 0.0]]), glass).astype(np.float64)
+    assert np.isclose(r[0, 6], RV.DIELECTRIC_SPOT_PDF, rtol=1e-5) and np.allclose(r[0, 0:3], [-math.sin(a), 0.0, math.cos(a)], atol=1e-6)
+    t = math.radians(RV.DIELECTRIC_SPOT_REFRACTED_DEG)
+    assert np.isclose(r[1, 6], 1 - RV.DIELECTRIC_SPOT_PDF, rtol=1e-5) and np.allclose(r[1, 0:3], [-math.sin(t), 0.0, -math.cos(t)], atol=1e-6)
+    back = probe(PROBE["BSDF_SAMPLE"], rows_of([list(r[1, 0:3]) + [1.0, 0.0, 0.0]]), glass).astype(np.float64)
+    assert np.isclose(back[0, 6], 1 - RV.DIELECTRIC_SPOT_PDF, rtol=1e-5) and np.allclose(back[0, 0:3], wi, atol=1e-6)
+    # diffuse (test_diffuse.py:24-35)
+    wos = [[math.sin(th), 0.0, math.cos(th)] for th in RV.DIFFUSE_THETAS]
+    e = probe(PROBE["BSDF_EVAL"], rows_of([[0.0, 0.0, 1.0] + wo for wo in wos]), _plugin("diffuse", reflectance=RV.DIFFUSE_DEFAULT_REFLECTANCE)).astype(np.float64)
+    cos = np.array([wo[2] for wo in wos])
+    live = cos > 1e-6                                  # (the last angle is pi / 2: cos = 6e-17 there, "> 0" in float64 only)
+    assert np.allclose(e[live, 3], cos[live] / math.pi, rtol=1e-5) and np.allclose(e[live, 0], 0.5 * cos[live] / math.pi, rtol=1e-5)
+    # twosided(diffuse) (test_twosided.py:29-45)
+    two = _plugin("diffuse", twosided=1)
+    e = probe(PROBE["BSDF_EVAL"], rows_of([[0, 0, 1, 0, 0, 1], [0, 0, 1, 0, 0, -1]]), two).astype(np.float64)
+    assert np.isclose(e[0, 3], 1 / math.pi, rtol=1e-5) and e[1, 3] == 0.0
+
+
+ALL_PROBE_CHECKS = (check_tea, check_pcg32, check_microfacet, check_microfacet_sample, check_fresnel, check_rfilter, check_camera,
+                    check_bsdf_plugins)
 
 
 # ------------------------------------------------------------------------------------------------- tangent and scatter

@@ -151,3 +151,22 @@ CAMERA = dict(fov=34.0, width=512, height=256, near_clip=1.0, far_clip=35.0, up=
 CAMERA_ORIGINS = [(1.0, 0.0, 1.5), (1.0, 4.0, 1.5)]
 CAMERA_DIRECTIONS = [(0.0, 0.0, 1.0), (1.0, 0.0, 0.0)]
 CAMERA_POS_SAMPLES = [(0.2, 0.6), (0.1, 0.9), (0.2, 0.2)]      # :99 pos_sample = [[0.2, 0.1, 0.2], [0.6, 0.9, 0.2]] (x row, y row)
+
+# ----------------------------------------------------------------------------------------------------------------------
+# whole BSDFs.  src/bsdfs/tests/test_dielectric.py (int_ior 1.5, ext_ior 1, specular_reflectance 0.3, specular_transmittance 0.6;
+# the tracer's dielectric has no transmittance parameter -- T = 1 -- and transports radiance: the reference's radiance-mode
+# weights divided by 0.6), test_diffuse.py:13-35 (default reflectance 0.5), test_twosided.py:29-45.
+# rows: (wi, sample1) -> (weight, pdf, eta, wo, sampled_type): DeltaReflection = 0x20, DeltaTransmission = 0x40 (bsdf.h:31-101)
+DIELECTRIC = dict(int_ior=1.5, ext_ior=1.0, reflectance=0.3, reference_transmittance=0.6)
+DIELECTRIC_SAMPLE_ROWS = [
+    ((0, 0, 1), 0.0, 0.3, 0.04, 1.0, (0, 0, 1), 0x20),                          # test_dielectric.py:40-46
+    ((0, 0, 1), 0.05, 0.6 / 1.5 ** 2 / 0.6, 1 - 0.04, 1.5, (0, 0, -1), 0x40),   # :49-58 (radiance transport)
+    ((0, 0, -1), 0.0, 0.3, 0.04, 1.0, (0, 0, -1), 0x20),                        # :71-77
+    ((0, 0, -1), 0.05, 0.6 * 1.5 ** 2 / 0.6, 1 - 0.04, 1 / 1.5, (0, 0, 1), 0x40),   # :80-89
+]
+# spot check at 80 degrees (:141-158): reflection pdf 0.387704354691473; refraction at 41.03641052520335 degrees; and back again
+DIELECTRIC_SPOT_ANGLE_DEG, DIELECTRIC_SPOT_PDF, DIELECTRIC_SPOT_REFRACTED_DEG = 80.0, 0.387704354691473, 41.03641052520335
+# diffuse: pdf = cos / pi, eval = 0.5 cos / pi for wo = (sin t, 0, cos t), t = i / 19 * pi / 2, wi = (0, 0, 1) (test_diffuse.py:24-31)
+DIFFUSE_DEFAULT_REFLECTANCE = 0.5
+DIFFUSE_THETAS = [i / 19.0 * (math.pi / 2) for i in range(20)]
+# twosided(diffuse): pdf(wi = +z, wo = +z) = 1 / pi, pdf(wi = +z, wo = -z) = 0 (test_twosided.py:29-45)
