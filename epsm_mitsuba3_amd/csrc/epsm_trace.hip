@@ -5,6 +5,7 @@
 #include "epsm_common.h"
 #include "epsm_trace_core.h"
 #include "epsm_trace_wavefront.h"
+#include "epsm_trace_quad.h"
 
 using namespace epsm;
 using epsm_host::fail;
@@ -161,6 +162,25 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_compact_kernel(TraceArgs A, 
         (which == 0 ? W.queue[(b + 1) & 1] : W.shadow_queue)[off] = i;
     }
 #endif
+}
+// EPSM_WF_QUAD (A/B build, round 5): the closest-hit stage of the bounces >= 1 with FOUR LANES PER RAY (epsm_trace_quad.h): a
+// workgroup of 128 lanes takes 32 rays at a time.
+__global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_quad_kernel(TraceArgs A, WfState W, int b) {
+    __shared__ uint32_t s_stack[kQuadStack * (kWfThreads / 4)];
+    const int64_t count = wf_count(A, W, b);
+    const int lane = threadIdx.x & 63, quad = threadIdx.x >> 2;
+    for (int64_t q0 = (int64_t) blockIdx.x * (kWfThreads / 4); q0 < count; q0 += (int64_t) gridDim.x * (kWfThreads / 4)) {
+        const int64_t q = q0 + quad;
+        const bool has = q < count;
+        const int64_t i = has ? (int64_t) W.queue[b & 1][q] : 0;
+        Ray r; r.o = r.d = zero3<float>(); r.maxt = 0.f;
+        if (has) { const W4 o = W.ray_o[i], d = W.ray_d[i]; r.o = xyz(o); r.maxt = u2f(o.w); r.d = xyz(d); }
+        const TriHit th = quad_intersect<false>(A.S, r, has, s_stack + quad, kWfThreads / 4, lane);
+        if (has && (lane & 3) == 0) {
+            W4 h; h.x = th.hit ? th.tri : kNoIndex; h.y = f2u(th.t); h.z = f2u(th.u); h.w = f2u(th.v);
+            W.hit[i] = h;
+        }
+    }
 }
 __global__ __launch_bounds__(kWfThreads) void epsm_wf_shadow_kernel(TraceArgs A, WfState W, int b) {
     __shared__ uint32_t s_stack[kWfStackLds * kWfThreads];
@@ -446,7 +466,11 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
         // the queue lengths of bounce b live on the device: every stage is launched for the worst case and its
         // surplus workgroups leave at once (no host round trip between the bounces)
         if (b == 0) hipLaunchKernelGGL(epsm_wf_extend_kernel<true>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
+#ifdef EPSM_WF_QUAD
+        else hipLaunchKernelGGL(epsm_wf_extend_quad_kernel, blocks(kWfThreads / 4), dim3(kWfThreads), 0, s, A, W, b);
+#else
         else hipLaunchKernelGGL(epsm_wf_extend_kernel<false>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
+#endif
         hipLaunchKernelGGL(epsm_wf_shade_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_scan_kernel, dim3(2), dim3(1024), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_compact_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
