@@ -220,6 +220,11 @@ int epsm_scatter(int variant, int64_t N, int K,
  *     paths inside 1024-path windows, so the order also differs from run to run).  This is what
  *     EPSMIntegrator.render_backward uses; the two-call form exists for callers that
  *     want calc_grad's lists (the drop-in of INTEGRATION.md section 1).
+ *     Range of the sums (this and the two entry points below): with clip <= 1 the rows of a window of <= 2048 paths are summed
+ *     on chip in 64-bit fixed point (44 fractional bits, |sum| < 2^19); only terms of magnitude < 16 enter those rows -- a path
+ *     adds at most 16 terms to one row, 2048 x 16 x 16 = 2^19 is never reached, the integer cannot wrap -- larger ones (a
+ *     clamped term times an emitter weight or 1 / |n| beyond ~10^2) are added to the caller's buffers directly as float atomics,
+ *     non-finite ones add nothing.  With clip > 1 (the clamp switched off) the rows are float.
  * ------------------------------------------------------------------------- */
 int epsm_manifold_grad_scatter(int variant, int64_t N, int K,
                                const float *cam, const EpsmVertexRecord *verts,
