@@ -453,14 +453,14 @@ class PRBReparamIntegrator(PRBIntegrator):
             was = [(m, bool(getattr(m, "pos_attached", False))) for m in scene.meshes]
             for m, _ in was:
                 m.pos_attached = True
-            scene._upload()
+            scene._refresh_attach_flags(sync_host=False)
             try:
                 full = ParamGrads(params.V, params.B, device=params.flat.device, mesh_slices=params.mesh_slices, n_colors=params.C)
                 self._geometry_backward(scene, full, grad_in, sensor, seed, spp)
             finally:
                 for m, a in was:
                     m.pos_attached = a
-                scene._upload()
+                scene._refresh_attach_flags(sync_host=False)
             params.cam_origin -= full.pos.sum(dim=0)
             for m, a in was:                                   # the meshes the caller attached keep their own rows
                 if a:

@@ -843,7 +843,22 @@ class Scene:
         """``dr.enable_grad(params['<mesh>.vertex_positions' / '.vertex_normals'])``."""
         m = self.mesh(mesh_name)
         m.pos_attached, m.nrm_attached = positions, normals
-        self._upload()
+        self._refresh_attach_flags()
+
+    def _refresh_attach_flags(self, sync_host: bool = True):
+        """What `dr.enable_grad` changes on the device: the mode bits of the meshes -- in the mesh table the tracer reads and
+        in the last column of the triangle table the gradient kernels read.  Rewritten IN PLACE (the scene struct's pointers
+        stay valid); nothing else of the upload is repeated."""
+        if (getattr(self, "_mesh_structs", None) is None or getattr(self, "tri_table", None) is None
+                or (sync_host and any(getattr(m, "host_stale", False) for m in self.meshes))):   # (vertices moved on the device: the full upload syncs the host copies)
+            return self._upload()
+        for c, m in zip(self._mesh_structs, self.meshes):
+            c.flags = m.flags()
+        self._mesh_buf.copy_(torch.frombuffer(bytearray(bytes(self._mesh_structs)), dtype=torch.uint8))
+        if self.T > 0:
+            mode = torch.tensor([(m.flags() & 0xF) | ((self.alpha_slots.get(m.bsdf, -1) + 1) << 8) for m in self.meshes],
+                                dtype=torch.int32, device=self.device)
+            self.tri_table[:, 3] = mode[self.tri_mesh.long()]
 
     def attach_sensor(self, attached: bool = True):
         """``dr.enable_grad(params['sensor.to_world'])`` for its translation: ``prb_reparam``'s render_backward then leaves
@@ -1040,6 +1055,7 @@ class Scene:
             c.color_slot = self.color_slots.index(("emitter", i)) if ("emitter", i) in self.color_slots else -1
         as_dev = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self._mesh_buf, self._bsdf_buf, self._em_buf = as_dev(mesh_c), as_dev(bs), as_dev(em)
+        self._mesh_structs = mesh_c                              # host copy: _refresh_attach_flags rewrites the flags in place
         self._tex_struct_buf = as_dev(tx)
         s = EpsmSceneC()
         s.positions, s.normals = self.positions.data_ptr(), self.normals.data_ptr()
