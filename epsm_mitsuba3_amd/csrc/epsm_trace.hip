@@ -476,7 +476,9 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
         hipLaunchKernelGGL(epsm_wf_compact_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_shadow_kernel, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
     }
-    hipLaunchKernelGGL(epsm_wf_finish_kernel, blocks(256), dim3(256), 0, s, A, W);
+    // (radiance / valid not asked for and the native log: nothing is left to write -- the gradient-only trace of render_backward)
+    if (A.radiance || A.valid || !(A.flags & EPSM_TRACE_PACKED_LOG))
+        hipLaunchKernelGGL(epsm_wf_finish_kernel, blocks(256), dim3(256), 0, s, A, W);
     e = hipGetLastError();
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_trace_paths_wavefront", e);
     return EPSM_OK;

@@ -176,7 +176,9 @@ EPSM_HD void wf_shade(const TraceArgs &A, const WfState &W, int64_t i, int itera
     if (alive) {
         wf_store(W, i, s, iteration + 1);
     } else {                                                             // a path that ends here: only what finish / shadow read
-        W.L[i] = pack4u(s.L, (uint32_t) s.depth | ((uint32_t) (iteration + 1) << 16));
+        // (nothing when nobody asked for radiance / valid and the log is the native one: the gradient-only trace)
+        if (A.radiance || A.valid || !(A.flags & EPSM_TRACE_PACKED_LOG))
+            W.L[i] = pack4u(s.L, (uint32_t) s.depth | ((uint32_t) (iteration + 1) << 16));
         if (vis.want_occluder) W.prev_p[i] = pack4(s.prev_p, 0.f);
     }
     if (vis.pending) {
@@ -214,7 +216,7 @@ EPSM_HD bool wf_shadow_round(const TraceArgs &A, const WfState &W, int iteration
                 if (A.flags & EPSM_TRACE_PACKED_LOG) A.rec[0].packed[(i * A.K_log + iteration) * 32 + 27] = 0.f;
                 else A.rec[iteration].emit[4 * i + 3] = 0u;
             }
-        } else {
+        } else if (A.radiance) {
             const W4 l = W.L[i];
             const F3 L = xyz(l) + xyz(W.sh_L[i]);                        // (L + Le) + Lr_dir, epsm.py:658
             W.L[i] = pack4u(L, l.w);

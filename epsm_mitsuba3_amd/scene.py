@@ -1201,9 +1201,11 @@ class Scene:
         n = hi - lo
         assert K >= 1
         rays = torch.empty((n, 12), device=dev, dtype=torch.float32)
-        radiance = torch.empty((n, 3), device=dev, dtype=torch.float32)
-        film_pos = torch.empty((n, 2), device=dev, dtype=torch.float32)
-        valid = torch.empty((n,), device=dev, dtype=torch.uint8)
+        # a gradient-only trace forms no image: radiance / film positions / valid are not asked for, and nothing is written for them
+        want_image = not gradient_only
+        radiance = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_image else None
+        film_pos = torch.empty((n, 2), device=dev, dtype=torch.float32) if want_image else None
+        valid = torch.empty((n,), device=dev, dtype=torch.uint8) if want_image else None
         flags = torch.empty((n,), device=dev, dtype=torch.int32)
         verts = torch.empty((n, K, REC_WORDS), device=dev, dtype=torch.float32)
         shadow = torch.empty((n, 4), device=dev, dtype=torch.int32) if max_depth <= 3 else None
@@ -1213,7 +1215,8 @@ class Scene:
         cs = sensor.c_struct()
         args = [C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
                 C.c_int64(lo), C.c_int64(n), K, C.c_void_p(rays.data_ptr()), None, None, None,
-                C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()), C.c_void_p(valid.data_ptr()),
+                C.c_void_p(film_pos.data_ptr()) if want_image else None, C.c_void_p(radiance.data_ptr()) if want_image else None,
+                C.c_void_p(valid.data_ptr()) if want_image else None,
                 C.c_void_p(C.addressof(recs)),
                 C.c_uint32(EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG | self._gradient_only_flags(gradient_only))]
         if self.use_wavefront() and n > 0:

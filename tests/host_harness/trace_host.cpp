@@ -159,7 +159,8 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
         }
         for (int64_t q = 0; q < (int64_t) W.counters[8 + b]; ++q) wf_shadow(A, W, (int64_t) W.shadow_queue[q], b, stack, 1);
     }
-    for (int64_t i = 0; i < N; ++i) wf_finish(A, W, i);
+    if (A.radiance || A.valid || !(A.flags & EPSM_TRACE_PACKED_LOG))           // as the device entry point
+        for (int64_t i = 0; i < N; ++i) wf_finish(A, W, i);
     return 0;
 }
 
