@@ -73,7 +73,8 @@ enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
  * retires its path by the rule -- a chain's end point, a diffuse first hit: only ever LOOKED at -- gets the first sector of its
  * record and its Diffuse / Null / active / mesh bits, nothing else (no emitter or BSDF sample is drawn for it; its active_em
  * bit stays 0).  Every word calc_grad reads is the one the full trace writes, so the gradients are identical; `radiance`,
- * the eweight words nobody reads and the second sector / active_em bit of such vertices are NOT those of the full trace.  bench.py's real_scene leg: trace + log 14.3 -> see DESIGN.md 5b. */
+ * the eweight words nobody reads and the second sector / active_em bit of such vertices are NOT those of the full trace: pass
+ * radiance = valid = film_pos = NULL (with the native log nothing is then written for them and the finishing pass is skipped).  bench.py's real_scene leg: trace + log 14.3 -> see DESIGN.md 5b. */
 #define EPSM_TRACE_GRADIENT_ONLY    0x4u
 #define EPSM_TRACE_GRADIENT_CAUSTIC 0x8u
 
