@@ -23,6 +23,12 @@
 #if !defined(EPSM_CP_NO_STASH) && !defined(EPSM_CP_STASH)
 #define EPSM_CP_STASH
 #endif
+// ... and the lane's own record of the wave's NEXT round is requested before this round's emission (EPSM_CP_PREFETCH = 1, below):
+// headline slab 1.89 -> 1.81 ms, config 2 2.23 -> 2.19, pool slab 2.61 -> 2.59; = 2 (+ the rays) and = 3 (+ the end-point record)
+// spill 13-16 more registers and are slower (1.89 / 2.09 ms).  -DEPSM_CP_NO_PREFETCH: loads at the start of the round.
+#if defined(EPSM_CP_STASH) && !defined(EPSM_CP_NO_PREFETCH) && !defined(EPSM_CP_PREFETCH)
+#define EPSM_CP_PREFETCH 1
+#endif
 #include "epsm_fused.h"
 #include "epsm_cp_core.h"
 #include "epsm_wave_scatter.h"
@@ -490,6 +496,38 @@ __device__ __forceinline__ void addr_issue(AddrFetch &A, const FusedArgs &F, con
     if (R.d1 && B.shadow) A.sh = load_u4(B.shadow, R.loc);
 }
 
+// ---- EPSM_CP_PREFETCH (round 5; the product build): the lane's OWN record of the wave's NEXT round -- quads 0..5 and the
+// emission's words -- requested before this round's emission, into 36 registers that only the emission has to live with (its
+// pressure is ~80 registers below the recursions' peak: no additional spill), so that the trip to memory runs under the LDS work
+// of the emission.  (Round 3 prefetched everything a round reads into 62 registers and paid for it with the third wave per SIMD.)
+template <int VARIANT>
+__device__ __forceinline__ void own_issue(GeoFetch &X, AddrFetch &A, const FusedArgs &F, const LaneId &L, const WinBase &B) {
+    const LaneRole R = role_of(F, L, B);
+    if (R.live || R.d1) { X.o0 = ldq(R.rec, 0); X.o1 = ldq(R.rec, 1); X.o2 = ldq(R.rec, 2); }
+    if (R.live) { X.o3 = ldq(R.rec, 3); X.o4 = ldq(R.rec, 4); X.o5 = ldq(R.rec, 5); }
+    addr_issue<VARIANT>(A, F, L, B);
+#if EPSM_CP_PREFETCH >= 2            // ... and the rays + image gradient of a path's first lane
+    if (R.ok && R.first) {
+        const float *rays = B.rays + 12u * R.loc;
+        X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
+        const F2v g = ld2(pixel_grad(F.tin, B, R.loc));
+        X.gx = g.x; X.gy = g.y;
+    }
+#endif
+#if EPSM_CP_PREFETCH >= 3            // ... and the end-point record of its last lane
+    if (R.end_next) {
+        const float *nx = R.rec + kRecWords;
+        X.n0 = ldq(nx, 0); X.n1 = ldq(nx, 1); X.n2 = ldq(nx, 2);
+    }
+#endif
+}
+__device__ __forceinline__ void fetch_zero(GeoFetch &X, AddrFetch &A) {
+    const F4v z4 = {0.f, 0.f, 0.f, 0.f};
+    X.o0 = X.o1 = X.o2 = X.o3 = X.o4 = X.o5 = X.p0 = X.p1 = X.p2 = X.n0 = X.n1 = X.n2 = z4;
+    X.o_lz = X.gx = X.gy = 0.f;
+    A.q6 = A.q7 = z4; A.sh.x = kNoIndex; A.sh.y = A.sh.z = A.sh.w = 0u;
+}
+
 // kWindow: the largest window (paths a workgroup plans, sorts and works through at a time); `window` <= kWindow, a multiple
 // of 64, is what this launch uses -- a small wavefront is cut into smaller windows so that every CU gets some (launch()).
 // Large wavefronts take windows of 2048 paths: every class of paths ends in a partly filled round, six of the 23 rounds of
@@ -633,6 +671,11 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
         // is made of cheap rounds: 6.3 ms, three times slower, for no reason found.)
         const int n_rounds = RS.rb[kKeys];
         LaneId L = RS.lane_of(wv, lane);
+#ifdef EPSM_CP_PREFETCH
+        GeoFetch Xp; AddrFetch Ap;
+        fetch_zero(Xp, Ap);
+        if (PACKED) own_issue<VARIANT>(Xp, Ap, F, L, WB);           // the window's first round: nothing to hide it under
+#endif
 #pragma unroll 1
         for (int r = wv; r < n_rounds; r += kWaves) {
             const int q = L.q, c = L.c, k = L.k;
@@ -685,7 +728,19 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                 geo_stage_dma<VARIANT>(X, F, L, WB, s_stage[wv], lane);
 #endif
 #else
+#ifdef EPSM_CP_PREFETCH
+#if EPSM_CP_PREFETCH >= 3
+                X = Xp;
+#elif EPSM_CP_PREFETCH >= 2
+                X = Xp;
+                if (role_of(F, L, WB).end_next) { const float *nx = role_of(F, L, WB).rec + kRecWords; X.n0 = ldq(nx, 0); X.n1 = ldq(nx, 1); X.n2 = ldq(nx, 2); }
+#else
+                geo_issue_rest(X, F, L, WB);
+                X.o0 = Xp.o0; X.o1 = Xp.o1; X.o2 = Xp.o2; X.o3 = Xp.o3; X.o4 = Xp.o4; X.o5 = Xp.o5;
+#endif
+#else
                 geo_issue<VARIANT>(X, F, L, WB);
+#endif
 #ifdef EPSM_CP_STASH
                 // ONE trip to memory per record: the words only the emission needs (quads 6 and 7: the same line as the geometry,
                 // second sector) are requested together with it and parked in LDS until the emission -- 32 bytes per lane in the
@@ -697,7 +752,11 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     AddrFetch A0;
                     const F4v z4s = {0.f, 0.f, 0.f, 0.f};
                     A0.q6 = A0.q7 = z4s; A0.sh.x = kNoIndex; A0.sh.y = A0.sh.z = A0.sh.w = 0u;
+#ifdef EPSM_CP_PREFETCH
+                    A0 = Ap;
+#else
                     addr_issue<VARIANT>(A0, F, L, WB);
+#endif
                     float *st = (float *) s_queue[wv] + 4 * kStashFirstItem + 8 * lane;
                     const bool has_sh = d1 && F.pk_shadow;
                     const F4v shv = {__uint_as_float(A0.sh.x), __uint_as_float(A0.sh.y), __uint_as_float(A0.sh.z), __uint_as_float(A0.sh.w)};
@@ -908,6 +967,9 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             // through that queue -- by the touch at HBM latency, again by the round that uses it at L2 latency, the L1 having lost
             // it in between.  TCP_PENDING_STALL_CYCLES: 65 % of the kernel; without the touch 2.046 -> 1.970 ms.)
             const LaneId Ln = RS.lane_of(r + kWaves, lane);          // (past the last round: no lane has a path)
+#ifdef EPSM_CP_PREFETCH
+            if (PACKED) { fetch_zero(Xp, Ap); own_issue<VARIANT>(Xp, Ap, F, Ln, WB); }
+#endif
             // ---- emission
             asm volatile("; EPSM_MARK emit");
             if (PACKED) bid = (t_own.w >> 8) - 1u;                    // packed log: alpha slot + 1 in the table row
