@@ -968,6 +968,8 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             // it in between.  TCP_PENDING_STALL_CYCLES: 65 % of the kernel; without the touch 2.046 -> 1.970 ms.)
             const LaneId Ln = RS.lane_of(r + kWaves, lane);          // (past the last round: no lane has a path)
 #ifdef EPSM_CP_PREFETCH
+            // (issued here, behind the table rows' loads -- vmcnt counts in order: waiting for those does not wait for these -- and
+            // not earlier: before the solve the same 36 registers spill 117)
             if (PACKED) { fetch_zero(Xp, Ap); own_issue<VARIANT>(Xp, Ap, F, Ln, WB); }
 #endif
             // ---- emission
