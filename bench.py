@@ -339,9 +339,16 @@ def real_scene_leg(variant, res, spp, dev):
         for tr in scene.iter_traces(**dict(kw, **over)):
             del tr
     trace = timed(trace_only)
-    queues = scene.wavefront_queue_lengths() if scene.use_wavefront() else None
     trace_full = timed(lambda: trace_only(gradient_only=None))          # the full trace (what `render` and round 4 ran)
-    queues_full = scene.wavefront_queue_lengths() if scene.use_wavefront() else None
+    queues = queues_full = None
+    n_tile = min(res * res * spp, scene.WAVEFRONT_TILE_PATHS)          # paths per launch
+    if scene.use_wavefront(n_tile):
+        # the per-bounce queue lengths (device counters): with the three stages kept for every bounce -- the product hands the last
+        # few paths to one launch (EPSM_TRACE_NO_TAIL, include/epsm_trace.h) and then counts nothing behind that point
+        scene.wavefront_tail = False
+        trace_only(); torch.cuda.synchronize(); queues = scene.wavefront_queue_lengths()
+        trace_only(gradient_only=None); torch.cuda.synchronize(); queues_full = scene.wavefront_queue_lengths()
+        scene.wavefront_tail = True
     tiles = list(scene.iter_traces(**kw))
 
     def backward_only():
@@ -351,7 +358,7 @@ def real_scene_leg(variant, res, spp, dev):
     del tiles
     n = res * res * spp
     return {"scene": f"exp/clutter.py: floor + 100 tessellated spheres + area light = {scene.T} triangles", "variant": variant,
-            "paths": n, "max_depth": clutter.max_depth, "tracer": "wavefront" if scene.use_wavefront() else "one launch",
+            "paths": n, "max_depth": clutter.max_depth, "tracer": "wavefront" if scene.use_wavefront(n_tile) else "one launch",
             "grad_image_ms": total, "trace_and_log_ms": trace, "backward_ms": back, "paths_per_s": n / (total * 1e-3),
             "full_trace_and_log_ms": trace_full,
             "paths_alive_into_bounce": {"gradient_only": queues["alive"][1:clutter.max_depth] if queues else None,

@@ -6,6 +6,7 @@
 #include "epsm_trace_core.h"
 #include "epsm_trace_wavefront.h"
 #include "epsm_trace_quad.h"
+#include "epsm_trace_packet.h"
 
 using namespace epsm;
 using epsm_host::fail;
@@ -21,15 +22,35 @@ __global__ __launch_bounds__(128, 4) void epsm_trace_kernel(TraceArgs A) {
     __shared__ uint32_t s_stack[kLds * 128];
     uint32_t deep[kBvhStack - kLds];
     const int64_t i = (int64_t) blockIdx.x * 128 + threadIdx.x;
-    if (i >= A.N) return;
     BvhStack st{s_stack + threadIdx.x, 128};
     st.cap = kLds; st.ovf = deep; st.ovf_stride = 1;
+#ifdef EPSM_MEGA_NO_PACKET
+    if (i >= A.N) return;
     trace_one_path(A, i, st);
+#else
+    // trace_one_path with the PRIMARY rays walked by the wave (epsm_trace_packet.h: the lanes of a wave are the samples of one
+    // pixel or of a few neighbours); the packet's LDS column is entry 0 of the wave's own per-lane stacks, not yet in use
+    const bool has = i < A.N;
+    if (__ballot(has) == 0ull) return;
+    PathState s = path_begin(A, has ? i : A.N - 1, has);
+    const TriHit th0 = packet_intersect<false>(A.S, s.ray, has, s_stack + (threadIdx.x & ~63));
+    if (!has) return;
+    InlineVis vis{st};
+    const int max_depth = path_max_depth(A);
+    for (int iteration = 0; iteration < max_depth; ++iteration) {
+        TriHit th; th.hit = false; th.tri = 0; th.t = kInf; th.u = th.v = 0.f;
+        if (iteration == 0) th = th0;
+        else if (s.active) th = intersect<false>(A.S, s.ray, st);
+        path_bounce(A, i, iteration, s, th, vis);
+    }
+    path_end(A, i, s);
+#endif
 }
 
 // ---- the wavefront form (epsm_trace_wavefront.h): queues of live paths, three small kernels per bounce ----
 constexpr int kWfThreads = 128;                         // traversal kernels
 constexpr int kWfMaxBlocks = 16384;
+constexpr int kWfMaxChunkBlocks = 8192;                 // compaction: workgroups of 256, each takes chunks in turn
 
 __device__ __forceinline__ int64_t wf_count(const TraceArgs &A, const WfState &W, int b) {
     return b == 0 ? A.N : (int64_t) W.counters[b];
@@ -48,8 +69,65 @@ template <bool FIRST>
 __global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_kernel(TraceArgs A, WfState W, int b) {
     __shared__ uint32_t s_stack[kWfStackLds * kWfThreads];
     const int64_t count = wf_count(A, W, b);
+    if (!FIRST && wf_in_tail(A, b, count)) return;
     for (int64_t q = (int64_t) blockIdx.x * kWfThreads + threadIdx.x; q < count; q += (int64_t) gridDim.x * kWfThreads)
         wf_extend(A, W, FIRST ? q : (int64_t) W.queue[b & 1][q], s_stack + threadIdx.x, kWfThreads, FIRST ? 0 : 1);
+}
+// The closest-hit stage with the WAVE as the unit (epsm_trace_packet.h).  FIRST: the primary rays -- a wave is the samples of one
+// pixel or of a few neighbours.
+template <bool FIRST>
+__global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_packet_kernel(TraceArgs A, WfState W, int b) {
+    __shared__ uint32_t s_stack[kPacketStack * (kWfThreads / 64)];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t count = wf_count(A, W, b);
+    if (!FIRST && wf_in_tail(A, b, count)) return;
+    for (int64_t q0 = (int64_t) blockIdx.x * kWfThreads + wv * 64; q0 < count; q0 += (int64_t) gridDim.x * kWfThreads) {     // wave-uniform
+        const int64_t q = q0 + lane;
+        const bool has = q < count;
+        const int64_t i = FIRST ? (has ? q : q0) : (int64_t) W.queue[b & 1][has ? q : q0];
+        Ray r;
+        if (FIRST) {
+            r = path_begin(A, i, false).ray;
+        } else {
+            const W4 o = W.ray_o[i], d = W.ray_d[i];
+            r.o = xyz(o); r.maxt = u2f(o.w); r.d = xyz(d);
+        }
+        const TriHit th = packet_intersect<false>(A.S, r, has, s_stack + wv * kPacketStack);
+        if (has) {
+            W4 h; h.x = th.hit ? th.tri : kNoIndex; h.y = f2u(th.t); h.z = f2u(th.u); h.w = f2u(th.v);
+            W.hit[i] = h;
+        }
+    }
+}
+// The visibility rays the same way (A/B build).
+__global__ __launch_bounds__(kWfThreads) void epsm_wf_shadow_packet_kernel(TraceArgs A, WfState W, int b) {
+    __shared__ uint32_t s_stack[kPacketStack * (kWfThreads / 64)];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t count = (int64_t) W.counters[8 + b];
+    for (int64_t q0 = (int64_t) blockIdx.x * kWfThreads + wv * 64; q0 < count; q0 += (int64_t) gridDim.x * kWfThreads) {     // wave-uniform
+        const int64_t q = q0 + lane;
+        const bool has = q < count;
+        const int64_t i = (int64_t) W.shadow_queue[has ? q : q0];
+        const W4 o = W.sh_o[i], d = W.sh_d[i];
+        Ray sr; sr.o = xyz(o); sr.maxt = u2f(o.w); sr.d = xyz(d);
+        const TriHit th = packet_intersect<true>(A.S, sr, has, s_stack + wv * kPacketStack);
+        const bool owed = has && wf_shadow_resolve(A, W, i, b, th.hit);
+        if (__ballot(owed) != 0ull) {                                    // (integrators with max_depth <= 3: the occluder record)
+            F3 sip = zero3<float>(), esp = sip;
+            Ray r2; r2.o = r2.d = sip; r2.maxt = 0.f;
+            if (owed) r2 = wf_occluder_ray(A, W, i, sip, esp);
+            const TriHit oh = packet_intersect<false>(A.S, r2, owed, s_stack + wv * kPacketStack);
+            if (owed) write_occluder(A.S, A.rec[0].shadow + 4 * i, r2, oh, sip, esp);
+        }
+    }
+}
+// The rest of the loop of the paths alive into bounce b, once they are few (wf_tail, epsm_trace_wavefront.h).
+__global__ __launch_bounds__(kWfThreads) void epsm_wf_tail_kernel(TraceArgs A, WfState W, int b) {
+    __shared__ uint32_t s_stack[kWfStackLds * kWfThreads];
+    const int64_t count = wf_count(A, W, b);
+    if (!wf_in_tail(A, b, count)) return;
+    for (int64_t q = (int64_t) blockIdx.x * kWfThreads + threadIdx.x; q < count; q += (int64_t) gridDim.x * kWfThreads)
+        wf_tail(A, W, (int64_t) W.queue[b & 1][q], b, s_stack + threadIdx.x, kWfThreads);
 }
 // (160 registers, 3 waves per SIMD; capped at 128 for 4 waves it spills 96 B/lane and is no faster.)
 // One 256-slot chunk of the queue per workgroup.  Appending the survivors to the next queue with one atomic per
@@ -58,7 +136,9 @@ __global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_kernel(TraceArgs A,
 // side); it leaves a flag per slot and two counts per chunk instead.
 __global__ __launch_bounds__(kWfChunk) void epsm_wf_shade_kernel(TraceArgs A, WfState W, int b) {
     const int64_t count = wf_count(A, W, b), q = (int64_t) blockIdx.x * kWfChunk + threadIdx.x;
-    if ((int64_t) blockIdx.x * kWfChunk >= count) return;           // workgroup-uniform
+    if ((int64_t) blockIdx.x * kWfChunk >= count || wf_in_tail(A, b, count)) return;           // workgroup-uniform
+    // (Tried: a capped grid whose workgroups take chunks in turn, as the compaction does -- the launch of a bounce nobody reaches
+    // 15 -> 5 us, but the stage itself 1.08 -> 1.19 ms at 2^24 paths: the hardware's dispatch order balances better.)
     bool alive = false, shadow = false;
     if (q < count) {
         wf_shade(A, W, b == 0 ? q : (int64_t) W.queue[b & 1][q], b, alive, shadow);
@@ -68,45 +148,63 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_shade_kernel(TraceArgs A, Wf
     const unsigned long long ma = __ballot(alive), ms = __ballot(shadow);
     if ((threadIdx.x & 63) == 0) { s_n[0][threadIdx.x >> 6] = (uint32_t) __popcll(ma); s_n[1][threadIdx.x >> 6] = (uint32_t) __popcll(ms); }
     __syncthreads();
-    if (threadIdx.x < 2)
-        W.chunk_counts[threadIdx.x * W.chunks + blockIdx.x] = s_n[threadIdx.x][0] + s_n[threadIdx.x][1] + s_n[threadIdx.x][2] + s_n[threadIdx.x][3];
+    if (threadIdx.x < 2) {
+        const uint32_t n = s_n[threadIdx.x][0] + s_n[threadIdx.x][1] + s_n[threadIdx.x][2] + s_n[threadIdx.x][3];
+        W.chunk_counts[threadIdx.x * W.chunks + blockIdx.x] = n;
+        if (n) atomicAdd(&W.group_counts[threadIdx.x * W.groups + blockIdx.x / kWfGroup], n);     // (64 adds per address at most)
+    }
 }
-// Exclusive scan of the chunk counts of both queues (<= 65 536 chunks each at 2^24 paths), one workgroup PER QUEUE:
-// thread t sums a strip, the strips' sums are scanned over the workgroup, the strip is rewritten as offsets.  Also
-// publishes the queue length of the next stage.  A strip is read in batches of 16 independent loads (as a loop of
-// dependent-looking loads the 64-element strips of a 2^24-path tile took 209 us per bounce, four bounces per tile).
+// Exclusive scan of the chunk counts of both queues (<= 65 536 chunks each at 2^24 paths), one workgroup PER QUEUE, two
+// levels: the counts of the GROUPS of 64 chunks (summed by the shade stage) are scanned over the workgroup -- one coalesced
+// load per thread at 2^24 paths --, then every wave takes groups in turn: one count per lane, a wave scan, the group's offset
+// added.  Publishes the queue length of the next stage and leaves the group counts zeroed for the next bounce.
+// (One level -- thread t sums a strip of 64 counts, the strips' sums are scanned, the strip is rewritten -- took 100 us for
+// the first bounce of a 2^24-path tile: two passes of strided, dependent loads by two workgroups.)
 __global__ __launch_bounds__(1024) void epsm_wf_scan_kernel(TraceArgs A, WfState W, int b) {
-    const int64_t count = wf_count(A, W, b), n = (count + kWfChunk - 1) / kWfChunk;
-    const int64_t strip = (n + 1023) / 1024, lo = (int64_t) threadIdx.x * strip, hi = lo + strip < n ? lo + strip : n;
+    const int64_t count = wf_count(A, W, b), n = (count + kWfChunk - 1) / kWfChunk, groups = (n + kWfGroup - 1) / kWfGroup;
+    if (wf_in_tail(A, b, count)) return;                          // (the counters of the later bounces stay 0: their stages leave at once)
     __shared__ uint32_t s_w[16];
-    const int which = blockIdx.x;
-    uint32_t *c = W.chunk_counts + which * W.chunks;
-    constexpr int kBatch = 16;
-    uint32_t sum = 0;
-    for (int64_t k0 = lo; k0 < hi; k0 += kBatch) {
-        uint32_t v[kBatch];
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) v[j] = k0 + j < hi ? c[k0 + j] : 0u;
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) sum += v[j];
-    }
-    uint32_t inc = sum;                                           // inclusive scan over the wave, then over the 16 waves
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t) __shfl_up((int) inc, off); if ((int) (threadIdx.x & 63) >= off) inc += t; }
-    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+    __shared__ uint32_t s_carry;
+    const int which = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *c = W.chunk_counts + which * W.chunks, *gc = W.group_counts + which * W.groups, *go = W.group_offsets + which * W.groups;
+    if (threadIdx.x == 0) s_carry = 0u;
     __syncthreads();
-    uint32_t before = 0, all = 0;
+    for (int64_t base = 0; base < groups; base += 1024) {         // (one turn up to 2^24 paths)
+        const int64_t g = base + threadIdx.x;
+        const uint32_t v = g < groups ? gc[g] : 0u;
+        if (g < groups) gc[g] = 0u;
+        uint32_t inc = v;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) { const uint32_t v = s_w[w]; if (w < (int) (threadIdx.x >> 6)) before += v; all += v; }
-    uint32_t run = before + inc - sum;
-    for (int64_t k0 = lo; k0 < hi; k0 += kBatch) {
-        uint32_t v[kBatch];
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t) __shfl_up((int) inc, off); if (lane >= off) inc += t; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        uint32_t before = s_carry, all = 0;
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) v[j] = k0 + j < hi ? c[k0 + j] : 0u;
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) { if (k0 + j < hi) c[k0 + j] = run; run += v[j]; }
+        for (int w = 0; w < 16; ++w) { const uint32_t t = s_w[w]; if (w < wv) before += t; all += t; }
+        if (g < groups) go[g] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += all;
+        __syncthreads();
     }
-    if (threadIdx.x == 0) W.counters[which == 0 ? b + 1 : 8 + b] = all;
+    if (threadIdx.x == 0) W.counters[which == 0 ? b + 1 : 8 + b] = s_carry;
+    constexpr int kBatch = 4;                                     // groups a wave has in flight
+    for (int64_t g0 = (int64_t) wv * kBatch; g0 < groups; g0 += 16 * kBatch) {
+        uint32_t v[kBatch], o[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int64_t k = (g0 + j) * kWfGroup + lane;
+            v[j] = (g0 + j < groups && k < n) ? c[k] : 0u;
+            o[j] = g0 + j < groups ? go[g0 + j] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            uint32_t inc = v[j];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t) __shfl_up((int) inc, off); if (lane >= off) inc += t; }
+            const int64_t k = (g0 + j) * kWfGroup + lane;
+            if (g0 + j < groups && k < n) c[k] = o[j] + inc - v[j];
+        }
+    }
 }
 // Writes the queue of bounce b + 1 and the shadow queue of bounce b, in path order (stable).
 // (Tried: grouping the survivors of a chunk by the octant of their new direction, 8-bucket counting sort in LDS --
@@ -117,8 +215,10 @@ __global__ __launch_bounds__(1024) void epsm_wf_scan_kernel(TraceArgs A, WfState
 // rays that leave one triangle (or one BVH leaf: ids are leaf-ordered) start together.  Different from the octant sort above:
 // the chunk, and with it the pixel neighbourhood, is kept.
 __global__ __launch_bounds__(kWfChunk) void epsm_wf_compact_kernel(TraceArgs A, WfState W, int b) {
-    const int64_t count = wf_count(A, W, b), q = (int64_t) blockIdx.x * kWfChunk + threadIdx.x;
-    if ((int64_t) blockIdx.x * kWfChunk >= count) return;           // workgroup-uniform
+    const int64_t count = wf_count(A, W, b);
+    if (wf_in_tail(A, b, count)) return;
+    for (int64_t chunk = blockIdx.x; chunk * kWfChunk < count; chunk += gridDim.x) {              // workgroup-uniform
+    const int64_t q = chunk * kWfChunk + threadIdx.x;
     const uint8_t f = q < count ? W.flags[q] : (uint8_t) 0;
     const uint32_t i = q < count ? (b == 0 ? (uint32_t) q : W.queue[b & 1][q]) : 0u;
 #ifdef EPSM_WF_REKEY
@@ -144,7 +244,7 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_compact_kernel(TraceArgs A, 
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         if (!((f >> which) & 1)) continue;
-        const uint32_t off = W.chunk_counts[which * W.chunks + blockIdx.x] + s_hist[which][key] + rank[which];
+        const uint32_t off = W.chunk_counts[which * W.chunks + chunk] + s_hist[which][key] + rank[which];
         (which == 0 ? W.queue[(b + 1) & 1] : W.shadow_queue)[off] = i;
     }
 #else
@@ -156,18 +256,21 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_compact_kernel(TraceArgs A, 
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         if (!((f >> which) & 1)) continue;
-        uint32_t off = W.chunk_counts[which * W.chunks + blockIdx.x];
+        uint32_t off = W.chunk_counts[which * W.chunks + chunk];
         for (int w = 0; w < wv; ++w) off += s_n[which][w];
         off += (uint32_t) __popcll(m[which] & ((1ull << lane) - 1ull));
         (which == 0 ? W.queue[(b + 1) & 1] : W.shadow_queue)[off] = i;
     }
 #endif
+    __syncthreads();
+    }
 }
 // EPSM_WF_QUAD (A/B build, round 5): the closest-hit stage of the bounces >= 1 with FOUR LANES PER RAY (epsm_trace_quad.h): a
 // workgroup of 128 lanes takes 32 rays at a time.
 __global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_quad_kernel(TraceArgs A, WfState W, int b) {
     __shared__ uint32_t s_stack[kQuadStack * (kWfThreads / 4)];
     const int64_t count = wf_count(A, W, b);
+    if (wf_in_tail(A, b, count)) return;
     const int lane = threadIdx.x & 63, quad = threadIdx.x >> 2;
     for (int64_t q0 = (int64_t) blockIdx.x * (kWfThreads / 4); q0 < count; q0 += (int64_t) gridDim.x * (kWfThreads / 4)) {
         const int64_t q = q0 + quad;
@@ -374,7 +477,7 @@ static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene
                                    !scene->meshes || !scene->bsdfs || !scene->bvh || !scene->prim_index || !scene->tri_verts))
         return bad("NULL scene array");
     if (const char *why = epsm_host::scene_tables_invalid(scene)) return bad(why);
-    if (flags & ~(uint32_t) (EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG | EPSM_TRACE_GRADIENT_ONLY | EPSM_TRACE_GRADIENT_CAUSTIC))
+    if (flags & ~(uint32_t) (EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG | EPSM_TRACE_GRADIENT_ONLY | EPSM_TRACE_GRADIENT_CAUSTIC | EPSM_TRACE_NO_TAIL))
         return bad("unknown flag");
     if ((flags & EPSM_TRACE_GRADIENT_CAUSTIC) && !(flags & EPSM_TRACE_GRADIENT_ONLY)) return bad("EPSM_TRACE_GRADIENT_CAUSTIC modifies EPSM_TRACE_GRADIENT_ONLY");
     if ((flags & EPSM_TRACE_GRADIENT_ONLY) && K_log < 1) return bad("EPSM_TRACE_GRADIENT_ONLY needs a vertex log (K_log >= 1)");
@@ -457,24 +560,40 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
     if (N > 0xFFFFFFF0LL) return fail(EPSM_EINVAL, "epsm_trace_paths_wavefront: N must fit the 32-bit queues");
     hipStream_t s = (hipStream_t) stream;
     const WfState W = wf_carve(workspace, N);
-    hipError_t e = hipMemsetAsync(W.counters, 0, kWfCounters * sizeof(uint32_t), s);
+    hipError_t e = hipMemsetAsync(W.counters, 0, wf_zeroed_bytes(N), s);          // the counters and the group counts behind them
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_trace_paths_wavefront", e);
     auto blocks = [&](int threads) { const int64_t b = (N + threads - 1) / threads; return dim3((unsigned) (b < kWfMaxBlocks ? b : kWfMaxBlocks)); };
     const int depth = path_max_depth(A);
-    const dim3 chunks((unsigned) W.chunks);
+    const dim3 chunks((unsigned) W.chunks), chunk_blocks((unsigned) (W.chunks < kWfMaxChunkBlocks ? W.chunks : kWfMaxChunkBlocks));
+    const int64_t tail_most = N < kWfTailBelow ? N : kWfTailBelow;
+    const dim3 tail_blocks((unsigned) ((tail_most + kWfThreads - 1) / kWfThreads));
     for (int b = 0; b < depth; ++b) {
         // the queue lengths of bounce b live on the device: every stage is launched for the worst case and its
         // surplus workgroups leave at once (no host round trip between the bounces)
-        if (b == 0) hipLaunchKernelGGL(epsm_wf_extend_kernel<true>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
-#ifdef EPSM_WF_QUAD
+        // (bounces >= 1: the tail first -- it runs once, when the queue has become short, and the stages behind it leave at once)
+        if (b >= 1 && !(A.flags & EPSM_TRACE_NO_TAIL)) hipLaunchKernelGGL(epsm_wf_tail_kernel, tail_blocks, dim3(kWfThreads), 0, s, A, W, b);
+        if (b == 0) {
+#ifdef EPSM_WF_NO_PACKET
+            hipLaunchKernelGGL(epsm_wf_extend_kernel<true>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
+#else
+            hipLaunchKernelGGL(epsm_wf_extend_packet_kernel<true>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
+#endif
+        }
+#if defined(EPSM_WF_QUAD)
         else hipLaunchKernelGGL(epsm_wf_extend_quad_kernel, blocks(kWfThreads / 4), dim3(kWfThreads), 0, s, A, W, b);
+#elif defined(EPSM_WF_PACKET_BOUNCE)
+        else hipLaunchKernelGGL(epsm_wf_extend_packet_kernel<false>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
 #else
         else hipLaunchKernelGGL(epsm_wf_extend_kernel<false>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
 #endif
         hipLaunchKernelGGL(epsm_wf_shade_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_scan_kernel, dim3(2), dim3(1024), 0, s, A, W, b);
-        hipLaunchKernelGGL(epsm_wf_compact_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
+        hipLaunchKernelGGL(epsm_wf_compact_kernel, chunk_blocks, dim3(kWfChunk), 0, s, A, W, b);
+#ifdef EPSM_WF_PACKET_SHADOW
+        hipLaunchKernelGGL(epsm_wf_shadow_packet_kernel, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
+#else
         hipLaunchKernelGGL(epsm_wf_shadow_kernel, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
+#endif
     }
     // (radiance / valid not asked for and the native log: nothing is left to write -- the gradient-only trace of render_backward)
     if (A.radiance || A.valid || !(A.flags & EPSM_TRACE_PACKED_LOG))

@@ -56,10 +56,14 @@ struct WfState {                              // device pointers into the worksp
     // scan turns the counts into offsets, a compaction pass writes the two queues -- in path order
     uint8_t *flags;           // per slot of the current queue: kWfAlive | kWfShadow
     uint32_t *chunk_counts;   // (2, chunks): alive, shadow per chunk; exclusive offsets after the scan
+    uint32_t *group_counts;   // (2, groups): the same per GROUP of kWfGroup chunks (summed by the shade stage; the scan zeroes them again)
+    uint32_t *group_offsets;  // (2, groups): exclusive offsets of the groups (scan, first level)
     int64_t chunks;           // ceil(N / kWfChunk)
+    int64_t groups;           // ceil(chunks / kWfGroup)
     int64_t N;
 };
 constexpr int kWfChunk = 256;
+constexpr int kWfGroup = 64;                  // chunks per group: one wave scans a group
 constexpr uint8_t kWfAlive = 1, kWfShadow = 2;
 constexpr int kWfStackLds = 16, kWfStackOvf = kBvhStack - kWfStackLds;
 // path i's traversal stack: `lds` = its LDS column (entry k at lds[k * stride])
@@ -70,14 +74,23 @@ EPSM_HD BvhStack wf_stack(const WfState &W, int64_t i, uint32_t *lds, int stride
 }
 EPSM_HD size_t wf_align(size_t x) { return (x + 255) & ~(size_t) 255; }
 EPSM_HD size_t wf_workspace_bytes(int64_t N) {
-    const size_t chunks = (size_t) ((N + kWfChunk - 1) / kWfChunk);
-    return wf_align(kWfCounters * 4) + (size_t) kWfArrays * wf_align((size_t) N * 16) + 3 * wf_align((size_t) N * 4) +
+    const size_t chunks = (size_t) ((N + kWfChunk - 1) / kWfChunk), groups = (chunks + kWfGroup - 1) / kWfGroup;
+    return wf_align(kWfCounters * 4) + 2 * wf_align(groups * 8) + (size_t) kWfArrays * wf_align((size_t) N * 16) + 3 * wf_align((size_t) N * 4) +
            wf_align((size_t) N * 4 * kWfStackOvf) + wf_align((size_t) N) + wf_align(chunks * 8);
+}
+// what a trace zeroes before its first stage: the counters and, behind them, the group counts
+EPSM_HD size_t wf_zeroed_bytes(int64_t N) {
+    const size_t chunks = (size_t) ((N + kWfChunk - 1) / kWfChunk), groups = (chunks + kWfGroup - 1) / kWfGroup;
+    return wf_align(kWfCounters * 4) + wf_align(groups * 8);
 }
 EPSM_HD WfState wf_carve(void *workspace, int64_t N) {
     char *p = (char *) workspace;
     WfState W;
     W.counters = (uint32_t *) p; p += wf_align(kWfCounters * 4);
+    W.chunks = (N + kWfChunk - 1) / kWfChunk;
+    W.groups = (W.chunks + kWfGroup - 1) / kWfGroup;
+    W.group_counts = (uint32_t *) p; p += wf_align((size_t) W.groups * 8);
+    W.group_offsets = (uint32_t *) p; p += wf_align((size_t) W.groups * 8);
     W4 **arr[kWfArrays] = {&W.ray_o, &W.ray_d, &W.hit, &W.beta, &W.L, &W.prev_p, &W.rng, &W.sh_o, &W.sh_d, &W.sh_L};
     for (int a = 0; a < kWfArrays; ++a) { *arr[a] = (W4 *) p; p += wf_align((size_t) N * 16); }
     W.queue[0] = (uint32_t *) p; p += wf_align((size_t) N * 4);
@@ -86,7 +99,6 @@ EPSM_HD WfState wf_carve(void *workspace, int64_t N) {
     W.stack_ovf = (uint32_t *) p; p += wf_align((size_t) N * 4 * kWfStackOvf);
     W.flags = (uint8_t *) p; p += wf_align((size_t) N);
     W.chunk_counts = (uint32_t *) p;
-    W.chunks = (N + kWfChunk - 1) / kWfChunk;
     W.N = N;
     return W;
 }
@@ -205,39 +217,44 @@ EPSM_HD F3 wf_logged_light0(const TraceArgs &A, int64_t i) {
     }
     return ld3(A.rec[0].light + 3 * i);
 }
+// the visibility ray's answer applied; true when the occluder record is owed as well
+EPSM_HD bool wf_shadow_resolve(const TraceArgs &A, const WfState &W, int64_t i, int iteration, bool occluded) {
+    if (occluded) {
+        if (iteration < A.K_log) {                                       // Lr_dir = 0: the logged weight with it
+            if (A.flags & EPSM_TRACE_PACKED_LOG) A.rec[0].packed[(i * A.K_log + iteration) * 32 + 27] = 0.f;
+            else A.rec[iteration].emit[4 * i + 3] = 0u;
+        }
+    } else if (A.radiance) {
+        const W4 l = W.L[i];
+        const F3 L = xyz(l) + xyz(W.sh_L[i]);                            // (L + Le) + Lr_dir, epsm.py:658
+        W.L[i] = pack4u(L, l.w);
+    }
+    return (W.sh_d[i].w & kWfOccluder) != 0;
+}
+// iteration 0, max_depth <= 3, K_log > 0: si.p is the path's prev_p by now, ds.p was logged as the vertex's
+// light point; ds.d as in sample_emitter_direction, the origin of spawn_ray(si, ds.d) is that of the visibility ray
+EPSM_HD Ray wf_occluder_ray(const TraceArgs &A, const WfState &W, int64_t i, F3 &sip, F3 &esp) {
+    sip = xyz(W.prev_p[i]); esp = wf_logged_light0(A, i);
+    const F3 dd = esp - sip;
+    const float dist = sqrtf(dot(dd, dd));
+    Ray r2; r2.o = xyz(W.sh_o[i]); r2.d = dd * (1.f / dist); r2.maxt = kInf;
+    return r2;
+}
 EPSM_HD bool wf_shadow_round(const TraceArgs &A, const WfState &W, int iteration, WfJob &J, uint32_t *lds, int stride) {
     const BvhStack st = wf_stack(W, J.i, lds, stride);
     const int64_t i = J.i;
+    F3 sip, esp;
     if (J.phase == 0) {
         if (!trav_done(J.T)) trav_round<true>(J.T, A.S, st);
         if (!trav_done(J.T)) return false;
-        if (J.T.best.hit) {                                              // occluded
-            if (iteration < A.K_log) {                                       // Lr_dir = 0: the logged weight with it
-                if (A.flags & EPSM_TRACE_PACKED_LOG) A.rec[0].packed[(i * A.K_log + iteration) * 32 + 27] = 0.f;
-                else A.rec[iteration].emit[4 * i + 3] = 0u;
-            }
-        } else if (A.radiance) {
-            const W4 l = W.L[i];
-            const F3 L = xyz(l) + xyz(W.sh_L[i]);                        // (L + Le) + Lr_dir, epsm.py:658
-            W.L[i] = pack4u(L, l.w);
-        }
-        if (!(W.sh_d[i].w & kWfOccluder)) return true;
-        // iteration 0, max_depth <= 3, K_log > 0: si.p is the path's prev_p by now, ds.p was logged as the vertex's
-        // light point; ds.d as in sample_emitter_direction, the origin of spawn_ray(si, ds.d) is that of the visibility ray
-        const F3 sip = xyz(W.prev_p[i]), esp = wf_logged_light0(A, i);
-        const F3 dd = esp - sip;
-        const float dist = sqrtf(dot(dd, dd));
-        Ray r2; r2.o = xyz(W.sh_o[i]); r2.d = dd * (1.f / dist); r2.maxt = kInf;
+        if (!wf_shadow_resolve(A, W, i, iteration, J.T.best.hit)) return true;
         J.phase = 1;
-        trav_begin(J.T, A.S, r2);
+        trav_begin(J.T, A.S, wf_occluder_ray(A, W, i, sip, esp));
         return false;
     }
     if (!trav_done(J.T)) trav_round<false>(J.T, A.S, st);
     if (!trav_done(J.T)) return false;
-    const F3 sip = xyz(W.prev_p[i]), esp = wf_logged_light0(A, i);
-    const F3 dd = esp - sip;
-    const float dist = sqrtf(dot(dd, dd));
-    Ray r2; r2.o = xyz(W.sh_o[i]); r2.d = dd * (1.f / dist); r2.maxt = kInf;
+    const Ray r2 = wf_occluder_ray(A, W, i, sip, esp);
     write_occluder(A.S, A.rec[0].shadow + 4 * i, r2, trav_result(J.T, A.S), sip, esp);
     return true;
 }
@@ -245,6 +262,32 @@ EPSM_HD void wf_shadow(const TraceArgs &A, const WfState &W, int64_t i, int iter
     WfJob J;
     wf_shadow_begin(A, W, i, J);
     while (!wf_shadow_round(A, W, iteration, J, lds, stride)) {}
+}
+
+// ---- the tail.  A stage's time has a floor of one traversal's dependent misses (~0.1 ms: every launch starts with cold
+//      caches), so the bounces a few thousand paths reach cost five floors each.  Once the queue into bounce b is shorter than
+//      kWfTailBelow, ONE launch carries those paths through the rest of their loop, every visibility ray answered on the spot --
+//      the same path_bounce, so the same results per path.  The stages of the bounces >= b find wf_in_tail() and leave.
+#ifndef EPSM_WF_TAIL_BELOW
+#define EPSM_WF_TAIL_BELOW (1 << 19)
+#endif
+constexpr int64_t kWfTailBelow = EPSM_WF_TAIL_BELOW;
+EPSM_HD bool wf_in_tail(const TraceArgs &A, int b, int64_t count) {
+    return b >= 1 && !(A.flags & EPSM_TRACE_NO_TAIL) && count < kWfTailBelow;
+}
+EPSM_HD void wf_tail(const TraceArgs &A, const WfState &W, int64_t i, int b, uint32_t *lds, int stride) {
+    PathState s = wf_load(W, i);
+    const BvhStack st = wf_stack(W, i, lds, stride);
+    InlineVis vis{st};
+    const int max_depth = path_max_depth(A);
+    int iteration = b;
+    for (; iteration < max_depth && s.active; ++iteration) {
+        const TriHit th = intersect<false>(A.S, s.ray, st);
+        path_bounce(A, i, iteration, s, th, vis);
+    }
+    // as the shade stage leaves a path that ends: what finish reads
+    if (A.radiance || A.valid || !(A.flags & EPSM_TRACE_PACKED_LOG))
+        W.L[i] = pack4u(s.L, (uint32_t) s.depth | ((uint32_t) iteration << 16));
 }
 
 // A bounce the path never reached: what path_bounce logs for a masked lane (epsm.py:551: inactive zeros).

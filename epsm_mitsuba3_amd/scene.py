@@ -47,6 +47,7 @@ EPSM_TRACE_SPARSE_LOG = 0x1          # include/epsm_trace.h
 EPSM_TRACE_PACKED_LOG = 0x2
 EPSM_TRACE_GRADIENT_ONLY = 0x4
 EPSM_TRACE_GRADIENT_CAUSTIC = 0x8
+EPSM_TRACE_NO_TAIL = 0x10
 
 
 class EpsmMesh(C.Structure):
@@ -1105,9 +1106,17 @@ class Scene:
     # workspace per path: 14.7 GB at 2^24, of 288).
     WAVEFRONT_TILE_PATHS = 1 << 24
 
-    def use_wavefront(self) -> bool:
+    # ... and from WAVEFRONT_MIN_PATHS paths per launch on: below, a stage is as long as its slowest traversal whatever the queue
+    # holds, and the one launch of the other form wins (128 k triangles, gradient-only trace: 0.45 / 0.68 ms at 2^19 paths, the
+    # reference's own backward size; 0.62 / 0.80 at 2^20; 1.22 / 1.02 at 2^21 -- MEASUREMENTS.md 10.10)
+    WAVEFRONT_MIN_PATHS = (1 << 20) + 1
+
+    def use_wavefront(self, n_paths=None) -> bool:
+        """The tracer form of a launch over ``n_paths`` paths (None: of a large one -- what sizes the tiles)."""
         if self.tracer not in ("auto", "mega", "wavefront"):
             raise ValueError("Scene.tracer must be 'auto', 'mega' or 'wavefront'")
+        if self.tracer == "auto" and n_paths is not None and n_paths < self.WAVEFRONT_MIN_PATHS:
+            return False
         return self.tracer == "wavefront" or (self.tracer == "auto" and self.T >= self.WAVEFRONT_MIN_TRIANGLES)
 
     def trace_color(self, sensor_index: int, seed: int, spp: int, max_depth: int, lo: int, hi: int):
@@ -1177,9 +1186,17 @@ class Scene:
             raise ValueError(f"gradient_only: 'manifold', 'manifold_caustic' or None, got {gradient_only!r}")
         return EPSM_TRACE_GRADIENT_ONLY | (EPSM_TRACE_GRADIENT_CAUSTIC if gradient_only == "manifold_caustic" else 0)
 
+    # The wavefront tracer hands the last few paths to ONE launch for the rest of their loop (include/epsm_trace.h,
+    # EPSM_TRACE_NO_TAIL); False keeps the stages for every bounce (reports of the per-bounce queue lengths).
+    wavefront_tail = True
+
+    def _tail_flag(self) -> int:
+        return 0 if self.wavefront_tail else EPSM_TRACE_NO_TAIL
+
     def wavefront_queue_lengths(self):
         """Paths alive into bounce 0..5 and visibility rays of bounce 0..5 of the LAST wavefront trace on the current stream
-        (the counters the stages keep on the device; a host read, for reports)."""
+        (the counters the stages keep on the device; a host read, for reports).  Complete only with ``wavefront_tail = False``:
+        the counters of the bounces the tail launch carried stay 0."""
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
         ws = self._wf_workspace.get(stream)
         if ws is None:
@@ -1218,8 +1235,9 @@ class Scene:
                 C.c_void_p(film_pos.data_ptr()) if want_image else None, C.c_void_p(radiance.data_ptr()) if want_image else None,
                 C.c_void_p(valid.data_ptr()) if want_image else None,
                 C.c_void_p(C.addressof(recs)),
-                C.c_uint32(EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG | self._gradient_only_flags(gradient_only))]
-        if self.use_wavefront() and n > 0:
+                C.c_uint32(EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG | self._gradient_only_flags(gradient_only) |
+                           (self._tail_flag() if self.use_wavefront(n) else 0))]
+        if self.use_wavefront(n) and n > 0:
             need = int(lib.epsm_trace_workspace_bytes(C.c_int64(n)))
             ws = self._wf_workspace.get(stream)
             if ws is None or ws.numel() < need:
@@ -1286,8 +1304,9 @@ class Scene:
                 C.c_void_p(ray[2].data_ptr()), C.c_void_p(ray[3].data_ptr()),
                 C.c_void_p(film_pos.data_ptr()), C.c_void_p(radiance.data_ptr()), C.c_void_p(valid.data_ptr()),
                 C.c_void_p(C.addressof(recs)),
-                C.c_uint32((EPSM_TRACE_SPARSE_LOG if sparse_log else 0) | (self._gradient_only_flags(gradient_only) if K >= 1 else 0))]
-        if self.use_wavefront() and n > 0:
+                C.c_uint32((EPSM_TRACE_SPARSE_LOG if sparse_log else 0) | (self._gradient_only_flags(gradient_only) if K >= 1 else 0) |
+                           (self._tail_flag() if self.use_wavefront(n) else 0))]
+        if self.use_wavefront(n) and n > 0:
             # queues of live paths, three small kernels per bounce (include/epsm_trace.h); the workspace is scratch
             # and is kept between calls
             need = int(lib.epsm_trace_workspace_bytes(C.c_int64(n)))
@@ -1356,7 +1375,10 @@ class Scene:
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
         if rank is None or world_size is None:
             rank, world_size = _dist.world()
-        tiles = _dist.tile_ranges(n_total, self.tile_paths)
+        tile = self.tile_paths
+        if self.use_wavefront():       # as iter_traces: launches as large as the sharding allows
+            tile = max(tile, min(self.WAVEFRONT_TILE_PATHS, -(-n_total // max(1, world_size))))
+        tiles = _dist.tile_ranges(n_total, tile)
         for t in _dist.my_tiles(len(tiles), rank, world_size):
             lo, hi = tiles[t]
             tr = self._trace(si, seed, spp, max_depth, 0, lo, hi)

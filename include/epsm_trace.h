@@ -77,6 +77,11 @@ enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
  * radiance = valid = film_pos = NULL (with the native log nothing is then written for them and the finishing pass is skipped).  bench.py's real_scene leg: trace + log 14.3 -> see DESIGN.md 5b. */
 #define EPSM_TRACE_GRADIENT_ONLY    0x4u
 #define EPSM_TRACE_GRADIENT_CAUSTIC 0x8u
+/* EPSM_TRACE_NO_TAIL (epsm_trace_paths_wavefront only; diagnostics): keep the three stages for EVERY bounce.  Without it the
+ * paths still alive into a bounce >= 1 are carried through the rest of their loop by ONE launch as soon as fewer than 2^19 of
+ * them are left (a stage cannot take less than one traversal's chain of cache misses, ~0.1 ms, however short its queue) --
+ * same arithmetic per path, same results; the queue-length counters of the bounces behind that point then stay 0. */
+#define EPSM_TRACE_NO_TAIL          0x10u
 
 typedef struct EpsmMesh {
     uint32_t tri_begin, tri_count;   /* this mesh's range in the triangle arrays */

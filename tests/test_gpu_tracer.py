@@ -83,17 +83,20 @@ def test_primal_render_and_backward_on_a_scene():
     assert float((img2 - img).abs().mean()) > 1e-4
 
 
+@pytest.mark.parametrize("tail", [True, False])
 @pytest.mark.parametrize("max_depth,K", [(5, 5), (3, 2)])
-def test_gpu_wavefront_tracer_equals_one_launch(max_depth, K):
+def test_gpu_wavefront_tracer_equals_one_launch(max_depth, K, tail):
     """epsm_trace_paths_wavefront (queues of live paths, extend / shade / shadow kernels per bounce, ballot +
     prefix-count compaction) against epsm_trace_paths on the GPU: the same per-path code in another visiting order.
     The host builds of the two forms agree bit for bit (tests/test_tracer_wavefront_host.py); on the device the
     compiler may contract a product into an fma in one kernel and not in the other, so a borderline decision
-    (hit / miss at a triangle's edge) may flip on a handful of paths."""
+    (hit / miss at a triangle's edge) may flip on a handful of paths.  ``tail``: with fewer than 2^19 paths alive the
+    bounces >= 1 are ONE launch (wf_tail, csrc/epsm_trace_wavefront.h); EPSM_TRACE_NO_TAIL keeps the three stages."""
     from test_tracer_wavefront_host import _rich_scene, _all_arrays
     dev = torch.device("cuda", 0)
     res, spp = 48, 16
     sc = _rich_scene(res, spp, point_light=True, occluder=max_depth <= 3, device=dev)
+    sc.wavefront_tail = tail
     n = res * res * spp
     sc.tracer = "mega"
     a = sc._trace(0, seed=5, spp=spp, max_depth=max_depth, K=K, lo=0, hi=n)
@@ -135,7 +138,8 @@ def test_gpu_wavefront_edge_sizes_and_empty_scene():
     from epsm_mitsuba3_amd import scene as S
     dev = torch.device("cuda", 0)
     sc = _rich_scene(8, 8, device=dev)
-    for n in (1, 65, 257):
+    for n, tail in ((1, True), (65, True), (257, True), (65, False), (257, False)):
+        sc.wavefront_tail = tail
         sc.tracer = "mega"
         a = sc._trace(0, seed=3, spp=8, max_depth=4, K=3, lo=5, hi=5 + n)
         sc.tracer = "wavefront"
@@ -322,3 +326,39 @@ def test_gradient_image_does_not_depend_on_the_tile_size():
         out.append(p.flat.double().cpu())
     m = float(out[0].abs().max())
     assert m > 0 and float((out[0] - out[1]).abs().max()) <= 2e-4 * m
+
+
+@pytest.mark.parametrize("gradient_only", [False, True])
+def test_tail_launch_gives_the_same_gradients(gradient_only):
+    """The tail of the wavefront form (wf_tail: the paths still alive carried through the rest of their loop by one launch
+    once fewer than 2^19 are left) against the three stages per bounce (EPSM_TRACE_NO_TAIL), at a size where the tail
+    takes over in the MIDDLE of the loop: same parameter gradients from render_backward."""
+    import epsm_mitsuba3_amd as epsm
+    from epsm_mitsuba3_amd.exp import clutter
+    dev = torch.device("cuda", 0)
+    res, spp = 256, 16
+    sc = clutter.load_scene(dev, n_spheres=40, res=res, spp=spp)
+    sc.tracer = "wavefront"
+    for i in range(0, 40, 3):
+        sc.attach(f"s{i}", positions=True, normals=True)
+    sc.attach("floor", positions=True)
+    g = torch.Generator().manual_seed(3)
+    grad_in = (torch.randn((res, res, 5), generator=g) * 1e-3).to(dev)
+    out = []
+    for tail in (False, True):
+        sc.wavefront_tail = tail
+        integ = epsm.load_dict({"type": "manifold", "max_depth": clutter.max_depth, "gradient_only": gradient_only})
+        integ.backward_spp = spp
+        p = sc.param_grads()
+        integ.render_backward(sc, p, grad_in, seed=5)
+        torch.cuda.synchronize()
+        out.append(p.flat.double().cpu())
+        if not tail:
+            alive = sc.wavefront_queue_lengths()["alive"]
+            if not gradient_only:                      # the tail starts at bounce 2 here, not at bounce 1
+                assert alive[1] >= (1 << 19) > alive[2] > 0, alive
+            else:
+                assert (1 << 19) > alive[1] > alive[2] > 0, alive
+    m = float(out[0].abs().max())
+    assert m > 0
+    assert float((out[0] - out[1]).abs().max()) <= 1e-5 * m, (m, float((out[0] - out[1]).abs().max()))

@@ -111,6 +111,10 @@ def test_auto_picks_the_wavefront_for_large_scenes():
     assert sc.tracer == "auto" and not sc.use_wavefront()
     sc.WAVEFRONT_MIN_TRIANGLES = 2
     assert sc.use_wavefront()
+    # ... for launches of more than 2^20 paths: below, the one launch wins (the reference's own backward size is 2^19)
+    assert not sc.use_wavefront(1 << 19) and not sc.use_wavefront(1 << 20) and sc.use_wavefront((1 << 20) + 1)
+    sc.tracer = "wavefront"
+    assert sc.use_wavefront(1)
     sc.tracer = "nope"
     with pytest.raises(ValueError):
         sc.use_wavefront()

@@ -7,10 +7,11 @@ from epsm_mitsuba3_amd.exp import clutter
 
 variant = sys.argv[1] if len(sys.argv) > 1 else "manifold"
 dev = torch.device("cuda", 0)
-res, spp = 512, 64
+res, spp = int(os.environ.get("EPSM_PROF_RES", 512)), int(os.environ.get("EPSM_PROF_SPP", 64))
 sc = clutter.load_scene(dev, n_spheres=100, res=res, spp=spp)
-sc.tracer = "wavefront"
-for go in (None, variant):
+sc.tracer = os.environ.get("EPSM_PROF_TRACER", "wavefront")
+only = len(sys.argv) > 2 and sys.argv[2] == "only"           # (profiler runs: the gradient-only trace alone)
+for go in ((variant,) if only else (None, variant)):
     times = []
     for rep in range(4):
         torch.cuda.synchronize()
@@ -20,6 +21,6 @@ for go in (None, variant):
         e1.record()
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1))
-        q = sc.wavefront_queue_lengths()
+        q = sc.wavefront_queue_lengths() if sc.use_wavefront() else {'alive': None, 'shadow': None}
         del tr
-    print(f"gradient_only={go}: trace+log ms per 2^24 paths {min(times[1:]):.2f} (runs {['%.2f' % t for t in times]}); alive into bounce b {q['alive']}; visibility rays {q['shadow']}", flush=True)
+    print(f"gradient_only={go}: trace+log ms per {res * res * spp} paths {min(times[1:]):.2f} (runs {['%.2f' % t for t in times]}); alive into bounce b {q['alive']}; visibility rays {q['shadow']}", flush=True)
