@@ -225,7 +225,10 @@ EPSM_HD float boundary_test(const EpsmScene &S, const TriHit &th, F3 ray_d) {
 // ray), so that the rays of a warp can be traced by different lanes (the device's second stage) or one after the other
 // (the host build) with the same numbers.
 struct WarpId { uint32_t key, widx; int n; };
-EPSM_HD Aux aux_ray(const EpsmScene &S, const ReparamCfg &cfg, const WarpId &id, int r, F3 o, F3 d, F3 fs, F3 ft, const BvhStack &st) {
+// An auxiliary ray in two halves, so that the device can walk the rays of a wave TOGETHER between them (epsm_trace_packet.h):
+// aux_begin draws the ray, aux_finish turns its closest hit into the warp's weight and its derivative.
+struct AuxDraw { Ray ray; F3 tangent; float sy_; };                        // tangent = fs * omega.x + ft * omega.y
+EPSM_HD AuxDraw aux_begin(const ReparamCfg &cfg, const WarpId &id, int r, F3 o, F3 d, F3 fs, F3 ft) {
     // antithetic pairs (reparam.py:82-84, 189-196): rays 2m and 2m + 1 share one sample; the even one mirrors it about the
     // ray (omega_local.x, .y negated), which cancels the odd part of the warp field's estimator
     const bool anti = (cfg.flags & EPSM_REPARAM_ANTITHETIC) != 0;
@@ -240,8 +243,14 @@ EPSM_HD Aux aux_ray(const EpsmScene &S, const ReparamCfg &cfg, const WarpId &id,
     const float phi = 2.f * kPi * sx;
     const float mirror = anti && !(r & 1) ? -1.f : 1.f;
     const F3 ol = f3(mirror * cosf(phi) * sin_theta, mirror * sinf(phi) * sin_theta, cos_theta);
-    Ray ar; ar.o = o; ar.d = fs * ol.x + ft * ol.y + d * ol.z; ar.maxt = kInf;
-    const TriHit th = intersect<false>(S, ar, st);
+    AuxDraw D;
+    D.tangent = fs * ol.x + ft * ol.y;
+    D.ray.o = o; D.ray.d = D.tangent + d * ol.z; D.ray.maxt = kInf;
+    D.sy_ = sy_;
+    return D;
+}
+EPSM_HD Aux aux_finish(const EpsmScene &S, const ReparamCfg &cfg, const AuxDraw &D, const TriHit &th, F3 o, F3 d) {
+    const float kappa = cfg.kappa;
     Aux A;
     float B = 1.f;                                                         // reparam.py:104
     A.tri = kNoIndex; A.b1 = A.b2 = 0.f; A.inv_dist = 0.f; A.v = d;
@@ -253,17 +262,21 @@ EPSM_HD Aux aux_ray(const EpsmScene &S, const ReparamCfg &cfg, const WarpId &id,
         const float dist = sqrtf(dot(r3, r3));
         if (dist > 0.f) {
             A.tri = th.tri; A.b1 = th.u; A.b2 = th.v; A.inv_dist = 1.f / dist; A.v = r3 * A.inv_dist;
-            B = boundary_test(S, th, ar.d);
+            B = boundary_test(S, th, D.ray.d);
         }
     }
-    const float inv_vmf = 1.f / (sy_ * expf(-2.f * kappa) + (1.f - sy_));                // reparam.py:111
+    const float inv_vmf = 1.f / (D.sy_ * expf(-2.f * kappa) + (1.f - D.sy_));              // reparam.py:111
     const float w_denom = inv_vmf - 1.f + B;
     const float w_denom_rcp = w_denom > 1e-4f ? 1.f / w_denom : 0.f;
     const float w = powf(w_denom_rcp, cfg.exponent) * inv_vmf;
     const float tmp1 = fminf(fmaxf(inv_vmf * w * w_denom_rcp * kappa * cfg.exponent, -1e10f), 1e10f);
     A.w = w;
-    A.dw = (fs * ol.x + ft * ol.y) * tmp1;
+    A.dw = D.tangent * tmp1;
     return A;
+}
+EPSM_HD Aux aux_ray(const EpsmScene &S, const ReparamCfg &cfg, const WarpId &id, int r, F3 o, F3 d, F3 fs, F3 ft, const BvhStack &st) {
+    const AuxDraw D = aux_begin(cfg, id, r, o, d, fs, ft);
+    return aux_finish(S, cfg, D, intersect<false>(S, D.ray, st), o, d);
 }
 // One call of reparameterize_ray's sampling loops (reparam.py:249-267 and 300-328 trace the same rays: kept instead of
 // traced twice).

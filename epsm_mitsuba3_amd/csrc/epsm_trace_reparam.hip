@@ -5,6 +5,7 @@
 
 #include "epsm_common.h"
 #include "epsm_trace_reparam.h"
+#include "epsm_trace_packet.h"
 
 using namespace epsm;
 using epsm_host::fail;
@@ -25,15 +26,18 @@ __global__ __launch_bounds__(EPSM_RP_THREADS, EPSM_RP_OCC) void epsm_reparam_pat
     __shared__ uint32_t s_stack[kLds * EPSM_RP_THREADS];
     uint32_t deep[kBvhStack - kLds];
     const int64_t i = (int64_t) blockIdx.x * EPSM_RP_THREADS + threadIdx.x;
-    if (i >= R.A.N) return;
     BvhStack st{s_stack + threadIdx.x, EPSM_RP_THREADS};
     st.cap = kLds; st.ovf = deep; st.ovf_stride = 1;
+    if (i >= R.A.N) return;
     rp::QueueSink sink{req, R.A.N, i, 0};
+    // (the camera rays of a wave walked together first, as the tracers do: 41.6 -> 42.3 ms per call; not kept)
     rp::reparam_one_path(R, i, st, sink);
     count[i] = sink.n;
 }
 
-// Stage 2: one lane = one auxiliary ray, a group of G lanes (G = 16, 32 or 64 >= reparam_rays) = one request.  A workgroup
+// Stage 2: one lane = one auxiliary ray, a group of G lanes (G = 16, 32 or 64 >= reparam_rays) = one request.  The rays of a wave
+// walk the tree TOGETHER (epsm_trace_packet.h; round 5): 46.3 -> 42.5 ms per call at 4.26 M paths / 16 rays, 26.5 -> 22.0 ms at
+// 1.08 M paths / 64 rays (-DEPSM_RP_NO_WARP_PACKET: every lane its own walk).  A workgroup
 // serves the requests of 256 consecutive paths: it lists the ones that exist -- (call n, path), n-major, so that neighbouring
 // groups hold the same call of neighbouring paths: rays that start next to each other and point the same way -- and works
 // through the list 256 / G requests at a time.  (Round 3 launched one group per (n, path) slot and let the empty ones leave:
@@ -42,7 +46,11 @@ __global__ __launch_bounds__(EPSM_RP_THREADS, EPSM_RP_OCC) void epsm_reparam_pat
 template <int G>
 __global__ __launch_bounds__(256) void epsm_reparam_warp_kernel(rp::ReparamArgs R, const rp::WarpReq *req, const int *count, int n_max) {
     constexpr int kLds = 32, kPaths = 256, kGroups = 256 / G;
+#ifndef EPSM_RP_NO_WARP_PACKET
+    __shared__ uint32_t s_pstack[kPacketStack * 4];                        // one column per wave (epsm_trace_packet.h)
+#else
     __shared__ uint32_t s_stack[kLds * 256];
+#endif
     __shared__ uint16_t s_list[kPaths * rp::kMaxReq];                      // (n << 8) | path of the block
     __shared__ int s_off[rp::kMaxReq * 4 + 1];
     uint32_t deep[kBvhStack - kLds];
@@ -70,10 +78,19 @@ __global__ __launch_bounds__(256) void epsm_reparam_warp_kernel(rp::ReparamArgs 
     __syncthreads();
     const int total = s_off[rp::kMaxReq * 4];
     const int r = tid % G;
+#ifndef EPSM_RP_NO_WARP_PACKET
+    (void) deep; (void) kLds;
+    for (int b0 = 0; b0 < total; b0 += kGroups) {                          // (uniform over the workgroup: the wave walks its rays together)
+        const int b = b0 + tid / G;
+        const bool live = b < total;
+        const int e = s_list[live ? b : 0], n = e >> 8;
+#else
+    constexpr bool live = true;
     BvhStack st{s_stack + threadIdx.x, 256};
     st.cap = kLds; st.ovf = deep; st.ovf_stride = 1;
     for (int b = tid / G; b < total; b += kGroups) {                       // (uniform over the group)
         const int e = s_list[b], n = e >> 8;
+#endif
         const int64_t i = p0 + (e & 255);
         const rp::WarpReq q = req[(int64_t) n * N + i];
         const F3 o = f3(q.o[0], q.o[1], q.o[2]), d = f3(q.d[0], q.d[1], q.d[2]), g_dir = f3(q.gdir[0], q.gdir[1], q.gdir[2]);
@@ -81,8 +98,17 @@ __global__ __launch_bounds__(256) void epsm_reparam_warp_kernel(rp::ReparamArgs 
         coordinate_system(d, fs, ft);
         rp::Aux A;
         A.w = 0.f; A.dw = zero3<float>(); A.v = d; A.tri = kNoIndex; A.b1 = A.b2 = A.inv_dist = 0.f;
-        const bool mine = r < R.cfg.rays;
+        const bool mine = live && r < R.cfg.rays;
+#ifndef EPSM_RP_NO_WARP_PACKET
+        // the rays of a request leave one point within a fraction of a degree, the requests of a wave are the same call of
+        // neighbouring paths: the wave walks the tree once for all of them
+        rp::AuxDraw D; D.ray.o = o; D.ray.d = d; D.ray.maxt = 0.f; D.tangent = zero3<float>(); D.sy_ = 0.f;
+        if (mine) D = rp::aux_begin(R.cfg, rp::WarpId{0xffffffffu ^ R.A.seed, (uint32_t) (R.A.path_offset + i), n}, r, o, d, fs, ft);
+        const TriHit ath = packet_intersect<false>(R.A.S, D.ray, mine, s_pstack + wv * kPacketStack);
+        if (mine) A = rp::aux_finish(R.A.S, R.cfg, D, ath, o, d);
+#else
         if (mine) A = rp::aux_ray(R.A.S, R.cfg, rp::WarpId{0xffffffffu ^ R.A.seed, (uint32_t) (R.A.path_offset + i), n}, r, o, d, fs, ft, st);
+#endif
         float Z = A.w; F3 dZ = A.dw;
 #pragma unroll
         for (int m = 1; m < G; m <<= 1) { Z += __shfl_xor(Z, m); dZ.x += __shfl_xor(dZ.x, m); dZ.y += __shfl_xor(dZ.y, m); dZ.z += __shfl_xor(dZ.z, m); }
@@ -129,7 +155,7 @@ __global__ __launch_bounds__(256) void epsm_reparam_warp_kernel(rp::ReparamArgs 
             g_o.x += __shfl_xor(g_o.x, m); g_o.y += __shfl_xor(g_o.y, m); g_o.z += __shfl_xor(g_o.z, m);
             g_d.x += __shfl_xor(g_d.x, m); g_d.y += __shfl_xor(g_d.y, m); g_d.z += __shfl_xor(g_d.z, m);
         }
-        if (r == 0 && q.ftri != kNoIndex) {
+        if (live && r == 0 && q.ftri != kNoIndex) {
             if (q.em_inv_dist != 0.f) g_o = g_o - (g_d - d * dot(d, g_d)) * q.em_inv_dist;
             rp::add_follow_point(R.A.S, R.G, q.ftri, q.fb1, q.fb2, g_o);
         }
