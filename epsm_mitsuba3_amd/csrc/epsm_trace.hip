@@ -149,7 +149,9 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_shade_kernel(TraceArgs A, Wf
     if ((threadIdx.x & 63) == 0) { s_n[0][threadIdx.x >> 6] = (uint32_t) __popcll(ma); s_n[1][threadIdx.x >> 6] = (uint32_t) __popcll(ms); }
     __syncthreads();
     if (threadIdx.x < 2) {
-        const uint32_t n = s_n[threadIdx.x][0] + s_n[threadIdx.x][1] + s_n[threadIdx.x][2] + s_n[threadIdx.x][3];
+        uint32_t n = 0;
+#pragma unroll
+        for (int w = 0; w < kWfChunk / 64; ++w) n += s_n[threadIdx.x][w];
         W.chunk_counts[threadIdx.x * W.chunks + blockIdx.x] = n;
         if (n) atomicAdd(&W.group_counts[threadIdx.x * W.groups + blockIdx.x / kWfGroup], n);     // (64 adds per address at most)
     }

@@ -62,7 +62,11 @@ struct WfState {                              // device pointers into the worksp
     int64_t groups;           // ceil(chunks / kWfGroup)
     int64_t N;
 };
-constexpr int kWfChunk = 256;
+#ifndef EPSM_WF_CHUNK
+#define EPSM_WF_CHUNK 256
+#endif
+constexpr int kWfChunk = EPSM_WF_CHUNK;      // slots per chunk = lanes of a shade / compaction workgroup (64 / 128 / 512: the backward
+                                              // trace of 2^24 paths 3.76 / 3.58 / 3.59 ms against 3.47)
 constexpr int kWfGroup = 64;                  // chunks per group: one wave scans a group
 constexpr uint8_t kWfAlive = 1, kWfShadow = 2;
 constexpr int kWfStackLds = 16, kWfStackOvf = kBvhStack - kWfStackLds;
