@@ -94,6 +94,9 @@ def parse(argv=None):
     ap.add_argument("--soa", action="store_true",
                     help="records in the reference's tensor layout (one (N,3) array per field) instead of the native packed "
                          "log (one 128-byte record per path vertex)")
+    ap.add_argument("--log-layout", default=None, choices=["interleaved", "dense"],
+                    help="where the native log's rays and records lie (records.alloc_log): two dense arrays (the default) or one "
+                         "block of K + 1 cache lines per path (ABI v7; A/B measurements, MEASUREMENTS.md 10.12)")
     ap.add_argument("--two-stage", action="store_true",
                     help="calc_grad lists + separate scatter (the reference's shape) instead of the fused kernel")
     ap.add_argument("--max-resident-gb", type=float, default=0.0,
@@ -508,7 +511,8 @@ def main():
     cap = args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else float("inf")
     # bytes a slab keeps (its final layout) and the most its construction needs on top (the generator's per-field
     # records, before they are repacked / trimmed)
-    keep_per_path = (52 + 128 * K) if packed_log else (48 + K * 139)
+    layout = args.log_layout or "dense"
+    keep_per_path = ((4 + 128 * (K + 1)) if layout == "interleaved" else (52 + 128 * K)) if packed_log else (48 + K * 139)
     build_per_path = 48 + K * 200
     slabs, used0 = [], torch.cuda.memory_allocated(dev)
     live0 = None
@@ -523,7 +527,7 @@ def main():
         trace = scene.tile(s, lo, hi, seed=0, spp=spp, K=K, lean=True)
         if packed_log:
             keep_soa = rank == 0 and not slabs            # slab 0 of rank 0 also feeds the CPU baseline and the dense-kernel leg
-            packed = PackedLog.from_trace(trace, device=dev, table=scene.triangle_table(), free=not keep_soa)
+            packed = PackedLog.from_trace(trace, device=dev, table=scene.triangle_table(), free=not keep_soa, layout=layout)
             if not keep_soa:                              # only the log stays resident: the per-field arrays are released
                 trace = epsm.PathTrace(res=trace.res, spp=trace.spp, ray_o=None, ray_d=None, ray_dx=None, ray_dy=None,
                                        path_info=None, scatter_info=None, path_offset=trace.path_offset,
@@ -670,7 +674,9 @@ def main():
             "stages_ms": stage_ms,
             "pipeline": (("one launch per slab (epsm_backward_pass_packed, native log)" if packed_log else
                           "one launch per slab (epsm_backward_pass)") if one_launch else "tangent + fused") if fused else "two-stage",
-            "record_layout": "packed: one 128-byte record per (path, vertex) + rays (N,12) + flag word" if packed_log
+            "record_layout": (("packed, interleaved: one block of K + 1 cache lines per path = [rays | 16 B free | K records of 128 B], "
+                               "+ flag word (include/epsm.h, EpsmPackedLog)") if layout == "interleaved" else
+                              "packed, dense: one 128-byte record per (path, vertex) + rays (N,12) + flag word") if packed_log
                              else "reference tensors: one (N,3) array per field",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

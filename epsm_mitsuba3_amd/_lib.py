@@ -15,7 +15,7 @@ import subprocess
 import torch  # noqa: F401  (must be loaded before libepsm_hip.so, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 6          # EPSM_ABI_VERSION of include/epsm.h
+ABI_VERSION = 7          # EPSM_ABI_VERSION of include/epsm.h
 LIB_PATH = os.path.join(_HERE, os.environ.get("EPSM_LIB_NAME", "libepsm_hip.so"))   # EPSM_LIB_NAME: A/B builds
 _lib = None
 

@@ -302,8 +302,8 @@ struct WinBase {
 __device__ __forceinline__ WinBase win_base(const FusedArgs &F, int64_t base) {
     WinBase B;
     B.base = base;
-    B.verts = F.pk_verts + base * F.K * kRecWords;
-    B.rays = F.pk_rays + 12 * base;
+    B.verts = F.pk_verts + base * F.pk_path_stride;
+    B.rays = F.pk_rays + base * F.pk_ray_stride;
     B.shadow = F.pk_shadow ? F.pk_shadow + 4 * base : nullptr;
     const int64_t p0 = F.tin.path_offset + base, q0 = p0 / F.tin.spp;
     B.small = (int64_t) F.tin.res * F.tin.res < (1 << 24) && q0 + 4096 < (1 << 24) && F.tin.spp < (1 << 20);
@@ -329,7 +329,7 @@ __device__ __forceinline__ LaneRole role_of(const FusedArgs &F, const LaneId &L,
     R.d1 = R.ok && R.first && cp::plan_diffuse1(L.plan);
     R.act1 = (L.plan & cp::kPlanActive1) != 0;
     R.loc = (uint32_t) L.loc;
-    R.rec = B.verts + (uint32_t) ((R.loc * (uint32_t) F.K + (uint32_t) (L.k - 1)) * (uint32_t) kRecWords);
+    R.rec = B.verts + (uint32_t) (R.loc * (uint32_t) F.pk_path_stride + (uint32_t) (L.k - 1) * (uint32_t) kRecWords);
     return R;
 }
 // pixel of path i: (path_offset + i) / spp, row-major on the res x res crop (epsm.py:250)
@@ -363,7 +363,7 @@ __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const
 #endif
     }
     if (R.ok && R.first) {
-        const float *rays = B.rays + 12u * R.loc;
+        const float *rays = B.rays + (uint32_t) F.pk_ray_stride * R.loc;
 #ifdef EPSM_CPKO_NORAYS                 // (knock-out build: what reading the rays costs; results are wrong)
         { const float v = (float) R.loc * 1e-3f; const F4v f4 = {v, 0.5f, -0.25f, 1.f}; X.p0 = f4; X.p1 = f4 * 0.5f; X.p2 = f4 * 0.25f; }
 #elif defined(EPSM_CPKO_RAYS0)          // (knock-out build: every path takes the rays of its window's first path -- realistic values, no gather)
@@ -400,7 +400,7 @@ template <int VARIANT>
 __device__ __forceinline__ void geo_stage_dma(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B, float *stage, int lane) {
     const LaneRole R = role_of(F, L, B);
     const uint32_t want = R.live ? 2u : R.d1 ? 1u : 0u;
-    const uint32_t roff = (uint32_t) ((R.loc * (uint32_t) F.K + (uint32_t) (L.k - 1)) * (uint32_t) kRecWords) | want;   // (a multiple of 32: the low bits are free)
+    const uint32_t roff = (uint32_t) (R.loc * (uint32_t) F.pk_path_stride + (uint32_t) (L.k - 1) * (uint32_t) kRecWords) | want;   // (a multiple of 32: the low bits are free)
     const int s = lane & 7, grp = lane >> 3;
     const int quad = s ^ (grp & 7);                          // owner % 8 == (l / 8) % 8 in every instruction
     const bool want_lz = VARIANT == EPSM_VARIANT_MANIFOLD && R.live && cp::plan_a(L.plan, L.k);
@@ -433,7 +433,7 @@ template <int VARIANT>
 __device__ __forceinline__ void geo_stage_coop(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B, float *stage, int lane) {
     const LaneRole R = role_of(F, L, B);
     const uint32_t want = R.live ? 2u : R.d1 ? 1u : 0u;
-    const uint32_t roff = (uint32_t) ((R.loc * (uint32_t) F.K + (uint32_t) (L.k - 1)) * (uint32_t) kRecWords) | want;
+    const uint32_t roff = (uint32_t) (R.loc * (uint32_t) F.pk_path_stride + (uint32_t) (L.k - 1) * (uint32_t) kRecWords) | want;
     const int s = lane & 7, grp = lane >> 3;
     const bool want_lz = VARIANT == EPSM_VARIANT_MANIFOLD && R.live && cp::plan_a(L.plan, L.k);
     const F4v z4 = {0.f, 0.f, 0.f, 0.f};
@@ -467,7 +467,7 @@ __device__ __forceinline__ void geo_stage_coop(GeoFetch &X, const FusedArgs &F, 
 __device__ __forceinline__ void geo_issue_rest(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B) {
     const LaneRole R = role_of(F, L, B);
     if (R.ok && R.first) {
-        const float *rays = B.rays + 12u * R.loc;
+        const float *rays = B.rays + (uint32_t) F.pk_ray_stride * R.loc;
         X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
         const F2v g = ld2(pixel_grad(F.tin, B, R.loc));
         X.gx = g.x; X.gy = g.y;
@@ -508,7 +508,7 @@ __device__ __forceinline__ void own_issue(GeoFetch &X, AddrFetch &A, const Fused
     addr_issue<VARIANT>(A, F, L, B);
 #if EPSM_CP_PREFETCH >= 2            // ... and the rays + image gradient of a path's first lane
     if (R.ok && R.first) {
-        const float *rays = B.rays + 12u * R.loc;
+        const float *rays = B.rays + (uint32_t) F.pk_ray_stride * R.loc;
         X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
         const F2v g = ld2(pixel_grad(F.tin, B, R.loc));
         X.gx = g.x; X.gy = g.y;

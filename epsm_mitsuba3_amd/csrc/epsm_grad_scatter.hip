@@ -235,6 +235,10 @@ extern "C" int epsm_backward_pass_packed(int variant, int64_t N, int K, int64_t 
         return fail(EPSM_EINVAL, "epsm_backward_pass_packed: NULL argument / bad N");
     if ((((uintptr_t) log->rays) | ((uintptr_t) log->verts) | ((uintptr_t) log->shadow) | ((uintptr_t) tri_table)) & 15)
         return fail(EPSM_EINVAL, "epsm_backward_pass_packed: rays / verts / shadow / tri_table must be 16-byte aligned");
+    // (strides: 16-byte quads stay aligned; a window's 32-bit word offsets -- 2048 paths x stride -- stay far below 2^31)
+    if (log->ray_stride < 0 || log->path_stride < 0 || (log->ray_stride & 3) || (log->path_stride & 3) || log->ray_stride > 4096 ||
+        log->path_stride > 4096 || (log->ray_stride && log->ray_stride < 12) || (log->path_stride && log->path_stride < (int64_t) K * 32))
+        return fail(EPSM_EINVAL, "epsm_backward_pass_packed: ray_stride / path_stride must be 0 or multiples of 4 words in [12 | 32 K, 4096]");
     if (V < 0 || B < 0 || 2 * V + B >= 0xFFFFFFFFLL || T < 0 || (T > 0 && !tri_table))
         return fail(EPSM_EINVAL, "epsm_backward_pass_packed: bad buffer sizes");
     if (spp < 1 || res < 1 || img_width < res || img_channels < 5)
@@ -251,6 +255,8 @@ extern "C" int epsm_backward_pass_packed(int variant, int64_t N, int K, int64_t 
     F.P = epsm_num_param_grads(variant, K);
     F.K = K;
     F.pk_rays = log->rays; F.pk_flags = log->flags; F.pk_verts = (const float *) log->verts; F.pk_shadow = log->shadow;
+    F.pk_ray_stride = log->ray_stride ? log->ray_stride : 12;
+    F.pk_path_stride = log->path_stride ? log->path_stride : (int64_t) K * kRecWords;
     F.tin = TangentIn{path_offset, spp, res, img_width, img_channels, nullptr, nullptr, nullptr, nullptr, grad_img};
     F.grad_o_sum = grad_o_sum;
     const hipError_t e = launch_backward_cp(variant, kTangentsInKernel, true, F, 2, (hipStream_t) stream);

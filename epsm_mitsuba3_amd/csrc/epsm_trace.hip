@@ -475,6 +475,11 @@ static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene
     if (!ray_o || (!packed && (!ray_d || !ray_dx || !ray_dy)) || (K_log > 0 && !recs)) return bad("NULL output");
     if (packed && ((((uintptr_t) ray_o) & 15) || (K_log > 0 && (!recs[0].packed || !recs[0].pflags || (((uintptr_t) recs[0].packed) & 15)))))
         return bad("EPSM_TRACE_PACKED_LOG needs 16-byte aligned ray_o (N,12), recs[0].packed and recs[0].pflags");
+    if (packed && K_log > 0) {
+        const int64_t rs = recs[0].ray_stride, ps = recs[0].packed_stride;
+        if (rs < 0 || ps < 0 || (rs & 3) || (ps & 3) || (rs && rs < 12) || (ps && ps < (int64_t) K_log * 32))
+            return bad("EpsmRecordOut.ray_stride / packed_stride must be 0 or multiples of 4 words >= 12 / 32 K_log");
+    }
     if (scene->n_triangles > 0 && (!scene->positions || !scene->normals || !scene->tri || !scene->tri_mesh ||
                                    !scene->meshes || !scene->bsdfs || !scene->bvh || !scene->prim_index || !scene->tri_verts))
         return bad("NULL scene array");
@@ -498,6 +503,7 @@ static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene
             return bad("NULL pointer in a record (p / normal may be NULL)");
         A.rec[k] = r;
     }
+    trace_args_log_strides(A);
     return EPSM_OK;
 }
 

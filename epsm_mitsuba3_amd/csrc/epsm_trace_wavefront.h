@@ -216,7 +216,7 @@ EPSM_HD void wf_shadow_begin(const TraceArgs &A, const WfState &W, int64_t i, Wf
 // ds.p of the first bounce, as logged (per-field array or packed record)
 EPSM_HD F3 wf_logged_light0(const TraceArgs &A, int64_t i) {
     if (A.flags & EPSM_TRACE_PACKED_LOG) {                                 // light = words 22, 23, 28 (include/epsm.h, EpsmPackedLog)
-        const float *r = A.rec[0].packed + i * A.K_log * 32;
+        const float *r = packed_record(A, i, 0);
         return f3(r[22], r[23], r[28]);
     }
     return ld3(A.rec[0].light + 3 * i);
@@ -225,7 +225,7 @@ EPSM_HD F3 wf_logged_light0(const TraceArgs &A, int64_t i) {
 EPSM_HD bool wf_shadow_resolve(const TraceArgs &A, const WfState &W, int64_t i, int iteration, bool occluded) {
     if (occluded) {
         if (iteration < A.K_log) {                                       // Lr_dir = 0: the logged weight with it
-            if (A.flags & EPSM_TRACE_PACKED_LOG) A.rec[0].packed[(i * A.K_log + iteration) * 32 + 27] = 0.f;
+            if (A.flags & EPSM_TRACE_PACKED_LOG) packed_record(A, i, iteration)[27] = 0.f;
             else A.rec[iteration].emit[4 * i + 3] = 0u;
         }
     } else if (A.radiance) {

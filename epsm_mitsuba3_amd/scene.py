@@ -95,7 +95,8 @@ class EpsmSceneC(C.Structure):
 class EpsmRecordOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "p0", "p1", "p2", "p", "n0", "n1", "n2", "normal", "b0", "b1", "eta", "hf", "light",
-        "bsdf", "active", "active_em", "ismesh", "tri", "aux", "emit", "packed", "pflags", "shadow")]
+        "bsdf", "active", "active_em", "ismesh", "tri", "aux", "emit", "packed", "pflags", "shadow")] + [
+        ("ray_stride", C.c_int64), ("packed_stride", C.c_int64)]
 
 
 # ---------------------------------------------------------------------------- transforms
@@ -711,6 +712,10 @@ class Scene:
         # three kernels per bounce; "auto": wavefront from WAVEFRONT_MIN_TRIANGLES triangles on (where the
         # one-launch form is bound by divergence; below, the wavefront's state traffic costs more than it saves)
         self.tracer = "auto"
+        # where the native log's rays and records lie (records.alloc_log): "dense" = two arrays; "interleaved" = one block of
+        # K + 1 cache lines per path (ABI v7: 16 % fewer bytes read by the backward kernel, but slower where it counts --
+        # MEASUREMENTS.md 10.12)
+        self.log_layout = "dense"
         self._wf_workspace = {}        # scratch of the wavefront tracer, one per stream it was used on
         self._upload()
 
@@ -1208,7 +1213,7 @@ class Scene:
         """The same trace with the vertex log in the NATIVE layout of the backward kernel (EPSM_TRACE_PACKED_LOG,
         include/epsm.h EpsmPackedLog): the PathTrace carries ``log`` (a PackedLog) instead of per-field arrays."""
         from .integrators import PathTrace
-        from .records import PackedLog, REC_WORDS
+        from .records import PackedLog, alloc_log
         dev = self.device
         if dev.type != "cuda" and self._backend is None:
             raise _lib.EpsmError("the tracer runs on the GPU only (no CPU fallback)")
@@ -1217,17 +1222,18 @@ class Scene:
         sensor = self.sensors[sensor_index]
         n = hi - lo
         assert K >= 1
-        rays = torch.empty((n, 12), device=dev, dtype=torch.float32)
+        rays, verts = alloc_log(n, K, dev, self.log_layout)
         # a gradient-only trace forms no image: radiance / film positions / valid are not asked for, and nothing is written for them
         want_image = not gradient_only
         radiance = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_image else None
         film_pos = torch.empty((n, 2), device=dev, dtype=torch.float32) if want_image else None
         valid = torch.empty((n,), device=dev, dtype=torch.uint8) if want_image else None
         flags = torch.empty((n,), device=dev, dtype=torch.int32)
-        verts = torch.empty((n, K, REC_WORDS), device=dev, dtype=torch.float32)
         shadow = torch.empty((n, 4), device=dev, dtype=torch.int32) if max_depth <= 3 else None
         recs = (EpsmRecordOut * K)()
         recs[0].packed, recs[0].pflags = verts.data_ptr(), flags.data_ptr()
+        if n > 1:
+            recs[0].ray_stride, recs[0].packed_stride = rays.stride(0), verts.stride(0)
         recs[0].shadow = shadow.data_ptr() if shadow is not None else None
         cs = sensor.c_struct()
         args = [C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
@@ -1289,7 +1295,7 @@ class Scene:
             shadow = quad[2 * K] if (k == 0 and want_shadow) else None
             r = recs[k]
             for name, _ in EpsmRecordOut._fields_:
-                if name in ("packed", "pflags"):
+                if name in ("packed", "pflags", "ray_stride", "packed_stride"):
                     continue
                 setattr(r, name, t[name].data_ptr() if name != "shadow" else (shadow.data_ptr() if shadow is not None else None))
             info.append({"it": k, "active": t["active"], "bsdf": t["bsdf"], "ismesh": t["ismesh"], "light": t["light"],

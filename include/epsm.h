@@ -34,8 +34,10 @@ extern "C" {
  * the native log's vertex record, round 4 -- EpsmPackedLog below).  Entry points added since without touching the others:
  * epsm_backward_pass_packed, epsm_release_workspace, epsm_sinkhorn_*, epsm_set_option / epsm_get_option, epsm_probe.
  * 6 (round 5): EpsmEnvironment starts with `kind` (0 = none: a zeroed EpsmScene has no environment; until 5 `emitter = -1` said
- * so); note of 5, late: epsm_trace_paths_reparam had gained its `flags` parameter mid-signature in that version. */
-#define EPSM_ABI_VERSION 6
+ * so); note of 5, late: epsm_trace_paths_reparam had gained its `flags` parameter mid-signature in that version.
+ * 7 (round 5): EpsmPackedLog ends with ray_stride / path_stride, EpsmRecordOut (epsm_trace.h) with ray_stride / packed_stride: the
+ * native log may interleave a path's rays and records in one block (zeroed strides = the dense arrays of version 6). */
+#define EPSM_ABI_VERSION 7
 
 /* BSDF flag bits tested by the hot path (include/mitsuba/render/bsdf.h:40-46,101). */
 #define EPSM_BSDF_NULL     0x1u
@@ -268,6 +270,18 @@ int epsm_backward_pass(int variant, int64_t N, int K, int64_t path_offset, int s
  *          the alpha slot of the vertex's BSDF travels with the triangle: bits 8.. of the table row's mode word hold
  *          slot + 1 (0 = none)
  *   shadow (N,4) as EpsmScatterRecord.shadow, or NULL
+ *   ray_stride, path_stride (ABI v7)   words between the rays / the first records of consecutive paths; 0 = the dense arrays above
+ *          (12 and 32 K).  An INTERLEAVED form for hosts that keep one block per path: 32 (K + 1) words = K + 1 cache lines,
+ *          128-byte aligned --
+ *              words 0..11 the rays, 12..15 free | 16..: the K records          (rays = block, verts = block + 16, both strides 32 (K + 1))
+ *          -- which puts the records HALF a line off the lines: line 0 of a path = [rays | first sector of vertex 1], line k =
+ *          [second sector of vertex k | first sector of vertex k + 1].  What a path's lanes read is then a run of WHOLE lines: a
+ *          diffuse first hit = line 0 alone (rays + geometry; the dense form: a line of rays and half a record line), a chain of
+ *          m constraint vertices and its end point = lines 0..m, every byte of which is wanted (the dense form: a line of rays, m
+ *          record lines and half of one more for the end point's first sector).  Same words, same records; only where they lie.
+ *          Measured on MI355X (MEASUREMENTS.md 10.12): 16 % fewer bytes from HBM, 1 % less kernel time on the headline slab -- the
+ *          kernel is bound by its vector instructions, not by those bytes -- and a tracer whose 48-byte ray stores no longer
+ *          coalesce (trace + log + 8 %): this library's tracer and benchmark keep the dense arrays.
  * epsm_backward_pass_packed = epsm_backward_pass on this log (same sums, same arguments otherwise).
  * ------------------------------------------------------------------------- */
 typedef struct EpsmPackedLog {
@@ -275,6 +289,7 @@ typedef struct EpsmPackedLog {
     const uint32_t *flags;
     const void *verts;
     const uint32_t *shadow;
+    int64_t ray_stride, path_stride;   /* words; 0 = 12 / 32 K */
 } EpsmPackedLog;
 #define EPSM_FLAG_DIFFUSE   1u
 #define EPSM_FLAG_NULL      2u

@@ -56,7 +56,7 @@ enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
  * (path, bounce) written with eight 16-byte stores, recs[0].pflags = (N) flag words (5 bits per bounce); bounces a path
  * did not reach are not touched (the flag word says so).  ray_o must then point to an (N,12) array that receives
  * o, d, d_x, d_y of a path side by side (ray_d / ray_dx / ray_dy are ignored); only `shadow` of the per-field pointers is
- * still used.  The alpha slot of a vertex's BSDF is NOT in the record: the consumer takes it from the triangle table
+ * still used.  recs[0].ray_stride / packed_stride (words per path, multiples of 4) place both in one interleaved block per path.  The alpha slot of a vertex's BSDF is NOT in the record: the consumer takes it from the triangle table
  * (bits 8.. of the mode word). */
 #define EPSM_TRACE_PACKED_LOG 0x2u
 /* EPSM_TRACE_GRADIENT_ONLY: the trace feeds calc_grad and nothing else (render_backward's 5-channel branch, epsm.py:235-297:
@@ -205,6 +205,9 @@ typedef struct EpsmRecordOut {
     uint32_t *pflags;                /* EPSM_TRACE_PACKED_LOG, recs[0] only: (N) flag words */
     uint32_t *shadow;                /* (N,4): EpsmScatterRecord.shadow [stri, sb0, sb1, dis]; written for the first logged vertex only and
                                         only meaningful when max_depth <= 3 (epsm.py:610); may be NULL */
+    int64_t ray_stride, packed_stride; /* EPSM_TRACE_PACKED_LOG, recs[0] only (ABI v7): words between the rays (at ray_o) / the first
+                                        records (at packed) of consecutive paths; 0 = dense, 12 and 32 K_log.  The interleaved block
+                                        of include/epsm.h (EpsmPackedLog): ray_o = block, packed = block + 16, both 32 (K_log + 1) */
 } EpsmRecordOut;
 
 /* ---------------------------------------------------------------------------

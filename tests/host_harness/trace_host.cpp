@@ -23,6 +23,7 @@ extern "C" int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor
     A.ray_o = ray_o; A.ray_d = ray_d; A.ray_dx = ray_dx; A.ray_dy = ray_dy;
     A.film_pos = film_pos; A.radiance = radiance; A.valid = valid;
     for (int k = 0; k < K_log; ++k) A.rec[k] = recs[k];
+    trace_args_log_strides(A);
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < N; ++i) {
         uint32_t stack[kBvhStack];
@@ -144,6 +145,7 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
     A.ray_o = ray_o; A.ray_d = ray_d; A.ray_dx = ray_dx; A.ray_dy = ray_dy;
     A.film_pos = film_pos; A.radiance = radiance; A.valid = valid;
     for (int k = 0; k < K_log; ++k) A.rec[k] = recs[k];
+    trace_args_log_strides(A);
     const WfState W = wf_carve(workspace, N);
     memset(W.counters, 0, kWfCounters * sizeof(uint32_t));
     uint32_t stack[kWfStackLds];

@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_counts(lib):
-    assert lib.epsm_abi_version() == 6
+    assert lib.epsm_abi_version() == 7
     assert lib.epsm_num_param_grads(0, 5) == 25
     assert lib.epsm_num_param_grads(1, 5) == 23
 

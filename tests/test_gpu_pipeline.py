@@ -405,12 +405,16 @@ def test_packed_log_gives_the_sums_of_the_per_array_records(kind, profile, K, ma
     (trace,) = scene.trace_paths(seed=4, spp=spp, max_depth=max_depth)
     a, b = epsm.ParamGrads(V, B, device=dev), epsm.ParamGrads(V, B, device=dev)
     integ.backward_from_trace(trace, a, grad_in)
-    log = PackedLog.from_trace(trace)
-    assert (log.shadow is not None) == (max_depth <= 3)
-    integ.backward_from_trace(trace, b, grad_in, packed=log)
-    torch.cuda.synchronize()
-    for x, y, name in ((a.pos, b.pos, "pos"), (a.nrm, b.nrm, "nrm"), (a.alpha, b.alpha, "alpha"), (a.cam_origin, b.cam_origin, "cam")):
-        m = float(x.abs().max())
-        if name in ("pos", "cam"):
-            assert m > 0, name
-        assert float((x - y).abs().max()) <= 2e-4 * m + 1e-12, name
+    # both placements of the log (ABI v7): one interleaved block of K + 1 cache lines per path, or two dense arrays
+    for layout in ("interleaved", "dense"):
+        log = PackedLog.from_trace(trace, layout=layout)
+        assert log.layout == layout and (log.shadow is not None) == (max_depth <= 3)
+        assert log.rays.data_ptr() % 128 == 0 and (layout == "dense" or log.verts.data_ptr() % 128 == 64)
+        b.flat.zero_()
+        integ.backward_from_trace(trace, b, grad_in, packed=log)
+        torch.cuda.synchronize()
+        for x, y, name in ((a.pos, b.pos, "pos"), (a.nrm, b.nrm, "nrm"), (a.alpha, b.alpha, "alpha"), (a.cam_origin, b.cam_origin, "cam")):
+            m = float(x.abs().max())
+            if name in ("pos", "cam"):
+                assert m > 0, name
+            assert float((x - y).abs().max()) <= 2e-4 * m + 1e-12, (name, layout)

@@ -264,7 +264,9 @@ def test_render_backward_on_the_native_packed_log(tracer, max_depth):
     grad_in = grad_in.to(dev)
     for variant in ("manifold", "manifold_caustic"):
         out = []
-        for packed in (False, True):
+        # per-field tensors; the native log as two dense arrays (the default); as one interleaved block per path (ABI v7)
+        for packed, layout in ((False, "dense"), (True, "dense"), (True, "interleaved")):
+            sc.log_layout = layout
             integ = epsm.load_dict({"type": variant, "max_depth": max_depth, "packed_log": packed, "backward_sensor": 0})
             integ.backward_spp = spp
             poison = [torch.full((res * res * spp * 40,), float("nan"), device=dev) for _ in range(4)]
@@ -277,9 +279,11 @@ def test_render_backward_on_the_native_packed_log(tracer, max_depth):
         m = float(out[0].abs().max())
         assert m > 0
         assert float((out[0] - out[1]).abs().max()) <= 2e-4 * m, variant
+        assert float((out[0] - out[2]).abs().max()) <= 2e-4 * m, variant
+    sc.log_layout = "dense"
     tiles = list(sc.iter_traces(sensor=0, seed=2, spp=spp, max_depth=max_depth, packed_log=True))
     assert len(tiles) == -(-res * res * spp // (max(5000, 1))) or sc.use_wavefront()
-    assert all(t.log is not None and t.path_info is None for t in tiles)
+    assert all(t.log is not None and t.path_info is None and t.log.layout == "dense" for t in tiles)
 
 
 def test_unlimited_depth_integrator_renders_and_differentiates():

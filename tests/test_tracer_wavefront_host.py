@@ -187,21 +187,31 @@ def test_wavefront_tiles_follow_the_sharding():
     assert len(sc.trace_paths(sensor=0, seed=1, spp=8, max_depth=3)) == n_total // 64
 
 
+@pytest.mark.parametrize("layout", ["interleaved", "dense"])
 @pytest.mark.parametrize("tracer", ["mega", "wavefront"])
 @pytest.mark.parametrize("max_depth,K,occluder", [(5, 4, False), (3, 3, True), (2, 1, True)])
-def test_packed_log_is_the_per_field_log_in_another_layout(tracer, max_depth, K, occluder):
+def test_packed_log_is_the_per_field_log_in_another_layout(tracer, max_depth, K, occluder, layout):
     """EPSM_TRACE_PACKED_LOG: the tracer writes the backward kernel's native layout (one 128-byte record per path
     vertex, rays (N,12), one flag word per path: include/epsm.h EpsmPackedLog).  Bit for bit the per-field log repacked
-    by PackedLog.from_trace wherever a vertex is live; the flag words agree everywhere."""
+    by PackedLog.from_trace wherever a vertex is live; the flag words agree everywhere.  Both placements of the rays and the
+    records (ABI v7: one interleaved block of K + 1 cache lines per path -- rays at word 0, records from word 16 -- or two
+    dense arrays): the tracer writes through the strides of EpsmRecordOut, nothing lands outside its words."""
     from epsm_mitsuba3_amd.records import PackedLog
     res, spp = 12, 8
     sc = _rich_scene(res, spp, point_light=True, occluder=occluder)
     sc.tracer = tracer
+    sc.log_layout = layout
     n = res * res * spp
     a = sc._trace(0, seed=5, spp=spp, max_depth=max_depth, K=K, lo=0, hi=n)
     b = sc._trace_packed(0, seed=5, spp=spp, max_depth=max_depth, K=K, lo=0, hi=n)
-    want = PackedLog.from_trace(a)
+    want = PackedLog.from_trace(a, layout=layout)
     got = b.log
+    assert got.layout == want.layout == layout
+    if layout == "interleaved":
+        assert (got.ray_stride, got.path_stride) == (32 * (K + 1), 32 * (K + 1))
+        assert got.verts.data_ptr() - got.rays.data_ptr() == 64
+    else:
+        assert (got.ray_stride, got.path_stride) == (12, 32 * K) and got.rays.is_contiguous() and got.verts.is_contiguous()
     assert torch.equal(want.rays.view(torch.int32), got.rays.view(torch.int32))
     assert torch.equal(want.flags, got.flags)
     assert torch.equal(a.radiance, b.radiance) and torch.equal(a.film_pos, b.film_pos) and torch.equal(a.valid, b.valid)
