@@ -183,7 +183,34 @@ struct LdsTable {
             slot = next(slot);
         }
         if (placed) add_at(slot, x, y, z);
+#ifdef EPSM_KO_NOOVERFLOW                       // (knock-out build: what the rows that find no slot cost; results are wrong)
+        else if (key == 0x12345678u) global_add(key, x, y, z);
+#else
         else global_add(key, x, y, z);          // crowded neighbourhood: go straight to HBM (out of line it cost 11 spilled registers: 2.55 -> 2.70 ms)
+#endif
+    }
+    // add() without the way out: false = the row found no slot (or does not fit a fixed-point row) and is still owed to the
+    // buffers (drain_queue collects such rows and sends x, y, z of a row as ONE atomic request, global_add_component)
+    __device__ __forceinline__ bool try_add(uint32_t key, float x, float y, float z) const {
+        if (x == 0.f && y == 0.f && z == 0.f) return true;
+        if (!Acc::fits(x, y, z)) return false;
+        uint32_t slot = home(key);
+        bool placed = false;
+#pragma unroll 1
+        for (int probe = 0; probe < kMaxProbe; ++probe) {
+            const uint32_t prev = atomicCAS(&keys[slot], kEmptyKey, key);
+            if (prev == kEmptyKey || prev == key) { placed = true; break; }
+            slot = next(slot);
+        }
+        if (placed) add_at(slot, x, y, z);
+        return placed;
+    }
+    // component c (0..2) of a row straight to the buffers; alpha rows carry one component
+    __device__ __forceinline__ void global_add_component(uint32_t key, int c, float v) const {
+        if (!adds_something(v)) return;
+        if (key < V) atomicAdd(gpos + 3 * (int64_t) key + c, v);
+        else if (key < 2u * V) atomicAdd(gnrm + 3 * (int64_t) (key - V) + c, v);
+        else if (c == 0) atomicAdd(galpha + (key - 2u * V), v);
     }
     // all threads of the workgroup; barriers inside
     __device__ __forceinline__ void clear() const {
@@ -385,23 +412,51 @@ struct QItem { uint32_t key; float x, y, z; };
 // LDS round trips -- measured on the constraint-parallel kernel, headline slab, ms: kU = 1 2.89, 2 2.75, 4 3.02, 8 3.46
 // against 2.66 for the loop below: the drain is not waiting for its own latency.)
 template <typename Table>
-__device__ __forceinline__ void drain_queue(const QItem *q, int n, Table T) {
+__device__ __forceinline__ void drain_queue(QItem *q, int n, Table T) {
     // q is LDS: say so.  Through the generic pointer of this out-of-line function the read was a FLAT load, whose
     // s_waitcnt vmcnt(0) also waits for every global load in flight -- the vertex records the path code had
     // prefetched -- at each drain.
-    typedef __attribute__((address_space(3))) const uint32_t LdsWord;
+    typedef __attribute__((address_space(3))) uint32_t LdsWord;
     LdsWord *ql = (LdsWord *) q;
     // (Two items per lane and turn, their compare-and-swaps in flight together -- a probe is an LDS round trip the lane
     // waits for -- was slower: headline slab 3.67 -> 4.16 ms, config 2 4.19 -> 4.73, pool caustic 3.79 -> 4.03.)
+    // Rows that find no slot within kMaxProbe buckets (a window whose distinct rows outnumber the table: the deep vertices of
+    // the caustic and specular profiles) used to leave from the lane that held them, three float atomics = three requests per
+    // row.  Now the wave collects them -- compacted into the slots of the queue this turn has just read -- and sends them
+    // FOUR LANES PER ROW, x, y, z side by side in one instruction, as the flush does: one request per row (knock-out of the
+    // overflow rows: pool slab 2.59 -> 2.23 ms, dense specular slab 13.7 -> 6.0: that is what they cost).
+    const int lane = lane_id();
 #pragma unroll 1
-    for (int idx = lane_id(); idx < n; idx += 64) {
-        QItem it;
-        it.key = ql[4 * idx]; it.x = __uint_as_float(ql[4 * idx + 1]); it.y = __uint_as_float(ql[4 * idx + 2]); it.z = __uint_as_float(ql[4 * idx + 3]);
+    for (int base = 0; base < n; base += 64) {                       // wave-uniform
+        const int idx = base + lane;
+        bool owed = false;
+        QItem it; it.key = 0u; it.x = it.y = it.z = 0.f;
+        if (idx < n) {
+            it.key = ql[4 * idx]; it.x = __uint_as_float(ql[4 * idx + 1]); it.y = __uint_as_float(ql[4 * idx + 2]); it.z = __uint_as_float(ql[4 * idx + 3]);
 #ifndef EPSM_KO_NOINSERT                   // (knock-out build: what the insertion into the table costs)
-        T.add(it.key, it.x, it.y, it.z);
+            owed = !T.try_add(it.key, it.x, it.y, it.z);
 #else
-        if (it.key == 0x12345678u && it.x == 1.2345f) T.add(it.key, it.x, it.y, it.z);
+            if (it.key == 0x12345678u && it.x == 1.2345f) owed = !T.try_add(it.key, it.x, it.y, it.z);
 #endif
+        }
+#ifdef EPSM_KO_NOOVERFLOW                  // (knock-out build: what the rows that find no slot cost; results are wrong)
+        owed = owed && it.key == 0x12345678u;
+#endif
+        const unsigned long long m = __ballot(owed);
+        if (m != 0ull) {                                             // wave-uniform, rare where the table holds the window's rows
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
+            if (owed) { LdsWord *d = ql + 4 * (base + rank); d[0] = it.key; d[1] = __float_as_uint(it.x); d[2] = __float_as_uint(it.y); d[3] = __float_as_uint(it.z); }
+            const int n_owed = __popcll(m);
+            __builtin_amdgcn_wave_barrier();                         // (LDS operations of one wave execute in order; this keeps the compiler from moving the reads up)
+#pragma unroll 1
+            for (int j0 = 0; j0 < n_owed; j0 += 16) {
+                const int j = j0 + (lane >> 2), c = lane & 3;
+                if (j < n_owed && c < 3) {
+                    const uint32_t key = ql[4 * (base + j)];
+                    T.global_add_component(key, c, __uint_as_float(ql[4 * (base + j) + 1 + c]));
+                }
+            }
+        }
     }
 }
 
