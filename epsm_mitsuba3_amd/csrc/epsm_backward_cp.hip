@@ -1058,11 +1058,12 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
 #ifndef EPSM_CP_SLOTS
 #define EPSM_CP_SLOTS 768
 #endif
-    // `manifold_caustic` walks windows of 1024 paths: its paths carry three to four constraint vertices with normal and alpha rows
-    // each, and 2048 of them overflow the 960-row table into global atomics (pool slab 3.18 -> 2.80 ms; `manifold`, whose
-    // windows hold fewer rows, loses 5 % with the smaller ones -- every class of paths ends in a partly filled round).
+    // `manifold_caustic` walked windows of 1024 paths while a row that found no slot in the table cost three atomic requests (its paths
+    // carry three to four constraint vertices with normal and alpha rows each, and 2048 of them overflow the 960-row table: pool slab
+    // 3.18 -> 2.80 ms then).  With one request per such row (epsm_wave_scatter.h, drain_queue) and four probes the larger window wins
+    // again -- fewer partly filled rounds: pool slab 2.27 -> 2.18 ms.
 #ifndef EPSM_CP_WINDOW_CAUSTIC
-#define EPSM_CP_WINDOW_CAUSTIC 1024
+#define EPSM_CP_WINDOW_CAUSTIC 2048
 #endif
     constexpr int kSmall = 1024, kSlots = EPSM_CP_SLOTS;
     constexpr int kLargeRT = VARIANT == EPSM_VARIANT_MANIFOLD ? EPSM_CP_WINDOW : EPSM_CP_WINDOW_CAUSTIC;      // paths per window of a large wavefront

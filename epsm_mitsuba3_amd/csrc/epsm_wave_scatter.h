@@ -67,7 +67,14 @@ __device__ __forceinline__ V3<float> seg_sum3(V3<float> v, int head) {
 // Key space: row r of buffer `which` (0 pos, 1 nrm) -> which*V + r; alpha slot b -> 2V + b.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
-constexpr int kMaxProbe = 8;
+// Buckets an insertion tries before its row leaves for the buffers directly.  8 while such a row cost three atomic requests; since
+// drain_queue sends it as one (four lanes per row), a crowded neighbourhood is better left early -- headline / pool / dense
+// specular slab, ms: 8 probes 1.82 / 2.38 / 6.56, 16: 1.90 / 2.61 / 7.72, 4: 1.79 / 2.27 / 6.17, 3: 1.79 / 2.18* / 7.09, 2: 1.79 /
+// 2.25 / 24.8 (the table no longer holds the rows the window shares)   (*: with windows of 2048 paths)
+#ifndef EPSM_MAX_PROBE
+#define EPSM_MAX_PROBE 4
+#endif
+constexpr int kMaxProbe = EPSM_MAX_PROBE;
 
 // What a table row sums in.  float: 12 B of values per row, ds_add_f32.  Fixed64: 64-bit fixed point with 44 fractional
 // bits, 24 B per row, ds_add_u64: a resolution of 5.7e-14 -- float32's own on terms down to 1e-6, the terms being clamped to
@@ -198,7 +205,12 @@ struct LdsTable {
         bool placed = false;
 #pragma unroll 1
         for (int probe = 0; probe < kMaxProbe; ++probe) {
+#ifdef EPSM_READ_BEFORE_CAS                // (A/B build: a plain read first -- most rows of a window are already there)
+            uint32_t prev = keys[slot];
+            if (prev == kEmptyKey) prev = atomicCAS(&keys[slot], kEmptyKey, key);
+#else
             const uint32_t prev = atomicCAS(&keys[slot], kEmptyKey, key);
+#endif
             if (prev == kEmptyKey || prev == key) { placed = true; break; }
             slot = next(slot);
         }

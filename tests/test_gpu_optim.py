@@ -85,7 +85,8 @@ def test_body_pose_converges_and_stays_at_the_reference_settings():
     chained with sum(verts * grad).backward(); Adam lr 0.01, match_Sinkhorn, pose clamped to +-0.1, primal and differential
     seeds de-correlated (util.py:505-513); the first 200 of its 1000 iterations.  The assertions are on the END of the history
     and on its minimum, at what is measured plus ~5 % (a threshold must not encode a loop that got 15 % worse):
-    6.0 -> 2.5 cm around iteration 30 (measured 0.42-0.43 of the start), then 3.4-3.5 cm and staying (last-20 mean 0.58-0.60,
+    6.0 -> 2.5-2.9 cm around iteration 30 (the loop is chaotic in the order of its float atomics: 0.42-0.48 of the start over eight
+    runs of three builds of the kernel, round 5), then 3.4-3.5 cm and staying (last-20 mean 0.58-0.60,
     maximum of the last 60 iterations 0.61).  Why it stays there is decided in profiles/r04_i_human_fd.txt: at the
     start EPSM's pose field is a descent direction of the matcher's own loss (cosine 0.77 with its finite differences), at the
     plateau it is not (-0.34 .. -0.45 on the best-determined angles the clamp does not hold) -- the occluder term, which the
@@ -99,7 +100,7 @@ def test_body_pose_converges_and_stays_at_the_reference_settings():
     assert len(hist) == 201 and 0.05 < hist[0] < 0.07
     print("last-20 mean / start", np.mean(hist[-20:]) / hist[0], "max of last 60 / start", max(hist[-60:]) / hist[0], "best", min(hist) / hist[0])
     assert np.mean(hist[-20:]) < 0.63 * hist[0] and max(hist[-60:]) < 0.65 * hist[0], hist[::10]
-    assert min(hist) < 0.47 * hist[0], hist[::10]
+    assert min(hist) < 0.51 * hist[0], hist[::10]
     assert float(opt["pose"].detach().abs().max()) <= human.POSE_CLAMP + human.lr * 1.5
 
 
