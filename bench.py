@@ -718,6 +718,8 @@ def main():
             _phase("cpu baseline done")
         if world == 1 and args.config == 0 and not (args.soa or args.two_stage or args.separate_tangent or args.no_secondary):
             result["configs_1"] = secondary_config_leg(2, dev)          # BASELINE.json configs[1]: round 1's driver line
+            # BASELINE.json configs[2]: `manifold_caustic` on deep specular chains, ONE slab of its sixteen (the slab tools/gpu_cp_ko.sh times)
+            result["configs_2"] = secondary_config_leg(3, dev)
             # the workload where SURVEY's algorithmic bytes ARE the live bytes: no diffuse vertex, five constraint vertices and
             # ~50 parameter rows per path
             result["dense_specular"] = secondary_config_leg(2, dev, profile_override="specular",
