@@ -668,9 +668,17 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
         // were 1.6 ms and 1.5 ms per 2^24-path slab, and their sum when a wave did one after the other).
         // (Round r goes to wave r mod 4.  Handing the rounds out dynamically -- a wave takes the next one nobody has, one LDS
         // atomic per round -- measured 2.15 against 2.08 ms; the classes with the longest chains first, so that a window's tail
-        // is made of cheap rounds: 6.3 ms, three times slower, for no reason found.)
+        // is made of cheap rounds: 6.3 ms, three times slower -- 9.8 ms in round 5, -DEPSM_CP_REVERSE_ROUNDS.  The reason: the ORDER fills the table.  The light
+        // rounds come first and bring the rows a window shares -- the first-hit triangles of its pixels -- into their home slots; the deep vertices' rows,
+        // which nobody shares, come last and leave for the buffers directly when their neighbourhood is full.  Reversed, the unshared rows take the slots
+        // and the SHARED ones overflow: thousands of float atomics on the same few addresses.)
         const int n_rounds = RS.rb[kKeys];
-        LaneId L = RS.lane_of(wv, lane);
+#ifdef EPSM_CP_REVERSE_ROUNDS            // (A/B build: the rounds of the longest chains first, the window's tail made of light rounds)
+#define EPSM_RR(x) (n_rounds - 1 - (x))
+#else
+#define EPSM_RR(x) (x)
+#endif
+        LaneId L = RS.lane_of(EPSM_RR(wv), lane);
 #ifdef EPSM_CP_PREFETCH
         GeoFetch Xp; AddrFetch Ap;
         fetch_zero(Xp, Ap);
@@ -966,7 +974,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             // flight, every 64 bytes a wave reads is one of them for as long as its latency, and a touched line is fetched TWICE
             // through that queue -- by the touch at HBM latency, again by the round that uses it at L2 latency, the L1 having lost
             // it in between.  TCP_PENDING_STALL_CYCLES: 65 % of the kernel; without the touch 2.046 -> 1.970 ms.)
-            const LaneId Ln = RS.lane_of(r + kWaves, lane);          // (past the last round: no lane has a path)
+            const LaneId Ln = RS.lane_of(EPSM_RR(r + kWaves), lane);  // (past the last round: no lane has a path)
 #ifdef EPSM_CP_PREFETCH
             // (issued here, behind the table rows' loads -- vmcnt counts in order: waiting for those does not wait for these -- and
             // not earlier: before the solve the same 36 registers spill 117)
