@@ -76,8 +76,24 @@ __device__ __forceinline__ int div_small(int lane, int c) {
     return (lane * inv) >> 16;
 }
 
+// A lane's value of the lane below / above it.  __shfl_up / __shfl_down are ds_bpermute_b32 -- a trip through the LDS crossbar, ~50 of
+// them per round with a constraint chain, each waited for inside the recursions' dependency chains, on the same LDS pipe as the other
+// waves' table atomics; the whole-wave shifts of the data-parallel primitives (DPP wave_shr:1 / wave_shl:1, gfx9 only) do the same in
+// ONE vector instruction without leaving the SIMD.  With `old` = the lane's own value and bound_ctrl off, lane 0 / lane 63 keep
+// theirs, as __shfl_up / __shfl_down leave them.  (-DEPSM_CP_NO_DPP_SHIFT: the shuffles.)
+#ifndef EPSM_CP_NO_DPP_SHIFT
+__device__ __forceinline__ int up1_bits(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }      // wave_shr:1
+__device__ __forceinline__ int down1_bits(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }    // wave_shl:1
+__device__ __forceinline__ float up1(float v) { return __int_as_float(up1_bits(__float_as_int(v))); }
+__device__ __forceinline__ float down1(float v) { return __int_as_float(down1_bits(__float_as_int(v))); }
+__device__ __forceinline__ int up1(int v) { return up1_bits(v); }
+__device__ __forceinline__ int down1(int v) { return down1_bits(v); }
+__device__ __forceinline__ uint32_t up1(uint32_t v) { return (uint32_t) up1_bits((int) v); }
+__device__ __forceinline__ uint32_t down1(uint32_t v) { return (uint32_t) down1_bits((int) v); }
+#else
 template <typename T> __device__ __forceinline__ T up1(T v) { return __shfl_up(v, 1); }
 template <typename T> __device__ __forceinline__ T down1(T v) { return __shfl_down(v, 1); }
+#endif
 __device__ __forceinline__ V2<float> up1(V2<float> v) { return mk2<float>(up1(v.x), up1(v.y)); }
 __device__ __forceinline__ M2<float> up1(M2<float> m) { M2<float> o; o.a = up1(m.a); o.b = up1(m.b); o.c = up1(m.c); o.d = up1(m.d); return o; }
 __device__ __forceinline__ V3<float> down1(V3<float> v) { return mk3<float>(down1(v.x), down1(v.y), down1(v.z)); }

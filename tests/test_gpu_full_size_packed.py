@@ -31,7 +31,9 @@ def _cut(trace, a, n):
                           n_paths_total=trace.n_paths_total)
 
 
-@pytest.mark.parametrize("variant,profile", [("manifold", "bathroom"), ("manifold_caustic", "pool")])
+# ("manifold", "specular"): bench.py's dense_specular slab -- no diffuse vertex, ~40 rows per path, most of which find no slot in the
+# LDS table and leave four lanes per row (epsm_wave_scatter.h, drain_queue): the slab that exercises that way out at full size
+@pytest.mark.parametrize("variant,profile", [("manifold", "bathroom"), ("manifold_caustic", "pool"), ("manifold", "specular")])
 def test_headline_slab_on_the_timed_kernel(variant, profile):
     import epsm_mitsuba3_amd as epsm
     from epsm_mitsuba3_amd import _lib
