@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
         // than workgroups only beyond 2^31 paths)
         if (wi + 1 < windows_per_block && win + 1 < n_windows) T.flush();
     }
-    T.flush();
+    T.flush(true);
     if (DMODE == kTangentsInKernel && F.grad_o_sum) {      // epsm.py:260-261: d/d ray.o = -sum grad_d, one atomic triple per workgroup
         __shared__ float s_part[kWaves][3];
         float sx = -gd_acc.x, sy = -gd_acc.y, sz = -gd_acc.z;

@@ -235,7 +235,8 @@ struct LdsTable {
     // Lanes 4e..4e+2 add the x,y,z of row e in ONE wave instruction, so the three
     // components of a row (and neighbouring rows of a 64-B line) leave as one atomic
     // request instead of three (TCC_EA0_ATOMIC: -3x on the flush).
-    __device__ __forceinline__ void flush() const {
+    // `last`: the workgroup's final flush -- the table is not used again, so it is not cleared (one window per workgroup: every flush)
+    __device__ __forceinline__ void flush(bool last = false) const {
         __syncthreads();
         for (int q = threadIdx.x; q < 4 * kTableSize; q += blockDim.x) {
             const int e = q >> 2, c = q & 3;
@@ -253,6 +254,7 @@ struct LdsTable {
                 }
             }
         }
+        if (last) return;                                            // (workgroup-uniform)
         __syncthreads();
         for (int e = threadIdx.x; e < kTableSize; e += blockDim.x) {
             keys[e] = kEmptyKey; vals[3 * e] = Val(0); vals[3 * e + 1] = Val(0); vals[3 * e + 2] = Val(0);

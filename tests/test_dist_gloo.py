@@ -15,6 +15,17 @@ from epsm_mitsuba3_amd.params import ParamGrads
 from epsm_mitsuba3_amd.synthetic_scene import SyntheticScene
 
 
+def _ship(*items):
+    """Tensors cross the queue BY VALUE (numpy arrays pickle inline).  A torch tensor crosses as a handle the receiver redeems from
+    the sender's process -- which may have left by then: FileNotFoundError / ConnectionResetError under load (sanitizer run, xdist)."""
+    return tuple(i.detach().cpu().numpy().copy() if torch.is_tensor(i) else i for i in items)
+
+
+def _unship(item):
+    import numpy as np
+    return tuple(torch.from_numpy(i) if isinstance(i, np.ndarray) else i for i in item)
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -47,7 +58,7 @@ def _worker(rank, world, port, q):
     assert (r, w) == (rank, world) and edist.world() == (rank, world)
     params, offsets = _rank_work(rank, world)
     edist.allreduce_param_grads(params.flat)
-    q.put((rank, offsets, params.flat.clone()))
+    q.put(_ship(rank, offsets, params.flat))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,7 +79,7 @@ def test_two_rank_backward_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=180) for _ in procs]
+    got = [_unship(q.get(timeout=180)) for _ in procs]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -110,7 +121,7 @@ def _accumulate_worker(rank, world, port, q):
     integ.render_backward(scene, params, _grad_image(), seed=5)
     once = params.flat.clone()
     integ.render_backward(scene, params, _grad_image(), seed=5)      # dr.backward accumulates: NOT zeroed in between
-    q.put((rank, once, params.flat.clone()))
+    q.put(_ship(rank, once, params.flat))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -124,7 +135,7 @@ def test_two_rank_render_backward_accumulates_without_rescaling():
     procs = [ctx.Process(target=_accumulate_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    got = sorted([_unship(q.get(timeout=180)) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -145,7 +156,7 @@ def _render_worker(rank, world, port, q):
     sc = on_host(floor_and_light(res=16, device="cpu"))
     sc.tile_paths = 256                                  # 16*16*4 = 1024 paths -> 4 tiles, 2 per rank
     img = sc.render_primal(sensor=0, seed=4, spp=4, max_depth=3)       # rank / world from the process group
-    q.put((rank, img.clone()))
+    q.put(_ship(rank, img))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -162,7 +173,7 @@ def test_two_rank_primal_render_matches_single_process():
     procs = [ctx.Process(target=_render_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    got = sorted([_unship(q.get(timeout=180)) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -196,7 +207,7 @@ def _reparam_worker(rank, world, port, q):
                       LOCAL_RANK=str(rank))
     edist.init_from_env("gloo")
     once, twice = _reparam_single(512)
-    q.put((rank, once, twice))
+    q.put(_ship(rank, once, twice))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -211,7 +222,7 @@ def test_two_rank_prb_reparam_matches_single_process():
     procs = [ctx.Process(target=_reparam_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    got = sorted([_unship(q.get(timeout=240)) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
