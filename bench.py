@@ -336,7 +336,10 @@ def real_scene_leg(variant, res, spp, dev):
     total = timed(lambda: integ.render_backward(scene, params, grad_in, seed=1))
 
     # as render_backward traces: native log, gradient-dead paths retired (EPSM_TRACE_GRADIENT_ONLY, include/epsm_trace.h)
-    kw = dict(sensor=2, seed=1, spp=spp, max_depth=clutter.max_depth, sparse_log=True, packed_log=True, gradient_only=variant)
+    # ... and with the first hit's share of the backward pass done by the stage that shades it (EPSM_TRACE_FUSE_FIRST_HIT: the paths
+    # without a chain -- 94 % of this scene's -- are neither logged nor read again); `trace_and_log_ms` includes that work
+    kw = dict(sensor=2, seed=1, spp=spp, max_depth=clutter.max_depth, sparse_log=True, packed_log=True, gradient_only=variant,
+              first_hit=(grad_in, params, integ.outlier_clip, True) if integ.fuse_first_hit else None)
 
     def trace_only(**over):
         for tr in scene.iter_traces(**dict(kw, **over)):
@@ -353,6 +356,7 @@ def real_scene_leg(variant, res, spp, dev):
         trace_only(gradient_only=None); torch.cuda.synchronize(); queues_full = scene.wavefront_queue_lengths()
         scene.wavefront_tail = True
     tiles = list(scene.iter_traces(**kw))
+    tiles_fused = all(t.log.first_hit_done for t in tiles)
 
     def backward_only():
         for tr in tiles:
@@ -363,7 +367,7 @@ def real_scene_leg(variant, res, spp, dev):
     return {"scene": f"exp/clutter.py: floor + 100 tessellated spheres + area light = {scene.T} triangles", "variant": variant,
             "paths": n, "max_depth": clutter.max_depth, "tracer": "wavefront" if scene.use_wavefront(n_tile) else "one launch",
             "grad_image_ms": total, "trace_and_log_ms": trace, "backward_ms": back, "paths_per_s": n / (total * 1e-3),
-            "full_trace_and_log_ms": trace_full,
+            "full_trace_and_log_ms": trace_full, "first_hit_fusion": bool(tiles_fused),
             "paths_alive_into_bounce": {"gradient_only": queues["alive"][1:clutter.max_depth] if queues else None,
                                         "full": queues_full["alive"][1:clutter.max_depth] if queues_full else None},
             "visibility_rays_per_bounce": {"gradient_only": queues["shadow"][:clutter.max_depth] if queues else None,

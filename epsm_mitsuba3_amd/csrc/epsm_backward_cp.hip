@@ -555,7 +555,8 @@ __device__ __forceinline__ void fetch_zero(GeoFetch &X, AddrFetch &A) {
 #define EPSM_CP_WINDOW 2048
 #endif
 
-template <int VARIANT, int DMODE, bool PACKED, bool FLOAT_ROWS, int kWindow>
+// DROP: paths without any term take no lane (see kSortKeys below)
+template <int VARIANT, int DMODE, bool PACKED, bool FLOAT_ROWS, int kWindow, bool DROP>
 __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel(FusedArgs F, int dcols, int64_t windows_per_block, int window) {
     // float rows where the window's distinct rows need the larger table (epsm_wave_scatter.h, AccFixed64)
     // Rows of the accumulator table: 64-bit fixed point (epsm_wave_scatter.h, AccFixed64: the LDS integer atomic inserts an
@@ -583,9 +584,13 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
     const Emitter<Table> E{F, T, Q};
     if (!PACKED && threadIdx.x < F.K) { s_ptrs.v[threadIdx.x] = F.g.v[threadIdx.x]; s_ptrs.s[threadIdx.x] = F.s[threadIdx.x]; }
     constexpr int kPer = (kWindow + kThreads - 1) / kThreads;        // paths a thread plans
-    // classes the window is sorted into: the kKeys classes of the rounds; with the caller's tangents one more, the paths without a
-    // term, which then take no lane of any round (with in-kernel tangents they give their share of d/d ray.o on a lane of class 0)
-    constexpr int kSortKeys = DMODE == kTangentsInKernel ? kKeys : kKeys + 1;
+    // classes the window is sorted into: the kKeys classes of the rounds; with DROP one more, the paths without a term, sorted behind
+    // the others and handed to no round.  DROP is set with the caller's tangents, and with in-kernel tangents when the caller did not
+    // ask for d loss / d ray.o = -sum grad_d (grad_o_sum == NULL): the reference forms that sum only `if dr.grad_enabled(ray.o)`
+    // (epsm.py:258-259), i.e. when the sensor is being optimised -- EPSM/exp/bedroom.py, not bathroom.py and the others -- and without
+    // it such a path (27 % of the bathroom profile) has nothing to give: no lane, no rays read.  Otherwise it gives its share of the
+    // sum on a lane of class 0.  (A template parameter: as a run-time switch it cost the camera-gradient form 9 %, 1.78 -> 1.95 ms.)
+    constexpr int kSortKeys = DROP ? kKeys + 1 : kKeys;
     constexpr int kStride = kPer * kWaves, kEntries = kSortKeys * kStride;
     __shared__ uint32_t s_plan[kWindow];
     __shared__ uint16_t s_perm[kWindow];
@@ -1121,13 +1126,18 @@ hipError_t launch(const FusedArgs &F0, int dcols, hipStream_t s) {
     // not for a caller who switched the clamp off
     const bool float_rows = !(F.g.clip <= 1.f);
     // (the small form's instantiation plans at most 1024 paths per window: the planning loops are unrolled over kWindow / 256)
+    const bool drop = DMODE != kTangentsInKernel || F.grad_o_sum == nullptr;      // (paths without a term take no lane: kernel, kSortKeys)
+#define EPSM_CP_LAUNCH(FLOAT_ROWS_, WINDOW_, DROP_) \
+    hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, FLOAT_ROWS_, WINDOW_, (DROP_) || DMODE != kTangentsInKernel>), \
+                       dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window)
     if (float_rows) {
-        if (small) hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, true, kSmall>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
-        else hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, true, kLarge>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
+        if (small) { if (drop) EPSM_CP_LAUNCH(true, kSmall, true); else EPSM_CP_LAUNCH(true, kSmall, false); }
+        else { if (drop) EPSM_CP_LAUNCH(true, kLarge, true); else EPSM_CP_LAUNCH(true, kLarge, false); }
     } else {
-        if (small) hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, false, kSmall>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
-        else hipLaunchKernelGGL((epsm_backward_cp_kernel<VARIANT, DMODE, PACKED, false, kLarge>), dim3((unsigned) blocks), dim3(kThreads), 0, s, F, dcols, per, window);
+        if (small) { if (drop) EPSM_CP_LAUNCH(false, kSmall, true); else EPSM_CP_LAUNCH(false, kSmall, false); }
+        else { if (drop) EPSM_CP_LAUNCH(false, kLarge, true); else EPSM_CP_LAUNCH(false, kLarge, false); }
     }
+#undef EPSM_CP_LAUNCH
     hipError_t le = hipGetLastError();
     if (le == hipSuccess && F.rep && !F.rep_done) {
         const int64_t n = 6 * F.V + F.B + 3;

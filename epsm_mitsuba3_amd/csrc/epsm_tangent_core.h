@@ -18,11 +18,10 @@ struct TangentIn {
 };
 struct Tangent { float db0, db1; V3<float> dp, gd; };     // d b0, d b1, d si.p, grad_d
 
-// the arithmetic, on values
-EPSM_HD Tangent tangent_from(V3<float> o, V3<float> d, V3<float> dx, V3<float> dy, float gx, float gy,
-                             V3<float> p0, V3<float> p1, V3<float> p2, bool active) {
+// the arithmetic, on values; `gd` = the image-space motion of the ray direction, (d_x - d) gx + (d_y - d) gy  (epsm.py:255)
+EPSM_HD Tangent tangent_from_gd(V3<float> o, V3<float> d, V3<float> gd, V3<float> p0, V3<float> p1, V3<float> p2, bool active) {
     Tangent t;
-    t.gd = (dx - d) * gx + (dy - d) * gy;
+    t.gd = gd;
     t.db0 = t.db1 = 0.f;
     t.dp = zero3<float>();
     if (active) {
@@ -43,6 +42,10 @@ EPSM_HD Tangent tangent_from(V3<float> o, V3<float> d, V3<float> dx, V3<float> d
         t.dp = e1 * du + e2 * dv;                                  // d (p0 b0 + p1 b1 + p2 b2)
     }
     return t;
+}
+EPSM_HD Tangent tangent_from(V3<float> o, V3<float> d, V3<float> dx, V3<float> dy, float gx, float gy,
+                             V3<float> p0, V3<float> p1, V3<float> p2, bool active) {
+    return tangent_from_gd(o, d, (dx - d) * gx + (dy - d) * gy, p0, p1, p2, active);
 }
 
 EPSM_HD Tangent first_vertex_tangent(const TangentIn &A, int64_t i, const float *p0a, const float *p1a, const float *p2a,

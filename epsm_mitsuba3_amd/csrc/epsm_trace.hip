@@ -129,6 +129,72 @@ __global__ __launch_bounds__(kWfThreads) void epsm_wf_tail_kernel(TraceArgs A, W
     for (int64_t q = (int64_t) blockIdx.x * kWfThreads + threadIdx.x; q < count; q += (int64_t) gridDim.x * kWfThreads)
         wf_tail(A, W, (int64_t) W.queue[b & 1][q], b, s_stack + threadIdx.x, kWfThreads);
 }
+// EPSM_TRACE_FUSE_FIRST_HIT: what the lanes of a wave -- at bounce 0 the samples of one pixel or of a few neighbouring ones -- give the
+// backward pass: every path's grad_d into the wave's share of -sum grad_d, and the first-vertex rows of the paths retired at their
+// first hit.  Lanes on the same triangle are summed first (butterfly over the wave, in up to four turns of "the first lane still
+// owing and everybody on its triangle"), one lane adds the sum; what is left after four turns adds for itself.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ void first_hit_add(float *p, float v) { if (v != 0.f && fabsf(v) < __builtin_inff()) atomicAdd(p, v); }
+__device__ __forceinline__ void first_hit_scatter(const TraceArgs &A, const WfState &W, const WfFirstHit &fh) {
+    const int lane = threadIdx.x & 63;
+    if (A.fh.grad_o_sum) {
+        // epsm.py:258-261: d / d ray.o = -sum grad_d.  One triple per WAVE on the three words themselves was 2 ms per 2^24 paths
+        // (262 144 same-address float atomics retire one at a time); the waves add to one of 256 slots of the workspace, which
+        // epsm_wf_first_hit_finish_kernel sums into the caller's three words.
+        const float sx = wave_sum(fh.gd.x), sy = wave_sum(fh.gd.y), sz = wave_sum(fh.gd.z);
+        if (lane < 3) first_hit_add(W.fh_partial + 4 * ((blockIdx.x * (kWfChunk / 64) + (threadIdx.x >> 6)) % kWfFirstHitSlots) + lane,
+                                    lane == 0 ? sx : lane == 1 ? sy : sz);
+    }
+    bool owing = fh.rows.on;
+#pragma unroll 1
+    for (int turn = 0; turn < 4; ++turn) {
+        const unsigned long long m = __ballot(owing);
+        if (m == 0ull) return;
+        const int leader = __ffsll((long long) m) - 1;
+        const uint32_t k0 = (uint32_t) __shfl((int) fh.rows.key[0], leader), k1 = (uint32_t) __shfl((int) fh.rows.key[1], leader),
+                       k2 = (uint32_t) __shfl((int) fh.rows.key[2], leader);
+        const bool mine = owing && fh.rows.key[0] == k0 && fh.rows.key[1] == k1 && fh.rows.key[2] == k2;
+        float v[9];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { v[3 * j] = mine ? fh.rows.val[j].x : 0.f; v[3 * j + 1] = mine ? fh.rows.val[j].y : 0.f; v[3 * j + 2] = mine ? fh.rows.val[j].z : 0.f; }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) v[c] = wave_sum(v[c]);
+        // lanes 0..8 add one component each: x, y, z of a row side by side -> one atomic request per row
+        if (lane < 9) {
+            const int j = lane / 3, c = lane - 3 * j;
+            const uint32_t row = j == 0 ? k0 : j == 1 ? k1 : k2;
+            float val = v[0];
+#pragma unroll
+            for (int e = 1; e < 9; ++e) val = lane == e ? v[e] : val;
+            first_hit_add(A.fh.grad_pos + 3 * (int64_t) row + c, val);
+        }
+        if (mine) owing = false;
+    }
+    if (owing) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float *p = A.fh.grad_pos + 3 * (int64_t) fh.rows.key[j];
+            first_hit_add(p, fh.rows.val[j].x); first_hit_add(p + 1, fh.rows.val[j].y); first_hit_add(p + 2, fh.rows.val[j].z);
+        }
+    }
+}
+__global__ __launch_bounds__(kWfFirstHitSlots) void epsm_wf_first_hit_finish_kernel(TraceArgs A, WfState W) {
+    __shared__ float s_sum[kWfFirstHitSlots / 64][3];
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = wave_sum(W.fh_partial[4 * threadIdx.x + c]);
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6][0] = v[0]; s_sum[threadIdx.x >> 6][1] = v[1]; s_sum[threadIdx.x >> 6][2] = v[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float t = 0.f;
+        for (int w = 0; w < kWfFirstHitSlots / 64; ++w) t += s_sum[w][threadIdx.x];
+        first_hit_add(A.fh.grad_o_sum + threadIdx.x, -t);
+    }
+}
 // (160 registers, 3 waves per SIMD; capped at 128 for 4 waves it spills 96 B/lane and is no faster.)
 // One 256-slot chunk of the queue per workgroup.  Appending the survivors to the next queue with one atomic per
 // wave on the queue's counter made this kernel 1.23 ms at 4.2 M paths whatever it computed (knock-outs: the log
@@ -140,10 +206,15 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_shade_kernel(TraceArgs A, Wf
     // (Tried: a capped grid whose workgroups take chunks in turn, as the compaction does -- the launch of a bounce nobody reaches
     // 15 -> 5 us, but the stage itself 1.08 -> 1.19 ms at 2^24 paths: the hardware's dispatch order balances better.)
     bool alive = false, shadow = false;
+    const bool fuse = b == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT);     // (kernel-uniform)
+    WfFirstHit fh;
+    fh.rows.on = false; fh.rows.key[0] = fh.rows.key[1] = fh.rows.key[2] = kNoIndex;
+    fh.rows.val[0] = fh.rows.val[1] = fh.rows.val[2] = fh.gd = zero3<float>();
     if (q < count) {
-        wf_shade(A, W, b == 0 ? q : (int64_t) W.queue[b & 1][q], b, alive, shadow);
+        wf_shade(A, W, b == 0 ? q : (int64_t) W.queue[b & 1][q], b, alive, shadow, fuse ? &fh : nullptr);
         W.flags[q] = (uint8_t) ((alive ? kWfAlive : 0) | (shadow ? kWfShadow : 0));
     }
+    if (fuse) first_hit_scatter(A, W, fh);                                    // (all lanes of the wave: the sums run over it)
     __shared__ uint32_t s_n[2][kWfChunk / 64];
     const unsigned long long ma = __ballot(alive), ms = __ballot(shadow);
     if ((threadIdx.x & 63) == 0) { s_n[0][threadIdx.x >> 6] = (uint32_t) __popcll(ma); s_n[1][threadIdx.x >> 6] = (uint32_t) __popcll(ms); }
@@ -484,8 +555,18 @@ static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene
                                    !scene->meshes || !scene->bsdfs || !scene->bvh || !scene->prim_index || !scene->tri_verts))
         return bad("NULL scene array");
     if (const char *why = epsm_host::scene_tables_invalid(scene)) return bad(why);
-    if (flags & ~(uint32_t) (EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG | EPSM_TRACE_GRADIENT_ONLY | EPSM_TRACE_GRADIENT_CAUSTIC | EPSM_TRACE_NO_TAIL))
+    if (flags & ~(uint32_t) (EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG | EPSM_TRACE_GRADIENT_ONLY | EPSM_TRACE_GRADIENT_CAUSTIC | EPSM_TRACE_NO_TAIL |
+                             EPSM_TRACE_FUSE_FIRST_HIT))
         return bad("unknown flag");
+    if (flags & EPSM_TRACE_FUSE_FIRST_HIT) {
+        if (!(flags & EPSM_TRACE_GRADIENT_ONLY) || !packed || K_log < 1) return bad("EPSM_TRACE_FUSE_FIRST_HIT needs EPSM_TRACE_GRADIENT_ONLY and EPSM_TRACE_PACKED_LOG");
+        const EpsmFirstHitBackward *f = recs[0].first_hit;
+        if (!f || !f->grad_img || !f->grad_pos || (f->T > 0 && !f->tri_table) || f->T < 0 || f->V < 0 || f->res < 1 || f->img_width < f->res ||
+            f->img_channels < 5 || (((uintptr_t) f->tri_table) & 15))
+            return bad("EPSM_TRACE_FUSE_FIRST_HIT: recs[0].first_hit needs grad_img (>= 5 channels, img_width >= res >= 1), grad_pos and a 16-byte aligned tri_table");
+        if (path_offset + N > (int64_t) f->res * f->res * spp) return bad("EPSM_TRACE_FUSE_FIRST_HIT: path range exceeds res * res * spp");
+        if (recs[0].shadow && max_depth <= 3) return bad("EPSM_TRACE_FUSE_FIRST_HIT: not with the occluder record (max_depth <= 3)");
+    }
     if ((flags & EPSM_TRACE_GRADIENT_CAUSTIC) && !(flags & EPSM_TRACE_GRADIENT_ONLY)) return bad("EPSM_TRACE_GRADIENT_CAUSTIC modifies EPSM_TRACE_GRADIENT_ONLY");
     if ((flags & EPSM_TRACE_GRADIENT_ONLY) && K_log < 1) return bad("EPSM_TRACE_GRADIENT_ONLY needs a vertex log (K_log >= 1)");
     memset(&A, 0, sizeof(A));
@@ -504,6 +585,7 @@ static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene
         A.rec[k] = r;
     }
     trace_args_log_strides(A);
+    if (flags & EPSM_TRACE_FUSE_FIRST_HIT) A.fh = *recs[0].first_hit;
     return EPSM_OK;
 }
 
@@ -516,6 +598,7 @@ extern "C" int epsm_trace_paths(const EpsmScene *scene, const EpsmSensor *sensor
     epsm_host::err_buf()[0] = 0;
     if (scene && sensor && N == 0) return EPSM_OK;
     TraceArgs A;
+    if (flags & EPSM_TRACE_FUSE_FIRST_HIT) return fail(EPSM_EINVAL, "epsm_trace_paths: EPSM_TRACE_FUSE_FIRST_HIT is the wavefront form's (epsm_trace_paths_wavefront)");
     const int rc = fill_trace_args(A, "epsm_trace_paths", scene, sensor, seed, spp, max_depth, rr_depth, path_offset, N, K_log,
                                    ray_o, ray_d, ray_dx, ray_dy, film_pos, radiance, valid, recs, flags);
     if (rc != EPSM_OK) return rc;
@@ -595,6 +678,8 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
         else hipLaunchKernelGGL(epsm_wf_extend_kernel<false>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
 #endif
         hipLaunchKernelGGL(epsm_wf_shade_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
+        if (b == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT) && A.fh.grad_o_sum)
+            hipLaunchKernelGGL(epsm_wf_first_hit_finish_kernel, dim3(1), dim3(kWfFirstHitSlots), 0, s, A, W);
         hipLaunchKernelGGL(epsm_wf_scan_kernel, dim3(2), dim3(1024), 0, s, A, W, b);
         hipLaunchKernelGGL(epsm_wf_compact_kernel, chunk_blocks, dim3(kWfChunk), 0, s, A, W, b);
 #ifdef EPSM_WF_PACKET_SHADOW

@@ -11,6 +11,7 @@
 #include "epsm_path_core.h"
 #include "epsm_cp_core.h"
 #include "epsm_scatter_core.h"
+#include "epsm_tangent_core.h"
 #include "../../include/epsm_trace.h"
 
 namespace epsm {
@@ -812,6 +813,7 @@ struct TraceArgs {
     float *color_sum;                // epsm_trace_paths_color: (N, n_color, 3), else null
     int n_color;
     int64_t pk_ray_stride, pk_stride; // EPSM_TRACE_PACKED_LOG: words between consecutive paths' rays / first records (EpsmRecordOut)
+    EpsmFirstHitBackward fh;         // EPSM_TRACE_FUSE_FIRST_HIT: copied from recs[0].first_hit
 };
 // after rec[], flags and K_log are set: the strides of the native log (EpsmRecordOut.ray_stride / packed_stride; 0 = dense)
 inline void trace_args_log_strides(TraceArgs &A) {
@@ -932,14 +934,45 @@ struct PathState {
     uint32_t gword;                  // flag word of the vertices logged so far (five bits each, vertex_flag_bits)
 };
 
+// ---- EPSM_TRACE_FUSE_FIRST_HIT: the backward pass of a path without a chain, as csrc/epsm_backward_cp.hip does it for a lane of
+// class 0 (epsm.py:250-272, 561-562, 791-792) -- the same functions on the same numbers.
+struct FirstHitRows { bool on; uint32_t key[3]; F3 val[3]; };              // rows of grad_pos this path adds to
+// d loss / d film position of path i's pixel (channels 3, 4 of the gradient image; epsm.py:250-255)
+EPSM_HD void first_hit_pixel_grad(const TraceArgs &A, int64_t i, float &gx, float &gy) {
+    const int64_t pix = (A.path_offset + i) / A.spp, y = pix / A.fh.res, x = pix - y * A.fh.res;
+    const float *g = A.fh.grad_img + (y * A.fh.img_width + x) * A.fh.img_channels;
+    gx = g[3]; gy = g[4];
+}
+// `w`: the flag word (vertex 1 alone), `gd` = (d_x - d) gx + (d_y - d) gy, `ray`: the primary ray
+EPSM_HD FirstHitRows first_hit_rows(const TraceArgs &A, uint32_t w, const SurfHit &si, const Ray &ray, F3 gd) {
+    FirstHitRows r;
+    r.on = false; r.key[0] = r.key[1] = r.key[2] = kNoIndex; r.val[0] = r.val[1] = r.val[2] = zero3<float>();
+    const bool mesh = si.valid && (si.mesh_flags & EPSM_MESH_IS_MESH);
+    const bool d1 = (w & 1u) != 0, act1 = (w & 4u) != 0;                    // cp::plan_diffuse1, cp::kPlanActive1
+    if (!d1 || !mesh) return r;                                            // (no Diffuse lobe: no diffuse_grad[0]; no triangle: no rows)
+    const F3 z = zero3<float>();
+    const Tangent t = tangent_from_gd(ray.o, ray.d, gd, act1 ? si.p0 : z, act1 ? si.p1 : z, act1 ? si.p2 : z, act1);
+    const U4 row = table_row(TriTable{A.fh.tri_table, A.fh.T}, si.tri);
+    const bool ok = row.x < (uint64_t) A.fh.V && row.y < (uint64_t) A.fh.V && row.z < (uint64_t) A.fh.V && (row.w & kModePos);
+    if (!ok) return r;
+    const float clip = (A.fh.clip > 0.0f && A.fh.clip <= 3.402823466e+38f) ? A.fh.clip : 3.402823466e+38f;
+    const F3 dpf = f3(finalize(t.dp.x, clip), finalize(t.dp.y, clip), finalize(t.dp.z, clip));
+    const float b0 = si.b0, b1 = si.b1, b2 = 1.f - b0 - b1;
+    r.key[0] = row.x; r.key[1] = row.y; r.key[2] = row.z;
+    r.val[0] = dpf * b0; r.val[1] = dpf * b1; r.val[2] = dpf * b2;
+    r.on = nz3(r.val[0]) || nz3(r.val[1]) || nz3(r.val[2]);
+    return r;
+}
+
 // sample_rays (common.py:291-422) + the initial loop state
 // `log = false`: the ray only, nothing written (the wavefront tracer's first closest-hit stage re-derives the primary ray
 // instead of reading a stored one)
-EPSM_HD PathState path_begin(const TraceArgs &A, int64_t i, bool log = true) {
+EPSM_HD PathState path_begin(const TraceArgs &A, int64_t i, bool log = true, PrimaryRay *pr_out = nullptr) {
     const int64_t widx = A.path_offset + i;
     PathState s;
     s.rng = seed_sampler(A.seed, (uint32_t) widx);                        // common.py:475 sampler.seed(seed, wavefront_size)
     const PrimaryRay pr = sample_primary_ray(A.C, widx, A.spp, s.rng);
+    if (pr_out) *pr_out = pr;
     if (!log) {
     } else if (A.flags & EPSM_TRACE_PACKED_LOG) {                         // (N,12): o, d, d_x, d_y side by side
         float *r = A.ray_o + A.pk_ray_stride * i;
@@ -1000,7 +1033,10 @@ EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState
         const uint32_t w = s.gword | (vertex_flag_bits(si.valid, si, flags, false) << (5 * iteration));
         if (!cp::gradient_live(w, iteration + 1, (A.flags & EPSM_TRACE_GRADIENT_CAUSTIC) != 0)) {
             s.gword = w;
-            write_record_packed_first_sector(packed_record(A, i, iteration), A.rec[0].pflags, i, w, si);
+            // EPSM_TRACE_FUSE_FIRST_HIT: a path retired at its FIRST vertex has no chain; what the backward pass would do for it
+            // (first_hit_rows below) the shading stage does, and the log holds nothing of it (flag word 0)
+            if (!(iteration == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT) && vis.first_hit(A, i, w, si, s.ray)))
+                write_record_packed_first_sector(packed_record(A, i, iteration), A.rec[0].pflags, i, w, si);
             if (si.valid) s.depth += 1;
             s.active = false;
             return;
@@ -1133,6 +1169,7 @@ struct InlineVis {
     const BvhStack &st;
     EPSM_HD bool occluded(const EpsmScene &S, const Ray &sr) { return intersect<true>(S, sr, st).hit; }
     EPSM_HD void direct(F3 &L, F3 Le, F3 Lr_dir) { L = L + Le + Lr_dir; }
+    EPSM_HD bool first_hit(const TraceArgs &, int64_t, uint32_t, const SurfHit &, const Ray &) { return false; }   // (the wavefront's shade stage only)
     EPSM_HD void occluder(const TraceArgs &A, int64_t i, const SurfHit &si, const EmitterSample &es, bool active_em) {
         uint32_t *o = A.rec[0].shadow + 4 * i;
         if (A.max_depth <= 3 && active_em) {

@@ -33,6 +33,7 @@ EPSM_HD F3 xyz(const W4 &q) { return f3(u2f(q.x), u2f(q.y), u2f(q.z)); }
 
 constexpr int kWfArrays = 10;                 // 16-byte words per path in the workspace
 constexpr int kWfMaxDepth = 6;                // epsm.py:549
+constexpr int kWfFirstHitSlots = 256;         // EPSM_TRACE_FUSE_FIRST_HIT: partial sums of grad_d, [slot][4] floats behind the counters
 constexpr int kWfCounters = 64;               // uint32 header: [b] = paths alive into bounce b, [8 + b] = shadow rays of bounce b
 constexpr uint32_t kWfOccluder = 1u;          // sh_d.w: the shadow stage also owes the occluder record
 
@@ -58,6 +59,7 @@ struct WfState {                              // device pointers into the worksp
     uint32_t *chunk_counts;   // (2, chunks): alive, shadow per chunk; exclusive offsets after the scan
     uint32_t *group_counts;   // (2, groups): the same per GROUP of kWfGroup chunks (summed by the shade stage; the scan zeroes them again)
     uint32_t *group_offsets;  // (2, groups): exclusive offsets of the groups (scan, first level)
+    float *fh_partial;        // (kWfFirstHitSlots, 4): partial sums of grad_d (EPSM_TRACE_FUSE_FIRST_HIT), zeroed with the counters
     int64_t chunks;           // ceil(N / kWfChunk)
     int64_t groups;           // ceil(chunks / kWfGroup)
     int64_t N;
@@ -79,18 +81,19 @@ EPSM_HD BvhStack wf_stack(const WfState &W, int64_t i, uint32_t *lds, int stride
 EPSM_HD size_t wf_align(size_t x) { return (x + 255) & ~(size_t) 255; }
 EPSM_HD size_t wf_workspace_bytes(int64_t N) {
     const size_t chunks = (size_t) ((N + kWfChunk - 1) / kWfChunk), groups = (chunks + kWfGroup - 1) / kWfGroup;
-    return wf_align(kWfCounters * 4) + 2 * wf_align(groups * 8) + (size_t) kWfArrays * wf_align((size_t) N * 16) + 3 * wf_align((size_t) N * 4) +
+    return wf_align(kWfCounters * 4) + wf_align(kWfFirstHitSlots * 16) + 2 * wf_align(groups * 8) + (size_t) kWfArrays * wf_align((size_t) N * 16) + 3 * wf_align((size_t) N * 4) +
            wf_align((size_t) N * 4 * kWfStackOvf) + wf_align((size_t) N) + wf_align(chunks * 8);
 }
 // what a trace zeroes before its first stage: the counters and, behind them, the group counts
 EPSM_HD size_t wf_zeroed_bytes(int64_t N) {
     const size_t chunks = (size_t) ((N + kWfChunk - 1) / kWfChunk), groups = (chunks + kWfGroup - 1) / kWfGroup;
-    return wf_align(kWfCounters * 4) + wf_align(groups * 8);
+    return wf_align(kWfCounters * 4) + wf_align(kWfFirstHitSlots * 16) + wf_align(groups * 8);
 }
 EPSM_HD WfState wf_carve(void *workspace, int64_t N) {
     char *p = (char *) workspace;
     WfState W;
     W.counters = (uint32_t *) p; p += wf_align(kWfCounters * 4);
+    W.fh_partial = (float *) p; p += wf_align(kWfFirstHitSlots * 16);
     W.chunks = (N + kWfChunk - 1) / kWfChunk;
     W.groups = (W.chunks + kWfGroup - 1) / kWfGroup;
     W.group_counts = (uint32_t *) p; p += wf_align((size_t) W.groups * 8);
@@ -171,6 +174,16 @@ struct DeferredVis {
     bool pending, want_occluder;
     Ray sr;
     F3 Lr;
+    // EPSM_TRACE_FUSE_FIRST_HIT: `gd` in (wf_shade, bounce 0), the rows out
+    F3 gd;
+    FirstHitRows fh;
+    bool fh_taken;
+    EPSM_HD bool first_hit(const TraceArgs &A, int64_t i, uint32_t w, const SurfHit &si, const Ray &ray) {
+        fh_taken = true;
+        fh = first_hit_rows(A, w, si, ray, gd);
+        A.rec[0].pflags[i] = 0u;                                         // no vertex: the backward kernel gives this path no lane
+        return true;
+    }
     EPSM_HD bool occluded(const EpsmScene &, const Ray &r) { pending = true; sr = r; return false; }   // optimistic
     EPSM_HD void direct(F3 &L, F3 Le, F3 Lr_dir) { L = L + Le; Lr = Lr_dir; }                           // + Lr_dir if visible
     EPSM_HD void occluder(const TraceArgs &A, int64_t i, const SurfHit &, const EmitterSample &, bool active_em) {
@@ -181,13 +194,31 @@ struct DeferredVis {
 
 // ---- stage: shade.  Returns through `alive` / `shadow` whether path i goes on to bounce `iteration + 1` / has a
 //      visibility ray pending; the caller compacts.
-EPSM_HD void wf_shade(const TraceArgs &A, const WfState &W, int64_t i, int iteration, bool &alive, bool &shadow) {
-    PathState s = iteration == 0 ? path_begin(A, i) : wf_load(W, i);
-    const W4 h = W.hit[i];
-    TriHit th; th.hit = h.x != kNoIndex; th.tri = th.hit ? h.x : 0u; th.t = u2f(h.y); th.u = u2f(h.z); th.v = u2f(h.w);
+// what path i gives the backward pass at its first hit (EPSM_TRACE_FUSE_FIRST_HIT; the caller sums it over the wave and adds it)
+struct WfFirstHit { FirstHitRows rows; F3 gd; };
+EPSM_HD void wf_shade(const TraceArgs &A, const WfState &W, int64_t i, int iteration, bool &alive, bool &shadow, WfFirstHit *out = nullptr) {
     DeferredVis vis; vis.pending = false; vis.want_occluder = false; vis.Lr = zero3<float>();
     vis.sr.o = vis.sr.d = zero3<float>(); vis.sr.maxt = 0.f;
+    vis.gd = zero3<float>(); vis.fh_taken = false; vis.fh.on = false; vis.fh.key[0] = vis.fh.key[1] = vis.fh.key[2] = kNoIndex;
+    vis.fh.val[0] = vis.fh.val[1] = vis.fh.val[2] = zero3<float>();
+    PathState s;
+    const bool fuse = iteration == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT);
+    if (fuse) {
+        PrimaryRay pr;
+        s = path_begin(A, i, false, &pr);                               // (the rays are logged below, for the paths that keep a log)
+        float gx, gy;
+        first_hit_pixel_grad(A, i, gx, gy);
+        vis.gd = (pr.dx - pr.ray.d) * gx + (pr.dy - pr.ray.d) * gy;      // epsm.py:255, as tangent_from forms it
+    } else {
+        s = iteration == 0 ? path_begin(A, i) : wf_load(W, i);
+    }
+    const W4 h = W.hit[i];
+    TriHit th; th.hit = h.x != kNoIndex; th.tri = th.hit ? h.x : 0u; th.t = u2f(h.y); th.u = u2f(h.z); th.v = u2f(h.w);
     path_bounce(A, i, iteration, s, th, vis);
+    if (out) { out->rows = vis.fh; out->gd = vis.gd; }
+    // a path the first-hit stage has dealt with leaves nothing in the log, its rays included (48 bytes x 94 % of the paths of the
+    // clutter scene); the others get theirs now -- derived again rather than carried through the bounce in twelve registers
+    if (fuse && !vis.fh_taken) path_begin(A, i, true);
     alive = s.active && iteration + 1 < path_max_depth(A);
     if (alive) {
         wf_store(W, i, s, iteration + 1);

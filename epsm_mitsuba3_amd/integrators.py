@@ -104,6 +104,10 @@ class EPSMIntegrator:
         # (EPSM_TRACE_GRADIENT_ONLY, include/epsm_trace.h): identical gradients, the image of that pass -- which the 5-channel
         # branch never uses (epsm.py:729-732) -- is not formed
         self.gradient_only = bool(props.get("gradient_only", True))
+        # True: with the native log and the gradient-only trace, the stage that shades a path's FIRST hit also does what the backward
+        # pass would do for a path without a chain (EPSM_TRACE_FUSE_FIRST_HIT, include/epsm_trace.h: first-vertex rows, d / d ray.o);
+        # such paths -- most of a real wavefront -- are neither logged nor read again.  Same sums.
+        self.fuse_first_hit = bool(props.get("fuse_first_hit", True))
 
     def to_string(self):
         md = 0xFFFFFFFF if self.max_depth < 0 else self.max_depth
@@ -159,6 +163,8 @@ class EPSMIntegrator:
             kw["packed_log"] = True        # the tracer writes the backward kernel's native layout (EpsmPackedLog)
         if self.gradient_only and getattr(scene, "supports_gradient_only", False):
             kw["gradient_only"] = self.variant
+            if self.fuse_first_hit and kw.get("packed_log") and getattr(scene, "supports_first_hit_fusion", False):
+                kw["first_hit"] = (grad_in if grad_in.is_contiguous() else grad_in.contiguous(), target, self.outlier_clip, True)
         traces = tracer(sensor=self.backward_sensor, seed=seed, spp=self.backward_spp,
                         max_depth=self.tracer_depth(), max_log_depth=self.max_log_depth, rank=rank, world_size=world,
                         sparse_log=True,   # the log is consumed here and nowhere else: skip the zeros of dead bounces
@@ -195,9 +201,10 @@ class EPSMIntegrator:
             # the native log (one 128-byte record per path vertex): one launch, nothing else
             log = packed if isinstance(packed, PackedLog) else trace.log
             mark("tangent")
+            # (a log traced under EPSM_TRACE_FUSE_FIRST_HIT: d / d ray.o and the paths without a chain are in the buffers already)
             backward_pass_packed(self.variant, log, grad_in, trace.spp, trace.res, params.pos, params.nrm,
-                                 params.alpha if params.B else None, params.cam_origin, clip=self.outlier_clip,
-                                 path_offset=trace.path_offset)
+                                 params.alpha if params.B else None, None if log.first_hit_done else params.cam_origin,
+                                 clip=self.outlier_clip, path_offset=trace.path_offset)
             mark("grad"); mark("scatter")
             return None
         dev = trace.ray_d.device

@@ -284,6 +284,9 @@ class PackedLog:
         self.layout = "dense" if (self.ray_stride, self.path_stride) == (12, REC_WORDS * self.K) else "interleaved"
         self.c = EpsmPackedLog(rays.data_ptr(), flags.data_ptr(), verts.data_ptr(), shadow.data_ptr() if shadow is not None else None,
                                self.ray_stride, self.path_stride)
+        # set by the tracer under EPSM_TRACE_FUSE_FIRST_HIT: the paths without a chain (their flag words are 0) and the sum d / d ray.o
+        # are already in the gradient buffers -- the backward kernel is then called without grad_o_sum and gives such paths no lane
+        self.first_hit_done = False
 
     def table_ptr(self) -> int:
         return self.table.data_ptr()

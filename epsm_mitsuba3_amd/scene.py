@@ -48,6 +48,7 @@ EPSM_TRACE_PACKED_LOG = 0x2
 EPSM_TRACE_GRADIENT_ONLY = 0x4
 EPSM_TRACE_GRADIENT_CAUSTIC = 0x8
 EPSM_TRACE_NO_TAIL = 0x10
+EPSM_TRACE_FUSE_FIRST_HIT = 0x20
 
 
 class EpsmMesh(C.Structure):
@@ -92,11 +93,17 @@ class EpsmSceneC(C.Structure):
                 ("texcoords", C.c_void_p), ("textures", C.c_void_p), ("n_textures", C.c_int32)]
 
 
+class EpsmFirstHitBackward(C.Structure):
+    """Mirror of ``struct EpsmFirstHitBackward`` (include/epsm_trace.h)."""
+    _fields_ = [("grad_img", C.c_void_p), ("img_width", C.c_int), ("img_channels", C.c_int), ("res", C.c_int), ("clip", C.c_float),
+                ("tri_table", C.c_void_p), ("T", C.c_int64), ("V", C.c_int64), ("grad_pos", C.c_void_p), ("grad_o_sum", C.c_void_p)]
+
+
 class EpsmRecordOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "p0", "p1", "p2", "p", "n0", "n1", "n2", "normal", "b0", "b1", "eta", "hf", "light",
         "bsdf", "active", "active_em", "ismesh", "tri", "aux", "emit", "packed", "pflags", "shadow")] + [
-        ("ray_stride", C.c_int64), ("packed_stride", C.c_int64)]
+        ("ray_stride", C.c_int64), ("packed_stride", C.c_int64), ("first_hit", C.c_void_p)]
 
 
 # ---------------------------------------------------------------------------- transforms
@@ -1209,7 +1216,8 @@ class Scene:
         c = ws[:64].view(torch.int32).cpu().tolist()
         return {"alive": c[0:6], "shadow": c[8:14]}
 
-    def _trace_packed(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int, gradient_only=None):
+    def _trace_packed(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int, gradient_only=None,
+                      first_hit=None):
         """The same trace with the vertex log in the NATIVE layout of the backward kernel (EPSM_TRACE_PACKED_LOG,
         include/epsm.h EpsmPackedLog): the PathTrace carries ``log`` (a PackedLog) instead of per-field arrays."""
         from .integrators import PathTrace
@@ -1235,6 +1243,19 @@ class Scene:
         if n > 1:
             recs[0].ray_stride, recs[0].packed_stride = rays.stride(0), verts.stride(0)
         recs[0].shadow = shadow.data_ptr() if shadow is not None else None
+        # EPSM_TRACE_FUSE_FIRST_HIT (include/epsm_trace.h): the backward pass of the paths WITHOUT a chain -- and every path's share of
+        # d / d ray.o -- done by the stage that shades the first hit; nothing of such a path is logged.  ``first_hit`` = (grad_in,
+        # ParamGrads, clip).  The wavefront form's, with the gradient-only rule, without the occluder record.
+        fuse = (first_hit is not None and bool(gradient_only) and shadow is None and n > 0 and self.use_wavefront(n)
+                and self._backend_supports_fusion())
+        fh = None
+        if fuse:
+            grad_in, target, clip, want_origin = first_hit
+            assert grad_in.is_contiguous() and grad_in.dtype == torch.float32 and grad_in.shape[-1] >= 5
+            fh = EpsmFirstHitBackward(grad_in.data_ptr(), int(grad_in.shape[1]), int(grad_in.shape[2]), int(sensor.width), float(clip),
+                                      self.tri_table.data_ptr(), int(self.tri_table.shape[0]), int(target.V), target.pos.data_ptr(),
+                                      target.cam_origin.data_ptr() if want_origin else None)
+            recs[0].first_hit = C.addressof(fh)
         cs = sensor.c_struct()
         args = [C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
                 C.c_int64(lo), C.c_int64(n), K, C.c_void_p(rays.data_ptr()), None, None, None,
@@ -1242,7 +1263,7 @@ class Scene:
                 C.c_void_p(valid.data_ptr()) if want_image else None,
                 C.c_void_p(C.addressof(recs)),
                 C.c_uint32(EPSM_TRACE_SPARSE_LOG | EPSM_TRACE_PACKED_LOG | self._gradient_only_flags(gradient_only) |
-                           (self._tail_flag() if self.use_wavefront(n) else 0))]
+                           (self._tail_flag() if self.use_wavefront(n) else 0) | (EPSM_TRACE_FUSE_FIRST_HIT if fuse else 0))]
         if self.use_wavefront(n) and n > 0:
             need = int(lib.epsm_trace_workspace_bytes(C.c_int64(n)))
             ws = self._wf_workspace.get(stream)
@@ -1257,6 +1278,8 @@ class Scene:
                        path_info=None, scatter_info=None, path_offset=lo, n_paths_total=sensor.wavefront_size(spp))
         tr.film_pos, tr.radiance, tr.valid = film_pos, radiance, valid
         tr.log = PackedLog(rays, flags, verts, shadow, self.tri_table, K)
+        # the tracer has accounted for every path without a chain and for d / d ray.o: the backward kernel is called without grad_o_sum
+        tr.log.first_hit_done = bool(fuse)
         return tr
 
     def _trace(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int,
@@ -1295,7 +1318,7 @@ class Scene:
             shadow = quad[2 * K] if (k == 0 and want_shadow) else None
             r = recs[k]
             for name, _ in EpsmRecordOut._fields_:
-                if name in ("packed", "pflags", "ray_stride", "packed_stride"):
+                if name in ("packed", "pflags", "ray_stride", "packed_stride", "first_hit"):
                     continue
                 setattr(r, name, t[name].data_ptr() if name != "shadow" else (shadow.data_ptr() if shadow is not None else None))
             info.append({"it": k, "active": t["active"], "bsdf": t["bsdf"], "ismesh": t["ismesh"], "light": t["light"],
@@ -1332,8 +1355,12 @@ class Scene:
 
     supports_packed_log = True
     supports_gradient_only = True
+    supports_first_hit_fusion = True
 
-    def iter_traces(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1, sparse_log=False,
+    def _backend_supports_fusion(self) -> bool:
+        return True
+
+    def iter_traces(self, sensor=2, seed=0, spp=8, max_depth=6, max_log_depth=5, rank=0, world_size=1, sparse_log=False, first_hit=None,
                     packed_log=False, gradient_only=None):
         """Generator over this rank's tiles of the backward wavefront of ``sensors[sensor]`` (epsm.py:142-181): a tile
         is traced when the consumer asks for it, so ``render_backward`` holds ONE tile's records (~0.8 KB per path at
@@ -1359,7 +1386,7 @@ class Scene:
         tiles = _dist.tile_ranges(n_total, tile)
         for t in _dist.my_tiles(len(tiles), rank, world_size):
             if packed_log and K >= 1:
-                yield self._trace_packed(si, seed, spp, max_depth, K, *tiles[t], gradient_only=gradient_only)
+                yield self._trace_packed(si, seed, spp, max_depth, K, *tiles[t], gradient_only=gradient_only, first_hit=first_hit)
             else:
                 yield self._trace(si, seed, spp, max_depth, K, *tiles[t], sparse_log=sparse_log, gradient_only=gradient_only)
 

@@ -82,6 +82,16 @@ enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
  * them are left (a stage cannot take less than one traversal's chain of cache misses, ~0.1 ms, however short its queue) --
  * same arithmetic per path, same results; the queue-length counters of the bounces behind that point then stay 0. */
 #define EPSM_TRACE_NO_TAIL          0x10u
+/* EPSM_TRACE_FUSE_FIRST_HIT (with EPSM_TRACE_GRADIENT_ONLY + EPSM_TRACE_PACKED_LOG, wavefront form only; recs[0].first_hit names the
+ * backward pass's inputs): what epsm_backward_pass_packed would do for a path WITHOUT a chain is done by the stage that shades its
+ * first hit, and nothing of such a path is logged --
+ *   - every path's share of d loss / d ray.o = -sum grad_d (epsm.py:255-261) goes into first_hit->grad_o_sum (when not NULL);
+ *   - a path the rule retires at its first vertex (a diffuse, non-mesh or missed first hit: 94 % of the paths of the clutter scene)
+ *     gives its first-vertex tangent's rows -- si_follow.p * diffuse_grad[0] = clamp(dldp) b_j into the hit triangle's vertex rows of
+ *     first_hit->grad_pos (epsm.py:250-272, 561-562, 791-792) -- there, summed over the wave first, and its flag word is written as 0:
+ *     the backward kernel, called with grad_o_sum = NULL for this log, gives it no lane and reads nothing of it.
+ * Same sums as the unfused pair of calls (float order aside).  Not with the occluder record (max_depth <= 3). */
+#define EPSM_TRACE_FUSE_FIRST_HIT   0x20u
 
 typedef struct EpsmMesh {
     uint32_t tri_begin, tri_count;   /* this mesh's range in the triangle arrays */
@@ -192,6 +202,17 @@ typedef struct EpsmScene {           /* host struct holding DEVICE pointers */
     const EpsmTexture *textures;     int32_t n_textures;
 } EpsmScene;
 
+/* EPSM_TRACE_FUSE_FIRST_HIT: the arguments epsm_backward_pass_packed takes for the same tile (include/epsm.h) */
+typedef struct EpsmFirstHitBackward {
+    const float *grad_img;           /* (.., img_width, img_channels): channels 3, 4 = d loss / d film position */
+    int img_width, img_channels, res;
+    float clip;                      /* outlier clamp of calc_grad (0.1 in the reference); <= 0 or non-finite: none */
+    const uint32_t *tri_table;       /* (T,4) [v0, v1, v2, mode] */
+    int64_t T, V;
+    float *grad_pos;                 /* (V,3), accumulated */
+    float *grad_o_sum;               /* (3), accumulated; may be NULL */
+} EpsmFirstHitBackward;
+
 /* Writable twin of EpsmVertexRecord + EpsmScatterRecord for one logged bounce. */
 typedef struct EpsmRecordOut {
     float *p0, *p1, *p2, *p;         /* (N,3) */
@@ -208,6 +229,7 @@ typedef struct EpsmRecordOut {
     int64_t ray_stride, packed_stride; /* EPSM_TRACE_PACKED_LOG, recs[0] only (ABI v7): words between the rays (at ray_o) / the first
                                         records (at packed) of consecutive paths; 0 = dense, 12 and 32 K_log.  The interleaved block
                                         of include/epsm.h (EpsmPackedLog): ray_o = block, packed = block + 16, both 32 (K_log + 1) */
+    const EpsmFirstHitBackward *first_hit; /* EPSM_TRACE_FUSE_FIRST_HIT, recs[0] only (a HOST pointer: read during the call) */
 } EpsmRecordOut;
 
 /* ---------------------------------------------------------------------------

@@ -146,6 +146,7 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
     A.film_pos = film_pos; A.radiance = radiance; A.valid = valid;
     for (int k = 0; k < K_log; ++k) A.rec[k] = recs[k];
     trace_args_log_strides(A);
+    if (flags & EPSM_TRACE_FUSE_FIRST_HIT) { if (K_log < 1 || !recs[0].first_hit) return -22; A.fh = *recs[0].first_hit; }
     const WfState W = wf_carve(workspace, N);
     memset(W.counters, 0, kWfCounters * sizeof(uint32_t));
     uint32_t stack[kWfStackLds];
@@ -155,7 +156,18 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
         for (int64_t q = 0; q < count; ++q) {
             const int64_t i = b == 0 ? q : (int64_t) W.queue[b & 1][q];
             bool alive, shadow;
-            wf_shade(A, W, i, b, alive, shadow);
+            WfFirstHit fh;
+            const bool fuse = b == 0 && (flags & EPSM_TRACE_FUSE_FIRST_HIT);
+            wf_shade(A, W, i, b, alive, shadow, fuse ? &fh : nullptr);
+            if (fuse) {                                                     // (the device sums over the wave first: epsm_trace.hip, first_hit_scatter)
+                auto add = [](float *p, float v) { if (v != 0.f && fabsf(v) < INFINITY) *p += v; };
+                if (A.fh.grad_o_sum) { add(A.fh.grad_o_sum, -fh.gd.x); add(A.fh.grad_o_sum + 1, -fh.gd.y); add(A.fh.grad_o_sum + 2, -fh.gd.z); }
+                if (fh.rows.on)
+                    for (int j = 0; j < 3; ++j) {
+                        float *p = A.fh.grad_pos + 3 * (int64_t) fh.rows.key[j];
+                        add(p, fh.rows.val[j].x); add(p + 1, fh.rows.val[j].y); add(p + 2, fh.rows.val[j].z);
+                    }
+            }
             if (alive) W.queue[(b + 1) & 1][W.counters[b + 1]++] = (uint32_t) i;
             if (shadow) W.shadow_queue[W.counters[8 + b]++] = (uint32_t) i;
         }

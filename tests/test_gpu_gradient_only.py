@@ -103,3 +103,46 @@ def test_zeroed_environment_is_no_environment_and_bad_tables_are_refused(scenes)
     bad.textures = None
     assert call(bad) == -22
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("variant", ["manifold", "manifold_caustic"])
+def test_first_hit_fusion_gives_the_same_gradients(scenes, variant):
+    """EPSM_TRACE_FUSE_FIRST_HIT (include/epsm_trace.h): the stage that shades a path's first hit does what the backward pass would do
+    for a path WITHOUT a chain -- the first-vertex rows clamp(dldp) b_j of a diffuse first hit (epsm.py:250-272, 561-562, 791-792)
+    and every path's share of d loss / d ray.o (:255-261) -- and such paths are not logged; the backward kernel is called without
+    grad_o_sum and gives them no lane.  ``render_backward`` with and without it: the same buffers, the camera-origin gradient
+    included (float order aside).  Scenes with the occluder record (max_depth <= 3) and launches the one-launch tracer takes are
+    not fused and must agree trivially."""
+    import epsm_mitsuba3_amd as epsm
+    dev = torch.device("cuda", 0)
+    fused_somewhere = 0
+    for name, sc, max_depth in scenes:
+        sc.tracer = "wavefront"
+        res = sc.sensors[2].width
+        g = torch.Generator().manual_seed(7)
+        grad_in = (torch.randn((res, res, 5), generator=g) * 1e-3).to(dev)
+        out = []
+        for fuse in (False, True):
+            integ = epsm.load_dict({"type": variant, "max_depth": max_depth, "fuse_first_hit": fuse})
+            p = sc.param_grads()
+            integ.render_backward(sc, p, grad_in, seed=11)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(p.flat).all())
+            out.append((p.flat.double().cpu(), p.cam_origin.double().cpu()))
+        tiles = list(sc.iter_traces(sensor=2, seed=11, spp=integ.backward_spp, max_depth=integ.tracer_depth(), sparse_log=True,
+                                    packed_log=True, gradient_only=variant,
+                                    first_hit=(grad_in, sc.param_grads(), 0.1, True)))
+        done = [t.log.first_hit_done for t in tiles]
+        assert all(done) == (max_depth > 3), (name, done)                  # (the occluder record rides on the first vertex's emitter sample)
+        if all(done):
+            fused_somewhere += 1
+            flags = torch.cat([t.log.flags for t in tiles])
+            assert float((flags == 0).float().mean()) > (0.3 if variant == "manifold" else 0.1), name   # paths without a chain: most of a `manifold` wavefront
+        m = float(out[0][0].abs().max())
+        assert m > 0 or variant == "manifold_caustic", name
+        assert float((out[0][0] - out[1][0]).abs().max()) <= 2e-5 * m + 1e-12, (name, m, float((out[0][0] - out[1][0]).abs().max()))
+        # the camera-origin sum on its own scale (three numbers next to 10^5 rows)
+        o0, o1 = out[0][1], out[1][1]
+        assert float(o0.abs().max()) > 0, name
+        assert float((o0 - o1).abs().max()) <= 2e-5 * float(o0.abs().max()) + 1e-12, (name, o0, o1)
+    assert fused_somewhere >= 3

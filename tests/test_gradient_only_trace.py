@@ -122,3 +122,57 @@ def test_oracle_pipeline_gives_the_same_gradients_from_both_traces(variant):
     # and the cut trace did stop early: fewer active vertices in its log
     act = lambda trs: sum(int(r["active"].sum()) for tr in trs for r in tr.path_info[1:])
     assert act(cut) < act(full) - 40
+
+
+@pytest.mark.parametrize("variant", ["manifold", "manifold_caustic"])
+def test_first_hit_fusion_on_the_host_build(variant):
+    """EPSM_TRACE_FUSE_FIRST_HIT (include/epsm_trace.h) on the host build of the wavefront tracer: a path the rule retires at its first
+    vertex leaves flag word 0 and nothing else in the log; every other path's rays, flag word and records are those of the unfused
+    trace; and what the stage added to the buffers is what the float64 oracle tangent gives -- d / d ray.o = -sum grad_d over ALL
+    paths (epsm.py:255-261), clamp(dldp) b_j on the vertex rows of a diffuse first hit (epsm.py:561-562, 791-792, 932-944)."""
+    from oracle.binding import oracle_first_vertex_tangent
+    scene = _scene("wavefront")
+    _, live = _plan_fns()
+    caustic = int(variant == "manifold_caustic")
+    res, spp = 24, 4
+    g = torch.Generator().manual_seed(4)
+    grad_in = (torch.randn((res, res, 5), generator=g) * 1e-2).contiguous()
+    params = scene.param_grads()
+    kw = dict(sensor=2, seed=3, spp=spp, max_depth=6, max_log_depth=5, sparse_log=True, packed_log=True, gradient_only=variant)
+    (cut,) = scene.trace_paths(**kw)
+    (fus,) = scene.trace_paths(**kw, first_hit=(grad_in, params, 0.1, True))
+    assert fus.log.first_hit_done and not cut.log.first_hit_done
+    wc, wf = cut.log.flags.numpy().astype(np.uint32), fus.log.flags.numpy().astype(np.uint32)
+    fused = np.array([(int(w) >> 5) == 0 and not live(int(w) & 31, 1, caustic) for w in wc])
+    assert 50 < fused.sum() < fused.size
+    assert (wf[fused] == 0).all() and (wf[~fused] == wc[~fused]).all()
+    keep = torch.from_numpy(~fused)
+    assert torch.equal(cut.log.rays[keep], fus.log.rays[keep])
+    for k in range(cut.log.K):
+        has = keep & (((cut.log.flags >> (5 * k)) & 4) != 0)
+        a, b = cut.log.verts[has, k].view(torch.int32), fus.log.verts[has, k].view(torch.int32)
+        assert torch.equal(a[:, :15], b[:, :15]), k                       # first sector (eta, word 15, is not drawn for a retiring vertex)
+        # ... and the whole record where the path goes on behind it (a vertex that retires its path gets its first sector only)
+        goes_on = (((cut.log.flags[has] >> (5 * (k + 1))) & 4) != 0) if k + 1 < cut.log.K else torch.zeros(int(has.sum()), dtype=torch.bool)
+        assert torch.equal(a[goes_on], b[goes_on]), k
+    # the sums, from the UNFUSED log and the float64 oracle
+    v0 = cut.log.verts[:, 0]
+    act = torch.from_numpy((wc & 4) != 0)
+    _, dldp, go = oracle_first_vertex_tangent(cut.ray_o, cut.ray_d, cut.ray_dx, cut.ray_dy, grad_in, spp, res, v0[:, 0:3], v0[:, 3:6], v0[:, 6:9], act)
+    m = float(go.abs().max())
+    assert m > 0 and float((params.cam_origin.double() - go).abs().max()) <= 1e-4 * m
+    tri = v0[:, 11].contiguous().view(torch.int32).long()
+    rows_on = torch.from_numpy(fused & ((wc & 1) != 0)) & act & (tri >= 0)
+    dp = torch.where(dldp.abs() <= 0.1, dldp, torch.zeros_like(dldp))          # the clamp of epsm.py:932-944, per component
+    want = torch.zeros((params.V, 3), dtype=torch.float64)
+    table = scene.tri_table.long()
+    b = [v0[:, 9].double(), v0[:, 10].double()]; b.append(1 - b[0] - b[1])
+    for j in range(3):
+        want.index_add_(0, table[tri[rows_on], j], dp[rows_on] * b[j][rows_on, None])
+    mp = float(want.abs().max())
+    if caustic:            # a manifold_caustic path with a diffuse mesh first hit goes on: no path of its fused set has rows to give
+        assert int(rows_on.sum()) == 0 and float(params.pos.abs().max()) == 0
+    else:
+        assert int(rows_on.sum()) > 20 and mp > 0
+        assert float((params.pos.double() - want).abs().max()) <= 2e-4 * mp
+    assert float(params.nrm.abs().max()) == 0 and float(params.alpha.abs().max() if params.B else 0) == 0
