@@ -61,6 +61,19 @@ def test_headline_slab_on_the_timed_kernel(variant, profile):
     assert m > 0
     assert float((runs[0] - runs[1]).abs().max()) <= 1e-5 * m
 
+    # ---- (1b) the same launch WITHOUT the camera-origin sum (grad_o_sum = NULL: what a log traced under EPSM_TRACE_FUSE_FIRST_HIT gets):
+    # paths without a term take no lane (the kernel's DROP instantiation) at full size.  Same rows.
+    from epsm_mitsuba3_amd.tangent_scatter import backward_pass_packed
+    nocam = epsm.ParamGrads(V, B, device=dev)
+    backward_pass_packed(variant, log, grad_in, spp, res, nocam.pos, nocam.nrm, nocam.alpha, None, clip=0.1, path_offset=trace.path_offset)
+    torch.cuda.synchronize()
+    withcam = epsm.ParamGrads(V, B, device=dev)
+    withcam.flat.copy_(runs[0].float())
+    for a, b, name in ((nocam.pos, withcam.pos, "pos"), (nocam.nrm, withcam.nrm, "nrm"), (nocam.alpha, withcam.alpha, "alpha")):
+        assert float((a.double() - b.double()).abs().max()) <= 1e-5 * m, name
+    assert float(nocam.cam_origin.abs().max()) == 0
+    del nocam, withcam
+
     # ---- (2) the reference's three stages on the same records: dense calc_grad lists + scatter kernel (another restatement
     # of the per-path arithmetic: csrc/epsm_path_core.h), with the clamp moved by -+2 % for the threshold allowance
     packed = (PackedRecords(trace.path_info, device=dev), PackedScatter(trace.scatter_info, device=dev, table=scene.triangle_table()))
