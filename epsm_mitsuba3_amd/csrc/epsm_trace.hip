@@ -7,6 +7,7 @@
 #include "epsm_trace_wavefront.h"
 #include "epsm_trace_quad.h"
 #include "epsm_trace_packet.h"
+#include "epsm_wave_scatter.h"           // wave_total_lane63 (DPP sums): the first-hit stage
 
 using namespace epsm;
 using epsm_host::fail;
@@ -133,11 +134,16 @@ __global__ __launch_bounds__(kWfThreads) void epsm_wf_tail_kernel(TraceArgs A, W
 // backward pass: every path's grad_d into the wave's share of -sum grad_d, and the first-vertex rows of the paths retired at their
 // first hit.  Lanes on the same triangle are summed first (butterfly over the wave, in up to four turns of "the first lane still
 // owing and everybody on its triangle"), one lane adds the sum; what is left after four turns adds for itself.
+#ifdef EPSM_FH_SHUFFLE_SUM                // (A/B build: the butterfly through the LDS crossbar)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
     return v;
 }
+#else
+// sum over the wave by six DPP adds (epsm_wave_scatter.h: the total lands in lane 63) + one readlane: no trip through the LDS crossbar
+__device__ __forceinline__ float wave_sum(float v) { return lane63(wave_total_lane63(v)); }
+#endif
 __device__ __forceinline__ void first_hit_add(float *p, float v) { if (v != 0.f && fabsf(v) < __builtin_inff()) atomicAdd(p, v); }
 __device__ __forceinline__ void first_hit_scatter(const TraceArgs &A, const WfState &W, const WfFirstHit &fh) {
     const int lane = threadIdx.x & 63;
