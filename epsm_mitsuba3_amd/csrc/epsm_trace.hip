@@ -76,60 +76,7 @@ __global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_kernel(TraceArgs A,
 }
 // The closest-hit stage with the WAVE as the unit (epsm_trace_packet.h).  FIRST: the primary rays -- a wave is the samples of one
 // pixel or of a few neighbours.
-template <bool FIRST>
-__global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_packet_kernel(TraceArgs A, WfState W, int b) {
-    __shared__ uint32_t s_stack[kPacketStack * (kWfThreads / 64)];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t count = wf_count(A, W, b);
-    if (!FIRST && wf_in_tail(A, b, count)) return;
-    for (int64_t q0 = (int64_t) blockIdx.x * kWfThreads + wv * 64; q0 < count; q0 += (int64_t) gridDim.x * kWfThreads) {     // wave-uniform
-        const int64_t q = q0 + lane;
-        const bool has = q < count;
-        const int64_t i = FIRST ? (has ? q : q0) : (int64_t) W.queue[b & 1][has ? q : q0];
-        Ray r;
-        if (FIRST) {
-            r = path_begin(A, i, false).ray;
-        } else {
-            const W4 o = W.ray_o[i], d = W.ray_d[i];
-            r.o = xyz(o); r.maxt = u2f(o.w); r.d = xyz(d);
-        }
-        const TriHit th = packet_intersect<false>(A.S, r, has, s_stack + wv * kPacketStack);
-        if (has) {
-            W4 h; h.x = th.hit ? th.tri : kNoIndex; h.y = f2u(th.t); h.z = f2u(th.u); h.w = f2u(th.v);
-            W.hit[i] = h;
-        }
-    }
-}
-// The visibility rays the same way (A/B build).
-__global__ __launch_bounds__(kWfThreads) void epsm_wf_shadow_packet_kernel(TraceArgs A, WfState W, int b) {
-    __shared__ uint32_t s_stack[kPacketStack * (kWfThreads / 64)];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t count = (int64_t) W.counters[8 + b];
-    for (int64_t q0 = (int64_t) blockIdx.x * kWfThreads + wv * 64; q0 < count; q0 += (int64_t) gridDim.x * kWfThreads) {     // wave-uniform
-        const int64_t q = q0 + lane;
-        const bool has = q < count;
-        const int64_t i = (int64_t) W.shadow_queue[has ? q : q0];
-        const W4 o = W.sh_o[i], d = W.sh_d[i];
-        Ray sr; sr.o = xyz(o); sr.maxt = u2f(o.w); sr.d = xyz(d);
-        const TriHit th = packet_intersect<true>(A.S, sr, has, s_stack + wv * kPacketStack);
-        const bool owed = has && wf_shadow_resolve(A, W, i, b, th.hit);
-        if (__ballot(owed) != 0ull) {                                    // (integrators with max_depth <= 3: the occluder record)
-            F3 sip = zero3<float>(), esp = sip;
-            Ray r2; r2.o = r2.d = sip; r2.maxt = 0.f;
-            if (owed) r2 = wf_occluder_ray(A, W, i, sip, esp);
-            const TriHit oh = packet_intersect<false>(A.S, r2, owed, s_stack + wv * kPacketStack);
-            if (owed) write_occluder(A.S, A.rec[0].shadow + 4 * i, r2, oh, sip, esp);
-        }
-    }
-}
-// The rest of the loop of the paths alive into bounce b, once they are few (wf_tail, epsm_trace_wavefront.h).
-__global__ __launch_bounds__(kWfThreads) void epsm_wf_tail_kernel(TraceArgs A, WfState W, int b) {
-    __shared__ uint32_t s_stack[kWfStackLds * kWfThreads];
-    const int64_t count = wf_count(A, W, b);
-    if (!wf_in_tail(A, b, count)) return;
-    for (int64_t q = (int64_t) blockIdx.x * kWfThreads + threadIdx.x; q < count; q += (int64_t) gridDim.x * kWfThreads)
-        wf_tail(A, W, (int64_t) W.queue[b & 1][q], b, s_stack + threadIdx.x, kWfThreads);
-}
+constexpr uint8_t kWfDone = 4;                 // W.flags of a slot at bounce 0: the closest-hit stage has retired the path (EPSM_TRACE_FUSE_FIRST_HIT)
 // EPSM_TRACE_FUSE_FIRST_HIT: what the lanes of a wave -- at bounce 0 the samples of one pixel or of a few neighbouring ones -- give the
 // backward pass: every path's grad_d into the wave's share of -sum grad_d, and the first-vertex rows of the paths retired at their
 // first hit.  Lanes on the same triangle are summed first (butterfly over the wave, in up to four turns of "the first lane still
@@ -145,14 +92,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return lane63(wave_total_lane63(v)); }
 #endif
 __device__ __forceinline__ void first_hit_add(float *p, float v) { if (v != 0.f && fabsf(v) < __builtin_inff()) atomicAdd(p, v); }
-__device__ __forceinline__ void first_hit_scatter(const TraceArgs &A, const WfState &W, const WfFirstHit &fh) {
+__device__ __forceinline__ void first_hit_scatter(const TraceArgs &A, const WfState &W, const WfFirstHit &fh, unsigned wave_index) {
     const int lane = threadIdx.x & 63;
     if (A.fh.grad_o_sum) {
         // epsm.py:258-261: d / d ray.o = -sum grad_d.  One triple per WAVE on the three words themselves was 2 ms per 2^24 paths
         // (262 144 same-address float atomics retire one at a time); the waves add to one of 256 slots of the workspace, which
         // epsm_wf_first_hit_finish_kernel sums into the caller's three words.
         const float sx = wave_sum(fh.gd.x), sy = wave_sum(fh.gd.y), sz = wave_sum(fh.gd.z);
-        if (lane < 3) first_hit_add(W.fh_partial + 4 * ((blockIdx.x * (kWfChunk / 64) + (threadIdx.x >> 6)) % kWfFirstHitSlots) + lane,
+        if (lane < 3) first_hit_add(W.fh_partial + 4 * (wave_index % kWfFirstHitSlots) + lane,
                                     lane == 0 ? sx : lane == 1 ? sy : sz);
     }
     bool owing = fh.rows.on;
@@ -188,6 +135,87 @@ __device__ __forceinline__ void first_hit_scatter(const TraceArgs &A, const WfSt
         }
     }
 }
+template <bool FIRST>
+__global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_packet_kernel(TraceArgs A, WfState W, int b) {
+    __shared__ uint32_t s_stack[kPacketStack * (kWfThreads / 64)];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t count = wf_count(A, W, b);
+    if (!FIRST && wf_in_tail(A, b, count)) return;
+    for (int64_t q0 = (int64_t) blockIdx.x * kWfThreads + wv * 64; q0 < count; q0 += (int64_t) gridDim.x * kWfThreads) {     // wave-uniform
+        const int64_t q = q0 + lane;
+        const bool has = q < count;
+        const int64_t i = FIRST ? (has ? q : q0) : (int64_t) W.queue[b & 1][has ? q : q0];
+        Ray r;
+        // EPSM_TRACE_FUSE_FIRST_HIT: the primary rays' stage has ray and hit in registers -- it retires the paths the rule retires at
+        // their first vertex itself (first_hit_retires / first_hit_rows: the backward pass of a path without a chain, every path's
+        // share of d / d ray.o) and marks their slots; the shade stage passes them by: of 2^24 paths of the clutter scene it shades 2 M.
+        const bool fuse = FIRST && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT);      // (kernel-uniform)
+        WfFirstHit fh;
+        fh.rows.on = false; fh.rows.key[0] = fh.rows.key[1] = fh.rows.key[2] = kNoIndex;
+        fh.rows.val[0] = fh.rows.val[1] = fh.rows.val[2] = fh.gd = zero3<float>();
+        if (FIRST) {
+            PrimaryRay pr;
+            r = path_begin(A, i, false, &pr).ray;
+            if (fuse && has) {
+                float gx, gy;
+                first_hit_pixel_grad(A, i, gx, gy);
+                fh.gd = (pr.dx - pr.ray.d) * gx + (pr.dy - pr.ray.d) * gy;     // epsm.py:255, as tangent_from forms it
+            }
+        } else {
+            const W4 o = W.ray_o[i], d = W.ray_d[i];
+            r.o = xyz(o); r.maxt = u2f(o.w); r.d = xyz(d);
+        }
+        const TriHit th = packet_intersect<false>(A.S, r, has, s_stack + wv * kPacketStack);
+        bool done = false;
+        if (fuse) {
+            if (has) {
+                uint32_t w;
+                SurfHit lite;
+                if (first_hit_retires(A, th, w, lite)) {
+                    fh.rows = first_hit_rows(A, w, lite, r, fh.gd);
+                    A.rec[0].pflags[i] = 0u;                             // no vertex: the backward kernel gives this path no lane
+                    done = true;
+                }
+                W.flags[q] = done ? kWfDone : (uint8_t) 0;
+            }
+            first_hit_scatter(A, W, fh, (unsigned) (q0 >> 6));           // (all lanes of the wave: the sums run over it)
+        }
+        if (has && !done) {
+            W4 h; h.x = th.hit ? th.tri : kNoIndex; h.y = f2u(th.t); h.z = f2u(th.u); h.w = f2u(th.v);
+            W.hit[i] = h;
+        }
+    }
+}
+// The visibility rays the same way (A/B build).
+__global__ __launch_bounds__(kWfThreads) void epsm_wf_shadow_packet_kernel(TraceArgs A, WfState W, int b) {
+    __shared__ uint32_t s_stack[kPacketStack * (kWfThreads / 64)];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t count = (int64_t) W.counters[8 + b];
+    for (int64_t q0 = (int64_t) blockIdx.x * kWfThreads + wv * 64; q0 < count; q0 += (int64_t) gridDim.x * kWfThreads) {     // wave-uniform
+        const int64_t q = q0 + lane;
+        const bool has = q < count;
+        const int64_t i = (int64_t) W.shadow_queue[has ? q : q0];
+        const W4 o = W.sh_o[i], d = W.sh_d[i];
+        Ray sr; sr.o = xyz(o); sr.maxt = u2f(o.w); sr.d = xyz(d);
+        const TriHit th = packet_intersect<true>(A.S, sr, has, s_stack + wv * kPacketStack);
+        const bool owed = has && wf_shadow_resolve(A, W, i, b, th.hit);
+        if (__ballot(owed) != 0ull) {                                    // (integrators with max_depth <= 3: the occluder record)
+            F3 sip = zero3<float>(), esp = sip;
+            Ray r2; r2.o = r2.d = sip; r2.maxt = 0.f;
+            if (owed) r2 = wf_occluder_ray(A, W, i, sip, esp);
+            const TriHit oh = packet_intersect<false>(A.S, r2, owed, s_stack + wv * kPacketStack);
+            if (owed) write_occluder(A.S, A.rec[0].shadow + 4 * i, r2, oh, sip, esp);
+        }
+    }
+}
+// The rest of the loop of the paths alive into bounce b, once they are few (wf_tail, epsm_trace_wavefront.h).
+__global__ __launch_bounds__(kWfThreads) void epsm_wf_tail_kernel(TraceArgs A, WfState W, int b) {
+    __shared__ uint32_t s_stack[kWfStackLds * kWfThreads];
+    const int64_t count = wf_count(A, W, b);
+    if (!wf_in_tail(A, b, count)) return;
+    for (int64_t q = (int64_t) blockIdx.x * kWfThreads + threadIdx.x; q < count; q += (int64_t) gridDim.x * kWfThreads)
+        wf_tail(A, W, (int64_t) W.queue[b & 1][q], b, s_stack + threadIdx.x, kWfThreads);
+}
 __global__ __launch_bounds__(kWfFirstHitSlots) void epsm_wf_first_hit_finish_kernel(TraceArgs A, WfState W) {
     __shared__ float s_sum[kWfFirstHitSlots / 64][3];
     float v[3];
@@ -212,15 +240,25 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_shade_kernel(TraceArgs A, Wf
     // (Tried: a capped grid whose workgroups take chunks in turn, as the compaction does -- the launch of a bounce nobody reaches
     // 15 -> 5 us, but the stage itself 1.08 -> 1.19 ms at 2^24 paths: the hardware's dispatch order balances better.)
     bool alive = false, shadow = false;
+    // EPSM_TRACE_FUSE_FIRST_HIT: the primary rays' stage (packet kernel) has dealt with the paths that end at their first vertex and
+    // marked their slots; without that stage (EPSM_WF_NO_PACKET builds) this one does it, wf_shade's `out`
+#ifdef EPSM_WF_NO_PACKET
     const bool fuse = b == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT);     // (kernel-uniform)
+#else
+    constexpr bool fuse = false;
+    const bool marked = b == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT);
+#endif
     WfFirstHit fh;
     fh.rows.on = false; fh.rows.key[0] = fh.rows.key[1] = fh.rows.key[2] = kNoIndex;
     fh.rows.val[0] = fh.rows.val[1] = fh.rows.val[2] = fh.gd = zero3<float>();
     if (q < count) {
+#ifndef EPSM_WF_NO_PACKET
+        if (!(marked && W.flags[q] == kWfDone))
+#endif
         wf_shade(A, W, b == 0 ? q : (int64_t) W.queue[b & 1][q], b, alive, shadow, fuse ? &fh : nullptr);
         W.flags[q] = (uint8_t) ((alive ? kWfAlive : 0) | (shadow ? kWfShadow : 0));
     }
-    if (fuse) first_hit_scatter(A, W, fh);                                    // (all lanes of the wave: the sums run over it)
+    if (fuse) first_hit_scatter(A, W, fh, blockIdx.x * (kWfChunk / 64) + (threadIdx.x >> 6));   // (all lanes of the wave: the sums run over it)
     __shared__ uint32_t s_n[2][kWfChunk / 64];
     const unsigned long long ma = __ballot(alive), ms = __ballot(shadow);
     if ((threadIdx.x & 63) == 0) { s_n[0][threadIdx.x >> 6] = (uint32_t) __popcll(ma); s_n[1][threadIdx.x >> 6] = (uint32_t) __popcll(ms); }

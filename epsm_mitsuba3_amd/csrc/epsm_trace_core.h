@@ -1008,38 +1008,45 @@ EPSM_HD int path_max_depth(const TraceArgs &A) { return A.max_depth < 6 ? A.max_
 struct NoObserver {
     EPSM_HD void vertex(const SurfHit &, const EpsmBsdf &, uint32_t, F3, F3, const EmitterSample &, bool, float, const BsdfSample &, bool) {}
 };
+// EPSM_TRACE_FUSE_FIRST_HIT: does the rule retire a path at its FIRST vertex, hit `th`?  Follows from the mesh's and the BSDF's flag
+// bits alone; `lite` then holds what first_hit_rows reads -- validity, mesh flags, triangle id and, for a diffuse mesh hit, the
+// triangle's positions and the barycentrics -- and `w` the vertex's five flag bits.
+EPSM_HD bool first_hit_retires(const TraceArgs &A, const TriHit &th, uint32_t &w, SurfHit &lite) {
+    const EpsmScene &S = A.S;
+    uint32_t mflags = 0, bflags = 0;
+    if (th.hit) {
+        const EpsmMesh m = S.meshes[S.tri_mesh[th.tri]];
+        mflags = m.flags;
+        if (m.bsdf >= 0) bflags = bsdf_flags(S.bsdfs[m.bsdf]);
+    }
+    lite.valid = th.hit; lite.mesh_flags = mflags; lite.tri = th.tri;
+    w = vertex_flag_bits(th.hit, lite, bflags, false);
+    if (cp::gradient_live(w, 1, (A.flags & EPSM_TRACE_GRADIENT_CAUSTIC) != 0)) return false;
+    lite.p0 = lite.p1 = lite.p2 = zero3<float>();
+    lite.b0 = lite.b1 = lite.b2 = 0.f;
+    if (th.hit && (w & 1u) && (mflags & EPSM_MESH_IS_MESH)) {              // (rows exist for a diffuse mesh hit only: first_hit_rows)
+        const uint32_t *iv = S.tri + 3 * (int64_t) th.tri;
+        lite.p0 = ld3(S.positions + 3 * (int64_t) iv[0]);
+        lite.p1 = ld3(S.positions + 3 * (int64_t) iv[1]);
+        lite.p2 = ld3(S.positions + 3 * (int64_t) iv[2]);
+        lite.b1 = th.u; lite.b2 = th.v; lite.b0 = 1.f - th.u - th.v;
+    }
+    return true;
+}
 template <class Vis, class Obs>
 EPSM_HD void path_bounce(const TraceArgs &A, int64_t i, int iteration, PathState &s, const TriHit &th, Vis &vis, Obs &obs) {
     const EpsmScene &S = A.S;
-    // ---- EPSM_TRACE_FUSE_FIRST_HIT, first bounce: whether the rule retires the path at this vertex follows from the mesh's and the
-    // BSDF's flag bits alone, and the first-hit stage then needs the triangle's positions and the barycentrics, nothing else -- no
-    // normals, no texture coordinates, no shading frame (94 % of the clutter scene's paths: the shade stage 0.94 -> 0.8x ms)
+    // ---- EPSM_TRACE_FUSE_FIRST_HIT, first bounce: a path the rule retires here needs no normals, no texture coordinates, no shading
+    // frame (94 % of the clutter scene's paths: the shade stage 0.94 -> 0.89 ms; the wavefront's packet stage does the same for its
+    // primary rays and such a path never reaches this function)
     if (iteration == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT) && s.active && A.K_log > 0) {
-        uint32_t mflags = 0, bflags = 0;
-        if (th.hit) {
-            const EpsmMesh m = S.meshes[S.tri_mesh[th.tri]];
-            mflags = m.flags;
-            if (m.bsdf >= 0) bflags = bsdf_flags(S.bsdfs[m.bsdf]);
-        }
+        uint32_t w;
         SurfHit lite;
-        lite.valid = th.hit; lite.mesh_flags = mflags; lite.tri = th.tri;
-        const uint32_t w = vertex_flag_bits(th.hit, lite, bflags, false);
-        if (!cp::gradient_live(w, 1, (A.flags & EPSM_TRACE_GRADIENT_CAUSTIC) != 0)) {
-            lite.p0 = lite.p1 = lite.p2 = zero3<float>();
-            lite.b0 = lite.b1 = lite.b2 = 0.f;
-            if (th.hit && (w & 1u) && (mflags & EPSM_MESH_IS_MESH)) {      // (rows exist for a diffuse mesh hit only: first_hit_rows)
-                const uint32_t *iv = S.tri + 3 * (int64_t) th.tri;
-                lite.p0 = ld3(S.positions + 3 * (int64_t) iv[0]);
-                lite.p1 = ld3(S.positions + 3 * (int64_t) iv[1]);
-                lite.p2 = ld3(S.positions + 3 * (int64_t) iv[2]);
-                lite.b1 = th.u; lite.b2 = th.v; lite.b0 = 1.f - th.u - th.v;
-            }
-            if (vis.first_hit(A, i, w, lite, s.ray)) {
-                s.gword = w;
-                if (th.hit) s.depth += 1;
-                s.active = false;
-                return;
-            }
+        if (first_hit_retires(A, th, w, lite) && vis.first_hit(A, i, w, lite, s.ray)) {
+            s.gword = w;
+            if (th.hit) s.depth += 1;
+            s.active = false;
+            return;
         }
     }
     const SurfHit si = surface_interaction(S, s.ray, th);                 // epsm.py:556-558

@@ -177,8 +177,9 @@ struct DeferredVis {
     // EPSM_TRACE_FUSE_FIRST_HIT: `gd` in (wf_shade, bounce 0), the rows out
     F3 gd;
     FirstHitRows fh;
-    bool fh_taken;
+    bool fh_taken, fh_enabled;       // fh_enabled: the caller collects the rows (wf_shade's `out`); otherwise the vertex is logged as ever
     EPSM_HD bool first_hit(const TraceArgs &A, int64_t i, uint32_t w, const SurfHit &si, const Ray &ray) {
+        if (!fh_enabled) return false;
         fh_taken = true;
         fh = first_hit_rows(A, w, si, ray, gd);
         A.rec[0].pflags[i] = 0u;                                         // no vertex: the backward kernel gives this path no lane
@@ -199,16 +200,18 @@ struct WfFirstHit { FirstHitRows rows; F3 gd; };
 EPSM_HD void wf_shade(const TraceArgs &A, const WfState &W, int64_t i, int iteration, bool &alive, bool &shadow, WfFirstHit *out = nullptr) {
     DeferredVis vis; vis.pending = false; vis.want_occluder = false; vis.Lr = zero3<float>();
     vis.sr.o = vis.sr.d = zero3<float>(); vis.sr.maxt = 0.f;
-    vis.gd = zero3<float>(); vis.fh_taken = false; vis.fh.on = false; vis.fh.key[0] = vis.fh.key[1] = vis.fh.key[2] = kNoIndex;
+    vis.gd = zero3<float>(); vis.fh_taken = false; vis.fh_enabled = out != nullptr; vis.fh.on = false; vis.fh.key[0] = vis.fh.key[1] = vis.fh.key[2] = kNoIndex;
     vis.fh.val[0] = vis.fh.val[1] = vis.fh.val[2] = zero3<float>();
     PathState s;
     const bool fuse = iteration == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT);
     if (fuse) {
         PrimaryRay pr;
         s = path_begin(A, i, false, &pr);                               // (the rays are logged below, for the paths that keep a log)
-        float gx, gy;
-        first_hit_pixel_grad(A, i, gx, gy);
-        vis.gd = (pr.dx - pr.ray.d) * gx + (pr.dy - pr.ray.d) * gy;      // epsm.py:255, as tangent_from forms it
+        if (out) {                                                      // (not when the closest-hit stage has dealt with the first hit already)
+            float gx, gy;
+            first_hit_pixel_grad(A, i, gx, gy);
+            vis.gd = (pr.dx - pr.ray.d) * gx + (pr.dy - pr.ray.d) * gy;  // epsm.py:255, as tangent_from forms it
+        }
     } else {
         s = iteration == 0 ? path_begin(A, i) : wf_load(W, i);
     }
