@@ -83,8 +83,8 @@ enum { EPSM_RFILTER_BOX = 0, EPSM_RFILTER_GAUSSIAN = 1 };
  * same arithmetic per path, same results; the queue-length counters of the bounces behind that point then stay 0. */
 #define EPSM_TRACE_NO_TAIL          0x10u
 /* EPSM_TRACE_FUSE_FIRST_HIT (with EPSM_TRACE_GRADIENT_ONLY + EPSM_TRACE_PACKED_LOG, wavefront form only; recs[0].first_hit names the
- * backward pass's inputs): what epsm_backward_pass_packed would do for a path WITHOUT a chain is done by the stage that shades its
- * first hit, and nothing of such a path is logged --
+ * backward pass's inputs): what epsm_backward_pass_packed would do for a path WITHOUT a chain is done by the stage that finds its
+ * first hit (the primary rays' packet stage; the shade stage in EPSM_WF_NO_PACKET builds), and nothing of such a path is logged --
  *   - every path's share of d loss / d ray.o = -sum grad_d (epsm.py:255-261) goes into first_hit->grad_o_sum (when not NULL);
  *   - a path the rule retires at its first vertex (a diffuse, non-mesh or missed first hit: 94 % of the paths of the clutter scene)
  *     gives its first-vertex tangent's rows -- si_follow.p * diffuse_grad[0] = clamp(dldp) b_j into the hit triangle's vertex rows of
