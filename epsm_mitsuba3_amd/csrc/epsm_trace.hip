@@ -53,8 +53,13 @@ constexpr int kWfThreads = 128;                         // traversal kernels
 constexpr int kWfMaxBlocks = 16384;
 constexpr int kWfMaxChunkBlocks = 8192;                 // compaction: workgroups of 256, each takes chunks in turn
 
+// Internal flag (never a caller's): under EPSM_TRACE_FUSE_FIRST_HIT the primary rays' stage retires most paths itself, and the few
+// it leaves are COMPACTED into a queue before bounce 0's shade stage (a scan + compaction pass numbered bounce -1) -- slot q of bounce 0
+// is then path queue[0][q] of counters[0], not path q of N.
+constexpr uint32_t kWfPreCompact = 0x80000000u;
+__device__ __forceinline__ bool wf_identity(const TraceArgs &A, int b) { return b < 0 || (b == 0 && !(A.flags & kWfPreCompact)); }   // slot == path
 __device__ __forceinline__ int64_t wf_count(const TraceArgs &A, const WfState &W, int b) {
-    return b == 0 ? A.N : (int64_t) W.counters[b];
+    return wf_identity(A, b) ? A.N : (int64_t) W.counters[b];
 }
 // Traversal kernels: 8 KB of LDS stacks per workgroup, 47-50 registers: 8 waves per SIMD.
 // (Tried and dropped: persistent waves whose idle lanes fetch new rays between two traversal rounds -- from a shared
@@ -76,7 +81,6 @@ __global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_kernel(TraceArgs A,
 }
 // The closest-hit stage with the WAVE as the unit (epsm_trace_packet.h).  FIRST: the primary rays -- a wave is the samples of one
 // pixel or of a few neighbours.
-constexpr uint8_t kWfDone = 4;                 // W.flags of a slot at bounce 0: the closest-hit stage has retired the path (EPSM_TRACE_FUSE_FIRST_HIT)
 // EPSM_TRACE_FUSE_FIRST_HIT: what the lanes of a wave -- at bounce 0 the samples of one pixel or of a few neighbouring ones -- give the
 // backward pass: every path's grad_d into the wave's share of -sum grad_d, and the first-vertex rows of the paths retired at their
 // first hit.  Lanes on the same triangle are summed first (butterfly over the wave, in up to four turns of "the first lane still
@@ -139,7 +143,7 @@ template <bool FIRST>
 __global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_packet_kernel(TraceArgs A, WfState W, int b) {
     __shared__ uint32_t s_stack[kPacketStack * (kWfThreads / 64)];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t count = wf_count(A, W, b);
+    const int64_t count = FIRST ? A.N : wf_count(A, W, b);     // (the primary rays: every path, whatever is compacted behind this stage)
     if (!FIRST && wf_in_tail(A, b, count)) return;
     for (int64_t q0 = (int64_t) blockIdx.x * kWfThreads + wv * 64; q0 < count; q0 += (int64_t) gridDim.x * kWfThreads) {     // wave-uniform
         const int64_t q = q0 + lane;
@@ -176,9 +180,15 @@ __global__ __launch_bounds__(kWfThreads) void epsm_wf_extend_packet_kernel(Trace
                     A.rec[0].pflags[i] = 0u;                             // no vertex: the backward kernel gives this path no lane
                     done = true;
                 }
-                W.flags[q] = done ? kWfDone : (uint8_t) 0;
+                W.flags[q] = done ? (uint8_t) 0 : kWfAlive;              // (the pass numbered bounce -1 compacts the survivors)
             }
             first_hit_scatter(A, W, fh, (unsigned) (q0 >> 6));           // (all lanes of the wave: the sums run over it)
+            const unsigned long long ma = __ballot(has && !done);
+            if (lane == 0 && ma != 0ull) {                               // the survivors of this quarter of a chunk, for the scan
+                const int64_t chunk = q0 / kWfChunk;
+                atomicAdd(&W.chunk_counts[chunk], (uint32_t) __popcll(ma));
+                atomicAdd(&W.group_counts[chunk / kWfGroup], (uint32_t) __popcll(ma));
+            }
         }
         if (has && !done) {
             W4 h; h.x = th.hit ? th.tri : kNoIndex; h.y = f2u(th.t); h.z = f2u(th.u); h.w = f2u(th.v);
@@ -241,21 +251,13 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_shade_kernel(TraceArgs A, Wf
     // 15 -> 5 us, but the stage itself 1.08 -> 1.19 ms at 2^24 paths: the hardware's dispatch order balances better.)
     bool alive = false, shadow = false;
     // EPSM_TRACE_FUSE_FIRST_HIT: the primary rays' stage (packet kernel) has dealt with the paths that end at their first vertex and
-    // marked their slots; without that stage (EPSM_WF_NO_PACKET builds) this one does it, wf_shade's `out`
-#ifdef EPSM_WF_NO_PACKET
-    const bool fuse = b == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT);     // (kernel-uniform)
-#else
-    constexpr bool fuse = false;
-    const bool marked = b == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT);
-#endif
+    // the survivors come here compacted (kWfPreCompact); without that stage (EPSM_WF_NO_PACKET builds) this one does it, wf_shade's `out`
+    const bool fuse = b == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT) && !(A.flags & kWfPreCompact);     // (kernel-uniform)
     WfFirstHit fh;
     fh.rows.on = false; fh.rows.key[0] = fh.rows.key[1] = fh.rows.key[2] = kNoIndex;
     fh.rows.val[0] = fh.rows.val[1] = fh.rows.val[2] = fh.gd = zero3<float>();
     if (q < count) {
-#ifndef EPSM_WF_NO_PACKET
-        if (!(marked && W.flags[q] == kWfDone))
-#endif
-        wf_shade(A, W, b == 0 ? q : (int64_t) W.queue[b & 1][q], b, alive, shadow, fuse ? &fh : nullptr);
+        wf_shade(A, W, wf_identity(A, b) ? q : (int64_t) W.queue[b & 1][q], b, alive, shadow, fuse ? &fh : nullptr);
         W.flags[q] = (uint8_t) ((alive ? kWfAlive : 0) | (shadow ? kWfShadow : 0));
     }
     if (fuse) first_hit_scatter(A, W, fh, blockIdx.x * (kWfChunk / 64) + (threadIdx.x >> 6));   // (all lanes of the wave: the sums run over it)
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_compact_kernel(TraceArgs A, 
     for (int64_t chunk = blockIdx.x; chunk * kWfChunk < count; chunk += gridDim.x) {              // workgroup-uniform
     const int64_t q = chunk * kWfChunk + threadIdx.x;
     const uint8_t f = q < count ? W.flags[q] : (uint8_t) 0;
-    const uint32_t i = q < count ? (b == 0 ? (uint32_t) q : W.queue[b & 1][q]) : 0u;
+    const uint32_t i = q < count ? (wf_identity(A, b) ? (uint32_t) q : W.queue[b & 1][q]) : 0u;
 #ifdef EPSM_WF_REKEY
     __shared__ uint32_t s_hist[2][64];
     if (threadIdx.x < 128) s_hist[threadIdx.x >> 6][threadIdx.x & 63] = 0u;
@@ -697,6 +699,13 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
     const WfState W = wf_carve(workspace, N);
     hipError_t e = hipMemsetAsync(W.counters, 0, wf_zeroed_bytes(N), s);          // the counters and the group counts behind them
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_trace_paths_wavefront", e);
+#ifndef EPSM_WF_NO_PACKET
+    if (A.flags & EPSM_TRACE_FUSE_FIRST_HIT) {
+        A.flags |= kWfPreCompact;                                                  // (the packet stage ADDS its survivors to the chunk counts)
+        e = hipMemsetAsync(W.chunk_counts, 0, (size_t) W.chunks * 8, s);
+        if (e != hipSuccess) return epsm_host::hip_fail("epsm_trace_paths_wavefront", e);
+    }
+#endif
     auto blocks = [&](int threads) { const int64_t b = (N + threads - 1) / threads; return dim3((unsigned) (b < kWfMaxBlocks ? b : kWfMaxBlocks)); };
     const int depth = path_max_depth(A);
     const dim3 chunks((unsigned) W.chunks), chunk_blocks((unsigned) (W.chunks < kWfMaxChunkBlocks ? W.chunks : kWfMaxChunkBlocks));
@@ -712,6 +721,10 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
             hipLaunchKernelGGL(epsm_wf_extend_kernel<true>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
 #else
             hipLaunchKernelGGL(epsm_wf_extend_packet_kernel<true>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
+            if (A.flags & kWfPreCompact) {                       // the survivors of the primary rays' stage, compacted: "bounce -1"
+                hipLaunchKernelGGL(epsm_wf_scan_kernel, dim3(2), dim3(1024), 0, s, A, W, -1);
+                hipLaunchKernelGGL(epsm_wf_compact_kernel, chunk_blocks, dim3(kWfChunk), 0, s, A, W, -1);
+            }
 #endif
         }
 #if defined(EPSM_WF_QUAD)
