@@ -310,6 +310,7 @@ __device__ __forceinline__ F2v ld2(const float *p) { return *(const __attribute_
 struct WinBase {
     const float *verts, *rays;
     const uint32_t *shadow;
+    const uint32_t *list;            // EpsmPackedLog.path_list + the window's first slot: path of slot loc = list[loc] (null: base + loc)
     int64_t base;
     uint32_t pix0, rem0;             // (path_offset + base) / spp and the remainder
     float rcp_spp, rcp_res;
@@ -321,6 +322,7 @@ __device__ __forceinline__ WinBase win_base(const FusedArgs &F, int64_t base) {
     B.verts = F.pk_verts + base * F.pk_path_stride;
     B.rays = F.pk_rays + base * F.pk_ray_stride;
     B.shadow = F.pk_shadow ? F.pk_shadow + 4 * base : nullptr;
+    B.list = F.pk_list ? F.pk_list + base : nullptr;
     const int64_t p0 = F.tin.path_offset + base, q0 = p0 / F.tin.spp;
     B.small = (int64_t) F.tin.res * F.tin.res < (1 << 24) && q0 + 4096 < (1 << 24) && F.tin.spp < (1 << 20);
     B.pix0 = (uint32_t) q0; B.rem0 = (uint32_t) (p0 - q0 * F.tin.spp);
@@ -335,7 +337,8 @@ __device__ __forceinline__ void divmod24(uint32_t x, uint32_t d, float rcp_d, ui
     if (r >= (int32_t) d) { ++q; r -= (int32_t) d; }
     qo = q; ro = (uint32_t) r;
 }
-struct LaneRole { bool ok, first, live, end_next, d1, act1; uint32_t loc; const float *rec; };
+struct LaneRole { bool ok, first, live, end_next, d1, act1; uint32_t loc; const float *rec, *rays; const uint32_t *shadow; int64_t path; };
+template <bool LIST>
 __device__ __forceinline__ LaneRole role_of(const FusedArgs &F, const LaneId &L, const WinBase &B) {
     LaneRole R;
     R.ok = L.plan != 0u;
@@ -345,7 +348,20 @@ __device__ __forceinline__ LaneRole role_of(const FusedArgs &F, const LaneId &L,
     R.d1 = R.ok && R.first && cp::plan_diffuse1(L.plan);
     R.act1 = (L.plan & cp::kPlanActive1) != 0;
     R.loc = (uint32_t) L.loc;
+    if (LIST && B.list) {
+        // the windows run over a LIST of paths (the tracer's survivors, EPSM_TRACE_FUSE_FIRST_HIT): slot -> path by one more load -- a
+        // line the planning has just read -- and the addresses from the path itself
+        const int64_t i = R.ok ? (int64_t) lds_(B.list, (int64_t) R.loc) : 0;
+        R.path = i;
+        R.rec = F.pk_verts + i * F.pk_path_stride + (L.k - 1) * kRecWords;
+        R.rays = F.pk_rays + i * F.pk_ray_stride;
+        R.shadow = F.pk_shadow ? F.pk_shadow + 4 * i : nullptr;
+        return R;
+    }
+    R.path = -1;
     R.rec = B.verts + (uint32_t) (R.loc * (uint32_t) F.pk_path_stride + (uint32_t) (L.k - 1) * (uint32_t) kRecWords);
+    R.rays = B.rays + (uint32_t) F.pk_ray_stride * R.loc;
+    R.shadow = B.shadow ? B.shadow + 4 * R.loc : nullptr;
     return R;
 }
 // pixel of path i: (path_offset + i) / spp, row-major on the res x res crop (epsm.py:250)
@@ -355,7 +371,8 @@ __device__ __attribute__((noinline)) int64_t pixel_offset_large(int64_t path, in
     const int64_t pix = path / spp, y = pix / res;
     return y * img_width + (pix - y * res);
 }
-__device__ __forceinline__ const float *pixel_grad(const TangentIn &A, const WinBase &B, uint32_t loc) {
+__device__ __forceinline__ const float *pixel_grad(const TangentIn &A, const WinBase &B, uint32_t loc, int64_t path = -1) {
+    if (path >= 0) return A.grad_img + pixel_offset_large(A.path_offset + path, A.spp, A.res, A.img_width) * A.img_channels + 3;
     if (!B.small) return A.grad_img + pixel_offset_large(A.path_offset + B.base + loc, A.spp, A.res, A.img_width) * A.img_channels + 3;
     int64_t y, x;
     {
@@ -366,9 +383,9 @@ __device__ __forceinline__ const float *pixel_grad(const TangentIn &A, const Win
     }
     return A.grad_img + (y * A.img_width + x) * A.img_channels + 3;
 }
-template <int VARIANT>
+template <int VARIANT, bool LIST>
 __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B) {
-    const LaneRole R = role_of(F, L, B);
+    const LaneRole R = role_of<LIST>(F, L, B);
     // (a path WITHOUT a constraint reads its first record only when its first hit is diffuse: diffuse_grad[0] = dldp needs the
     // triangle; otherwise all it gives is its share of d/d ray.o, which needs the rays alone -- 27 % of the bathroom paths)
     if (R.live || R.d1) { X.o0 = ldq(R.rec, 0); X.o1 = ldq(R.rec, 1); X.o2 = ldq(R.rec, 2); }
@@ -379,7 +396,7 @@ __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const
 #endif
     }
     if (R.ok && R.first) {
-        const float *rays = B.rays + (uint32_t) F.pk_ray_stride * R.loc;
+        const float *rays = R.rays;
 #ifdef EPSM_CPKO_NORAYS                 // (knock-out build: what reading the rays costs; results are wrong)
         { const float v = (float) R.loc * 1e-3f; const F4v f4 = {v, 0.5f, -0.25f, 1.f}; X.p0 = f4; X.p1 = f4 * 0.5f; X.p2 = f4 * 0.25f; }
 #elif defined(EPSM_CPKO_RAYS0)          // (knock-out build: every path takes the rays of its window's first path -- realistic values, no gather)
@@ -387,7 +404,7 @@ __device__ __forceinline__ void geo_issue(GeoFetch &X, const FusedArgs &F, const
 #else
         X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
 #endif
-        const F2v g = ld2(pixel_grad(F.tin, B, R.loc));
+        const F2v g = ld2(pixel_grad(F.tin, B, R.loc, R.path));
         X.gx = g.x; X.gy = g.y;
     }
     if (R.end_next) {
@@ -412,9 +429,9 @@ __device__ __forceinline__ void dma16(const float *src, float *lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src, (__attribute__((address_space(3))) void *) lds_dst, 16, 0, 0);
 }
 // want: 2 = the whole record (a constraint vertex), 1 = its first sector (a diffuse first hit without a constraint), 0 = nothing
-template <int VARIANT>
+template <int VARIANT, bool LIST>
 __device__ __forceinline__ void geo_stage_dma(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B, float *stage, int lane) {
-    const LaneRole R = role_of(F, L, B);
+    const LaneRole R = role_of<LIST>(F, L, B);
     const uint32_t want = R.live ? 2u : R.d1 ? 1u : 0u;
     const uint32_t roff = (uint32_t) (R.loc * (uint32_t) F.pk_path_stride + (uint32_t) (L.k - 1) * (uint32_t) kRecWords) | want;   // (a multiple of 32: the low bits are free)
     const int s = lane & 7, grp = lane >> 3;
@@ -445,9 +462,9 @@ __device__ __forceinline__ void geo_stage_dma(GeoFetch &X, const FusedArgs &F, c
 // once (32 registers that nothing else needs at the start of a round), ONE wait, then the transposition through the 2 304-byte
 // staging area in four batches of LDS round trips (~100 cycles each) instead of four trips to memory.
 typedef __attribute__((address_space(3))) F4v LdsF4w;
-template <int VARIANT>
+template <int VARIANT, bool LIST>
 __device__ __forceinline__ void geo_stage_coop(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B, float *stage, int lane) {
-    const LaneRole R = role_of(F, L, B);
+    const LaneRole R = role_of<LIST>(F, L, B);
     const uint32_t want = R.live ? 2u : R.d1 ? 1u : 0u;
     const uint32_t roff = (uint32_t) (R.loc * (uint32_t) F.pk_path_stride + (uint32_t) (L.k - 1) * (uint32_t) kRecWords) | want;
     const int s = lane & 7, grp = lane >> 3;
@@ -480,12 +497,13 @@ __device__ __forceinline__ void geo_stage_coop(GeoFetch &X, const FusedArgs &F, 
 }
 // what stays a per-lane load beside the staged records: the rays + image gradient of a path's first lane, the first sector of
 // the end-point record of its last lane
+template <bool LIST>
 __device__ __forceinline__ void geo_issue_rest(GeoFetch &X, const FusedArgs &F, const LaneId &L, const WinBase &B) {
-    const LaneRole R = role_of(F, L, B);
+    const LaneRole R = role_of<LIST>(F, L, B);
     if (R.ok && R.first) {
-        const float *rays = B.rays + (uint32_t) F.pk_ray_stride * R.loc;
+        const float *rays = R.rays;
         X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
-        const F2v g = ld2(pixel_grad(F.tin, B, R.loc));
+        const F2v g = ld2(pixel_grad(F.tin, B, R.loc, R.path));
         X.gx = g.x; X.gy = g.y;
     }
     if (R.end_next) {
@@ -497,9 +515,9 @@ __device__ __forceinline__ void geo_issue_rest(GeoFetch &X, const FusedArgs &F, 
 #endif
     }
 }
-template <int VARIANT>
+template <int VARIANT, bool LIST>
 __device__ __forceinline__ void addr_issue(AddrFetch &A, const FusedArgs &F, const LaneId &L, const WinBase &B) {
-    const LaneRole R = role_of(F, L, B);
+    const LaneRole R = role_of<LIST>(F, L, B);
     if (R.live) {
         const bool wN = VARIANT == EPSM_VARIANT_MANIFOLD && cp::plan_a(L.plan, L.k);
 #ifdef EPSM_CP_STASH
@@ -509,24 +527,24 @@ __device__ __forceinline__ void addr_issue(AddrFetch &A, const FusedArgs &F, con
 #endif
         if (wN) A.q6 = ldq(R.rec, 6);
     }
-    if (R.d1 && B.shadow) A.sh = load_u4(B.shadow, R.loc);
+    if (R.d1 && R.shadow) A.sh = load_u4(R.shadow, 0);
 }
 
 // ---- EPSM_CP_PREFETCH (round 5; the product build): the lane's OWN record of the wave's NEXT round -- quads 0..5 and the
 // emission's words -- requested before this round's emission, into 36 registers that only the emission has to live with (its
 // pressure is ~80 registers below the recursions' peak: no additional spill), so that the trip to memory runs under the LDS work
 // of the emission.  (Round 3 prefetched everything a round reads into 62 registers and paid for it with the third wave per SIMD.)
-template <int VARIANT>
+template <int VARIANT, bool LIST>
 __device__ __forceinline__ void own_issue(GeoFetch &X, AddrFetch &A, const FusedArgs &F, const LaneId &L, const WinBase &B) {
-    const LaneRole R = role_of(F, L, B);
+    const LaneRole R = role_of<LIST>(F, L, B);
     if (R.live || R.d1) { X.o0 = ldq(R.rec, 0); X.o1 = ldq(R.rec, 1); X.o2 = ldq(R.rec, 2); }
     if (R.live) { X.o3 = ldq(R.rec, 3); X.o4 = ldq(R.rec, 4); X.o5 = ldq(R.rec, 5); }
-    addr_issue<VARIANT>(A, F, L, B);
+    addr_issue<VARIANT, LIST>(A, F, L, B);
 #if EPSM_CP_PREFETCH >= 2            // ... and the rays + image gradient of a path's first lane
     if (R.ok && R.first) {
-        const float *rays = B.rays + (uint32_t) F.pk_ray_stride * R.loc;
+        const float *rays = R.rays;
         X.p0 = ldq(rays, 0); X.p1 = ldq(rays, 1); X.p2 = ldq(rays, 2);
-        const F2v g = ld2(pixel_grad(F.tin, B, R.loc));
+        const F2v g = ld2(pixel_grad(F.tin, B, R.loc, R.path));
         X.gx = g.x; X.gy = g.y;
     }
 #endif
@@ -591,14 +609,19 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
     // it such a path (27 % of the bathroom profile) has nothing to give: no lane, no rays read.  Otherwise it gives its share of the
     // sum on a lane of class 0.  (A template parameter: as a run-time switch it cost the camera-gradient form 9 %, 1.78 -> 1.95 ms.)
     constexpr int kSortKeys = DROP ? kKeys + 1 : kKeys;
+    // kList: the windows may run over a LIST of paths (EpsmPackedLog.path_list: the tracer's survivors under EPSM_TRACE_FUSE_FIRST_HIT --
+    // 12 % of a traced wavefront, half of them with a term) instead of over all N: slot p of the launch is path list[p]
+    constexpr bool kList = DROP && PACKED;
     constexpr int kStride = kPer * kWaves, kEntries = kSortKeys * kStride;
     __shared__ uint32_t s_plan[kWindow];
     __shared__ uint16_t s_perm[kWindow];
     __shared__ int s_cnt[kEntries];                                  // [m][j][wave]: histogram, then offsets
     __shared__ int s_cls[kKeys + 2];                                 // first sorted position of class m; [kKeys]: of the paths without a term
     V3<float> gd_acc = zero3<float>();                               // kTangentsInKernel: sum of grad_d over this lane's paths
+    const int64_t n_slots = (kList && F.pk_list) ? (int64_t) lds_(F.pk_list_count, (int64_t) 0) : F.g.N;      // paths the windows run over
+    const int64_t n_windows = (n_slots + window - 1) / window;
+    if (kList && (int64_t) blockIdx.x * windows_per_block >= n_windows) return;      // (workgroup-uniform: a launch sized for all N)
     T.clear();                                                       // ends with a barrier: the table of pointers is visible too
-    const int64_t n_windows = (F.g.N + window - 1) / window;
 #pragma unroll 1
     for (int64_t wi = 0; wi < windows_per_block; ++wi) {
         // a workgroup walks a CONTIGUOUS range of windows: neighbouring pixels keep hitting the rows its table holds
@@ -616,15 +639,16 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             uint32_t fw[kPer];
 #pragma unroll
             for (int j = 0; j < kPer; ++j) {                         // all flag loads first
-                const int64_t p = base + j * kThreads + threadIdx.x;
-                const Records<PACKED> R{F, s_ptrs, p < F.g.N ? p : F.g.N - 1};
-                fw[j] = (j * kThreads + (int) threadIdx.x < window) ? R.flag_word() : 0u;
+                int64_t p = base + j * kThreads + threadIdx.x;
+                if (kList && F.pk_list) p = p < n_slots ? (int64_t) lds_(F.pk_list, p) : -1;      // slot -> path
+                const Records<PACKED> R{F, s_ptrs, (p >= 0 && p < F.g.N) ? p : F.g.N - 1};
+                fw[j] = (j * kThreads + (int) threadIdx.x < window && p >= 0 && p < F.g.N) ? R.flag_word() : 0u;
             }
 #pragma unroll
             for (int j = 0; j < kPer; ++j) {
                 const int loc = j * kThreads + threadIdx.x;
                 const int64_t p = base + loc;
-                const bool in = loc < window && p < F.g.N;
+                const bool in = loc < window && p < n_slots;
                 uint32_t w = fw[j];
                 if (F.K < 5) w &= (1u << (5 * F.K)) - 1u;
                 uint32_t plan = VARIANT == EPSM_VARIANT_MANIFOLD ? cp::manifold_plan(w) : cp::caustic_plan(w);
@@ -703,7 +727,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
 #ifdef EPSM_CP_PREFETCH
         GeoFetch Xp; AddrFetch Ap;
         fetch_zero(Xp, Ap);
-        if (PACKED) own_issue<VARIANT>(Xp, Ap, F, L, WB);           // the window's first round: nothing to hide it under
+        if (PACKED) own_issue<VARIANT, kList>(Xp, Ap, F, L, WB);           // the window's first round: nothing to hide it under
 #endif
 #pragma unroll 1
         for (int r = wv; r < n_rounds; r += kWaves) {
@@ -745,16 +769,16 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     X.o_lz = X.gx = X.gy = 0.f;
                 }
 #if defined(EPSM_CP_COOP)
-                geo_issue_rest(X, F, L, WB);
+                geo_issue_rest<kList>(X, F, L, WB);
                 Q.drain(T);                                          // the staging area IS the wave's (now empty) row queue
-                geo_stage_coop<VARIANT>(X, F, L, WB, (float *) s_queue[wv], lane);
+                geo_stage_coop<VARIANT, kList>(X, F, L, WB, (float *) s_queue[wv], lane);
 #elif defined(EPSM_CP_DMA)
-                geo_issue_rest(X, F, L, WB);
+                geo_issue_rest<kList>(X, F, L, WB);
 #ifdef EPSM_CP_DMA_ALIAS
                 Q.drain(T);                                          // the staging area IS the wave's (now empty) row queue
-                geo_stage_dma<VARIANT>(X, F, L, WB, (float *) s_queue[wv], lane);
+                geo_stage_dma<VARIANT, kList>(X, F, L, WB, (float *) s_queue[wv], lane);
 #else
-                geo_stage_dma<VARIANT>(X, F, L, WB, s_stage[wv], lane);
+                geo_stage_dma<VARIANT, kList>(X, F, L, WB, s_stage[wv], lane);
 #endif
 #else
 #ifdef EPSM_CP_PREFETCH
@@ -762,13 +786,13 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                 X = Xp;
 #elif EPSM_CP_PREFETCH >= 2
                 X = Xp;
-                if (role_of(F, L, WB).end_next) { const float *nx = role_of(F, L, WB).rec + kRecWords; X.n0 = ldq(nx, 0); X.n1 = ldq(nx, 1); X.n2 = ldq(nx, 2); }
+                if (role_of<kList>(F, L, WB).end_next) { const float *nx = role_of<kList>(F, L, WB).rec + kRecWords; X.n0 = ldq(nx, 0); X.n1 = ldq(nx, 1); X.n2 = ldq(nx, 2); }
 #else
-                geo_issue_rest(X, F, L, WB);
+                geo_issue_rest<kList>(X, F, L, WB);
                 X.o0 = Xp.o0; X.o1 = Xp.o1; X.o2 = Xp.o2; X.o3 = Xp.o3; X.o4 = Xp.o4; X.o5 = Xp.o5;
 #endif
 #else
-                geo_issue<VARIANT>(X, F, L, WB);
+                geo_issue<VARIANT, kList>(X, F, L, WB);
 #endif
 #ifdef EPSM_CP_STASH
                 // ONE trip to memory per record: the words only the emission needs (quads 6 and 7: the same line as the geometry,
@@ -784,7 +808,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
 #ifdef EPSM_CP_PREFETCH
                     A0 = Ap;
 #else
-                    addr_issue<VARIANT>(A0, F, L, WB);
+                    addr_issue<VARIANT, kList>(A0, F, L, WB);
 #endif
                     float *st = (float *) s_queue[wv] + 4 * kStashFirstItem + 8 * lane;
                     const bool has_sh = d1 && F.pk_shadow;
@@ -876,7 +900,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
             }
 #ifdef EPSM_CPKO_NOSOLVE
             gd_acc.x += own.x.x + own.n.y + own.light.z + own.eta + prev.x.x + prev.e1.y + next.x.z + next.e2.x + dk.x + dp.y;
-            if (PACKED) addr_issue<VARIANT>(A, F, L, WB);
+            if (PACKED) addr_issue<VARIANT, kList>(A, F, L, WB);
             if (false) {
 #else
             if (VARIANT == EPSM_VARIANT_MANIFOLD) {
@@ -919,7 +943,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the emission's pushes may overwrite the stash
                 }
 #else
-                if (PACKED) addr_issue<VARIANT>(A, F, L, WB);
+                if (PACKED) addr_issue<VARIANT, kList>(A, F, L, WB);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (q > 0) {
@@ -960,7 +984,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the emission's pushes may overwrite the stash
                 }
 #else
-                if (PACKED) addr_issue<VARIANT>(A, F, L, WB);
+                if (PACKED) addr_issue<VARIANT, kList>(A, F, L, WB);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (q > 0) {
@@ -999,7 +1023,7 @@ __global__ __launch_bounds__(kThreads, EPSM_CP_OCC) void epsm_backward_cp_kernel
 #ifdef EPSM_CP_PREFETCH
             // (issued here, behind the table rows' loads -- vmcnt counts in order: waiting for those does not wait for these -- and
             // not earlier: before the solve the same 36 registers spill 117)
-            if (PACKED) { fetch_zero(Xp, Ap); own_issue<VARIANT>(Xp, Ap, F, Ln, WB); }
+            if (PACKED) { fetch_zero(Xp, Ap); own_issue<VARIANT, kList>(Xp, Ap, F, Ln, WB); }
 #endif
             // ---- emission
             asm volatile("; EPSM_MARK emit");

@@ -32,6 +32,7 @@ struct FusedArgs {
     const float *pk_verts;           // (N,K,32) one 128-byte record per (path, vertex)
     const uint32_t *pk_shadow;       // (N,4) or null
     int64_t pk_ray_stride, pk_path_stride;   // words between consecutive paths' rays / first records (dense: 12, 32 K)
+    const uint32_t *pk_list, *pk_list_count; // EpsmPackedLog.path_list / path_count: the windows run over these paths (null: over all N)
 };
 // where the tangents of a path come from
 enum { kTangentsTwoColumns = 0, kTangentsFullRows = 1, kTangentsInKernel = 2 };

@@ -257,6 +257,9 @@ extern "C" int epsm_backward_pass_packed(int variant, int64_t N, int K, int64_t 
     F.pk_rays = log->rays; F.pk_flags = log->flags; F.pk_verts = (const float *) log->verts; F.pk_shadow = log->shadow;
     F.pk_ray_stride = log->ray_stride ? log->ray_stride : 12;
     F.pk_path_stride = log->path_stride ? log->path_stride : (int64_t) K * kRecWords;
+    if ((log->path_list != nullptr) != (log->path_count != nullptr) || (log->path_list && grad_o_sum))
+        return fail(EPSM_EINVAL, "epsm_backward_pass_packed: path_list and path_count come together, and with grad_o_sum = NULL");
+    F.pk_list = log->path_list; F.pk_list_count = log->path_count;
     F.tin = TangentIn{path_offset, spp, res, img_width, img_channels, nullptr, nullptr, nullptr, nullptr, grad_img};
     F.grad_o_sum = grad_o_sum;
     const hipError_t e = launch_backward_cp(variant, kTangentsInKernel, true, F, 2, (hipStream_t) stream);

@@ -306,6 +306,7 @@ __global__ __launch_bounds__(1024) void epsm_wf_scan_kernel(TraceArgs A, WfState
         __syncthreads();
     }
     if (threadIdx.x == 0) W.counters[which == 0 ? b + 1 : 8 + b] = s_carry;
+    if (threadIdx.x == 0 && b < 0 && which == 0 && A.fh.survivor_count) *A.fh.survivor_count = s_carry;   // (the caller's copy: EpsmFirstHitBackward)
     constexpr int kBatch = 4;                                     // groups a wave has in flight
     for (int64_t g0 = (int64_t) wv * kBatch; g0 < groups; g0 += 16 * kBatch) {
         uint32_t v[kBatch], o[kBatch];
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_compact_kernel(TraceArgs A, 
         for (int w = 0; w < wv; ++w) off += s_n[which][w];
         off += (uint32_t) __popcll(m[which] & ((1ull << lane) - 1ull));
         (which == 0 ? W.queue[(b + 1) & 1] : W.shadow_queue)[off] = i;
+        if (b < 0 && which == 0 && A.fh.survivors) A.fh.survivors[off] = i;      // (the caller's copy: EpsmFirstHitBackward)
     }
 #endif
     __syncthreads();
@@ -612,6 +614,7 @@ static int fill_trace_args(TraceArgs &A, const char *who, const EpsmScene *scene
             return bad("EPSM_TRACE_FUSE_FIRST_HIT: recs[0].first_hit needs grad_img (>= 5 channels, img_width >= res >= 1), grad_pos and a 16-byte aligned tri_table");
         if (path_offset + N > (int64_t) f->res * f->res * spp) return bad("EPSM_TRACE_FUSE_FIRST_HIT: path range exceeds res * res * spp");
         if (recs[0].shadow && max_depth <= 3) return bad("EPSM_TRACE_FUSE_FIRST_HIT: not with the occluder record (max_depth <= 3)");
+        if ((f->survivors != nullptr) != (f->survivor_count != nullptr)) return bad("EPSM_TRACE_FUSE_FIRST_HIT: survivors and survivor_count come together");
     }
     if ((flags & EPSM_TRACE_GRADIENT_CAUSTIC) && !(flags & EPSM_TRACE_GRADIENT_ONLY)) return bad("EPSM_TRACE_GRADIENT_CAUSTIC modifies EPSM_TRACE_GRADIENT_ONLY");
     if ((flags & EPSM_TRACE_GRADIENT_ONLY) && K_log < 1) return bad("EPSM_TRACE_GRADIENT_ONLY needs a vertex log (K_log >= 1)");
@@ -699,7 +702,10 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
     const WfState W = wf_carve(workspace, N);
     hipError_t e = hipMemsetAsync(W.counters, 0, wf_zeroed_bytes(N), s);          // the counters and the group counts behind them
     if (e != hipSuccess) return epsm_host::hip_fail("epsm_trace_paths_wavefront", e);
-#ifndef EPSM_WF_NO_PACKET
+#ifdef EPSM_WF_NO_PACKET
+    if ((A.flags & EPSM_TRACE_FUSE_FIRST_HIT) && A.fh.survivors)
+        return fail(EPSM_EINVAL, "epsm_trace_paths_wavefront: this build (EPSM_WF_NO_PACKET) compacts no survivors: first_hit->survivors must be NULL");
+#else
     if (A.flags & EPSM_TRACE_FUSE_FIRST_HIT) {
         A.flags |= kWfPreCompact;                                                  // (the packet stage ADDS its survivors to the chunk counts)
         e = hipMemsetAsync(W.chunk_counts, 0, (size_t) W.chunks * 8, s);

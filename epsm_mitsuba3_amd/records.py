@@ -232,7 +232,8 @@ class PackedScatter:
 
 class EpsmPackedLog(C.Structure):
     """Mirror of ``struct EpsmPackedLog`` (include/epsm.h, ABI v7)."""
-    _fields_ = [(n, C.c_void_p) for n in ("rays", "flags", "verts", "shadow")] + [("ray_stride", C.c_int64), ("path_stride", C.c_int64)]
+    _fields_ = [(n, C.c_void_p) for n in ("rays", "flags", "verts", "shadow")] + [("ray_stride", C.c_int64), ("path_stride", C.c_int64),
+                                                                                ("path_list", C.c_void_p), ("path_count", C.c_void_p)]
 
 
 FLAG_DIFFUSE, FLAG_NULL, FLAG_ACTIVE, FLAG_ACTIVE_EM, FLAG_ISMESH = 1, 2, 4, 8, 16
@@ -287,6 +288,14 @@ class PackedLog:
         # set by the tracer under EPSM_TRACE_FUSE_FIRST_HIT: the paths without a chain (their flag words are 0) and the sum d / d ray.o
         # are already in the gradient buffers -- the backward kernel is then called without grad_o_sum and gives such paths no lane
         self.first_hit_done = False
+        self.path_list = self.path_count = None
+
+    def set_path_list(self, path_list: torch.Tensor, path_count: torch.Tensor) -> None:
+        """The paths the backward pass is to look at (EpsmPackedLog.path_list / path_count: the tracer's survivors under
+        EPSM_TRACE_FUSE_FIRST_HIT); every other path's flag word is 0.  The kernel reads the count on the device."""
+        assert path_list.dtype == torch.int32 and path_count.dtype == torch.int32 and path_list.is_contiguous() and path_count.numel() == 1
+        self.path_list, self.path_count = path_list, path_count
+        self.c.path_list, self.c.path_count = path_list.data_ptr(), path_count.data_ptr()
 
     def table_ptr(self) -> int:
         return self.table.data_ptr()

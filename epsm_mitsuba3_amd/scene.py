@@ -96,7 +96,8 @@ class EpsmSceneC(C.Structure):
 class EpsmFirstHitBackward(C.Structure):
     """Mirror of ``struct EpsmFirstHitBackward`` (include/epsm_trace.h)."""
     _fields_ = [("grad_img", C.c_void_p), ("img_width", C.c_int), ("img_channels", C.c_int), ("res", C.c_int), ("clip", C.c_float),
-                ("tri_table", C.c_void_p), ("T", C.c_int64), ("V", C.c_int64), ("grad_pos", C.c_void_p), ("grad_o_sum", C.c_void_p)]
+                ("tri_table", C.c_void_p), ("T", C.c_int64), ("V", C.c_int64), ("grad_pos", C.c_void_p), ("grad_o_sum", C.c_void_p),
+                ("survivors", C.c_void_p), ("survivor_count", C.c_void_p)]
 
 
 class EpsmRecordOut(C.Structure):
@@ -1252,9 +1253,14 @@ class Scene:
         if fuse:
             grad_in, target, clip, want_origin = first_hit
             assert grad_in.is_contiguous() and grad_in.dtype == torch.float32 and grad_in.shape[-1] >= 5
+            # the paths the first-hit stage does NOT retire, in path order: the backward pass then runs its windows over these alone
+            survivors = torch.empty((n,), device=dev, dtype=torch.int32) if self._backend is None else None
+            survivor_count = torch.zeros((1,), device=dev, dtype=torch.int32) if self._backend is None else None
             fh = EpsmFirstHitBackward(grad_in.data_ptr(), int(grad_in.shape[1]), int(grad_in.shape[2]), int(sensor.width), float(clip),
                                       self.tri_table.data_ptr(), int(self.tri_table.shape[0]), int(target.V), target.pos.data_ptr(),
-                                      target.cam_origin.data_ptr() if want_origin else None)
+                                      target.cam_origin.data_ptr() if want_origin else None,
+                                      survivors.data_ptr() if survivors is not None else None,
+                                      survivor_count.data_ptr() if survivor_count is not None else None)
             recs[0].first_hit = C.addressof(fh)
         cs = sensor.c_struct()
         args = [C.byref(self.c_scene), C.byref(cs), C.c_uint32(seed & 0xFFFFFFFF), int(spp), int(max_depth), int(self.rr_depth),
@@ -1280,6 +1286,8 @@ class Scene:
         tr.log = PackedLog(rays, flags, verts, shadow, self.tri_table, K)
         # the tracer has accounted for every path without a chain and for d / d ray.o: the backward kernel is called without grad_o_sum
         tr.log.first_hit_done = bool(fuse)
+        if fuse and survivors is not None and want_origin:      # (the list needs a backward pass without grad_o_sum: include/epsm.h)
+            tr.log.set_path_list(survivors, survivor_count)
         return tr
 
     def _trace(self, sensor_index: int, seed: int, spp: int, max_depth: int, K: int, lo: int, hi: int,

@@ -290,6 +290,9 @@ typedef struct EpsmPackedLog {
     const void *verts;
     const uint32_t *shadow;
     int64_t ray_stride, path_stride;   /* words; 0 = 12 / 32 K */
+    const uint32_t *path_list;         /* NULL, or (<= N) indices, ascending, of the only paths the backward pass is to look at -- every other
+                                          path's flag word is 0 (EPSM_TRACE_FUSE_FIRST_HIT: the tracer's list of survivors); needs grad_o_sum = NULL */
+    const uint32_t *path_count;        /* device word: how many entries path_list holds (read by the kernel: no host round trip) */
 } EpsmPackedLog;
 #define EPSM_FLAG_DIFFUSE   1u
 #define EPSM_FLAG_NULL      2u

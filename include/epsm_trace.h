@@ -211,6 +211,10 @@ typedef struct EpsmFirstHitBackward {
     int64_t T, V;
     float *grad_pos;                 /* (V,3), accumulated */
     float *grad_o_sum;               /* (3), accumulated; may be NULL */
+    uint32_t *survivors;             /* (N) or NULL: receives, in path order, the indices of the paths this stage did NOT retire -- the only
+                                        ones of which the log holds anything -- and *survivor_count their number: EpsmPackedLog.path_list /
+                                        path_count of the backward pass that follows (its windows then run over these paths alone) */
+    uint32_t *survivor_count;        /* (1) or NULL (both or neither) */
 } EpsmFirstHitBackward;
 
 /* Writable twin of EpsmVertexRecord + EpsmScatterRecord for one logged bounce. */
