@@ -418,3 +418,40 @@ def test_packed_log_gives_the_sums_of_the_per_array_records(kind, profile, K, ma
             if name in ("pos", "cam"):
                 assert m > 0, name
             assert float((x - y).abs().max()) <= 2e-4 * m + 1e-12, (name, layout)
+
+
+@pytest.mark.parametrize("res,spp", [(24, 16), (64, 512)])          # a small wavefront (one window per workgroup) and a large one (windows of 2048)
+@pytest.mark.parametrize("kind,profile", [("manifold", "bathroom"), ("manifold_caustic", "pool")])
+def test_path_list_gives_the_sums_of_the_whole_log(kind, profile, res, spp):
+    """EpsmPackedLog.path_list / path_count (include/epsm.h): the backward pass runs its windows over a LIST of paths -- what the tracer
+    hands over under EPSM_TRACE_FUSE_FIRST_HIT, every other path's flag word being 0 -- with the count read on the device.  A
+    synthetic log with 85 % of its flag words zeroed: the launch over the list of the others against the launch over all N (both
+    without the camera-origin sum, which the list form does not take): the same rows."""
+    import epsm_mitsuba3_amd as epsm
+    from epsm_mitsuba3_amd.records import PackedLog
+    from epsm_mitsuba3_amd.tangent_scatter import backward_pass_packed
+    dev = torch.device("cuda", 0)
+    K, V, B = 4, 3000, 3
+    N = res * res * spp
+    scene = epsm.SyntheticScene(res=res, n_vertices=K, n_scene_vertices=V, n_bsdfs=B, profile=profile, device=dev, tile_paths=N)
+    g = torch.Generator().manual_seed(9)
+    grad_in = (torch.randn((res, res, 5), generator=g) * 1e-3).to(dev)
+    (trace,) = scene.trace_paths(seed=4, spp=spp, max_depth=8)
+    log = PackedLog.from_trace(trace)
+    keep = torch.rand(N, generator=g) < 0.15
+    keep[:5] = True; keep[-3:] = True
+    log.flags[~keep.to(dev)] = 0
+    out = []
+    for use_list in (False, True):
+        if use_list:
+            lst = torch.nonzero(keep).flatten().to(torch.int32).to(dev)
+            cap = torch.zeros(N, dtype=torch.int32, device=dev); cap[:lst.numel()] = lst          # (capacity N, as the tracer allocates it)
+            log.set_path_list(cap, torch.tensor([lst.numel()], dtype=torch.int32, device=dev))
+        p = epsm.ParamGrads(V, B, device=dev)
+        backward_pass_packed(kind, log, grad_in, spp, res, p.pos, p.nrm, p.alpha, None, clip=0.1, path_offset=0)
+        torch.cuda.synchronize()
+        out.append(p.flat.double().cpu())
+    m = float(out[0].abs().max())
+    assert m > 0 and float((out[0] - out[1]).abs().max()) <= 1e-5 * m
+    with pytest.raises(Exception):                                   # the list form takes no grad_o_sum
+        backward_pass_packed(kind, log, grad_in, spp, res, p.pos, p.nrm, p.alpha, p.cam_origin, clip=0.1, path_offset=0)
