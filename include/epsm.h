@@ -36,7 +36,8 @@ extern "C" {
  * 6 (round 5): EpsmEnvironment starts with `kind` (0 = none: a zeroed EpsmScene has no environment; until 5 `emitter = -1` said
  * so); note of 5, late: epsm_trace_paths_reparam had gained its `flags` parameter mid-signature in that version.
  * 7 (round 5): EpsmPackedLog ends with ray_stride / path_stride, EpsmRecordOut (epsm_trace.h) with ray_stride / packed_stride: the
- * native log may interleave a path's rays and records in one block (zeroed strides = the dense arrays of version 6). */
+ * native log may interleave a path's rays and records in one block (zeroed strides = the dense arrays of version 6); EpsmPackedLog
+ * also ends with path_list / path_count (NULL = all N paths), EpsmRecordOut with first_hit (EPSM_TRACE_FUSE_FIRST_HIT, epsm_trace.h). */
 #define EPSM_ABI_VERSION 7
 
 /* BSDF flag bits tested by the hot path (include/mitsuba/render/bsdf.h:40-46,101). */
