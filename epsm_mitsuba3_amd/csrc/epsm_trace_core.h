@@ -939,8 +939,9 @@ struct PathState {
 struct FirstHitRows { bool on; uint32_t key[3]; F3 val[3]; };              // rows of grad_pos this path adds to
 // d loss / d film position of path i's pixel (channels 3, 4 of the gradient image; epsm.py:250-255)
 EPSM_HD void first_hit_pixel_grad(const TraceArgs &A, int64_t i, float &gx, float &gy) {
-    const int64_t pix = (A.path_offset + i) / A.spp, y = pix / A.fh.res, x = pix - y * A.fh.res;
-    const float *g = A.fh.grad_img + (y * A.fh.img_width + x) * A.fh.img_channels;
+    // (32-bit divisions: the wavefront index fits 32 bits -- fill_trace_args, common.py:468-475 -- and two 64-bit ones are ~200 instructions)
+    const uint32_t widx = (uint32_t) (A.path_offset + i), pix = widx / (uint32_t) A.spp, y = pix / (uint32_t) A.fh.res, x = pix - y * (uint32_t) A.fh.res;
+    const float *g = A.fh.grad_img + ((int64_t) y * A.fh.img_width + x) * A.fh.img_channels;
     gx = g[3]; gy = g[4];
 }
 // `w`: the flag word (vertex 1 alone), `gd` = (d_x - d) gx + (d_y - d) gy, `ray`: the primary ray
