@@ -245,10 +245,15 @@ __global__ __launch_bounds__(kWfFirstHitSlots) void epsm_wf_first_hit_finish_ker
 // writes cost nothing, each of the two queues 0.6 ms: 65 536 same-address atomics, ~9 ns apiece at the memory
 // side); it leaves a flag per slot and two counts per chunk instead.
 __global__ __launch_bounds__(kWfChunk) void epsm_wf_shade_kernel(TraceArgs A, WfState W, int b) {
-    const int64_t count = wf_count(A, W, b), q = (int64_t) blockIdx.x * kWfChunk + threadIdx.x;
+    const int64_t count = wf_count(A, W, b);
     if ((int64_t) blockIdx.x * kWfChunk >= count || wf_in_tail(A, b, count)) return;           // workgroup-uniform
-    // (Tried: a capped grid whose workgroups take chunks in turn, as the compaction does -- the launch of a bounce nobody reaches
-    // 15 -> 5 us, but the stage itself 1.08 -> 1.19 ms at 2^24 paths: the hardware's dispatch order balances better.)
+    // (A capped grid whose workgroups take chunks in turn, as the compaction does: the launch of a bounce nobody reaches 15 -> 5 us, but
+    // a stage whose every chunk has work 1.08 -> 1.19 ms at 2^24 paths -- the hardware's dispatch order balances better.  So the
+    // host caps the grid only where the queue is known to be short: behind the first-hit stage's compaction and from bounce 1 on.)
+    __shared__ uint32_t s_n[2][kWfChunk / 64];
+#pragma unroll 1
+    for (int64_t chunk = blockIdx.x; chunk * kWfChunk < count; chunk += gridDim.x) {           // workgroup-uniform
+    const int64_t q = chunk * kWfChunk + threadIdx.x;
     bool alive = false, shadow = false;
     // EPSM_TRACE_FUSE_FIRST_HIT: the primary rays' stage (packet kernel) has dealt with the paths that end at their first vertex and
     // the survivors come here compacted (kWfPreCompact); without that stage (EPSM_WF_NO_PACKET builds) this one does it, wf_shade's `out`
@@ -260,8 +265,7 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_shade_kernel(TraceArgs A, Wf
         wf_shade(A, W, wf_identity(A, b) ? q : (int64_t) W.queue[b & 1][q], b, alive, shadow, fuse ? &fh : nullptr);
         W.flags[q] = (uint8_t) ((alive ? kWfAlive : 0) | (shadow ? kWfShadow : 0));
     }
-    if (fuse) first_hit_scatter(A, W, fh, blockIdx.x * (kWfChunk / 64) + (threadIdx.x >> 6));   // (all lanes of the wave: the sums run over it)
-    __shared__ uint32_t s_n[2][kWfChunk / 64];
+    if (fuse) first_hit_scatter(A, W, fh, (unsigned) chunk * (kWfChunk / 64) + (threadIdx.x >> 6));   // (all lanes of the wave: the sums run over it)
     const unsigned long long ma = __ballot(alive), ms = __ballot(shadow);
     if ((threadIdx.x & 63) == 0) { s_n[0][threadIdx.x >> 6] = (uint32_t) __popcll(ma); s_n[1][threadIdx.x >> 6] = (uint32_t) __popcll(ms); }
     __syncthreads();
@@ -269,8 +273,10 @@ __global__ __launch_bounds__(kWfChunk) void epsm_wf_shade_kernel(TraceArgs A, Wf
         uint32_t n = 0;
 #pragma unroll
         for (int w = 0; w < kWfChunk / 64; ++w) n += s_n[threadIdx.x][w];
-        W.chunk_counts[threadIdx.x * W.chunks + blockIdx.x] = n;
-        if (n) atomicAdd(&W.group_counts[threadIdx.x * W.groups + blockIdx.x / kWfGroup], n);     // (64 adds per address at most)
+        W.chunk_counts[threadIdx.x * W.chunks + chunk] = n;
+        if (n) atomicAdd(&W.group_counts[threadIdx.x * W.groups + chunk / kWfGroup], n);     // (64 adds per address at most)
+    }
+    __syncthreads();                                                 // (the counts of this chunk are read before the next one writes its own)
     }
 }
 // Exclusive scan of the chunk counts of both queues (<= 65 536 chunks each at 2^24 paths), one workgroup PER QUEUE, two
@@ -714,6 +720,7 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
 #endif
     auto blocks = [&](int threads) { const int64_t b = (N + threads - 1) / threads; return dim3((unsigned) (b < kWfMaxBlocks ? b : kWfMaxBlocks)); };
     const int depth = path_max_depth(A);
+    const dim3 shade_short((unsigned) (W.chunks < 16384 ? W.chunks : 16384));
     const dim3 chunks((unsigned) W.chunks), chunk_blocks((unsigned) (W.chunks < kWfMaxChunkBlocks ? W.chunks : kWfMaxChunkBlocks));
     const int64_t tail_most = N < kWfTailBelow ? N : kWfTailBelow;
     const dim3 tail_blocks((unsigned) ((tail_most + kWfThreads - 1) / kWfThreads));
@@ -740,7 +747,8 @@ extern "C" int epsm_trace_paths_wavefront(const EpsmScene *scene, const EpsmSens
 #else
         else hipLaunchKernelGGL(epsm_wf_extend_kernel<false>, blocks(kWfThreads), dim3(kWfThreads), 0, s, A, W, b);
 #endif
-        hipLaunchKernelGGL(epsm_wf_shade_kernel, chunks, dim3(kWfChunk), 0, s, A, W, b);
+        // (the whole grid where every chunk has work -- bounce 0 of an unfused trace --, a capped one where the queue is short)
+        hipLaunchKernelGGL(epsm_wf_shade_kernel, (b == 0 && !(A.flags & kWfPreCompact)) ? chunks : shade_short, dim3(kWfChunk), 0, s, A, W, b);
         if (b == 0 && (A.flags & EPSM_TRACE_FUSE_FIRST_HIT) && A.fh.grad_o_sum)
             hipLaunchKernelGGL(epsm_wf_first_hit_finish_kernel, dim3(1), dim3(kWfFirstHitSlots), 0, s, A, W);
         hipLaunchKernelGGL(epsm_wf_scan_kernel, dim3(2), dim3(1024), 0, s, A, W, b);
